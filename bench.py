@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py -- iLQR solves/sec on BASELINE.json configs[1]: B=1024 random SE(3) starts per GPU,
+100 knots, fp64, model A.
+
+One "step" = one batched solve of the whole per-GPU batch, inputs already resident in HBM.
+N>1: launched by torch.distributed.run, one rank per GPU; each rank solves its own shard of
+1024 problems (weak scaling, no data-path collective) and the converged trajectories are
+gathered on rank 0 over RCCL inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     for the dominant kernel, from HIP events recorded on the solver's stream inside
+               the timed region (algorithmic flops/bytes from BASELINE.md section 4)
+  cpu_baseline the CPU oracle timed on this host's cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix peak (AMD CDNA4 datasheet)
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# algorithmic work per knot
+FLOP_BWD_KNOT, FLOP_FWD_KNOT = 30000.0, 1250.0
+BYTES_BWD_KNOT, BYTES_FWD_KNOT, BYTES_IO_KNOT = 86 * 8.0, 103 * 8.0, 53 * 8.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
+    ap.add_argument("--knots", type=int, default=100)
+    ap.add_argument("--sync-every", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from quadrotorilqr_amd import capi, problems as pb, sharding
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    B, N = args.batch, args.knots
+    cfg = pb.config2(B=B, N=N, seed=2, b0=rank * B)  # counter-based generator: shard-independent
+    solver = capi.from_config(cfg, device=dev.index, profile=True, sync_every=args.sync_every)
+
+    init = torch.from_numpy(cfg["init"]).to(dev)
+    out_traj = torch.empty_like(init)
+    out_cost = torch.empty(B, dtype=torch.float64, device=dev)
+    out_i = [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(4)]  # status, iters, n_bwd, n_fwd
+    sizes = [B] * world
+
+    def step():
+        solver.solve_batch_device(init, out_traj, out_cost, out_i[0], out_i[1], out_i[2], out_i[3])
+        if world > 1:  # the one exchange of the path: converged trajectories to rank 0
+            sharding.gather_to_root(out_traj, sizes)
+            sharding.gather_to_root(out_cost, sizes)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    solver.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    prof = solver.profile_get()
+
+    status, iters, n_bwd, n_fwd = (t.cpu().numpy() for t in out_i)
+    total = B * world * args.steps
+    value = total / dt
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (this rank's launches, timed region only)
+        knots_bwd = float(n_bwd.sum()) * N * args.steps
+        knots_fwd = float(n_fwd.sum()) * N * args.steps
+        kern = {
+            "k_backward": dict(ms=prof["backward_ms"], launches=prof["backward_launches"],
+                               flops=FLOP_BWD_KNOT * knots_bwd, bytes=BYTES_BWD_KNOT * knots_bwd),
+            "k_rollout": dict(ms=prof["rollout_ms"], launches=prof["rollout_launches"],
+                              flops=FLOP_FWD_KNOT * knots_fwd, bytes=BYTES_FWD_KNOT * knots_fwd),
+        }
+        dom = max(kern, key=lambda k: kern[k]["ms"])
+        kd = kern[dom]
+        sec = kd["ms"] * 1e-3
+        tflops = kd["flops"] / sec / 1e12
+        gbs = kd["bytes"] / sec / 1e9
+        roofline = {
+            "kernel": dom, "bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tflops / FP64_PEAK_TFLOPS, "traffic": None,
+            "avg_launch_us": kd["ms"] * 1e3 / max(kd["launches"], 1), "launches": kd["launches"],
+            "alg_flops_per_launch": kd["flops"] / max(kd["launches"], 1),
+            "alg_bytes_per_launch": kd["bytes"] / max(kd["launches"], 1),
+            "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+            "kernels_ms": {k: round(v["ms"], 3) for k, v in kern.items()}
+                          | {"k_linearize": round(prof["linearize_ms"], 3), "other": round(prof["other_ms"], 3)},
+        }
+        # ---- CPU baseline: the oracle on this host's cores, bounded sample of the same workload
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import oracle as orc
+            cores = max(1, min(os.cpu_count() or 1, 64))
+            sample = min(B, max(64, 24 * cores))
+            ref = orc.OracleSolver(orc.model_params(**cfg["model"]), cfg["Q"], cfg["R"], cfg["desired"],
+                                   cfg["dt"], orc.options(**cfg["options"]))
+            t1 = time.perf_counter()
+            r = ref.solve_batch(cfg["init"][:sample], n_threads=cores)
+            tc = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            ref.solve_batch(cfg["init"][:16], n_threads=1)
+            t1c = time.perf_counter() - t1
+            got = out_cost.cpu().numpy()[:sample]
+            cpu = {"value": sample / tc, "unit": "solves/s", "cores": cores, "kind": "port",
+                   "sample": f"first {sample} of the {B} problems of rank 0, {cores} threads, {tc:.2f} s; "
+                             f"single thread: {16 / t1c:.1f} solves/s on 16 problems",
+                   "parity_max_rel_cost_err": float(np.max(np.abs(got - r["cost"]) / np.abs(r["cost"])))}
+        line = {
+            "metric": "iLQR solves/sec (batch, 100-knot SE(3) quadrotor)", "value": value, "unit": "solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]: batch={B}/GPU random SE(3) starts -> hover, "
+                                   f"{N} knots, fp64, model A, seed 2", "batch_per_gpu": B, "knots": N,
+                       "parallelism": f"batch-shard x{world}" + (" + RCCL gather to rank 0" if world > 1 else "")},
+            "iters_mean": float(iters.mean()), "iters_max": int(iters.max()),
+            "status_counts": np.bincount(status, minlength=4).tolist(),
+            "knot_steps_per_s": float((n_bwd.sum() + n_fwd.sum()) * N * world * args.steps / dt),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

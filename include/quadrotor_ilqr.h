@@ -1,0 +1,149 @@
+/*
+ * quadrotor_ilqr.h -- C ABI of the MI355X-native batched iLQR solver for the
+ * SE(3) x R^6 quadrotor.  This is the drop-in boundary for the one hot path of
+ * nitishthatte/QuadrotorILQR: everything reachable from ILQR<QuadrotorModel>::solve
+ * (reference src/ilqr.hh:53-87).  Plain pointers and sizes, no exceptions, no C++
+ * or torch types.  The shared library is libquadrotor_ilqr.so (HIP, gfx950 only;
+ * there is no CPU fallback: every entry point that computes fails with
+ * QILQR_ERR_NO_DEVICE when no GPU is present).
+ *
+ * Conventions
+ *   knot   p[18]  = [time_s, tx,ty,tz, qw,qx,qy,qz, v_lin(3), v_ang(3), u0..u3]
+ *                   (= IDX of reference src/quadrotor_ilqr.py:19-37; quaternion in the
+ *                   wire order w,x,y,z of src/trajectory.proto:27-30)
+ *   trajectory    = n x 18 doubles, row-major; a batch is B x n x 18
+ *   tangent order = [rho(3), theta(3), dv_lin(3), dv_ang(3)]  (quadrotor_model.hh:30-37)
+ *   matrices      = row-major (Q is 12x12 in tangent order, R is 4x4)
+ *   gains  g[52]  = [k(4) ; K(4x12) column-major]  = the reference's
+ *                   ControlUpdate{ff_update, feedback} (ilqr.hh:43-46)
+ */
+#ifndef QUADROTOR_ILQR_H
+#define QUADROTOR_ILQR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QILQR_KNOT 18
+#define QILQR_GAIN 52
+
+/* return codes */
+#define QILQR_OK 0
+#define QILQR_ERR_BAD_INERTIA 1     /* "Inertia matrix is not positive definite!" quadrotor_model.cc:21-24 */
+#define QILQR_ERR_LENGTH_MISMATCH 2 /* initial trajectory longer than desired: cost.hh:39-40 (.at) */
+#define QILQR_ERR_INVALID_ARG 3
+#define QILQR_ERR_BAD_QUATERNION 4  /* manif's SO3 constructor check, | |q| - 1 | > 1e-10 */
+#define QILQR_ERR_NO_DEVICE 5
+#define QILQR_ERR_HIP 6
+#define QILQR_ERR_LINE_SEARCH 7     /* single solve only: ilqr.hh:191-193 throws */
+
+/* per-problem exit path of solve(), numbered after the reference's return sites */
+#define QILQR_STATUS_CONVERGED_EXPECTED 0 /* ilqr.hh:66-68 */
+#define QILQR_STATUS_CONVERGED 1          /* ilqr.hh:82-84 */
+#define QILQR_STATUS_MAX_ITERS 2          /* ilqr.hh:86    */
+#define QILQR_STATUS_LINE_SEARCH_FAILED 3 /* ilqr.hh:191-193 */
+
+/* QuadrotorModel constructor arguments: quadrotor_model.hh:7-9, binding.cc:20-23 */
+typedef struct {
+  double mass_kg;
+  double inertia[9];
+  double arm_length_m;
+  double torque_to_thrust_ratio_m;
+  double g_mpss;
+} qilqr_model;
+
+/* ILQROptions: ilqr_options.hh:4-22 / ilqr_options.proto:5-21 */
+typedef struct {
+  double step_update;            /* LineSearchParams */
+  double desired_reduction_frac;
+  int32_t ls_max_iters;
+  double rtol;                   /* ConvergenceCriteria */
+  double atol;
+  double max_iters;              /* a double in the reference */
+  int32_t populate_debug;
+} qilqr_options;
+
+/* device-side configuration (no counterpart in the reference, which is CPU only) */
+typedef struct {
+  int32_t device;   /* HIP device ordinal */
+  int32_t profile;  /* 1: bracket every kernel launch with HIP events (qilqr_profile_get) */
+  int32_t sync_every; /* host polls the active-problem counter every k outer iterations (>=1) */
+} qilqr_device_config;
+
+typedef struct qilqr_solver qilqr_solver;
+
+/* per-kernel device time accumulated since the last reset (profile = 1) */
+typedef struct {
+  double backward_ms;  int32_t backward_launches;
+  double rollout_ms;   int32_t rollout_launches;
+  double linearize_ms; int32_t linearize_launches;
+  double other_ms;     int32_t other_launches;
+} qilqr_profile;
+
+/* Replaces src::init, quadrotor_ilqr_binding.cc:20-32 (QuadrotorModel ctor + CostFunction +
+ * ILQR ctor).  `desired` is n_desired x 18 (time column ignored).  Everything is copied. */
+int qilqr_create(const qilqr_model *model, const double *Q, const double *R,
+                 const double *desired, int32_t n_desired, double dt_s,
+                 const qilqr_options *options, const qilqr_device_config *dev,
+                 qilqr_solver **out);
+void qilqr_destroy(qilqr_solver *s);
+
+/* text of the last error on the calling thread */
+const char *qilqr_last_error(void);
+
+/* Replaces src::solve, quadrotor_ilqr_binding.cc:34-41 -> ILQR::solve, ilqr.hh:53-87.
+ * One problem.  debug_cost[debug_cap] / debug_trajs[debug_cap x n x 18] receive, when
+ * options.populate_debug, one entry per completed forward pass (ilqr.hh:78-80); n_debug the
+ * count.  Returns QILQR_ERR_LINE_SEARCH where the reference throws (outputs untouched). */
+int qilqr_solve(qilqr_solver *s, const double *init, int32_t n, double *out_traj,
+                double *out_cost, int32_t *out_status, int32_t *out_iters,
+                double *debug_cost, double *debug_trajs, int32_t debug_cap, int32_t *n_debug);
+
+/* B independent problems sharing model, cost weights, dt and options.  Host buffers.
+ * init B x n x 18.  desired_batch: NULL (use the desired trajectory given at create) or
+ * B x n x 18 per-problem desired trajectories.  Any output pointer may be NULL.
+ * Line-search exhaustion is reported per problem in out_status, not as an error. */
+int qilqr_solve_batch(qilqr_solver *s, const double *init, const double *desired_batch,
+                      int32_t B, int32_t n, double *out_traj, double *out_cost,
+                      int32_t *out_status, int32_t *out_iters, int32_t *out_n_bwd,
+                      int32_t *out_n_fwd);
+
+/* Same, with every buffer already resident in device memory (HBM) of the solver's device.
+ * Runs on the solver's own stream and returns after that stream has drained. */
+int qilqr_solve_batch_device(qilqr_solver *s, const double *d_init, const double *d_desired_batch,
+                             int32_t B, int32_t n, double *d_out_traj, double *d_out_cost,
+                             int32_t *d_out_status, int32_t *d_out_iters, int32_t *d_out_n_bwd,
+                             int32_t *d_out_n_fwd);
+
+/* The passes the reference's tests call directly (ilqr_test.cc:102-190), batched, host buffers. */
+/* ILQR::cost_trajectory, ilqr.hh:89-95 */
+int qilqr_cost_trajectory(qilqr_solver *s, const double *traj, int32_t B, int32_t n, double *cost);
+/* ILQR::backwards_pass, ilqr.hh:97-147: gains B x n x 52, terms B x 2 = {QuTk, kTQuuk} */
+int qilqr_backwards_pass(qilqr_solver *s, const double *traj, int32_t B, int32_t n, double *gains,
+                         double *terms);
+/* ILQR::forward_sim, ilqr.hh:149-172: alpha[B] */
+int qilqr_forward_sim(qilqr_solver *s, const double *traj, const double *gains,
+                      const double *alpha, int32_t B, int32_t n, double *out_traj);
+/* ILQR::line_search, ilqr.hh:174-194: cost[B], terms B x 2 -> out_traj, out_cost[B], out_step[B],
+ * out_status[B] (0 accepted, QILQR_STATUS_LINE_SEARCH_FAILED where the reference throws) */
+int qilqr_line_search(qilqr_solver *s, const double *traj, const double *cost, const double *gains,
+                      const double *terms, int32_t B, int32_t n, double *out_traj,
+                      double *out_cost, double *out_step, int32_t *out_status);
+
+/* profiling (HIP events on the solver's stream) */
+int qilqr_profile_reset(qilqr_solver *s);
+int qilqr_profile_get(qilqr_solver *s, qilqr_profile *out);
+
+/* device the solver is bound to, and the HIP stream it launches on (hipStream_t as void*) */
+int qilqr_device(const qilqr_solver *s);
+void *qilqr_stream(const qilqr_solver *s);
+
+/* ABI version of this header */
+int qilqr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

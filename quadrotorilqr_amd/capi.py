@@ -1,0 +1,259 @@
+"""ctypes binding of libquadrotor_ilqr.so (include/quadrotor_ilqr.h) and the host-side mirror
+of the reference's ILQR<QuadrotorModel> interface (src/ilqr.hh:25-206): same method names,
+argument meaning and error behaviour, batched.
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present every compute
+entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libquadrotor_ilqr.so")
+
+KNOT = 18
+GAIN = 52
+
+OK = 0
+ERR_BAD_INERTIA = 1
+ERR_LENGTH_MISMATCH = 2
+ERR_INVALID_ARG = 3
+ERR_BAD_QUATERNION = 4
+ERR_NO_DEVICE = 5
+ERR_HIP = 6
+ERR_LINE_SEARCH = 7
+
+STATUS_CONVERGED_EXPECTED = 0
+STATUS_CONVERGED = 1
+STATUS_MAX_ITERS = 2
+STATUS_LINE_SEARCH_FAILED = 3
+
+# every symbol include/quadrotor_ilqr.h declares
+EXPORTS = (
+    "qilqr_create", "qilqr_destroy", "qilqr_last_error", "qilqr_solve", "qilqr_solve_batch",
+    "qilqr_solve_batch_device", "qilqr_cost_trajectory", "qilqr_backwards_pass", "qilqr_forward_sim",
+    "qilqr_line_search", "qilqr_profile_reset", "qilqr_profile_get", "qilqr_device", "qilqr_stream",
+    "qilqr_abi_version",
+)
+
+
+class Model(C.Structure):
+    _fields_ = [("mass_kg", C.c_double), ("inertia", C.c_double * 9), ("arm_length_m", C.c_double),
+                ("torque_to_thrust_ratio_m", C.c_double), ("g_mpss", C.c_double)]
+
+
+class Options(C.Structure):
+    _fields_ = [("step_update", C.c_double), ("desired_reduction_frac", C.c_double),
+                ("ls_max_iters", C.c_int32), ("rtol", C.c_double), ("atol", C.c_double),
+                ("max_iters", C.c_double), ("populate_debug", C.c_int32)]
+
+
+class DeviceConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("profile", C.c_int32), ("sync_every", C.c_int32)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("backward_ms", C.c_double), ("backward_launches", C.c_int32),
+                ("rollout_ms", C.c_double), ("rollout_launches", C.c_int32),
+                ("linearize_ms", C.c_double), ("linearize_launches", C.c_int32),
+                ("other_ms", C.c_double), ("other_launches", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        lib.qilqr_last_error.restype = C.c_char_p
+        lib.qilqr_stream.restype = C.c_void_p
+        _lib = lib
+    return _lib
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _raise(rc, ls_max_iters=None):
+    msg = load().qilqr_last_error().decode()
+    if rc == ERR_BAD_INERTIA:
+        raise RuntimeError("Inertia matrix is not positive definite!")  # quadrotor_model.cc:23
+    if rc == ERR_LENGTH_MISMATCH:
+        raise IndexError(msg)  # std::out_of_range from .at(i), cost.hh:39-40
+    if rc == ERR_BAD_QUATERNION:
+        raise ValueError(msg)
+    if rc == ERR_LINE_SEARCH:
+        raise RuntimeError(msg)  # ilqr.hh:191-193, same text
+    if rc == ERR_INVALID_ARG:
+        raise TypeError(msg)
+    raise RuntimeError(f"quadrotor_ilqr error {rc}: {msg}")
+
+
+class QuadrotorILQRBatch:
+    """ILQR<QuadrotorModel> (ilqr.hh:25-41) for batches of independent problems on one MI355X."""
+
+    def __init__(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired,
+                 dt_s, options, device=0, profile=False, sync_every=1):
+        lib = load()
+        m = Model()
+        m.mass_kg = mass_kg
+        I = _d(inertia)
+        if I.shape != (3, 3):
+            raise TypeError("inertia must be 3x3")
+        for i in range(9):
+            m.inertia[i] = I.reshape(9)[i]
+        m.arm_length_m = arm_length_m
+        m.torque_to_thrust_ratio_m = torque_to_thrust_ratio_m
+        m.g_mpss = g_mpss
+        Q, R = _d(Q), _d(R)
+        if Q.shape != (12, 12) or R.shape != (4, 4):
+            raise TypeError("Q must be 12x12 and R 4x4")
+        o = Options()
+        o.step_update = options["step_update"]
+        o.desired_reduction_frac = options["desired_reduction_frac"]
+        o.ls_max_iters = int(options["ls_max_iters"])
+        o.rtol = options["rtol"]
+        o.atol = options["atol"]
+        o.max_iters = float(options["max_iters"])
+        o.populate_debug = int(bool(options.get("populate_debug", False)))
+        self.options = dict(options)
+        self.desired = _d(desired).reshape(-1, KNOT)
+        dc = DeviceConfig(int(device), int(bool(profile)), int(sync_every))
+        self._h = C.c_void_p()
+        rc = lib.qilqr_create(C.byref(m), _p(Q), _p(R), _p(self.desired), C.c_int32(len(self.desired)),
+                              C.c_double(dt_s), C.byref(o), C.byref(dc), C.byref(self._h))
+        if rc:
+            self._h = None
+            _raise(rc)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().qilqr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- ILQR::solve, one problem (ilqr.hh:53-87) -> (traj, dict(cost, status, iters, debug...))
+    def solve(self, init):
+        init = _d(init).reshape(-1, KNOT)
+        n = len(init)
+        out = np.zeros_like(init)
+        cap = int(max(self.options["max_iters"], 0)) if self.options.get("populate_debug") else 0
+        dcost = np.zeros(max(cap, 1))
+        dtraj = np.zeros((max(cap, 1), n, KNOT))
+        cost, st, it, nd = C.c_double(), C.c_int32(), C.c_int32(), C.c_int32()
+        rc = load().qilqr_solve(self._h, _p(init), C.c_int32(n), _p(out), C.byref(cost), C.byref(st),
+                                C.byref(it), _p(dcost), _p(dtraj), C.c_int32(cap), C.byref(nd))
+        if rc:
+            _raise(rc)
+        k = nd.value
+        return out, dict(cost=cost.value, status=st.value, iters=it.value, debug_costs=dcost[:k].copy(),
+                         debug_trajs=dtraj[:k].copy())
+
+    # ---- batch of problems, host buffers
+    def solve_batch(self, init, desired_batch=None):
+        init = _d(init)
+        B, n = init.shape[0], init.shape[1]
+        des = None if desired_batch is None else _d(desired_batch)
+        out = np.zeros_like(init)
+        cost = np.zeros(B)
+        st, it, nb, nf = (np.zeros(B, dtype=np.int32) for _ in range(4))
+        rc = load().qilqr_solve_batch(self._h, _p(init), _p(des), C.c_int32(B), C.c_int32(n), _p(out), _p(cost),
+                                      _ip(st), _ip(it), _ip(nb), _ip(nf))
+        if rc:
+            _raise(rc)
+        return dict(traj=out, cost=cost, status=st, iters=it, n_bwd=nb, n_fwd=nf)
+
+    # ---- batch of problems, torch CUDA tensors already resident in HBM
+    def solve_batch_device(self, init, out_traj, out_cost, out_status, out_iters, out_n_bwd, out_n_fwd,
+                           desired_batch=None):
+        B, n = init.shape[0], init.shape[1]
+        vp = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+        rc = load().qilqr_solve_batch_device(self._h, vp(init), vp(desired_batch), C.c_int32(B), C.c_int32(n),
+                                             vp(out_traj), vp(out_cost), vp(out_status), vp(out_iters),
+                                             vp(out_n_bwd), vp(out_n_fwd))
+        if rc:
+            _raise(rc)
+
+    # ---- the passes the reference tests individually (ilqr_test.cc:102-190), batched
+    def cost_trajectory(self, traj):
+        traj = _d(traj)
+        B, n = traj.shape[0], traj.shape[1]
+        cost = np.zeros(B)
+        rc = load().qilqr_cost_trajectory(self._h, _p(traj), C.c_int32(B), C.c_int32(n), _p(cost))
+        if rc:
+            _raise(rc)
+        return cost
+
+    def backwards_pass(self, traj):
+        traj = _d(traj)
+        B, n = traj.shape[0], traj.shape[1]
+        gains = np.zeros((B, n, GAIN))
+        terms = np.zeros((B, 2))
+        rc = load().qilqr_backwards_pass(self._h, _p(traj), C.c_int32(B), C.c_int32(n), _p(gains), _p(terms))
+        if rc:
+            _raise(rc)
+        return gains, terms
+
+    def forward_sim(self, traj, gains, alpha=1.0):
+        traj, gains = _d(traj), _d(gains)
+        B, n = traj.shape[0], traj.shape[1]
+        alpha = _d(np.broadcast_to(alpha, (B,)))
+        out = np.zeros_like(traj)
+        rc = load().qilqr_forward_sim(self._h, _p(traj), _p(gains), _p(alpha), C.c_int32(B), C.c_int32(n), _p(out))
+        if rc:
+            _raise(rc)
+        return out
+
+    def line_search(self, traj, cost, gains, terms):
+        traj, gains, cost, terms = _d(traj), _d(gains), _d(cost), _d(terms)
+        B, n = traj.shape[0], traj.shape[1]
+        out = np.zeros_like(traj)
+        oc, step = np.zeros(B), np.zeros(B)
+        st = np.zeros(B, dtype=np.int32)
+        rc = load().qilqr_line_search(self._h, _p(traj), _p(cost), _p(gains), _p(terms), C.c_int32(B), C.c_int32(n),
+                                      _p(out), _p(oc), _p(step), _ip(st))
+        if rc:
+            _raise(rc)
+        return dict(traj=out, cost=oc, step=step, status=st)
+
+    # ---- profiling
+    def profile_reset(self):
+        rc = load().qilqr_profile_reset(self._h)
+        if rc:
+            _raise(rc)
+
+    def profile_get(self):
+        p = Profile()
+        rc = load().qilqr_profile_get(self._h, C.byref(p))
+        if rc:
+            _raise(rc)
+        return {f: getattr(p, f) for f, _ in Profile._fields_}
+
+
+def from_config(cfg, **kw):
+    """Build a solver from a quadrotorilqr_amd.problems config dict."""
+    m = cfg["model"]
+    return QuadrotorILQRBatch(m["mass_kg"], m["inertia"], m["arm_length_m"], m["torque_to_thrust_ratio_m"],
+                              m["g_mpss"], cfg["Q"], cfg["R"], cfg["desired"], cfg["dt"], cfg["options"], **kw)

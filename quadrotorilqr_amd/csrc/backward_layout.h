@@ -1,0 +1,49 @@
+// backward_layout.h -- where each lane of the backward-pass wavefront finds its operands.
+//
+// k_backward gives one 64-lane wavefront to one trajectory and contracts the per-knot
+// matrices on the fp64 matrix core: v_mfma_f64_16x16x4_f64, D(16x16) = A(16x4) B(4x16) + C.
+// Lane l = (j = l & 15, kk = l >> 4) supplies A[j][kk] and B[kk][j]; it receives
+// D[4 r + kk][j] in result register r (r = 0..3).  With the stacked Jacobian
+//        M = [ J_x | J_u ]          (12 x 16: the control Jacobian fills the tile exactly)
+// one knot of the Riccati recursion is
+//        T = V M          3 MFMA  (A = V, B = M, contraction index 4 kc + kk, kc = 0..2)
+//        H = C + M^T T    3 MFMA  (A = M^T, B = T: T's result registers ARE the B operand)
+// and H = [[Q_xx, Q_xu],[Q_ux, Q_uu]].  M^T in A layout is the same three registers as M in
+// B layout, so a lane holds exactly three elements of M: rows kk, 4+kk, 8+kk of column j.
+//
+// m_source() says where such an element lives in the knot record written by k_linearize
+// (se3_math.h, LIN_*), or that it is a constant (zero, identity or the constant J_u).
+#pragma once
+#include "se3_math.h"
+
+namespace qilqr {
+
+// element (row, col) of M = [J_x | J_u], row < 12, col < 16.
+// Returns the offset into the knot record, or -1 with *cst = the constant value.
+QILQR_HD int m_source(int row, int col, const double *Bu, double *cst) {
+  *cst = 0.0;
+  if (col >= 12) {
+    *cst = Bu[row * 4 + (col - 12)];
+    return -1;
+  }
+  const int br = row / 3, rr = row % 3, bc = col / 3, cc = col % 3;
+  int blk = -1;
+  if (br == 0) {
+    blk = bc;  // E^T | Ad top-right | dt Jr | dt Q
+  } else if (br == 1) {
+    if (bc == 1) blk = 0;       // E^T
+    else if (bc == 3) blk = 2;  // dt Jr
+  } else if (br == 2) {
+    if (bc == 1) blk = 4;  // -dt g hat(R^T e_z)
+    else if (bc == 2) {
+      *cst = (rr == cc) ? 1.0 : 0.0;
+      return -1;
+    }
+  } else {
+    if (bc == 3) blk = 5;  // I + dt D
+  }
+  if (blk < 0) return -1;
+  return LIN_BLK + blk * 9 + rr * 3 + cc;
+}
+
+}  // namespace qilqr

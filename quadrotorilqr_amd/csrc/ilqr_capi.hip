@@ -1,0 +1,554 @@
+// ilqr_capi.hip -- host side of libquadrotor_ilqr.so: the C ABI of include/quadrotor_ilqr.h
+// over the HIP kernels of ilqr_kernels.h.  C++ because the reference's host side is C++
+// (src/quadrotor_ilqr_binding.cc, src/ilqr.hh); no exceptions cross the ABI.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/quadrotor_ilqr.h"
+#include "host_model.h"
+#include "ilqr_kernels.h"
+
+using namespace qilqr;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return fail(QILQR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+  } while (0)
+
+enum Kind { K_BACKWARD = 0, K_ROLLOUT = 1, K_LINEARIZE = 2, K_OTHER = 3, K_KINDS = 4 };
+
+struct EventPair {
+  hipEvent_t a, b;
+  int kind;
+};
+
+}  // namespace
+
+struct qilqr_solver {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  ModelConsts<double> consts;
+  SolveParams params;
+  qilqr_options options;
+  qilqr_device_config dev;
+  int n_desired = 0;
+  double *d_desired = nullptr;  // shared desired trajectory
+  // workspace
+  long cap_B = 0, cap_n = 0;
+  int hist_cap = 0;
+  BatchState st{};
+  std::vector<void *> allocs;
+  int *h_counters = nullptr;  // pinned
+  // profiling
+  std::vector<EventPair> events;
+  size_t events_used = 0;
+  double prof_ms[K_KINDS] = {0, 0, 0, 0};
+  int prof_n[K_KINDS] = {0, 0, 0, 0};
+};
+
+namespace {
+
+struct Timed {
+  qilqr_solver *s;
+  EventPair *ep = nullptr;
+  Timed(qilqr_solver *s_, int kind) : s(s_) {
+    if (!s->dev.profile) return;
+    if (s->events_used == s->events.size()) {
+      EventPair e;
+      if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+      s->events.push_back(e);
+    }
+    ep = &s->events[s->events_used++];
+    ep->kind = kind;
+    (void)hipEventRecord(ep->a, s->stream);
+  }
+  ~Timed() {
+    if (ep) (void)hipEventRecord(ep->b, s->stream);
+  }
+};
+
+void drain_events(qilqr_solver *s) {
+  for (size_t i = 0; i < s->events_used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->events[i].a, s->events[i].b) == hipSuccess) {
+      s->prof_ms[s->events[i].kind] += ms;
+      s->prof_n[s->events[i].kind] += 1;
+    }
+  }
+  s->events_used = 0;
+}
+
+void free_workspace(qilqr_solver *s) {
+  for (void *p : s->allocs) (void)hipFree(p);
+  s->allocs.clear();
+  s->cap_B = s->cap_n = 0;
+}
+
+template <typename T>
+int dalloc(qilqr_solver *s, T **p, size_t count) {
+  void *q = nullptr;
+  hipError_t e = hipMalloc(&q, (count ? count : 1) * sizeof(T));
+  if (e != hipSuccess) return fail(QILQR_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+  s->allocs.push_back(q);
+  *p = static_cast<T *>(q);
+  return QILQR_OK;
+}
+
+int ensure_workspace(qilqr_solver *s, long B, long n) {
+  const int want_hist = s->options.populate_debug ? (int)std::fmin(std::fmax(s->params.max_iters, 0.0), 1e6) : 0;
+  if (B <= s->cap_B && n <= s->cap_n && want_hist <= s->hist_cap) return QILQR_OK;
+  free_workspace(s);
+  const long cB = B > s->cap_B ? B : s->cap_B, cn = n > s->cap_n ? n : s->cap_n;
+  BatchState &st = s->st;
+  int rc;
+  for (int k = 0; k < 2; ++k) {
+    if ((rc = dalloc(s, &st.traj[k], (size_t)cB * cn * 18))) return rc;
+    if ((rc = dalloc(s, &st.lin[k], (size_t)cB * cn * LIN_STRIDE))) return rc;
+    if ((rc = dalloc(s, &st.knot_cost[k], (size_t)cB * cn))) return rc;
+  }
+  if ((rc = dalloc(s, &st.gains, (size_t)cB * cn * 52))) return rc;
+  if ((rc = dalloc(s, &st.cur, cB))) return rc;
+  if ((rc = dalloc(s, &st.cost, cB))) return rc;
+  if ((rc = dalloc(s, &st.prev_cost, cB))) return rc;
+  if ((rc = dalloc(s, &st.terms, 2 * cB))) return rc;
+  if ((rc = dalloc(s, &st.alpha, cB))) return rc;
+  if ((rc = dalloc(s, &st.trial, cB))) return rc;
+  if ((rc = dalloc(s, &st.flags, cB))) return rc;
+  if ((rc = dalloc(s, &st.status, cB))) return rc;
+  if ((rc = dalloc(s, &st.iters, cB))) return rc;
+  if ((rc = dalloc(s, &st.n_bwd, cB))) return rc;
+  if ((rc = dalloc(s, &st.n_fwd, cB))) return rc;
+  if ((rc = dalloc(s, &st.counters, 4))) return rc;
+  st.cost_hist = nullptr;
+  st.hist_cap = 0;
+  if (want_hist > 0) {
+    if ((rc = dalloc(s, &st.cost_hist, (size_t)cB * want_hist))) return rc;
+    st.hist_cap = want_hist;
+  }
+  s->hist_cap = want_hist;
+  s->cap_B = cB;
+  s->cap_n = cn;
+  return QILQR_OK;
+}
+
+inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+
+// bind the desired trajectory (shared or per problem) and reset buffer selectors
+int begin_batch(qilqr_solver *s, long B, long n, const double *d_desired_batch) {
+  if (B <= 0 || n <= 0) return fail(QILQR_ERR_INVALID_ARG, "B and n must be positive");
+  if (!d_desired_batch && n > s->n_desired)
+    return fail(QILQR_ERR_LENGTH_MISMATCH, "trajectory longer than desired trajectory");
+  HIP_TRY(hipSetDevice(s->device));
+  int rc = ensure_workspace(s, B, n);
+  if (rc) return rc;
+  s->st.desired = d_desired_batch ? d_desired_batch : s->d_desired;
+  s->st.desired_stride = d_desired_batch ? n * 18 : 0;
+  HIP_TRY(hipMemsetAsync(s->st.cur, 0, sizeof(int) * B, s->stream));
+  HIP_TRY(hipMemsetAsync(s->st.flags, 0, sizeof(int) * B, s->stream));
+  return QILQR_OK;
+}
+
+int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag) {
+  Timed t(s, K_LINEARIZE);
+  hipLaunchKernelGGL(k_linearize, dim3(cdiv(B * n, 128)), dim3(128), 0, s->stream, s->consts, s->st, (int)B,
+                     (int)n, which, need_flag);
+  return QILQR_OK;
+}
+int launch_backward(qilqr_solver *s, long B, long n, int force) {
+  Timed t(s, K_BACKWARD);
+  hipLaunchKernelGGL(k_backward, dim3((unsigned)B), dim3(64), 0, s->stream, s->consts, s->params, s->st,
+                     (int)B, (int)n, force);
+  return QILQR_OK;
+}
+int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
+  Timed t(s, K_ROLLOUT);
+  hipLaunchKernelGGL(k_rollout, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->consts, s->st, (int)B, (int)n,
+                     need_flag);
+  return QILQR_OK;
+}
+int launch_accept(qilqr_solver *s, long B, long n, int ls_only) {
+  Timed t(s, K_OTHER);
+  hipLaunchKernelGGL(k_accept, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->params, s->st, (int)B, (int)n,
+                     ls_only);
+  return QILQR_OK;
+}
+
+int read_active(qilqr_solver *s, int *n_active) {
+  HIP_TRY(hipMemcpyAsync(s->h_counters, s->st.counters, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  *n_active = s->h_counters[0];
+  return QILQR_OK;
+}
+
+// The outer loop of ILQR::solve (ilqr.hh:53-87) for trajectories already in st.traj[0].
+// on_round (optional) is called after every synchronised round (debug capture).
+template <typename F>
+int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round) {
+  int rc;
+  if ((rc = launch_linearize(s, B, n, 0, 0))) return rc;
+  {
+    Timed t(s, K_OTHER);
+    hipLaunchKernelGGL(k_init, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->params, s->st, (int)B, (int)n);
+  }
+  if (!(0.0 < s->params.max_iters)) {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return QILQR_OK;
+  }
+  // a trajectory needs at most max_iters backward passes and max_iters * ls_max_iters trials
+  const double bound = (std::fmin(s->params.max_iters, 1e7) + 1.0) * ((double)std::max(s->params.ls_max_iters, 1) + 1.0);
+  const long max_rounds = (long)std::fmin(bound, 2e9);
+  if (sync_every < 1) sync_every = 1;
+  for (long round = 0; round < max_rounds; ++round) {
+    if ((rc = launch_backward(s, B, n, 0))) return rc;
+    if ((rc = launch_rollout(s, B, n, F_SEARCH))) return rc;
+    if ((rc = launch_linearize(s, B, n, 1, F_SEARCH))) return rc;
+    if ((rc = launch_accept(s, B, n, 0))) return rc;
+    if ((round + 1) % sync_every == 0) {
+      int n_active = 0;
+      if ((rc = read_active(s, &n_active))) return rc;
+      if ((rc = on_round())) return rc;
+      if (n_active == 0) break;
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipGetLastError());
+  return QILQR_OK;
+}
+
+int gather(qilqr_solver *s, long B, long n, double *d_traj, double *d_cost, int *d_status, int *d_iters,
+           int *d_bwd, int *d_fwd) {
+  Timed t(s, K_OTHER);
+  hipLaunchKernelGGL(k_gather, dim3(cdiv(B * n * 18, 256)), dim3(256), 0, s->stream, s->st, (int)B, (int)n,
+                     d_traj, d_cost, d_status, d_iters, d_bwd, d_fwd);
+  return QILQR_OK;
+}
+
+int check_quaternions(const double *traj, long count, const char *what) {
+  // manif's SO3 constructor rejects quaternions that are not unit within 1e-10
+  for (long i = 0; i < count; ++i) {
+    const double *q = traj + i * 18 + 4;
+    const double nn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (!(std::fabs(nn - 1.0) <= 1e-10))
+      return fail(QILQR_ERR_BAD_QUATERNION, std::string(what) + ": quaternion not normalized at knot " + std::to_string(i));
+  }
+  return QILQR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qilqr_abi_version(void) { return 1; }
+
+const char *qilqr_last_error(void) { return g_last_error.c_str(); }
+
+int qilqr_create(const qilqr_model *model, const double *Q, const double *R, const double *desired,
+                 int32_t n_desired, double dt_s, const qilqr_options *options,
+                 const qilqr_device_config *dev, qilqr_solver **out) {
+  if (!model || !Q || !R || !options || !out || n_desired < 0 || (n_desired > 0 && !desired))
+    return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  // QuadrotorModel ctor, quadrotor_model.cc:6-25
+  ModelConsts<double> mc;
+  if (!make_model_consts(model->mass_kg, model->inertia, model->arm_length_m, model->torque_to_thrust_ratio_m,
+                         model->g_mpss, Q, R, dt_s, &mc))
+    return fail(QILQR_ERR_BAD_INERTIA, "Inertia matrix is not positive definite!");
+  if (n_desired > 0) {
+    int rc = check_quaternions(desired, n_desired, "desired trajectory");
+    if (rc) return rc;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(QILQR_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+  qilqr_device_config dc = {0, 0, 1};
+  if (dev) dc = *dev;
+  if (dc.device < 0 || dc.device >= ndev) return fail(QILQR_ERR_INVALID_ARG, "bad device ordinal");
+  if (dc.sync_every < 1) dc.sync_every = 1;
+
+  qilqr_solver *s = new qilqr_solver();
+  s->device = dc.device;
+  s->dev = dc;
+  s->options = *options;
+  s->params = SolveParams{options->step_update, options->desired_reduction_frac, options->rtol, options->atol,
+                          options->max_iters, options->ls_max_iters};
+  s->consts = mc;
+  s->n_desired = n_desired;
+
+  hipError_t e = hipSetDevice(s->device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc((void **)&s->d_desired, sizeof(double) * 18 * (n_desired > 0 ? n_desired : 1));
+  if (e == hipSuccess && n_desired > 0)
+    e = hipMemcpy(s->d_desired, desired, sizeof(double) * 18 * n_desired, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_counters, sizeof(int) * 4, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    const int rc = fail(QILQR_ERR_HIP, std::string("qilqr_create: ") + hipGetErrorString(e));
+    qilqr_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return QILQR_OK;
+}
+
+void qilqr_destroy(qilqr_solver *s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  free_workspace(s);
+  for (auto &e : s->events) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  if (s->d_desired) (void)hipFree(s->d_desired);
+  if (s->h_counters) (void)hipHostFree(s->h_counters);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+int qilqr_device(const qilqr_solver *s) { return s ? s->device : -1; }
+void *qilqr_stream(const qilqr_solver *s) { return s ? (void *)s->stream : nullptr; }
+
+int qilqr_profile_reset(qilqr_solver *s) {
+  if (!s) return fail(QILQR_ERR_INVALID_ARG, "null solver");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->events_used = 0;
+  for (int k = 0; k < K_KINDS; ++k) {
+    s->prof_ms[k] = 0;
+    s->prof_n[k] = 0;
+  }
+  return QILQR_OK;
+}
+
+int qilqr_profile_get(qilqr_solver *s, qilqr_profile *out) {
+  if (!s || !out) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  drain_events(s);
+  out->backward_ms = s->prof_ms[K_BACKWARD];
+  out->backward_launches = s->prof_n[K_BACKWARD];
+  out->rollout_ms = s->prof_ms[K_ROLLOUT];
+  out->rollout_launches = s->prof_n[K_ROLLOUT];
+  out->linearize_ms = s->prof_ms[K_LINEARIZE];
+  out->linearize_launches = s->prof_n[K_LINEARIZE];
+  out->other_ms = s->prof_ms[K_OTHER];
+  out->other_launches = s->prof_n[K_OTHER];
+  return QILQR_OK;
+}
+
+int qilqr_solve_batch_device(qilqr_solver *s, const double *d_init, const double *d_desired_batch, int32_t B,
+                             int32_t n, double *d_out_traj, double *d_out_cost, int32_t *d_out_status,
+                             int32_t *d_out_iters, int32_t *d_out_n_bwd, int32_t *d_out_n_fwd) {
+  if (!s || !d_init) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  int rc = begin_batch(s, B, n, d_desired_batch);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(s->st.traj[0], d_init, sizeof(double) * 18 * (size_t)B * n, hipMemcpyDeviceToDevice,
+                         s->stream));
+  if ((rc = run_solve(s, B, n, s->dev.sync_every, [] { return QILQR_OK; }))) return rc;
+  if ((rc = gather(s, B, n, d_out_traj, d_out_cost, d_out_status, d_out_iters, d_out_n_bwd, d_out_n_fwd)))
+    return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipGetLastError());
+  if (s->dev.profile) drain_events(s);
+  return QILQR_OK;
+}
+
+// host-buffer wrapper: stage through device scratch owned by the call
+int qilqr_solve_batch(qilqr_solver *s, const double *init, const double *desired_batch, int32_t B, int32_t n,
+                      double *out_traj, double *out_cost, int32_t *out_status, int32_t *out_iters,
+                      int32_t *out_n_bwd, int32_t *out_n_fwd) {
+  if (!s || !init) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  if (B <= 0 || n <= 0) return fail(QILQR_ERR_INVALID_ARG, "B and n must be positive");
+  if (!desired_batch && n > s->n_desired)
+    return fail(QILQR_ERR_LENGTH_MISMATCH, "trajectory longer than desired trajectory");
+  int rc;
+  if ((rc = check_quaternions(init, (long)B * n, "initial trajectory"))) return rc;
+  if (desired_batch && (rc = check_quaternions(desired_batch, (long)B * n, "desired trajectory"))) return rc;
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t tb = sizeof(double) * 18 * (size_t)B * n;
+  double *d_io = nullptr, *d_des = nullptr, *d_cost = nullptr;
+  int *d_int = nullptr;
+  auto cleanup = [&] {
+    if (d_io) (void)hipFree(d_io);
+    if (d_des) (void)hipFree(d_des);
+    if (d_cost) (void)hipFree(d_cost);
+    if (d_int) (void)hipFree(d_int);
+  };
+  hipError_t e = hipMalloc((void **)&d_io, tb);
+  if (e == hipSuccess && desired_batch) e = hipMalloc((void **)&d_des, tb);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_cost, sizeof(double) * B);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_int, sizeof(int) * 4 * B);
+  if (e == hipSuccess) e = hipMemcpy(d_io, init, tb, hipMemcpyHostToDevice);
+  if (e == hipSuccess && desired_batch) e = hipMemcpy(d_des, desired_batch, tb, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    cleanup();
+    return fail(QILQR_ERR_HIP, std::string("staging: ") + hipGetErrorString(e));
+  }
+  rc = qilqr_solve_batch_device(s, d_io, d_des, B, n, d_io, d_cost, d_int, d_int + B, d_int + 2 * B, d_int + 3 * B);
+  if (rc == QILQR_OK) {
+    if (out_traj) e = hipMemcpy(out_traj, d_io, tb, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_cost) e = hipMemcpy(out_cost, d_cost, sizeof(double) * B, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_status) e = hipMemcpy(out_status, d_int, sizeof(int) * B, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_iters) e = hipMemcpy(out_iters, d_int + B, sizeof(int) * B, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_n_bwd) e = hipMemcpy(out_n_bwd, d_int + 2 * B, sizeof(int) * B, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_n_fwd) e = hipMemcpy(out_n_fwd, d_int + 3 * B, sizeof(int) * B, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(QILQR_ERR_HIP, std::string("copy back: ") + hipGetErrorString(e));
+  }
+  cleanup();
+  return rc;
+}
+
+int qilqr_solve(qilqr_solver *s, const double *init, int32_t n, double *out_traj, double *out_cost,
+                int32_t *out_status, int32_t *out_iters, double *debug_cost, double *debug_trajs,
+                int32_t debug_cap, int32_t *n_debug) {
+  if (!s || !init || !out_traj) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  if (n <= 0) return fail(QILQR_ERR_INVALID_ARG, "empty trajectory");
+  int rc;
+  if ((rc = check_quaternions(init, n, "initial trajectory"))) return rc;
+  if ((rc = begin_batch(s, 1, n, nullptr))) return rc;
+  const size_t tb = sizeof(double) * 18 * (size_t)n;
+  HIP_TRY(hipMemcpyAsync(s->st.traj[0], init, tb, hipMemcpyHostToDevice, s->stream));
+  int seen = 0;
+  const bool want_debug = s->options.populate_debug && debug_cap > 0 && (debug_cost || debug_trajs);
+  auto capture = [&]() -> int {
+    // ilqr.hh:78-80: one entry per completed forward pass (accepted iteration)
+    if (!want_debug) return QILQR_OK;
+    int it = 0, cur = 0;
+    HIP_TRY(hipMemcpy(&it, s->st.iters, sizeof(int), hipMemcpyDeviceToHost));
+    if (it > seen) {
+      HIP_TRY(hipMemcpy(&cur, s->st.cur, sizeof(int), hipMemcpyDeviceToHost));
+      if (seen < debug_cap) {
+        if (debug_cost) HIP_TRY(hipMemcpy(debug_cost + seen, s->st.cost, sizeof(double), hipMemcpyDeviceToHost));
+        if (debug_trajs) HIP_TRY(hipMemcpy(debug_trajs + (size_t)seen * 18 * n, s->st.traj[cur], tb, hipMemcpyDeviceToHost));
+      }
+      seen = it;
+    }
+    return QILQR_OK;
+  };
+  if ((rc = run_solve(s, 1, n, want_debug ? 1 : s->dev.sync_every, capture))) return rc;
+  int status = 0, iters = 0, cur = 0;
+  double cost = 0;
+  HIP_TRY(hipMemcpy(&status, s->st.status, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&iters, s->st.iters, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&cur, s->st.cur, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&cost, s->st.cost, sizeof(double), hipMemcpyDeviceToHost));
+  if (s->dev.profile) drain_events(s);
+  if (n_debug) *n_debug = want_debug ? (seen < debug_cap ? seen : debug_cap) : 0;
+  if (status == QILQR_STATUS_LINE_SEARCH_FAILED)
+    return fail(QILQR_ERR_LINE_SEARCH, "Reached maximum number of line search iterations, " +
+                                           std::to_string(s->options.ls_max_iters) + "\n");
+  HIP_TRY(hipMemcpy(out_traj, s->st.traj[cur], tb, hipMemcpyDeviceToHost));
+  if (out_cost) *out_cost = cost;
+  if (out_status) *out_status = status;
+  if (out_iters) *out_iters = iters;
+  return QILQR_OK;
+}
+
+int qilqr_cost_trajectory(qilqr_solver *s, const double *traj, int32_t B, int32_t n, double *cost) {
+  if (!s || !traj || !cost) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  int rc = begin_batch(s, B, n, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(s->st.traj[0], traj, sizeof(double) * 18 * (size_t)B * n, hipMemcpyHostToDevice, s->stream));
+  if ((rc = launch_linearize(s, B, n, 0, 0))) return rc;
+  hipLaunchKernelGGL(k_init, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->params, s->st, (int)B, (int)n);
+  HIP_TRY(hipMemcpyAsync(cost, s->st.cost, sizeof(double) * B, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipGetLastError());
+  return QILQR_OK;
+}
+
+int qilqr_backwards_pass(qilqr_solver *s, const double *traj, int32_t B, int32_t n, double *gains, double *terms) {
+  if (!s || !traj || !gains || !terms) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  int rc = begin_batch(s, B, n, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(s->st.traj[0], traj, sizeof(double) * 18 * (size_t)B * n, hipMemcpyHostToDevice, s->stream));
+  if ((rc = launch_linearize(s, B, n, 0, 0))) return rc;
+  hipLaunchKernelGGL(k_init, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->params, s->st, (int)B, (int)n);
+  if ((rc = launch_backward(s, B, n, 1))) return rc;
+  HIP_TRY(hipMemcpyAsync(gains, s->st.gains, sizeof(double) * 52 * (size_t)B * n, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(terms, s->st.terms, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipGetLastError());
+  return QILQR_OK;
+}
+
+int qilqr_forward_sim(qilqr_solver *s, const double *traj, const double *gains, const double *alpha, int32_t B,
+                      int32_t n, double *out_traj) {
+  if (!s || !traj || !gains || !alpha || !out_traj) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  int rc = begin_batch(s, B, n, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(s->st.traj[0], traj, sizeof(double) * 18 * (size_t)B * n, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->st.gains, gains, sizeof(double) * 52 * (size_t)B * n, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->st.alpha, alpha, sizeof(double) * B, hipMemcpyHostToDevice, s->stream));
+  if ((rc = launch_rollout(s, B, n, 0))) return rc;
+  HIP_TRY(hipMemcpyAsync(out_traj, s->st.traj[1], sizeof(double) * 18 * (size_t)B * n, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipGetLastError());
+  return QILQR_OK;
+}
+
+int qilqr_line_search(qilqr_solver *s, const double *traj, const double *cost, const double *gains,
+                      const double *terms, int32_t B, int32_t n, double *out_traj, double *out_cost,
+                      double *out_step, int32_t *out_status) {
+  if (!s || !traj || !cost || !gains || !terms) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  int rc = begin_batch(s, B, n, nullptr);
+  if (rc) return rc;
+  double *d_cost = nullptr, *d_terms = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_cost, sizeof(double) * B));
+  HIP_TRY(hipMalloc((void **)&d_terms, sizeof(double) * 2 * B));
+  HIP_TRY(hipMemcpyAsync(s->st.traj[0], traj, sizeof(double) * 18 * (size_t)B * n, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->st.gains, gains, sizeof(double) * 52 * (size_t)B * n, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(d_cost, cost, sizeof(double) * B, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(d_terms, terms, sizeof(double) * 2 * B, hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_seed_search, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->st, (int)B, d_cost, d_terms);
+  if (s->params.ls_max_iters <= 0) {
+    // ilqr.hh:178: the loop body never runs, the reference throws at once
+    std::vector<int> st3(B, QILQR_STATUS_LINE_SEARCH_FAILED);
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (out_status) std::memcpy(out_status, st3.data(), sizeof(int) * B);
+    (void)hipFree(d_cost);
+    (void)hipFree(d_terms);
+    return QILQR_OK;
+  }
+  for (int t = 0; t < s->params.ls_max_iters; ++t) {
+    HIP_TRY(hipMemsetAsync(s->st.counters, 0, sizeof(int), s->stream));
+    if ((rc = launch_rollout(s, B, n, F_SEARCH))) return rc;
+    if ((rc = launch_linearize(s, B, n, 1, F_SEARCH))) return rc;
+    if ((rc = launch_accept(s, B, n, 1))) return rc;
+    int n_active = 0;
+    if ((rc = read_active(s, &n_active))) return rc;
+    if (n_active == 0) break;
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  // results: accepted candidates are traj[cur] (cur flipped); failures keep the input
+  std::vector<int> cur(B), status(B);
+  HIP_TRY(hipMemcpy(cur.data(), s->st.cur, sizeof(int) * B, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(status.data(), s->st.status, sizeof(int) * B, hipMemcpyDeviceToHost));
+  if (out_status) std::memcpy(out_status, status.data(), sizeof(int) * B);
+  if (out_cost) HIP_TRY(hipMemcpy(out_cost, s->st.cost, sizeof(double) * B, hipMemcpyDeviceToHost));
+  if (out_step) HIP_TRY(hipMemcpy(out_step, s->st.alpha, sizeof(double) * B, hipMemcpyDeviceToHost));
+  if (out_traj)
+    for (long b = 0; b < B; ++b)
+      HIP_TRY(hipMemcpy(out_traj + b * n * 18, s->st.traj[cur[b]] + b * n * 18, sizeof(double) * 18 * n,
+                        hipMemcpyDeviceToHost));
+  (void)hipFree(d_cost);
+  (void)hipFree(d_terms);
+  HIP_TRY(hipGetLastError());
+  return QILQR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,384 @@
+// ilqr_kernels.h -- device kernels of the batched iLQR solver (gfx950 only).
+//
+// One outer "round" of the solver is four launches on one stream:
+//   k_backward   one wavefront per trajectory, fp64 MFMA Riccati recursion   (ilqr.hh:97-147)
+//   k_rollout    one lane per trajectory, closed-loop forward simulation     (ilqr.hh:149-172)
+//   k_linearize  one lane per knot: dynamics Jacobian blocks + cost differentials + knot cost
+//                of the candidate trajectory (quadrotor_model.cc:33-49, cost.hh:36-61)
+//   k_accept     one lane per trajectory: cost sum, Armijo test, convergence tests
+//                (ilqr.hh:61-84, 174-194)
+// Every trajectory carries its own outer-iteration counter, step size and state machine, so
+// trajectories that are back-tracking and trajectories that already accepted a step advance
+// in the same round; the host only polls one counter of still-active trajectories.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "backward_layout.h"
+#include "se3_math.h"
+
+namespace qilqr {
+
+constexpr int F_ACTIVE = 1;  // still iterating
+constexpr int F_SEARCH = 2;  // has gains, needs a (further) rollout trial
+
+struct SolveParams {
+  double step_update, reduction_frac, rtol, atol, max_iters;
+  int ls_max_iters;
+};
+
+// all device pointers; [B] unless noted
+struct BatchState {
+  double *traj[2];       // [B][n][18]  current / candidate trajectories
+  double *lin[2];        // [B][n][LIN_STRIDE] knot records of traj[k]
+  double *knot_cost[2];  // [B][n]
+  double *gains;         // [B][n][52]
+  const double *desired; // [n_desired][18] shared, or [B][n][18]
+  long desired_stride;   // 0 (shared) or n*18
+  int *cur;              // which of traj[] / lin[] is current
+  double *cost;          // cost of the current trajectory ("new_cost", ilqr.hh:56)
+  double *prev_cost;     // "cost" inside the iteration (ilqr.hh:61)
+  double *terms;         // [B][2] QuTk, kTQuuk
+  double *alpha;
+  int *trial;
+  int *flags;
+  int *status, *iters, *n_bwd, *n_fwd;
+  int *counters;         // [0] trajectories still active after k_accept
+  double *cost_hist;     // [B][hist_cap] or null
+  int hist_cap;
+};
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bool is_converged(const SolveParams &p, double cost, double new_cost) {
+  // ilqr.hh:196-205 (cost == 0 gives NaN < rtol == false and falls through to atol)
+  if (fabs(cost - new_cost) / fabs(cost) < p.rtol) return true;
+  if (fabs(cost - new_cost) < p.atol) return true;
+  return false;
+}
+__device__ __forceinline__ double cost_reduction(double QuTk, double kTQuuk, double step) {
+  return step * QuTk + step * step * kTQuuk / 2.0;  // ilqr.hh:18-22
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_linearize: thread (b, i).  which = 0: trajectory traj[cur[b]], 1: candidate traj[cur[b]^1].
+// need_flag: only problems whose flags contain it (0 = all).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_linearize(ModelConsts<double> c, BatchState st, int B, int n,
+                                                   int which, int need_flag) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)B * n) return;
+  const int b = (int)(id / n), i = (int)(id % n);
+  if (need_flag && !(st.flags[b] & need_flag)) return;
+  const int buf = st.cur[b] ^ which;
+  const double *pt = st.traj[buf] + ((long)b * n + i) * 18;
+  const double *pd = st.desired + (long)b * st.desired_stride + (long)i * 18;
+  double *rec = st.lin[buf] + ((long)b * n + i) * LIN_STRIDE;
+  linearize_knot(c, pt, pd, rec);
+  st.knot_cost[buf][(long)b * n + i] = rec[LIN_COST];
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_init: thread b.  cost = sum of knot costs (left to right, ilqr.hh:89-95); arm the state machine.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_init(SolveParams p, BatchState st, int B, int n) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double *kc = st.knot_cost[st.cur[b]] + (long)b * n;
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += kc[i];
+  st.cost[b] = s;
+  st.prev_cost[b] = s;
+  st.iters[b] = 0;
+  st.n_bwd[b] = 0;
+  st.n_fwd[b] = 0;
+  st.trial[b] = 0;
+  st.alpha[b] = 1.0;
+  st.terms[2 * b] = 0.0;
+  st.terms[2 * b + 1] = 0.0;
+  st.status[b] = 2;  // QILQR_STATUS_MAX_ITERS unless an exit path fires
+  st.flags[b] = (0.0 < p.max_iters) ? F_ACTIVE : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_backward: one wavefront per trajectory (block = 64 threads).  See backward_layout.h.
+// force = 1: run on every trajectory, no convergence test (the stand-alone backwards_pass API).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sel4(const double v[4], int kk) {
+  return kk == 0 ? v[0] : (kk == 1 ? v[1] : (kk == 2 ? v[2] : v[3]));
+}
+
+__global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolveParams p, BatchState st,
+                                                 int B, int n, int force) {
+  const int b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0) st.counters[0] = 0;  // k_accept of this round re-counts
+  if (b >= B) return;
+  const int fl = st.flags[b];
+  if (!force && (fl & (F_ACTIVE | F_SEARCH)) != F_ACTIVE) return;  // wave-uniform
+  const int lane = threadIdx.x;
+  const int j = lane & 15, kk = lane >> 4;
+  const double *lin = st.lin[st.cur[b]] + (long)b * n * LIN_STRIDE;
+  double *gains = st.gains + (long)b * n * 52;
+
+  constexpr int LD = 17;  // padded leading dimension: column reads of a row-major tile
+  __shared__ double Vs[12 * LD];
+  __shared__ double Hs[16 * LD];
+  __shared__ double gs[16];
+  __shared__ double vxs[12];
+
+  // where this lane's three elements of M = [J_x | J_u] live in a knot record
+  int moff[3];
+  double mconst[3];
+#pragma unroll
+  for (int kc = 0; kc < 3; ++kc) moff[kc] = m_source(4 * kc + kk, j, c.Bu, &mconst[kc]);
+  // C_xx in accumulator layout: register r <-> row 4 r + kk, column j
+  int coff[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) coff[r] = (j < 12) ? LIN_CXX + (4 * r + kk) * 12 + j : -1;
+  // register 3 <-> row 12 + kk: C_uu = 2 R (cost.hh:55) in columns 12..15
+  const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] : 0.0;
+
+  double va[3] = {0.0, 0.0, 0.0};   // V_xx[j][4 kc + kk]  (A operand)
+  double vxl[3] = {0.0, 0.0, 0.0};  // V_x[4 kc + kk]
+  double QuTk = 0.0, kTQuuk = 0.0;
+
+  for (int i = n - 1; i >= 0; --i) {
+    const double *rec = lin + (long)i * LIN_STRIDE;
+    double m[3], cx[3];
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) m[kc] = (moff[kc] >= 0) ? rec[moff[kc]] : mconst[kc];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cx[r] = (coff[r] >= 0) ? rec[coff[r]] : 0.0;
+    const double gcj = rec[LIN_G + j];
+
+    // T = V M
+    d4 T = {0.0, 0.0, 0.0, 0.0};
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0], m[0], T, 0, 0, 0);
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1], m[1], T, 0, 0, 0);
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2], m[2], T, 0, 0, 0);
+    // H = blkdiag(C_xx, C_uu) + M^T T   (ilqr.hh:118-124 in one tile)
+    d4 H = {cx[0], cx[1], cx[2], cuu};
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
+    // [Q_x ; Q_u] = [C_x ; C_u] + M^T V_x
+    double part = m[0] * vxl[0] + m[1] * vxl[1] + m[2] * vxl[2];
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    const double ghat = gcj + part;
+
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Hs[(4 * r + kk) * LD + j] = H[r];
+    if (kk == 0) gs[j] = ghat;
+    __syncthreads();
+
+    // every lane: Q_uu (4x4), Q_u; lane column j < 12: its row of Q_xu
+    double Quu[16], Qu[4], rhs[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) Quu[a * 4 + bb] = Hs[(12 + a) * LD + 12 + bb];
+      Qu[a] = gs[12 + a];
+      rhs[a] = (j < 12) ? Hs[j * LD + 12 + a] : 0.0;
+    }
+    // LDL^T of the lower triangle of Q_uu (the reference: Eigen LDLT, ilqr.hh:126; no pivoting here)
+    const double i0 = 1.0 / Quu[0];
+    const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
+    const double d1 = Quu[5] - l10 * Quu[4];
+    const double i1 = 1.0 / d1;
+    const double c21 = Quu[9] - l20 * Quu[4], c31 = Quu[13] - l30 * Quu[4];
+    const double l21 = c21 * i1, l31 = c31 * i1;
+    const double d2 = Quu[10] - l20 * Quu[8] - l21 * c21;
+    const double i2 = 1.0 / d2;
+    const double c32 = Quu[14] - l30 * Quu[8] - l31 * c21;
+    const double l32 = c32 * i2;
+    const double d3 = Quu[15] - l30 * Quu[12] - l31 * c31 - l32 * c32;
+    const double i3 = 1.0 / d3;
+    double kcol[4], kff[4];
+    {
+      // K[:, j] = -Quu^-1 Q_xu[j, :]^T ; k = -Quu^-1 Q_u   (ilqr.hh:127-128)
+      double y0 = rhs[0], y1 = rhs[1] - l10 * y0, y2 = rhs[2] - l20 * y0 - l21 * y1,
+             y3 = rhs[3] - l30 * y0 - l31 * y1 - l32 * y2;
+      double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
+             x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
+      kcol[0] = -x0; kcol[1] = -x1; kcol[2] = -x2; kcol[3] = -x3;
+      y0 = Qu[0]; y1 = Qu[1] - l10 * y0; y2 = Qu[2] - l20 * y0 - l21 * y1;
+      y3 = Qu[3] - l30 * y0 - l31 * y1 - l32 * y2;
+      x3 = y3 * i3; x2 = y2 * i2 - l32 * x3; x1 = y1 * i1 - l21 * x2 - l31 * x3;
+      x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
+      kff[0] = -x0; kff[1] = -x1; kff[2] = -x2; kff[3] = -x3;
+    }
+    // (K^T Quu)[j][:], then V_x = Q_x - (K^T Quu) k   (ilqr.hh:132)
+    double mc[4];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+      mc[bb] = kcol[0] * Quu[bb] + kcol[1] * Quu[4 + bb] + kcol[2] * Quu[8 + bb] + kcol[3] * Quu[12 + bb];
+    const double vx = ghat - (mc[0] * kff[0] + mc[1] * kff[1] + mc[2] * kff[2] + mc[3] * kff[3]);
+    // expected cost reduction terms (ilqr.hh:136-140), identical in every lane
+    QuTk += Qu[0] * kff[0] + Qu[1] * kff[1] + Qu[2] * kff[2] + Qu[3] * kff[3];
+    {
+      double s = 0.0;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb)
+        s += (kff[0] * Quu[bb] + kff[1] * Quu[4 + bb] + kff[2] * Quu[8 + bb] + kff[3] * Quu[12 + bb]) * kff[bb];
+      kTQuuk += s;
+    }
+    // V_xx = Q_xx - (K^T Quu) K   (ilqr.hh:133): one more MFMA on the same accumulator,
+    // A[j][kk] = -(K^T Quu)[j][kk], B[kk][j] = K[kk][j]
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(-sel4(mc, kk), sel4(kcol, kk), H, 0, 0, 0);
+
+    // gains of knot i: [k(4) | K column-major]; lane j < 12 owns column j, lane 12 owns k
+    if (kk == 0) {
+      double *g = gains + (long)i * 52;
+      if (j < 12) {
+        double2 *dst = reinterpret_cast<double2 *>(g + 4 + 4 * j);
+        dst[0] = make_double2(kcol[0], kcol[1]);
+        dst[1] = make_double2(kcol[2], kcol[3]);
+      } else if (j == 12) {
+        double2 *dst = reinterpret_cast<double2 *>(g);
+        dst[0] = make_double2(kff[0], kff[1]);
+        dst[1] = make_double2(kff[2], kff[3]);
+      }
+    }
+    // hand V_xx, V_x to the next knot: accumulator layout -> A-operand layout through LDS
+    if (j < 12) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) Vs[(4 * r + kk) * LD + j] = H[r];
+      if (kk == 0) vxs[j] = vx;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) {
+      va[kc] = (j < 12) ? Vs[j * LD + 4 * kc + kk] : 0.0;
+      vxl[kc] = vxs[4 * kc + kk];
+    }
+  }
+
+  if (lane == 0) {
+    st.terms[2 * b] = QuTk;
+    st.terms[2 * b + 1] = kTQuuk;
+    st.n_bwd[b] += 1;
+    if (!force) {
+      const double cost = st.cost[b];
+      st.prev_cost[b] = cost;  // ilqr.hh:61
+      const int it = st.iters[b];
+      if (it > 0 && is_converged(p, cost, cost + cost_reduction(QuTk, kTQuuk, 1.0))) {
+        st.status[b] = 0;  // ilqr.hh:66-68
+        st.flags[b] = 0;
+      } else if (it > 0 && p.ls_max_iters <= 0) {
+        st.status[b] = 3;  // line_search with no trial allowed throws at once
+        st.flags[b] = 0;
+      } else {
+        st.alpha[b] = 1.0;
+        st.trial[b] = 0;
+        st.flags[b] = F_ACTIVE | F_SEARCH;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rollout: thread b.  traj[cur] + gains + alpha -> traj[cur ^ 1]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_rollout(ModelConsts<double> c, BatchState st, int B, int n,
+                                                int need_flag) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (need_flag && !(st.flags[b] & need_flag)) return;
+  const int cur = st.cur[b];
+  rollout_problem(c, st.traj[cur] + (long)b * n * 18, st.gains + (long)b * n * 52, st.alpha[b],
+                  st.traj[cur ^ 1] + (long)b * n * 18, n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_accept: thread b.  Cost of the candidate, acceptance, convergence (ilqr.hh:70-84, 174-194)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_accept(SolveParams p, BatchState st, int B, int n, int ls_only) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int fl = st.flags[b];
+  if (fl & F_SEARCH) {
+    const int cur = st.cur[b];
+    const double *kc = st.knot_cost[cur ^ 1] + (long)b * n;
+    double new_cost = 0.0;
+    for (int i = 0; i < n; ++i) new_cost += kc[i];
+    st.n_fwd[b] += 1;
+    const int it = st.iters[b];
+    const double cost = st.prev_cost[b];
+    const double alpha = st.alpha[b];
+    bool accept;
+    if (it == 0) {
+      accept = true;  // ilqr.hh:71-73: the first rollout is taken unconditionally
+    } else {
+      const double desired = p.reduction_frac * cost_reduction(st.terms[2 * b], st.terms[2 * b + 1], alpha);
+      accept = (new_cost - cost < desired);  // ilqr.hh:186
+    }
+    if (accept && ls_only) {
+      // stand-alone ILQR::line_search: report the accepted candidate, no outer-loop bookkeeping
+      st.cur[b] = cur ^ 1;
+      st.cost[b] = new_cost;
+      st.status[b] = 0;
+      fl = 0;
+    } else if (accept) {
+      st.cur[b] = cur ^ 1;
+      st.cost[b] = new_cost;
+      if (st.cost_hist && it < st.hist_cap) st.cost_hist[(long)b * st.hist_cap + it] = new_cost;
+      st.iters[b] = it + 1;
+      fl = F_ACTIVE;
+      if (it > 0 && is_converged(p, cost, new_cost)) {
+        st.status[b] = 1;  // ilqr.hh:82-84
+        fl = 0;
+      } else if (!((double)(it + 1) < p.max_iters)) {
+        st.status[b] = 2;  // ilqr.hh:86
+        fl = 0;
+      }
+    } else {
+      const int trial = st.trial[b] + 1;
+      st.trial[b] = trial;
+      st.alpha[b] = alpha * p.step_update;  // ilqr.hh:189
+      if (trial >= p.ls_max_iters) {
+        st.status[b] = 3;  // ilqr.hh:191-193
+        fl = 0;
+      }
+    }
+    st.flags[b] = fl;
+  }
+  if (fl & F_ACTIVE) atomicAdd(&st.counters[0], 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gather: results into caller buffers (any may be null)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_gather(BatchState st, int B, int n, double *out_traj, double *out_cost, int *out_status,
+                         int *out_iters, int *out_n_bwd, int *out_n_fwd) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per = (long)n * 18;
+  if (id >= (long)B * per) return;
+  const int b = (int)(id / per);
+  if (out_traj) out_traj[id] = st.traj[st.cur[b]][id];
+  if (id % per == 0) {
+    if (out_cost) out_cost[b] = st.cost[b];
+    if (out_status) out_status[b] = st.status[b];
+    if (out_iters) out_iters[b] = st.iters[b];
+    if (out_n_bwd) out_n_bwd[b] = st.n_bwd[b];
+    if (out_n_fwd) out_n_fwd[b] = st.n_fwd[b];
+  }
+}
+
+// stand-alone line search support: seed per-problem scalars from caller data
+__global__ void k_seed_search(BatchState st, int B, const double *cost, const double *terms) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  st.prev_cost[b] = cost[b];
+  st.cost[b] = cost[b];
+  st.terms[2 * b] = terms[2 * b];
+  st.terms[2 * b + 1] = terms[2 * b + 1];
+  st.alpha[b] = 1.0;
+  st.trial[b] = 0;
+  st.iters[b] = 1;  // so that the Armijo test applies
+  st.n_fwd[b] = 0;
+  st.status[b] = 0;
+  st.flags[b] = F_ACTIVE | F_SEARCH;
+}
+
+}  // namespace qilqr

@@ -1,0 +1,524 @@
+// se3_math.h -- scalar SO(3)/SE(3) arithmetic and the per-knot quadrotor functions.
+//
+// Every function here is lane-local (no cross-lane traffic, no LDS) so that the same code
+// serves a thread that owns one knot (k_linearize) and a thread that owns one problem
+// (k_rollout).  Written from the closed forms of Sola et al., "A micro Lie theory" and
+// Barfoot's SE(3) Q block with the branch structure manif uses (theta^2 <= 1e-10
+// small-angle switches, atan2 log with the w<0 branch), because the reference calls manif
+// at quadrotor_model.cc:183-186, 204, 211, 217, 232-235.  Where a product can be formed
+// without materialising zero blocks it is; results differ from the dense reference
+// formulation at rounding level only.
+//
+// QILQR_HD expands to __host__ __device__ under hipcc so that tests/host_harness.cpp can
+// compile these functions with g++ and check them against the oracle on the CPU box;
+// the product library never runs them on the host.
+#pragma once
+
+#if defined(__HIPCC__)
+#define QILQR_HD __host__ __device__ __forceinline__
+#else
+#define QILQR_HD inline
+#endif
+
+#include <math.h>
+
+namespace qilqr {
+
+template <typename T>
+struct Eps {
+  static constexpr T manif = T(1e-10);  // manif Constants<double>::eps
+};
+
+// ----------------------------------------------------------------- 3-vectors / 3x3 (row-major)
+template <typename T>
+QILQR_HD void skew3(const T a[3], T S[9]) {
+  S[0] = T(0); S[1] = -a[2]; S[2] = a[1];
+  S[3] = a[2]; S[4] = T(0);  S[5] = -a[0];
+  S[6] = -a[1]; S[7] = a[0]; S[8] = T(0);
+}
+template <typename T>
+QILQR_HD void mat3_mul(const T A[9], const T B[9], T C[9]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+template <typename T>
+QILQR_HD void mat3_vec(const T A[9], const T v[3], T o[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
+}
+template <typename T>
+QILQR_HD void mat3_tvec(const T A[9], const T v[3], T o[3]) {  // A^T v
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o[i] = A[i] * v[0] + A[3 + i] * v[1] + A[6 + i] * v[2];
+}
+template <typename T>
+QILQR_HD void cross3(const T a[3], const T b[3], T o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// ----------------------------------------------------------------- quaternions (x,y,z,w)
+// rotation matrix of a unit quaternion (Eigen's toRotationMatrix form)
+template <typename T>
+QILQR_HD void quat_to_R(const T q[4], T R[9]) {
+  const T x = q[0], y = q[1], z = q[2], w = q[3];
+  const T tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const T twx = tx * w, twy = ty * w, twz = tz * w;
+  const T txx = tx * x, txy = ty * x, txz = tz * x;
+  const T tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+template <typename T>
+QILQR_HD void quat_mul(const T a[4], const T b[4], T o[4]) {
+  const T ax = a[0], ay = a[1], az = a[2], aw = a[3];
+  const T bx = b[0], by = b[1], bz = b[2], bw = b[3];
+  o[3] = aw * bw - ax * bx - ay * by - az * bz;
+  o[0] = aw * bx + ax * bw + ay * bz - az * by;
+  o[1] = aw * by + ay * bw + az * bx - ax * bz;
+  o[2] = aw * bz + az * bw + ax * by - ay * bx;
+}
+
+// ----------------------------------------------------------------- SO(3)
+// Exp: [sin(|th|/2) th/|th| ; cos(|th|/2)], small angle [th/2 ; 1]
+template <typename T>
+QILQR_HD void so3_exp(const T th[3], T q[4]) {
+  const T th2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2];
+  if (th2 > Eps<T>::manif) {
+    const T theta = sqrt(th2);
+    const T ha = T(0.5) * theta;
+    const T s = sin(ha), c = cos(ha);
+    q[0] = s * (th[0] / theta); q[1] = s * (th[1] / theta); q[2] = s * (th[2] / theta); q[3] = c;
+  } else {
+    q[0] = th[0] / 2; q[1] = th[1] / 2; q[2] = th[2] / 2; q[3] = T(1);
+  }
+}
+// Log: 2 atan2(|q_v|, w) q_v/|q_v| with the w<0 branch, small angle 2 q_v
+template <typename T>
+QILQR_HD void so3_log(const T q[4], T th[3]) {
+  const T s2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+  T coeff;
+  if (s2 > Eps<T>::manif) {
+    const T s = sqrt(s2);
+    const T c = q[3];
+    const T two_angle = T(2) * ((c < T(0)) ? atan2(-s, -c) : atan2(s, c));
+    coeff = two_angle / s;
+  } else {
+    coeff = T(2);
+  }
+  th[0] = q[0] * coeff; th[1] = q[1] * coeff; th[2] = q[2] * coeff;
+}
+// coefficients (a, b) of  Jl = I + a W + b W^2   (Jr = Jl^T = I - a W + b W^2)
+template <typename T>
+QILQR_HD void so3_jac_coeffs(T th2, T &a, T &b, bool &small) {
+  small = !(th2 > Eps<T>::manif);
+  if (small) {
+    a = T(0.5);
+    b = T(0);
+  } else {
+    const T theta = sqrt(th2);
+    a = (T(1) - cos(theta)) / th2;
+    b = (theta - sin(theta)) / (th2 * theta);
+  }
+}
+// Jl(th) as a matrix
+template <typename T>
+QILQR_HD void so3_ljac(const T th[3], T J[9]) {
+  const T th2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2];
+  T a, b;
+  bool small;
+  so3_jac_coeffs(th2, a, b, small);
+  T W[9], WW[9];
+  skew3(th, W);
+  mat3_mul(W, W, WW);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) J[i] = a * W[i] + (small ? T(0) : b * WW[i]);
+  J[0] += 1; J[4] += 1; J[8] += 1;
+}
+// Jl^-1(th) = I - W/2 + c W^2,  c = 1/th^2 - (1+cos)/(2 th sin)
+template <typename T>
+QILQR_HD void so3_ljacinv(const T th[3], T J[9]) {
+  const T th2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2];
+  T W[9], WW[9];
+  skew3(th, W);
+  if (!(th2 > Eps<T>::manif)) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) J[i] = T(-0.5) * W[i];
+  } else {
+    const T theta = sqrt(th2);
+    const T c = T(1) / th2 - (T(1) + cos(theta)) / (T(2) * theta * sin(theta));
+    mat3_mul(W, W, WW);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) J[i] = T(-0.5) * W[i] + c * WW[i];
+  }
+  J[0] += 1; J[4] += 1; J[8] += 1;
+}
+template <typename T>
+QILQR_HD void transpose3(const T A[9], T At[9]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) At[3 * i + j] = A[3 * j + i];
+}
+
+// ----------------------------------------------------------------- SE(3), pose = (t[3], q[4])
+// Barfoot's Q block at c = [rho ; theta]
+template <typename T>
+QILQR_HD void se3_fillQ(const T rho[3], const T th[3], T Qm[9]) {
+  const T th2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2];
+  T B, C, D;
+  if (!(th2 > Eps<T>::manif)) {
+    B = T(1. / 6.) - th2 / T(120);
+    C = T(-1. / 24.) + th2 / T(720);
+    D = T(-1. / 120.);
+  } else {
+    const T theta = sqrt(th2);
+    const T s = sin(theta), co = cos(theta);
+    B = (theta - s) / (th2 * theta);
+    C = (T(1) - th2 / T(2) - co) / (th2 * th2);
+    D = T(0.5) * (C - T(3) * (theta - s - th2 * theta / T(6)) / (th2 * th2 * theta));
+  }
+  T V[9], W[9], VW[9], WV[9], WVW[9], VWW[9], WW[9], WWV[9], WVWW[9], WWVW[9];
+  skew3(rho, V);
+  skew3(th, W);
+  mat3_mul(V, W, VW);
+  mat3_mul(W, V, WV);
+  mat3_mul(WV, W, WVW);
+  mat3_mul(VW, W, VWW);
+  mat3_mul(W, W, WW);
+  mat3_mul(WW, V, WWV);
+  mat3_mul(WVW, W, WVWW);
+  mat3_mul(WW, VW, WWVW);
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+    Qm[i] = T(0.5) * V[i] + B * (WV[i] + VW[i] + WVW[i]) - C * (WWV[i] + VWW[i] - T(3) * WVW[i]) -
+            D * (WVWW[i] + WWVW[i]);
+}
+
+// T_out = T * Exp(tau), tau = [rho ; th]
+template <typename T>
+QILQR_HD void se3_rplus(const T t[3], const T q[4], const T tau[6], T to[3], T qo[4]) {
+  T Jl[9], p[3], qe[4], R[9], Rp[3];
+  so3_ljac(tau + 3, Jl);
+  mat3_vec(Jl, tau, p);
+  so3_exp(tau + 3, qe);
+  quat_to_R(q, R);
+  mat3_vec(R, p, Rp);
+  quat_mul(q, qe, qo);
+  const T n = qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3];
+  if (fabs(n - T(1)) > Eps<T>::manif) {  // manif's compose renormalisation
+    const T sc = T(2) / (T(1) + n);
+    qo[0] *= sc; qo[1] *= sc; qo[2] *= sc; qo[3] *= sc;
+  }
+  to[0] = Rp[0] + t[0]; to[1] = Rp[1] + t[1]; to[2] = Rp[2] + t[2];
+}
+
+// tau = Log(X^-1 Y)   (Y (-) X)
+template <typename T>
+QILQR_HD void se3_rminus(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T tau[6]) {
+  // X^-1 = (-R(qx*) tx, qx*)
+  const T qc[4] = {-qx[0], -qx[1], -qx[2], qx[3]};
+  T Rc[9], a[3], b[3], qd[4];
+  quat_to_R(qc, Rc);
+  mat3_vec(Rc, tx, a);
+  mat3_vec(Rc, ty, b);
+  T td[3] = {b[0] + (-a[0]), b[1] + (-a[1]), b[2] + (-a[2])};
+  quat_mul(qc, qy, qd);
+  const T n = qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3];
+  if (fabs(n - T(1)) > Eps<T>::manif) {
+    const T sc = T(2) / (T(1) + n);
+    qd[0] *= sc; qd[1] *= sc; qd[2] *= sc; qd[3] *= sc;
+  }
+  T th[3], Ji[9];
+  so3_log(qd, th);
+  so3_ljacinv(th, Ji);
+  mat3_vec(Ji, td, tau);
+  tau[3] = th[0]; tau[4] = th[1]; tau[5] = th[2];
+}
+
+// ----------------------------------------------------------------- model constants on the device
+// Built on the host in qilqr_create (quadrotor_model.cc:6-25 + the constant parts of
+// continuous_dynamics :113-119); passed to every kernel by value.
+template <typename T>
+struct ModelConsts {
+  T dt, mass, g;
+  T inertia[9];
+  T inertia_inv[9];
+  T arms[12];  // moment_arms 3x4
+  T Bu[48];    // J_u (12x4), constant: row 8 = dt/m, rows 9-11 = dt I^-1 moment_arms
+  T Q[144];
+  T R[16];
+};
+
+// continuous dynamics (quadrotor_model.cc:65-78) -> body acceleration (6)
+template <typename T>
+QILQR_HD void body_acceleration(const ModelConsts<T> &c, const T q[4], const T v[6], const T u[4],
+                                T acc[6]) {
+  T R[9];
+  quat_to_R(q, R);
+  const T usum = ((u[0] + u[1]) + u[2]) + u[3];
+  acc[0] = -c.g * R[6];
+  acc[1] = -c.g * R[7];
+  acc[2] = -c.g * R[8] + usum / c.mass;  // no -omega x v term (quadrotor_model.cc:69-72)
+  T M[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    M[i] = c.arms[4 * i] * u[0] + c.arms[4 * i + 1] * u[1] + c.arms[4 * i + 2] * u[2] +
+           c.arms[4 * i + 3] * u[3];
+  const T *w = v + 3;
+  T Iw[3], wIw[3], rhs[3];
+  mat3_vec(c.inertia, w, Iw);
+  cross3(w, Iw, wIw);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) rhs[i] = M[i] - wIw[i];
+  mat3_vec(c.inertia_inv, rhs, acc + 3);
+}
+
+// one explicit-Euler step on SE(3) x R^6 (quadrotor_model.cc:33-49, 266-276)
+template <typename T>
+QILQR_HD void discrete_step(const ModelConsts<T> &c, T t[3], T q[4], T v[6], const T u[4]) {
+  T acc[6], tau[6], tn[3], qn[4];
+  body_acceleration(c, q, v, u, acc);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) tau[i] = c.dt * v[i];  // pose integrates with the OLD velocity
+  se3_rplus(t, q, tau, tn, qn);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t[i] = tn[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = qn[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) v[i] = v[i] + c.dt * acc[i];
+}
+
+// ----------------------------------------------------------------- knot record layout
+// What k_linearize hands to k_backward for one knot (doubles):
+//   [  0.. 53] six 3x3 blocks of J_x, row-major:
+//              0: E^T            (rows 0-2 x cols 0-2 and rows 3-5 x cols 3-5)
+//              1: hat(-E^T p)E^T (rows 0-2 x cols 3-5)            Ad(Exp(tau)^-1)
+//              2: dt Jr(theta)   (rows 0-2 x cols 6-8 and rows 3-5 x cols 9-11)
+//              3: dt Q(-tau)     (rows 0-2 x cols 9-11)
+//              4: -dt g hat(R^T e_z)                (rows 6-8 x cols 3-5)
+//              5: I - dt I^-1 (hat(w) I - hat(I w)) (rows 9-11 x cols 9-11)
+//   [ 54..197] C_xx (12x12 row-major)       cost.hh:52
+//   [198..213] C_x (12), C_u (4)            cost.hh:51,54
+//   [214]      knot cost                    cost.hh:47-48
+//   [215]      pad
+constexpr int LIN_BLK = 0;
+constexpr int LIN_CXX = 54;
+constexpr int LIN_G = 198;
+constexpr int LIN_COST = 214;
+constexpr int LIN_STRIDE = 216;
+
+// knot value of the cost only (cost.hh:36-48); pt/pd = 18-double knots
+template <typename T>
+QILQR_HD T knot_cost(const ModelConsts<T> &c, const T *pt, const T *pd, T dx[12], T du[4]) {
+  const T qx[4] = {pt[5], pt[6], pt[7], pt[4]};
+  const T qd[4] = {pd[5], pd[6], pd[7], pd[4]};
+  se3_rminus(pt + 1, qx, pd + 1, qd, dx);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dx[6 + i] = pt[8 + i] - pd[8 + i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) du[i] = pt[14 + i] - pd[14 + i];
+  T cx = T(0);
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    T s = T(0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s += dx[i] * c.Q[i * 12 + j];
+    cx += s * dx[j];
+  }
+  T cu = T(0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    T s = T(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += du[i] * c.R[i * 4 + j];
+    cu += s * du[j];
+  }
+  return cx + cu;
+}
+
+// Full linearisation of one knot: dynamics Jacobian blocks (quadrotor_model.cc:33-49, 84-119,
+// 174-200, 266-276) and cost differentials (cost.hh:36-61), written to rec[LIN_STRIDE].
+template <typename T>
+QILQR_HD void linearize_knot(const ModelConsts<T> &c, const T *pt, const T *pd, T *rec) {
+  const T q[4] = {pt[5], pt[6], pt[7], pt[4]};
+  const T *v = pt + 8;
+  // ---- dynamics: tau = dt v ; E = Exp(tau) = (p, qe)
+  T tau[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) tau[i] = c.dt * v[i];
+  {
+    T Jl[9], p[3], qe[4];
+    so3_ljac(tau + 3, Jl);
+    mat3_vec(Jl, tau, p);
+    so3_exp(tau + 3, qe);
+    // Ad(E^-1) = [[Rc, hat(ti) Rc],[0, Rc]],  Rc = R(qe*), ti = -Rc p
+    const T qc[4] = {-qe[0], -qe[1], -qe[2], qe[3]};
+    T Rc[9], r[3], ti[3], S[9], SR[9];
+    quat_to_R(qc, Rc);
+    mat3_vec(Rc, p, r);
+    ti[0] = -r[0]; ti[1] = -r[1]; ti[2] = -r[2];
+    skew3(ti, S);
+    mat3_mul(S, Rc, SR);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      rec[LIN_BLK + 0 + i] = Rc[i];
+      rec[LIN_BLK + 9 + i] = SR[i];
+    }
+    // dt * rjac(tau) = dt [[Jr, Q(-tau)],[0, Jr]],  Jr = Jl^T
+    T nrho[3] = {-tau[0], -tau[1], -tau[2]}, nth[3] = {-tau[3], -tau[4], -tau[5]}, Qm[9];
+    se3_fillQ(nrho, nth, Qm);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        rec[LIN_BLK + 18 + 3 * i + j] = Jl[3 * j + i] * c.dt;
+        rec[LIN_BLK + 27 + 3 * i + j] = Qm[3 * i + j] * c.dt;
+      }
+  }
+  {
+    // d(lin acc)/d(rot) = -g hat(R^T e_z), scaled by dt
+    T R[9];
+    quat_to_R(q, R);
+    const T rz[3] = {R[6], R[7], R[8]};
+    T H[9];
+    skew3(rz, H);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rec[LIN_BLK + 36 + i] = c.dt * (-c.g * H[i]);
+    // d(ang acc)/d(omega) = -I^-1 (hat(w) I - hat(I w)); block = I + dt * that
+    const T *w = v + 3;
+    T Wh[9], WI[9], Iw[3], IwH[9], Jd[9], S[9];
+    skew3(w, Wh);
+    mat3_mul(Wh, c.inertia, WI);
+    mat3_vec(c.inertia, w, Iw);
+    skew3(Iw, IwH);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Jd[i] = WI[i] - IwH[i];
+    mat3_mul(c.inertia_inv, Jd, S);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rec[LIN_BLK + 45 + i] = ((i % 4 == 0) ? T(1) : T(0)) + c.dt * (-S[i]);
+  }
+  // ---- cost: dx = x (-) x_d, J = blkdiag(Jri(tau_c), I6), Jri = [[a, b],[0, a]]
+  T dx[12], du[4];
+  const T cost = knot_cost(c, pt, pd, dx, du);
+  rec[LIN_COST] = cost;
+  rec[LIN_COST + 1] = T(0);
+  T Jri[36];
+  {
+    T Li[9], a[9], Qm[9], aq[9], b[9];
+    so3_ljacinv(dx + 3, Li);
+    transpose3(Li, a);  // rjacinv = ljacinv^T
+    T nrho[3] = {-dx[0], -dx[1], -dx[2]}, nth[3] = {-dx[3], -dx[4], -dx[5]};
+    se3_fillQ(nrho, nth, Qm);
+    mat3_mul(a, Qm, aq);
+    mat3_mul(aq, a, b);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        Jri[6 * i + j] = a[3 * i + j];
+        Jri[6 * i + 3 + j] = -b[3 * i + j];
+        Jri[6 * (3 + i) + j] = T(0);
+        Jri[6 * (3 + i) + 3 + j] = a[3 * i + j];
+      }
+  }
+  // C_x = ((2 dx^T) Q) J ; C_u = (2 du^T) R
+  {
+    T wq[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      T s = T(0);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) s += (T(2) * dx[i]) * c.Q[i * 12 + j];
+      wq[j] = s;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      T s = T(0);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) s += wq[r] * Jri[6 * r + j];
+      rec[LIN_G + j] = s;
+    }
+#pragma unroll
+    for (int j = 6; j < 12; ++j) rec[LIN_G + j] = wq[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      T s = T(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s += (T(2) * du[i]) * c.R[i * 4 + j];
+      rec[LIN_G + 12 + j] = s;
+    }
+  }
+  // C_xx = 2 J^T Q J, column by column: P[:,j] = Q J[:,j], C_xx[:,j] = 2 J^T P[:,j]
+  for (int j = 0; j < 12; ++j) {
+    T P[12];
+    if (j < 6) {
+#pragma unroll
+      for (int r = 0; r < 12; ++r) {
+        T s = T(0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s += c.Q[r * 12 + k] * Jri[6 * k + j];
+        P[r] = s;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 12; ++r) P[r] = c.Q[r * 12 + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      T s = T(0);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) s += Jri[6 * r + i] * P[r];
+      rec[LIN_CXX + i * 12 + j] = T(2) * s;
+    }
+#pragma unroll
+    for (int i = 6; i < 12; ++i) rec[LIN_CXX + i * 12 + j] = T(2) * P[i];
+  }
+}
+
+// closed-loop rollout of one problem (ilqr.hh:149-172).  traj/out are n x 18, gains n x 52.
+template <typename T>
+QILQR_HD void rollout_problem(const ModelConsts<T> &c, const T *traj, const T *gains, T alpha,
+                              T *out, int n) {
+  T t[3] = {traj[1], traj[2], traj[3]};
+  T q[4] = {traj[5], traj[6], traj[7], traj[4]};
+  T v[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) v[i] = traj[8 + i];
+  for (int i = 0; i < n; ++i) {
+    const T *pt = traj + (long)i * 18;
+    const T *g = gains + (long)i * 52;
+    // dx = state (-) x_i
+    T dx[12];
+    const T qi[4] = {pt[5], pt[6], pt[7], pt[4]};
+    se3_rminus(t, q, pt + 1, qi, dx);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) dx[6 + a] = v[a] - pt[8 + a];
+    // u = (u_i + alpha k) + K dx
+    T u[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      T kd = T(0);
+#pragma unroll
+      for (int col = 0; col < 12; ++col) kd += g[4 + col * 4 + a] * dx[col];
+      u[a] = (pt[14 + a] + alpha * g[a]) + kd;
+    }
+    T *o = out + (long)i * 18;
+    o[0] = pt[0];
+    o[1] = t[0]; o[2] = t[1]; o[3] = t[2];
+    o[4] = q[3]; o[5] = q[0]; o[6] = q[1]; o[7] = q[2];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) o[8 + a] = v[a];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) o[14 + a] = u[a];
+    if (i + 1 < n) discrete_step(c, t, q, v, u);  // the reference's step after the last knot is discarded
+  }
+}
+
+}  // namespace qilqr

@@ -1,0 +1,181 @@
+// host_harness.cpp -- CPU test harness (tests only, never part of the product library).
+//
+// Compiles the lane-local device functions of quadrotorilqr_amd/csrc/se3_math.h with g++ and
+// re-enacts k_backward's 64-lane data flow on the CPU (the MFMA and the cross-lane shuffles
+// are emulated from their documented lane maps) so that `pytest -m "not gpu"` can check the
+// knot records, the rollout and the operand layout of the backward pass against the oracle
+// before anything runs on a GPU.
+#include <cstring>
+#include <vector>
+
+#include "../quadrotorilqr_amd/csrc/backward_layout.h"
+#include "../quadrotorilqr_amd/csrc/host_model.h"
+#include "../quadrotorilqr_amd/csrc/se3_math.h"
+
+using namespace qilqr;
+
+namespace {
+// v_mfma_f64_16x16x4_f64: lane l = (j = l & 15, kk = l >> 4) supplies A[j][kk], B[kk][j];
+// result register r of lane l is D[4 r + kk][j]
+void mfma_f64_16x16x4(const double a[64], const double b[64], double acc[64][4]) {
+  double A[16][4], Bm[4][16], D[16][16];
+  for (int l = 0; l < 64; ++l) {
+    A[l & 15][l >> 4] = a[l];
+    Bm[l >> 4][l & 15] = b[l];
+  }
+  for (int i = 0; i < 16; ++i)
+    for (int j = 0; j < 16; ++j) {
+      double s = acc[j + 16 * (i & 3)][i >> 2];
+      for (int k = 0; k < 4; ++k) s += A[i][k] * Bm[k][j];
+      D[i][j] = s;
+    }
+  for (int l = 0; l < 64; ++l)
+    for (int r = 0; r < 4; ++r) acc[l][r] = D[4 * r + (l >> 4)][l & 15];
+}
+}  // namespace
+
+extern "C" {
+
+int hh_make_consts(double mass, const double *inertia, double arm, double ttr, double g, const double *Q,
+                   const double *R, double dt, ModelConsts<double> *out) {
+  return make_model_consts(mass, inertia, arm, ttr, g, Q, R, dt, out) ? 0 : 1;
+}
+int hh_consts_size() { return (int)sizeof(ModelConsts<double>); }
+int hh_lin_stride() { return LIN_STRIDE; }
+
+void hh_linearize(const ModelConsts<double> *c, const double *traj, const double *desired, int n, double *lin) {
+  for (int i = 0; i < n; ++i) linearize_knot(*c, traj + i * 18, desired + i * 18, lin + (long)i * LIN_STRIDE);
+}
+void hh_rollout(const ModelConsts<double> *c, const double *traj, const double *gains, double alpha, double *out,
+                int n) {
+  rollout_problem(*c, traj, gains, alpha, out, n);
+}
+// dense J_x (12x12) and J_u (12x4) rebuilt from a knot record through m_source()
+void hh_dense_jacobians(const ModelConsts<double> *c, const double *rec, double *Jx, double *Ju) {
+  for (int r = 0; r < 12; ++r)
+    for (int col = 0; col < 16; ++col) {
+      double cst;
+      const int off = m_source(r, col, c->Bu, &cst);
+      const double v = off >= 0 ? rec[off] : cst;
+      if (col < 12) Jx[r * 12 + col] = v;
+      else Ju[r * 4 + (col - 12)] = v;
+    }
+}
+
+// k_backward re-enacted lane by lane (same statements, loops over the 64 lanes between the
+// points where the kernel exchanges data)
+void hh_backward_emulated(const ModelConsts<double> *cp, const double *lin, int n, double *gains, double *terms) {
+  const ModelConsts<double> &c = *cp;
+  constexpr int LD = 17;
+  double Vs[12 * LD] = {0}, Hs[16 * LD] = {0}, gs[16] = {0}, vxs[12] = {0};
+  int moff[64][3], coff[64][3];
+  double mconst[64][3], cuu[64];
+  double va[64][3] = {{0}}, vxl[64][3] = {{0}};
+  double QuTk[64] = {0}, kTQuuk[64] = {0};
+  for (int l = 0; l < 64; ++l) {
+    const int j = l & 15, kk = l >> 4;
+    for (int kc = 0; kc < 3; ++kc) moff[l][kc] = m_source(4 * kc + kk, j, c.Bu, &mconst[l][kc]);
+    for (int r = 0; r < 3; ++r) coff[l][r] = (j < 12) ? LIN_CXX + (4 * r + kk) * 12 + j : -1;
+    cuu[l] = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] : 0.0;
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    const double *rec = lin + (long)i * LIN_STRIDE;
+    double m[64][3], cx[64][3], gcj[64], T[64][4], H[64][4], part[64], ghat[64];
+    for (int l = 0; l < 64; ++l) {
+      for (int kc = 0; kc < 3; ++kc) m[l][kc] = moff[l][kc] >= 0 ? rec[moff[l][kc]] : mconst[l][kc];
+      for (int r = 0; r < 3; ++r) cx[l][r] = coff[l][r] >= 0 ? rec[coff[l][r]] : 0.0;
+      gcj[l] = rec[LIN_G + (l & 15)];
+      for (int r = 0; r < 4; ++r) T[l][r] = 0.0;
+    }
+    double a[64], b[64];
+    for (int kc = 0; kc < 3; ++kc) {
+      for (int l = 0; l < 64; ++l) { a[l] = va[l][kc]; b[l] = m[l][kc]; }
+      mfma_f64_16x16x4(a, b, T);
+    }
+    for (int l = 0; l < 64; ++l) { H[l][0] = cx[l][0]; H[l][1] = cx[l][1]; H[l][2] = cx[l][2]; H[l][3] = cuu[l]; }
+    for (int kc = 0; kc < 3; ++kc) {
+      for (int l = 0; l < 64; ++l) { a[l] = m[l][kc]; b[l] = T[l][kc]; }
+      mfma_f64_16x16x4(a, b, H);
+    }
+    for (int l = 0; l < 64; ++l) part[l] = m[l][0] * vxl[l][0] + m[l][1] * vxl[l][1] + m[l][2] * vxl[l][2];
+    {
+      double t[64];
+      for (int l = 0; l < 64; ++l) t[l] = part[l] + part[l ^ 16];
+      for (int l = 0; l < 64; ++l) part[l] = t[l] + t[l ^ 32];
+    }
+    for (int l = 0; l < 64; ++l) {
+      const int j = l & 15, kk = l >> 4;
+      ghat[l] = gcj[l] + part[l];
+      for (int r = 0; r < 4; ++r) Hs[(4 * r + kk) * LD + j] = H[l][r];
+      if (kk == 0) gs[j] = ghat[l];
+    }
+    double aop[64], bop[64], vx[64];
+    for (int l = 0; l < 64; ++l) {
+      const int j = l & 15, kk = l >> 4;
+      double Quu[16], Qu[4], rhs[4];
+      for (int aa = 0; aa < 4; ++aa) {
+        for (int bb = 0; bb < 4; ++bb) Quu[aa * 4 + bb] = Hs[(12 + aa) * LD + 12 + bb];
+        Qu[aa] = gs[12 + aa];
+        rhs[aa] = (j < 12) ? Hs[j * LD + 12 + aa] : 0.0;
+      }
+      const double i0 = 1.0 / Quu[0];
+      const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
+      const double d1 = Quu[5] - l10 * Quu[4];
+      const double i1 = 1.0 / d1;
+      const double c21 = Quu[9] - l20 * Quu[4], c31 = Quu[13] - l30 * Quu[4];
+      const double l21 = c21 * i1, l31 = c31 * i1;
+      const double d2 = Quu[10] - l20 * Quu[8] - l21 * c21;
+      const double i2 = 1.0 / d2;
+      const double c32 = Quu[14] - l30 * Quu[8] - l31 * c21;
+      const double l32 = c32 * i2;
+      const double d3 = Quu[15] - l30 * Quu[12] - l31 * c31 - l32 * c32;
+      const double i3 = 1.0 / d3;
+      double kcol[4], kff[4];
+      double y0 = rhs[0], y1 = rhs[1] - l10 * y0, y2 = rhs[2] - l20 * y0 - l21 * y1,
+             y3 = rhs[3] - l30 * y0 - l31 * y1 - l32 * y2;
+      double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
+             x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
+      kcol[0] = -x0; kcol[1] = -x1; kcol[2] = -x2; kcol[3] = -x3;
+      y0 = Qu[0]; y1 = Qu[1] - l10 * y0; y2 = Qu[2] - l20 * y0 - l21 * y1;
+      y3 = Qu[3] - l30 * y0 - l31 * y1 - l32 * y2;
+      x3 = y3 * i3; x2 = y2 * i2 - l32 * x3; x1 = y1 * i1 - l21 * x2 - l31 * x3;
+      x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
+      kff[0] = -x0; kff[1] = -x1; kff[2] = -x2; kff[3] = -x3;
+      double mc[4];
+      for (int bb = 0; bb < 4; ++bb)
+        mc[bb] = kcol[0] * Quu[bb] + kcol[1] * Quu[4 + bb] + kcol[2] * Quu[8 + bb] + kcol[3] * Quu[12 + bb];
+      vx[l] = ghat[l] - (mc[0] * kff[0] + mc[1] * kff[1] + mc[2] * kff[2] + mc[3] * kff[3]);
+      QuTk[l] += Qu[0] * kff[0] + Qu[1] * kff[1] + Qu[2] * kff[2] + Qu[3] * kff[3];
+      double s = 0.0;
+      for (int bb = 0; bb < 4; ++bb)
+        s += (kff[0] * Quu[bb] + kff[1] * Quu[4 + bb] + kff[2] * Quu[8 + bb] + kff[3] * Quu[12 + bb]) * kff[bb];
+      kTQuuk[l] += s;
+      aop[l] = -mc[kk];
+      bop[l] = kcol[kk];
+      if (kk == 0) {
+        double *g = gains + (long)i * 52;
+        if (j < 12) for (int aa = 0; aa < 4; ++aa) g[4 + 4 * j + aa] = kcol[aa];
+        else if (j == 12) for (int aa = 0; aa < 4; ++aa) g[aa] = kff[aa];
+      }
+    }
+    mfma_f64_16x16x4(aop, bop, H);
+    for (int l = 0; l < 64; ++l) {
+      const int j = l & 15, kk = l >> 4;
+      if (j < 12) {
+        for (int r = 0; r < 3; ++r) Vs[(4 * r + kk) * LD + j] = H[l][r];
+        if (kk == 0) vxs[j] = vx[l];
+      }
+    }
+    for (int l = 0; l < 64; ++l) {
+      const int j = l & 15, kk = l >> 4;
+      for (int kc = 0; kc < 3; ++kc) {
+        va[l][kc] = (j < 12) ? Vs[j * LD + 4 * kc + kk] : 0.0;
+        vxl[l][kc] = vxs[4 * kc + kk];
+      }
+    }
+  }
+  terms[0] = QuTk[0];
+  terms[1] = kTQuuk[0];
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol the header declares,
+and the host-only logic (argument validation, error text) behaves like the reference's
+constructor.  No compute call is made here (that needs a GPU: tests/test_gpu_*.py)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from quadrotorilqr_amd import capi, problems as pb
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if not os.path.exists(capi.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "quadrotor_ilqr.h")).read()
+    declared = set(re.findall(r"\b(qilqr_[a-z_]+)\s*\(", header))
+    assert declared == set(capi.EXPORTS)
+    lib = capi.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.qilqr_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    assert C.sizeof(capi.Model) == 13 * 8
+    assert C.sizeof(capi.Options) == 56      # 2 doubles, int32 + pad, 3 doubles, int32 + pad
+    assert capi.Options.rtol.offset == 24 and capi.Options.populate_debug.offset == 48
+    assert C.sizeof(capi.DeviceConfig) == 12
+    assert C.sizeof(capi.Profile) == 64
+
+
+def test_bad_inertia_raises_runtime_error_with_reference_text():
+    cfg = pb.config2(B=1, N=4)
+    bad = dict(cfg["model"], inertia=np.diag([1.0, -1.0, 1.0]))
+    with pytest.raises(RuntimeError, match="Inertia matrix is not positive definite!"):
+        capi.from_config(dict(cfg, model=bad))
+    asym = np.eye(3)
+    asym[0, 1] = 0.2
+    with pytest.raises(RuntimeError, match="Inertia matrix is not positive definite!"):
+        capi.from_config(dict(cfg, model=dict(cfg["model"], inertia=asym)))
+
+
+def test_unnormalised_desired_quaternion_is_value_error():
+    cfg = pb.config2(B=1, N=4)
+    d = cfg["desired"].copy()
+    d[2, 4] = 1.1
+    with pytest.raises(ValueError, match="quaternion"):
+        capi.from_config(dict(cfg, desired=d))
+
+
+def test_wrong_shapes_are_type_errors():
+    cfg = pb.config2(B=1, N=4)
+    with pytest.raises(TypeError):
+        capi.from_config(dict(cfg, Q=np.eye(6)))
+    with pytest.raises(TypeError):
+        capi.from_config(dict(cfg, model=dict(cfg["model"], inertia=np.eye(2))))
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product refuses to construct a solver; it never computes on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cfg = pb.config2(B=1, N=4)
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU path"):
+        capi.from_config(cfg)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product path (package, include/, src/) may not import, link or call oracle/."""
+    bad = []
+    for base in ("quadrotorilqr_amd", "include", "src"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".h", ".hip", ".cpp", ".cc", "Makefile")):
+                    txt = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"ilqr_oracle|from oracle|import oracle|orc_", txt):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad

@@ -1,0 +1,138 @@
+"""The lane-local device functions (quadrotorilqr_amd/csrc/se3_math.h) and the backward pass's
+operand layout (backward_layout.h), compiled for the host by tests/host_harness.cpp and checked
+against the oracle.  This is test scaffolding: the shipped library has no host path.
+
+Tolerances: per-function 1e-12 relative, per-pass 1e-10 relative.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from quadrotorilqr_amd import problems as pb
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def hh():
+    so = os.path.join(HERE, "libhost_harness.so")
+    src = os.path.join(HERE, "host_harness.cpp")
+    hdrs = [os.path.join(HERE, "..", "quadrotorilqr_amd", "csrc", h)
+            for h in ("se3_math.h", "backward_layout.h", "host_model.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(f) for f in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src, "-lm"])
+    return C.CDLL(so)
+
+
+def P(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def consts(hh, model, Q, R, dt):
+    buf = np.zeros(hh.hh_consts_size() // 8)
+    rc = hh.hh_make_consts(C.c_double(model["mass_kg"]), P(np.ascontiguousarray(model["inertia"], dtype=float)),
+                           C.c_double(model["arm_length_m"]), C.c_double(model["torque_to_thrust_ratio_m"]),
+                           C.c_double(model["g_mpss"]), P(np.ascontiguousarray(Q, dtype=float)),
+                           P(np.ascontiguousarray(R, dtype=float)), C.c_double(dt), P(buf))
+    assert rc == 0
+    return buf
+
+
+def random_problem(seed, n=12, dense=False):
+    r = np.random.default_rng(seed)
+    A = r.uniform(-1, 1, (3, 3))
+    model = dict(mass_kg=1.3, inertia=A @ A.T + 3 * np.eye(3), arm_length_m=0.7,
+                 torque_to_thrust_ratio_m=0.2, g_mpss=9.81)
+    if dense:
+        Q = r.uniform(-1, 1, (12, 12))
+        Q = Q @ Q.T + 12 * np.eye(12) + 0.3 * r.uniform(-1, 1, (12, 12))  # not symmetric
+        R = r.uniform(-0.3, 0.3, (4, 4)) + 2 * np.eye(4)                   # not symmetric
+    else:
+        Q, R = pb.Q_DEMO, pb.R_DEMO
+    def rand_traj():
+        t = np.zeros((n, 18))
+        t[:, 0] = 0.1 * np.arange(n)
+        for i in range(n):
+            t[i, 1:8] = orc.se3_exp(np.concatenate([r.uniform(-2, 2, 3), r.uniform(-1.5, 1.5, 3)]))
+        t[:, 8:14] = r.uniform(-2, 2, (n, 6))
+        t[:, 14:18] = r.uniform(0, 5, (n, 4))
+        return t
+    return model, Q, R, rand_traj(), rand_traj()
+
+
+@pytest.mark.parametrize("seed,dense", [(1, False), (2, True), (3, True)])
+def test_knot_records_match_oracle(hh, seed, dense):
+    model, Q, R, traj, desired = random_problem(seed, dense=dense)
+    dt = 0.1
+    c = consts(hh, model, Q, R, dt)
+    n = len(traj)
+    stride = hh.hh_lin_stride()
+    lin = np.zeros((n, stride))
+    hh.hh_linearize(P(c), P(traj), P(desired), C.c_int(n), P(lin))
+    mp = orc.model_params(**model)
+    for i in range(n):
+        _, Jx, Ju = orc.discrete_dynamics(mp, traj[i, 1:14], traj[i, 14:18], dt, diffs=True)
+        jx, ju = np.zeros((12, 12)), np.zeros((12, 4))
+        hh.hh_dense_jacobians(P(c), P(lin[i]), P(jx), P(ju))
+        np.testing.assert_allclose(jx, Jx, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(ju, Ju, rtol=1e-12, atol=1e-15)
+        cost, D = orc.cost(Q, R, traj[i, 1:14], traj[i, 14:18], desired[i, 1:14], desired[i, 14:18], diffs=True)
+        np.testing.assert_allclose(lin[i, 214], cost, rtol=1e-13)
+        scale = np.abs(D["xx"]).max()
+        np.testing.assert_allclose(lin[i, 54:198].reshape(12, 12), D["xx"], rtol=1e-11, atol=1e-12 * scale)
+        np.testing.assert_allclose(lin[i, 198:210], D["x"], rtol=1e-11, atol=1e-12 * np.abs(D["x"]).max())
+        np.testing.assert_allclose(lin[i, 210:214], D["u"], rtol=1e-12, atol=1e-13)
+
+
+def test_knot_records_at_singular_points(hh):
+    # desired roll = pi (w = 0 branch of Log), zero rotation rate (small-angle Exp), zero error
+    model, Q, R = pb.MODEL_D, pb.Q_DEMO, pb.R_DEMO
+    desired = pb.box_climb_desired(4.0)
+    traj = desired.copy()
+    c = consts(hh, model, Q, R, 0.1)
+    n = len(traj)
+    lin = np.zeros((n, hh.hh_lin_stride()))
+    hh.hh_linearize(P(c), P(traj), P(desired), C.c_int(n), P(lin))
+    assert np.all(np.isfinite(lin))
+    np.testing.assert_array_equal(lin[:, 214], 0.0)  # cost_test.cc:27-39
+    mp = orc.model_params(**model)
+    for i in (0, 15, 39):
+        _, Jx, _ = orc.discrete_dynamics(mp, traj[i, 1:14], traj[i, 14:18], 0.1, diffs=True)
+        jx, ju = np.zeros((12, 12)), np.zeros((12, 4))
+        hh.hh_dense_jacobians(P(c), P(lin[i]), P(jx), P(ju))
+        np.testing.assert_allclose(jx, Jx, rtol=1e-13, atol=1e-15)
+
+
+@pytest.mark.parametrize("seed,dense", [(4, False), (5, True)])
+def test_rollout_matches_oracle(hh, seed, dense):
+    model, Q, R, traj, desired = random_problem(seed, n=30, dense=dense)
+    r = np.random.default_rng(seed)
+    gains = 0.05 * r.uniform(-1, 1, (30, 52))
+    c = consts(hh, model, Q, R, 0.1)
+    s = orc.OracleSolver(orc.model_params(**model), Q, R, desired, 0.1, orc.options())
+    for alpha in (1.0, 0.25):
+        out = np.zeros_like(traj)
+        hh.hh_rollout(P(c), P(traj), P(gains), C.c_double(alpha), P(out), C.c_int(30))
+        ref = s.forward_sim(traj, gains, alpha)
+        np.testing.assert_allclose(out, ref, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("seed,dense", [(6, False), (7, True), (8, True)])
+def test_backward_dataflow_matches_oracle(hh, seed, dense):
+    """k_backward re-enacted on the CPU with the documented v_mfma_f64_16x16x4_f64 lane maps:
+    proves the operand tables, the accumulator->operand hand-off and the gain layout."""
+    model, Q, R, traj, desired = random_problem(seed, n=15, dense=dense)
+    c = consts(hh, model, Q, R, 0.1)
+    n = len(traj)
+    lin = np.zeros((n, hh.hh_lin_stride()))
+    hh.hh_linearize(P(c), P(traj), P(desired), C.c_int(n), P(lin))
+    gains, terms = np.zeros((n, 52)), np.zeros(2)
+    hh.hh_backward_emulated(P(c), P(lin), C.c_int(n), P(gains), P(terms))
+    s = orc.OracleSolver(orc.model_params(**model), Q, R, desired, 0.1, orc.options())
+    g_ref, t_ref = s.backwards_pass(traj)
+    np.testing.assert_allclose(terms, t_ref, rtol=1e-10)
+    np.testing.assert_allclose(gains, g_ref, rtol=1e-9, atol=1e-10 * np.abs(g_ref).max())

@@ -1,0 +1,302 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs and against the committed golden fixtures.
+
+Stated fp64 tolerances (justified by the 1e-13-perturbation experiment of
+BASELINE.md section 2): one pass from identical inputs 1e-10 relative; full solve: cost history
+1e-8 relative per iteration, final cost 1e-9 relative, final trajectory 1e-6 absolute (the
+reference's own bar, ilqr_test.cc:189); iteration counts equal.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc  # noqa: E402  (the checker)
+from quadrotorilqr_amd import capi, problems as pb  # noqa: E402
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_golden.npz"))
+
+
+def oracle_for(cfg, **opt_over):
+    return orc.OracleSolver(orc.model_params(**cfg["model"]), cfg["Q"], cfg["R"], cfg["desired"], cfg["dt"],
+                            orc.options(**dict(cfg["options"], **opt_over)))
+
+
+def random_cfg(seed, n=25, dense=False, B=6):
+    r = np.random.default_rng(seed)
+    A = r.uniform(-1, 1, (3, 3))
+    model = dict(mass_kg=1.3, inertia=A @ A.T + 3 * np.eye(3), arm_length_m=0.7,
+                 torque_to_thrust_ratio_m=0.2, g_mpss=9.81)
+    if dense:
+        Q = r.uniform(-1, 1, (12, 12))
+        Q = Q @ Q.T + 12 * np.eye(12) + 0.3 * r.uniform(-1, 1, (12, 12))  # NOT symmetric
+        R = r.uniform(-0.3, 0.3, (4, 4)) + 2 * np.eye(4)
+    else:
+        Q, R = pb.Q_DEMO, pb.R_DEMO
+
+    def rand_traj():
+        t = np.zeros((n, 18))
+        t[:, 0] = 0.1 * np.arange(n)
+        for i in range(n):
+            t[i, 1:8] = orc.se3_exp(np.concatenate([r.uniform(-2, 2, 3), r.uniform(-1.5, 1.5, 3)]))
+        t[:, 8:14] = r.uniform(-2, 2, (n, 6))
+        t[:, 14:18] = r.uniform(0, 5, (n, 4))
+        return t
+
+    desired = rand_traj()
+    trajs = np.stack([rand_traj() for _ in range(B)])
+    return dict(model=model, Q=Q, R=R, dt=0.1, desired=desired, init=trajs,
+                options=dict(pb.OPTIONS_DEMO, populate_debug=False))
+
+
+# ------------------------------------------------------------------ ilqr_test.cc fixture on the GPU
+N, DT = 3, 0.1
+
+
+@pytest.fixture(scope="module")
+def fx():
+    cur = pb.identity_trajectory(N, DT)
+    model = dict(mass_kg=1.0, inertia=np.eye(3), arm_length_m=1.0, torque_to_thrust_ratio_m=1.0, g_mpss=0.0)
+    opts = dict(step_update=0.5, desired_reduction_frac=0.5, ls_max_iters=10, rtol=1e-12, atol=1e-12,
+                max_iters=100, populate_debug=True)
+    s = capi.QuadrotorILQRBatch(1.0, np.eye(3), 1.0, 1.0, 0.0, np.eye(12), np.eye(4), cur, DT, opts)
+    gains = orc.kK_to_gains(np.ones((N, 4)), np.zeros((N, 4, 12)))
+    return dict(s=s, cur=cur, gains=gains, model=model, opts=opts)
+
+
+def traj_close(a, b, tol=1e-6):
+    for pa, pb_ in zip(a, b):
+        rel = orc.se3_compose(orc.se3_inverse(pa[1:8]), pb_[1:8])
+        assert np.linalg.norm(orc.se3_log(rel)) < tol
+        np.testing.assert_allclose(pa[8:18], pb_[8:18], atol=tol, rtol=1e-12)
+
+
+def test_forward_sim_known_answer(fx):  # ilqr_test.cc:102-126
+    new = fx["s"].forward_sim(fx["cur"][None], fx["gains"][None])[0]
+    exp = pb.identity_trajectory(N, DT)
+    exp[:, 14:18] = 1.0
+    exp[1, 10] = DT * 4.0
+    exp[2, 3] = DT * DT * 4.0
+    exp[2, 10] = 2 * DT * 4.0
+    traj_close(new, exp)
+    np.testing.assert_array_equal(new[:, 0], fx["cur"][:, 0])
+
+
+def test_cost_trajectory_known_answer(fx):  # ilqr_test.cc:128-141, EXPECT_DOUBLE_EQ = 4 ULP
+    new = fx["s"].forward_sim(fx["cur"][None], fx["gains"][None])
+    cost = fx["s"].cost_trajectory(new)[0]
+    expected = (DT * 4.0) ** 2.0 + (DT * DT * 4.0) ** 2.0 + (2.0 * DT * 4.0) ** 2.0 + 3 * 4
+    assert abs(cost - expected) <= 4 * np.spacing(expected)
+
+
+def test_backward_pass_zero_gradient(fx):  # ilqr_test.cc:143-153: exact zeros
+    gains, terms = fx["s"].backwards_pass(fx["cur"][None])
+    assert terms[0, 0] == 0.0 and terms[0, 1] == 0.0
+    k, _ = orc.gains_to_kK(gains[0])
+    assert np.all(k == 0.0)
+
+
+def test_backward_pass_negative_expected_reduction(fx):  # ilqr_test.cc:155-164
+    new = fx["s"].forward_sim(fx["cur"][None], fx["gains"][None])
+    _, terms = fx["s"].backwards_pass(new)
+    assert terms[0, 0] < 0.0
+    assert abs(terms[0, 0] - (-25.6032)) < 1e-9
+
+
+def test_line_search_reduces_cost(fx):  # ilqr_test.cc:166-177
+    s = fx["s"]
+    traj = s.forward_sim(fx["cur"][None], fx["gains"][None])
+    cost = s.cost_trajectory(traj)
+    gains, terms = s.backwards_pass(traj)
+    ls = s.line_search(traj, cost, gains, terms)
+    assert ls["status"][0] == 0
+    dj = ls["step"][0] * terms[0, 0] + ls["step"][0] ** 2 * terms[0, 1] / 2.0
+    assert ls["cost"][0] - cost[0] < 0.5 * dj
+    ref = oracle_for(dict(model=fx["model"], Q=np.eye(12), R=np.eye(4), desired=fx["cur"], dt=DT,
+                          options=fx["opts"])).line_search(traj[0], cost[0], gains[0], terms[0])
+    assert ls["step"][0] == ref["step"]
+    np.testing.assert_allclose(ls["cost"][0], ref["cost"], rtol=1e-10)
+
+
+def test_solve_finds_optimal_trajectory(fx):  # ilqr_test.cc:179-190
+    k = np.ones((N, 4))
+    k[:, 0] *= 100
+    k[:, 2] *= 100
+    init = fx["s"].forward_sim(fx["cur"][None], orc.kK_to_gains(k, np.zeros((N, 4, 12)))[None])[0]
+    traj, info = fx["s"].solve(init)
+    traj_close(fx["cur"], traj, 1e-6)
+    assert info["cost"] < 1e-20
+    assert len(info["debug_costs"]) == info["iters"]
+    np.testing.assert_array_equal(info["debug_trajs"][-1], traj)
+
+
+# ------------------------------------------------------------------ per-pass parity on random inputs
+@pytest.mark.parametrize("seed,dense", [(11, False), (12, True), (13, True)])
+def test_passes_match_oracle(seed, dense):
+    cfg = random_cfg(seed, dense=dense)
+    s = capi.from_config(cfg)
+    ref = oracle_for(cfg)
+    trajs = cfg["init"]
+    cost = s.cost_trajectory(trajs)
+    gains, terms = s.backwards_pass(trajs)
+    for b in range(len(trajs)):
+        np.testing.assert_allclose(cost[b], ref.cost_trajectory(trajs[b]), rtol=1e-12)
+        g_ref, t_ref = ref.backwards_pass(trajs[b])
+        np.testing.assert_allclose(terms[b], t_ref, rtol=1e-10)
+        np.testing.assert_allclose(gains[b], g_ref, rtol=1e-9, atol=1e-10 * np.abs(g_ref).max())
+    r = np.random.default_rng(seed)
+    small_gains = 0.05 * r.uniform(-1, 1, gains.shape)
+    alpha = np.array([1.0, 0.5, 0.25, 1.0, 0.125, 1.0])
+    out = s.forward_sim(trajs, small_gains, alpha)
+    for b in range(len(trajs)):
+        np.testing.assert_allclose(out[b], ref.forward_sim(trajs[b], small_gains[b], alpha[b]), rtol=1e-10,
+                                   atol=1e-10)
+
+
+# ------------------------------------------------------------------ full solves
+def test_config2_batch_matches_oracle():
+    cfg = pb.config2(B=64)
+    s = capi.from_config(cfg)
+    out = s.solve_batch(cfg["init"])
+    ref = oracle_for(cfg).solve_batch(cfg["init"], n_threads=8)
+    np.testing.assert_array_equal(out["status"], ref["status"])
+    np.testing.assert_array_equal(out["iters"], ref["iters"])
+    np.testing.assert_array_equal(out["n_bwd"], ref["n_bwd"])
+    np.testing.assert_array_equal(out["n_fwd"], ref["n_fwd"])
+    np.testing.assert_allclose(out["cost"], ref["cost"], rtol=1e-9)
+    np.testing.assert_allclose(out["traj"], ref["traj"], atol=1e-6)
+    # and the first 8 against the committed fixture
+    np.testing.assert_allclose(out["cost"][:8], G["cfg2_cost"], rtol=1e-9)
+    np.testing.assert_allclose(out["traj"][:8], G["cfg2_traj"], atol=1e-6)
+    np.testing.assert_array_equal(out["iters"][:8], G["cfg2_iters"])
+
+
+@pytest.mark.parametrize("name,H", [("demo40", 4.0), ("demo100", 10.0)])
+def test_demo_single_solve_matches_golden(name, H):
+    # BASELINE.json configs[0] (100 knots) and the reference demo as shipped (40 knots)
+    cfg = pb.config1(H)
+    s = capi.from_config(cfg)
+    traj, info = s.solve(cfg["init"][0])
+    meta = G[name + "_meta"]
+    assert [info["status"], info["iters"]] == list(meta[:2])
+    np.testing.assert_allclose(info["debug_costs"], G[name + "_cost_hist"], rtol=1e-8)
+    np.testing.assert_allclose(info["cost"], G[name + "_cost_hist"][-1], rtol=1e-9)
+    np.testing.assert_allclose(traj, G[name + "_traj"], atol=1e-6)
+    np.testing.assert_array_equal(traj[:, 0], cfg["init"][0][:, 0])       # time_s passes through
+    np.testing.assert_array_equal(traj[0, 1:14], cfg["init"][0][0, 1:14])  # knot 0 state is the input's
+
+
+def test_dense_nonsymmetric_weights_solve():
+    cfg = random_cfg(21, n=20, dense=True, B=4)
+    cfg["init"][:, 1:] = cfg["desired"][1:]  # start near the desired trajectory
+    cfg["options"] = dict(cfg["options"], max_iters=15)
+    s = capi.from_config(cfg)
+    out = s.solve_batch(cfg["init"])
+    ref = oracle_for(cfg).solve_batch(cfg["init"])
+    ok = ref["status"] != orc.STATUS_LINE_SEARCH_FAILED
+    np.testing.assert_array_equal(out["status"], ref["status"])
+    np.testing.assert_allclose(out["cost"][ok], ref["cost"][ok], rtol=1e-8)
+    np.testing.assert_allclose(out["traj"][ok], ref["traj"][ok], atol=1e-6)
+
+
+def test_per_problem_desired_trajectories():
+    cfg = pb.config2(B=6, N=30)
+    r = np.random.default_rng(5)
+    des = np.broadcast_to(cfg["desired"], (6, 30, 18)).copy()
+    des[:, :, 1:4] += r.uniform(-0.5, 0.5, (6, 1, 3))  # a different hover point per problem
+    s = capi.from_config(cfg)
+    out = s.solve_batch(cfg["init"], desired_batch=des)
+    for b in range(6):
+        ref = oracle_for(dict(cfg, desired=des[b])).solve(cfg["init"][b])
+        assert out["status"][b] == ref["status"] and out["iters"][b] == ref["iters"]
+        np.testing.assert_allclose(out["cost"][b], ref["cost"], rtol=1e-9)
+        np.testing.assert_allclose(out["traj"][b], ref["traj"], atol=1e-6)
+
+
+# ------------------------------------------------------------------ failure paths
+def test_line_search_exhaustion():
+    # the demo at 200 knots exhausts the line search
+    cfg = pb.config1(20.0)
+    s = capi.from_config(cfg)
+    with pytest.raises(RuntimeError, match=r"Reached maximum number of line search iterations, 100\n"):
+        s.solve(cfg["init"][0])
+    out = s.solve_batch(cfg["init"])
+    ref = oracle_for(cfg).solve(cfg["init"][0])
+    assert out["status"][0] == capi.STATUS_LINE_SEARCH_FAILED == ref["status"]
+    assert out["n_fwd"][0] - out["iters"][0] >= 100 - 1
+
+
+def test_longer_than_desired_is_index_error():
+    cfg = pb.config2(B=2, N=10)
+    s = capi.from_config(cfg)
+    longer = np.concatenate([cfg["init"], cfg["init"][:, -1:]], axis=1)
+    with pytest.raises(IndexError):
+        s.solve_batch(longer)
+    with pytest.raises(IndexError):
+        s.cost_trajectory(longer)
+
+
+def test_unnormalised_initial_quaternion_is_value_error():
+    cfg = pb.config2(B=2, N=10)
+    s = capi.from_config(cfg)
+    bad = cfg["init"].copy()
+    bad[1, 3, 4:8] *= 1.01
+    with pytest.raises(ValueError):
+        s.solve_batch(bad)
+
+
+def test_ragged_and_edge_sizes():
+    # N = 1 (a single knot: no dynamics step at all), N = 2, B = 1, B not a multiple of 64
+    for B, n in [(1, 1), (3, 2), (65, 7), (130, 5)]:
+        cfg = pb.config2(B=B, N=n, seed=9)
+        s = capi.from_config(cfg)
+        out = s.solve_batch(cfg["init"])
+        ref = oracle_for(cfg).solve_batch(cfg["init"], n_threads=4)
+        np.testing.assert_array_equal(out["status"], ref["status"])
+        np.testing.assert_array_equal(out["iters"], ref["iters"])
+        np.testing.assert_allclose(out["cost"], ref["cost"], rtol=1e-9, atol=1e-18)
+        np.testing.assert_allclose(out["traj"], ref["traj"], atol=1e-6)
+
+
+def test_max_iters_zero_returns_input():
+    cfg = pb.config2(B=3, N=10)
+    cfg["options"] = dict(cfg["options"], max_iters=0)
+    out = capi.from_config(cfg).solve_batch(cfg["init"])
+    np.testing.assert_array_equal(out["traj"], cfg["init"])
+    assert (out["status"] == capi.STATUS_MAX_ITERS).all() and (out["iters"] == 0).all()
+
+
+# ------------------------------------------------------------------ full size (BASELINE.json configs[1])
+def test_config2_full_size_properties():
+    cfg = pb.config2()  # B = 1024, N = 100
+    s = capi.from_config(cfg)
+    out = s.solve_batch(cfg["init"])
+    init_cost = s.cost_trajectory(cfg["init"])
+    assert np.isfinite(out["traj"]).all() and np.isfinite(out["cost"]).all()
+    assert np.isin(out["status"], [0, 1]).all()
+    assert (out["cost"] < init_cost).all()
+    # time column and knot-0 state pass through
+    np.testing.assert_array_equal(out["traj"][:, :, 0], cfg["init"][:, :, 0])
+    np.testing.assert_array_equal(out["traj"][:, 0, 1:14], cfg["init"][:, 0, 1:14])
+    # the returned cost is the cost of the returned trajectory
+    np.testing.assert_allclose(s.cost_trajectory(out["traj"]), out["cost"], rtol=1e-13)
+    # problems are independent: any permutation of the batch gives the same per-problem bits
+    perm = np.random.default_rng(0).permutation(1024)
+    out_p = s.solve_batch(cfg["init"][perm])
+    np.testing.assert_array_equal(out_p["traj"], out["traj"][perm])
+    np.testing.assert_array_equal(out_p["iters"], out["iters"][perm])
+    # a batch of one gives the same bits as the same problem inside the batch
+    one = s.solve_batch(cfg["init"][17:18])
+    np.testing.assert_array_equal(one["traj"][0], out["traj"][17])
+    # warm start from the optimum is a fixed point: at most two more iterations, same cost
+    again = s.solve_batch(out["traj"])
+    assert (again["iters"] <= 2).all()
+    np.testing.assert_allclose(again["cost"], out["cost"], rtol=1e-9)
+    # a sample against the oracle
+    idx = np.arange(0, 1024, 32)
+    ref = oracle_for(cfg).solve_batch(cfg["init"][idx], n_threads=8)
+    np.testing.assert_array_equal(out["iters"][idx], ref["iters"])
+    np.testing.assert_allclose(out["cost"][idx], ref["cost"], rtol=1e-9)
+    np.testing.assert_allclose(out["traj"][idx], ref["traj"], atol=1e-6)
