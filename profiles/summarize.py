@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Condenses a rocprofv3 output tree (profiles/run_rocprof.sh) into small text/JSON summaries that
+are committed under profiles/: per-kernel time statistics and per-launch HBM traffic from the PMC
+passes (FETCH_SIZE is doubled as MI355X_MICROARCH.md section HBM prescribes for gfx950; both counters
+are reported by rocprofv3 in KiB)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def find(root, suffix):
+    return sorted(glob.glob(os.path.join(root, "**", "*" + suffix), recursive=True))
+
+
+def short(name):
+    for k in ("k_backward", "k_rollout", "k_linearize", "k_accept", "k_init", "k_gather", "k_seed_search"):
+        if k in name:
+            return k
+    return name[:60]
+
+
+def main():
+    out, tag = sys.argv[1], sys.argv[2]
+    summary = {"tag": tag}
+    # ---- kernel trace
+    rows = []
+    for f in find(os.path.join(out, "trace"), "kernel_trace.csv"):
+        rows += list(csv.DictReader(open(f)))
+    stat = defaultdict(list)
+    for r in rows:
+        stat[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    total = sum(sum(v) for v in stat.values()) or 1.0
+    ks = {}
+    lines = ["kernel                 calls   total_us    avg_us    min_us    max_us   pct"]
+    for k, v in sorted(stat.items(), key=lambda kv: -sum(kv[1])):
+        ks[k] = dict(calls=len(v), total_us=sum(v), avg_us=sum(v) / len(v), min_us=min(v), max_us=max(v),
+                     pct=100 * sum(v) / total)
+        lines.append(f"{k:20s} {len(v):7d} {sum(v):10.1f} {sum(v)/len(v):9.2f} {min(v):9.2f} {max(v):9.2f} {100*sum(v)/total:5.1f}")
+    summary["kernel_stats"] = ks
+    # ---- PMC passes
+    for name, sub, mult in (("FETCH_SIZE", "pmc_fetch", 2.0), ("WRITE_SIZE", "pmc_write", 1.0)):
+        acc = defaultdict(lambda: [0.0, 0])
+        for f in find(os.path.join(out, sub), "counter_collection.csv"):
+            for r in csv.DictReader(open(f)):
+                if r.get("Counter_Name") == name:
+                    a = acc[short(r["Kernel_Name"])]
+                    a[0] += float(r["Counter_Value"])
+                    a[1] += 1
+        summary[name] = {k: dict(launches=n, kib_per_launch_raw=v / max(n, 1),
+                                 bytes_per_launch_corrected=mult * 1024.0 * v / max(n, 1))
+                         for k, (v, n) in acc.items()}
+        lines.append("")
+        lines.append(f"{name} (KiB raw; corrected bytes = raw x 1024 x {mult:g})")
+        for k, d in sorted(summary[name].items()):
+            lines.append(f"  {k:20s} launches {d['launches']:6d}  raw KiB/launch {d['kib_per_launch_raw']:12.1f}  "
+                         f"corrected MB/launch {d['bytes_per_launch_corrected']/1e6:10.3f}")
+    for f in ("bench_trace.log",):
+        p = os.path.join(out, f)
+        if os.path.exists(p):
+            js = [l for l in open(p) if l.startswith("{")]
+            if js:
+                summary["bench_under_trace"] = json.loads(js[-1])
+    here = os.path.dirname(os.path.abspath(__file__))
+    open(os.path.join(here, f"{tag}_rocprof_summary.txt"), "w").write("\n".join(lines) + "\n")
+    json.dump(summary, open(os.path.join(here, f"{tag}_rocprof_summary.json"), "w"), indent=1)
+    # scratch copy too (gpurun merges gpurun_out back)
+    os.makedirs(os.path.join(out, "summary"), exist_ok=True)
+    open(os.path.join(out, "summary", f"{tag}_rocprof_summary.txt"), "w").write("\n".join(lines) + "\n")
+    json.dump(summary, open(os.path.join(out, "summary", f"{tag}_rocprof_summary.json"), "w"), indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
