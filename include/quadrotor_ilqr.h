@@ -70,6 +70,7 @@ typedef struct {
   int32_t device;   /* HIP device ordinal */
   int32_t profile;  /* 1: bracket every kernel launch with HIP events (qilqr_profile_get) */
   int32_t sync_every; /* host polls the active-problem counter every k outer iterations (>=1) */
+  int32_t force_general; /* 1: use the general (non-symmetric-safe) backward kernel even when Q, R are symmetric */
 } qilqr_device_config;
 
 typedef struct qilqr_solver qilqr_solver;

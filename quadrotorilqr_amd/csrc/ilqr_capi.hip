@@ -48,6 +48,7 @@ struct qilqr_solver {
   qilqr_options options;
   qilqr_device_config dev;
   int n_desired = 0;
+  bool symmetric = false;  // Q == Q^T and R == R^T exactly: transpose-free backward kernel
   double *d_desired = nullptr;  // shared desired trajectory
   // workspace
   long cap_B = 0, cap_n = 0;
@@ -172,8 +173,12 @@ int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag) 
 }
 int launch_backward(qilqr_solver *s, long B, long n, int force) {
   Timed t(s, K_BACKWARD);
-  hipLaunchKernelGGL(k_backward, dim3((unsigned)B), dim3(64), 0, s->stream, s->consts, s->params, s->st,
-                     (int)B, (int)n, force);
+  if (s->symmetric)
+    hipLaunchKernelGGL(k_backward<true>, dim3((unsigned)B), dim3(64), 0, s->stream, s->consts, s->params, s->st,
+                       (int)B, (int)n, force);
+  else
+    hipLaunchKernelGGL(k_backward<false>, dim3((unsigned)B), dim3(64), 0, s->stream, s->consts, s->params, s->st,
+                       (int)B, (int)n, force);
   return QILQR_OK;
 }
 int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
@@ -275,7 +280,7 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(QILQR_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
-  qilqr_device_config dc = {0, 0, 1};
+  qilqr_device_config dc = {0, 0, 1, 0};
   if (dev) dc = *dev;
   if (dc.device < 0 || dc.device >= ndev) return fail(QILQR_ERR_INVALID_ARG, "bad device ordinal");
   if (dc.sync_every < 1) dc.sync_every = 1;
@@ -287,6 +292,12 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   s->params = SolveParams{options->step_update, options->desired_reduction_frac, options->rtol, options->atol,
                           options->max_iters, options->ls_max_iters};
   s->consts = mc;
+  s->symmetric = true;
+  for (int i = 0; i < 12; ++i)
+    for (int k = 0; k < i; ++k) s->symmetric = s->symmetric && (Q[i * 12 + k] == Q[k * 12 + i]);
+  for (int i = 0; i < 4; ++i)
+    for (int k = 0; k < i; ++k) s->symmetric = s->symmetric && (R[i * 4 + k] == R[k * 4 + i]);
+  if (dc.force_general) s->symmetric = false;
   s->n_desired = n_desired;
 
   hipError_t e = hipSetDevice(s->device);

@@ -107,7 +107,27 @@ __global__ void k_init(SolveParams p, BatchState st, int B, int n) {
 __device__ __forceinline__ double sel4(const double v[4], int kk) {
   return kk == 0 ? v[0] : (kk == 1 ? v[1] : (kk == 2 ? v[2] : v[3]));
 }
+// 1/x to fp64 accuracy (not correctly rounded): hardware estimate + two Newton steps; half the
+// dependent depth of the IEEE division sequence, which matters on the per-knot serial chain
+__device__ __forceinline__ double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+// value of x in lane `src` (compile-time constant), broadcast to the wave
+__device__ __forceinline__ double bcast_lane(double x, int src) {
+  const long long v = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readlane((int)v, src);
+  const int hi = __builtin_amdgcn_readlane((int)(v >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 
+// SYM = true: Q and R are exactly symmetric, so V_xx and H are symmetric to rounding and the
+// accumulator tile can be reused as the next knot's A operand without a transpose; no LDS and no
+// barrier remain in the loop (Q_uu/Q_u are broadcast with v_readlane, the right-hand sides with
+// ds_bpermute).  SYM = false: general weights, hand-offs go through padded LDS tiles.
+template <bool SYM>
 __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolveParams p, BatchState st,
                                                  int B, int n, int force) {
   const int b = blockIdx.x;
@@ -121,10 +141,10 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   double *gains = st.gains + (long)b * n * 52;
 
   constexpr int LD = 17;  // padded leading dimension: column reads of a row-major tile
-  __shared__ double Vs[12 * LD];
-  __shared__ double Hs[16 * LD];
-  __shared__ double gs[16];
-  __shared__ double vxs[12];
+  __shared__ double Vs[SYM ? 1 : 12 * LD];
+  __shared__ double Hs[SYM ? 1 : 16 * LD];
+  __shared__ double gs[SYM ? 1 : 16];
+  __shared__ double vxs[SYM ? 1 : 12];
 
   // where this lane's three elements of M = [J_x | J_u] live in a knot record
   int moff[3];
@@ -142,14 +162,27 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   double vxl[3] = {0.0, 0.0, 0.0};  // V_x[4 kc + kk]
   double QuTk = 0.0, kTQuuk = 0.0;
 
-  for (int i = n - 1; i >= 0; --i) {
-    const double *rec = lin + (long)i * LIN_STRIDE;
-    double m[3], cx[3];
+  // software pipeline: the operands of knot i-1 are requested before the chain of knot i starts
+  double m[3], cx[3], gcj;
+  {
+    const double *rec = lin + (long)(n - 1) * LIN_STRIDE;
 #pragma unroll
     for (int kc = 0; kc < 3; ++kc) m[kc] = (moff[kc] >= 0) ? rec[moff[kc]] : mconst[kc];
 #pragma unroll
     for (int r = 0; r < 3; ++r) cx[r] = (coff[r] >= 0) ? rec[coff[r]] : 0.0;
-    const double gcj = rec[LIN_G + j];
+    gcj = rec[LIN_G + j];
+  }
+
+  for (int i = n - 1; i >= 0; --i) {
+    double m_n[3], cx_n[3], gcj_n;
+    {
+      const double *rec = lin + (long)(i > 0 ? i - 1 : 0) * LIN_STRIDE;
+#pragma unroll
+      for (int kc = 0; kc < 3; ++kc) m_n[kc] = (moff[kc] >= 0) ? rec[moff[kc]] : mconst[kc];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) cx_n[r] = (coff[r] >= 0) ? rec[coff[r]] : 0.0;
+      gcj_n = rec[LIN_G + j];
+    }
 
     // T = V M
     d4 T = {0.0, 0.0, 0.0, 0.0};
@@ -167,33 +200,44 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
     part += __shfl_xor(part, 32);
     const double ghat = gcj + part;
 
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Hs[(4 * r + kk) * LD + j] = H[r];
-    if (kk == 0) gs[j] = ghat;
-    __syncthreads();
-
     // every lane: Q_uu (4x4), Q_u; lane column j < 12: its row of Q_xu
     double Quu[16], Qu[4], rhs[4];
+    if constexpr (SYM) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+      for (int a = 0; a < 4; ++a) {
 #pragma unroll
-      for (int bb = 0; bb < 4; ++bb) Quu[a * 4 + bb] = Hs[(12 + a) * LD + 12 + bb];
-      Qu[a] = gs[12 + a];
-      rhs[a] = (j < 12) ? Hs[j * LD + 12 + a] : 0.0;
+        for (int bb = 0; bb < 4; ++bb) Quu[a * 4 + bb] = bcast_lane(H[3], 12 + bb + 16 * a);
+        Qu[a] = bcast_lane(ghat, 12 + a);
+        // Q_xu[j][a] = Q_ux[a][j] (symmetry) sits in register 3 of lane (j, kk = a)
+        const double r = __shfl(H[3], j + 16 * a);
+        rhs[a] = (j < 12) ? r : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Hs[(4 * r + kk) * LD + j] = H[r];
+      if (kk == 0) gs[j] = ghat;
+      __syncthreads();
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) Quu[a * 4 + bb] = Hs[(12 + a) * LD + 12 + bb];
+        Qu[a] = gs[12 + a];
+        rhs[a] = (j < 12) ? Hs[j * LD + 12 + a] : 0.0;
+      }
     }
     // LDL^T of the lower triangle of Q_uu (the reference: Eigen LDLT, ilqr.hh:126; no pivoting here)
-    const double i0 = 1.0 / Quu[0];
+    const double i0 = rcp_nr(Quu[0]);
     const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
     const double d1 = Quu[5] - l10 * Quu[4];
-    const double i1 = 1.0 / d1;
+    const double i1 = rcp_nr(d1);
     const double c21 = Quu[9] - l20 * Quu[4], c31 = Quu[13] - l30 * Quu[4];
     const double l21 = c21 * i1, l31 = c31 * i1;
     const double d2 = Quu[10] - l20 * Quu[8] - l21 * c21;
-    const double i2 = 1.0 / d2;
+    const double i2 = rcp_nr(d2);
     const double c32 = Quu[14] - l30 * Quu[8] - l31 * c21;
     const double l32 = c32 * i2;
     const double d3 = Quu[15] - l30 * Quu[12] - l31 * c31 - l32 * c32;
-    const double i3 = 1.0 / d3;
+    const double i3 = rcp_nr(d3);
     double kcol[4], kff[4];
     {
       // K[:, j] = -Quu^-1 Q_xu[j, :]^T ; k = -Quu^-1 Q_u   (ilqr.hh:127-128)
@@ -240,18 +284,33 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
         dst[1] = make_double2(kff[2], kff[3]);
       }
     }
-    // hand V_xx, V_x to the next knot: accumulator layout -> A-operand layout through LDS
-    if (j < 12) {
+    // hand V_xx, V_x to the next knot
+    if constexpr (SYM) {
 #pragma unroll
-      for (int r = 0; r < 3; ++r) Vs[(4 * r + kk) * LD + j] = H[r];
-      if (kk == 0) vxs[j] = vx;
+      for (int kc = 0; kc < 3; ++kc) {
+        va[kc] = (j < 12) ? H[kc] : 0.0;       // V symmetric: accumulator layout == A-operand layout
+        vxl[kc] = __shfl(vx, 4 * kc + kk);     // V_x[r] lives in lanes with j == r
+      }
+    } else {
+      // accumulator layout -> A-operand layout through LDS (a transpose)
+      if (j < 12) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Vs[(4 * r + kk) * LD + j] = H[r];
+        if (kk == 0) vxs[j] = vx;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kc = 0; kc < 3; ++kc) {
+        va[kc] = (j < 12) ? Vs[j * LD + 4 * kc + kk] : 0.0;
+        vxl[kc] = vxs[4 * kc + kk];
+      }
     }
-    __syncthreads();
 #pragma unroll
     for (int kc = 0; kc < 3; ++kc) {
-      va[kc] = (j < 12) ? Vs[j * LD + 4 * kc + kk] : 0.0;
-      vxl[kc] = vxs[4 * kc + kk];
+      m[kc] = m_n[kc];
+      cx[kc] = cx_n[kc];
     }
+    gcj = gcj_n;
   }
 
   if (lane == 0) {

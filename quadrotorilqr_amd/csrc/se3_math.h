@@ -295,6 +295,9 @@ QILQR_HD void discrete_step(const ModelConsts<T> &c, T t[3], T q[4], T v[6], con
   for (int i = 0; i < 6; ++i) v[i] = v[i] + c.dt * acc[i];
 }
 
+template <typename T>
+QILQR_HD void se3_rminus_fast(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T tau[6]);
+
 // ----------------------------------------------------------------- knot record layout
 // What k_linearize hands to k_backward for one knot (doubles):
 //   [  0.. 53] six 3x3 blocks of J_x, row-major:
@@ -319,7 +322,7 @@ template <typename T>
 QILQR_HD T knot_cost(const ModelConsts<T> &c, const T *pt, const T *pd, T dx[12], T du[4]) {
   const T qx[4] = {pt[5], pt[6], pt[7], pt[4]};
   const T qd[4] = {pd[5], pd[6], pd[7], pd[4]};
-  se3_rminus(pt + 1, qx, pd + 1, qd, dx);
+  se3_rminus_fast(pt + 1, qx, pd + 1, qd, dx);  // x (-) x_d; exactly zero at zero error
 #pragma unroll
   for (int i = 0; i < 6; ++i) dx[6 + i] = pt[8 + i] - pd[8 + i];
 #pragma unroll
@@ -482,6 +485,180 @@ QILQR_HD void linearize_knot(const ModelConsts<T> &c, const T *pt, const T *pd, 
   }
 }
 
+// ----------------------------------------------------------------- rollout arithmetic
+// The rollout is one serial chain per trajectory (state -> control -> next state), so its
+// per-knot latency is the solver's critical path.  The functions below compute exactly the
+// quantities of se3_rminus / se3_rplus but (a) with vector identities instead of 3x3 matrices
+// (Jl^-1 t = t - th x t / 2 + c th x (th x t),  R(q) v = v + 2 w (u x v) + 2 u x (u x v)) and
+// (b) with the analytic series of the four scalar functions involved when the relative rotation
+// is moderate, which removes sqrt / atan2 / sincos / divisions from the chain.  manif's
+// small-angle switch (theta^2 <= 1e-10) is kept as is.  All of it is the same function of the
+// same inputs as the dense formulation, to rounding.
+template <typename T>
+QILQR_HD T poly8(const T c[8], T x) {  // Estrin, degree 7
+  const T x2 = x * x, x4 = x2 * x2;
+  const T p01 = c[0] + c[1] * x, p23 = c[2] + c[3] * x, p45 = c[4] + c[5] * x, p67 = c[6] + c[7] * x;
+  return (p01 + p23 * x2) + (p45 + p67 * x2) * x4;
+}
+
+template <typename T>
+struct Series {
+  // in x = theta^2, valid for x <= EXP_MAX (truncation < 1e-19)
+  static constexpr T EXP_MAX = T(0.25);
+  static constexpr T cos_half[8] = {1.0, -0.125, 0.0026041666666666665, -2.170138888888889e-05,
+                                    9.68812003968254e-08, -2.691144455467372e-10, 5.096864498991235e-13,
+                                    -7.001187498614334e-16};
+  static constexpr T sin_half_over[8] = {0.5, -0.020833333333333332, 0.00026041666666666666,
+                                         -1.5500992063492063e-06, 5.382288910934745e-09,
+                                         -1.2232474797578965e-11, 1.9603324996120133e-14,
+                                         -2.333729166204778e-17};
+  static constexpr T jac_a[8] = {0.5, -0.041666666666666664, 0.001388888888888889, -2.48015873015873e-05,
+                                 2.755731922398589e-07, -2.08767569878681e-09, 1.1470745597729725e-11,
+                                 -4.779477332387385e-14};  // (1 - cos th)/th^2
+  static constexpr T jac_b[8] = {0.16666666666666666, -0.008333333333333333, 0.0001984126984126984,
+                                 -2.7557319223985893e-06, 2.505210838544172e-08, -1.6059043836821613e-10,
+                                 7.647163731819816e-13, -2.8114572543455206e-15};  // (th - sin th)/th^3
+  // asin(s)/s in y = s^2, valid for y <= LOG_MAX
+  static constexpr T LOG_MAX = T(0.0625);
+  static constexpr T asin_lo[8] = {1.0, 0.16666666666666666, 0.075, 0.044642857142857144,
+                                   0.030381944444444444, 0.022372159090909092, 0.017352764423076924,
+                                   0.01396484375};
+  static constexpr T asin_hi[8] = {0.011551800896139705, 0.009761609529194078, 0.008390335809616815,
+                                   0.0073125258735988454, 0.006447210311889649, 0.005740037670841924, 0.0, 0.0};
+  // 1/th^2 - (1 + cos th)/(2 th sin th) in x = theta^2, valid for x <= JINV_MAX
+  static constexpr T JINV_MAX = T(0.26);
+  static constexpr T jinv_c[8] = {0.08333333333333333, 0.001388888888888889, 3.306878306878307e-05,
+                                  8.267195767195768e-07, 2.08767569878681e-08, 5.284190138687493e-10,
+                                  1.3382536530684679e-11, 3.3896802963225827e-13};
+};
+
+// R(q) v for a unit quaternion q = (x,y,z,w)
+template <typename T>
+QILQR_HD void quat_rotate(const T q[4], const T v[3], T o[3]) {
+  T t[3], c[3];
+  cross3(q, v, t);
+  t[0] *= 2; t[1] *= 2; t[2] *= 2;
+  cross3(q, t, c);
+  o[0] = v[0] + q[3] * t[0] + c[0];
+  o[1] = v[1] + q[3] * t[1] + c[1];
+  o[2] = v[2] + q[3] * t[2] + c[2];
+}
+
+// tau = Log(X^-1 Y), same value as se3_rminus
+template <typename T>
+QILQR_HD void se3_rminus_fast(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T tau[6]) {
+#if defined(__clang__)
+#pragma clang fp contract(off)  // x (-) x must be exactly zero (cost_test.cc:27-39)
+#endif
+  const T qc[4] = {-qx[0], -qx[1], -qx[2], qx[3]};
+  const T d[3] = {ty[0] - tx[0], ty[1] - tx[1], ty[2] - tx[2]};
+  T td[3], qd[4];
+  quat_rotate(qc, d, td);
+  quat_mul(qc, qy, qd);
+  const T n = qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3];
+  if (fabs(n - T(1)) > Eps<T>::manif) {
+    const T sc = T(2) / (T(1) + n);
+    qd[0] *= sc; qd[1] *= sc; qd[2] *= sc; qd[3] *= sc;
+  }
+  const T s2 = qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2];
+  // so3_log: theta = coeff * q_v
+  T coeff;
+  if (!(s2 > Eps<T>::manif)) {
+    coeff = T(2);
+  } else if (qd[3] > T(0) && s2 <= Series<T>::LOG_MAX) {
+    const T y4 = (s2 * s2) * (s2 * s2);
+    coeff = T(2) * (poly8(Series<T>::asin_lo, s2) + poly8(Series<T>::asin_hi, s2) * (y4 * y4));
+  } else {
+    const T s = sqrt(s2);
+    const T w = qd[3];
+    coeff = T(2) * ((w < T(0)) ? atan2(-s, -w) : atan2(s, w)) / s;
+  }
+  // so3_ljacinv(theta) t = t - theta x t / 2 + c theta x (theta x t), with its own switch on theta^2
+  const T th2 = coeff * coeff * s2;
+  T c;
+  if (!(th2 > Eps<T>::manif)) {
+    c = T(0);
+  } else if (th2 <= Series<T>::JINV_MAX) {
+    c = poly8(Series<T>::jinv_c, th2);
+  } else {
+    // manif's closed form, evaluated as manif does (it is ill-conditioned near theta = pi, where
+    // only the same evaluation order reproduces the same digits)
+    const T theta = sqrt(th2);
+    c = T(1) / th2 - (T(1) + cos(theta)) / (T(2) * theta * sin(theta));
+  }
+  const T th[3] = {qd[0] * coeff, qd[1] * coeff, qd[2] * coeff};
+  T w1[3], w2[3];
+  cross3(th, td, w1);
+  cross3(th, w1, w2);
+  tau[0] = td[0] - T(0.5) * w1[0] + c * w2[0];
+  tau[1] = td[1] - T(0.5) * w1[1] + c * w2[1];
+  tau[2] = td[2] - T(0.5) * w1[2] + c * w2[2];
+  tau[3] = th[0]; tau[4] = th[1]; tau[5] = th[2];
+}
+
+// (t, q) <- (t, q) * Exp(tau), same value as se3_rplus
+template <typename T>
+QILQR_HD void se3_rplus_fast(T t[3], T q[4], const T tau[6]) {
+  const T *rho = tau, *th = tau + 3;
+  const T th2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2];
+  T ch, sh, a, b;
+  if (!(th2 > Eps<T>::manif)) {
+    ch = T(1); sh = T(0.5); a = T(0.5); b = T(0);
+  } else if (th2 <= Series<T>::EXP_MAX) {
+    ch = poly8(Series<T>::cos_half, th2);
+    sh = poly8(Series<T>::sin_half_over, th2);
+    a = poly8(Series<T>::jac_a, th2);
+    b = poly8(Series<T>::jac_b, th2);
+  } else {
+    const T theta = sqrt(th2);
+    const T ha = T(0.5) * theta;
+    const T s = sin(ha);
+    ch = cos(ha);
+    sh = s / theta;
+    a = (T(1) - cos(theta)) / th2;
+    b = (theta - sin(theta)) / (th2 * theta);
+  }
+  const T qe[4] = {sh * th[0], sh * th[1], sh * th[2], ch};
+  T w1[3], w2[3], p[3], Rp[3], qo[4];
+  cross3(th, rho, w1);
+  cross3(th, w1, w2);
+  p[0] = rho[0] + a * w1[0] + b * w2[0];
+  p[1] = rho[1] + a * w1[1] + b * w2[1];
+  p[2] = rho[2] + a * w1[2] + b * w2[2];
+  quat_rotate(q, p, Rp);
+  quat_mul(q, qe, qo);
+  const T n = qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3];
+  if (fabs(n - T(1)) > Eps<T>::manif) {
+    const T sc = T(2) / (T(1) + n);
+    qo[0] *= sc; qo[1] *= sc; qo[2] *= sc; qo[3] *= sc;
+  }
+  t[0] += Rp[0]; t[1] += Rp[1]; t[2] += Rp[2];
+  q[0] = qo[0]; q[1] = qo[1]; q[2] = qo[2]; q[3] = qo[3];
+}
+
+// body acceleration without forming the whole rotation matrix (only R^T e_z is needed)
+template <typename T>
+QILQR_HD void body_acceleration_fast(const ModelConsts<T> &c, const T q[4], const T v[6], const T u[4], T acc[6]) {
+  const T x = q[0], y = q[1], z = q[2], w = q[3];
+  const T tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const T r6 = tz * x - ty * w, r7 = tz * y + tx * w, r8 = T(1) - (tx * x + ty * y);
+  const T usum = ((u[0] + u[1]) + u[2]) + u[3];
+  acc[0] = -c.g * r6;
+  acc[1] = -c.g * r7;
+  acc[2] = -c.g * r8 + usum / c.mass;
+  T M[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    M[i] = c.arms[4 * i] * u[0] + c.arms[4 * i + 1] * u[1] + c.arms[4 * i + 2] * u[2] + c.arms[4 * i + 3] * u[3];
+  const T *om = v + 3;
+  T Iw[3], wIw[3], rhs[3];
+  mat3_vec(c.inertia, om, Iw);
+  cross3(om, Iw, wIw);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) rhs[i] = M[i] - wIw[i];
+  mat3_vec(c.inertia_inv, rhs, acc + 3);
+}
+
 // closed-loop rollout of one problem (ilqr.hh:149-172).  traj/out are n x 18, gains n x 52.
 template <typename T>
 QILQR_HD void rollout_problem(const ModelConsts<T> &c, const T *traj, const T *gains, T alpha,
@@ -497,17 +674,21 @@ QILQR_HD void rollout_problem(const ModelConsts<T> &c, const T *traj, const T *g
     // dx = state (-) x_i
     T dx[12];
     const T qi[4] = {pt[5], pt[6], pt[7], pt[4]};
-    se3_rminus(t, q, pt + 1, qi, dx);
+    se3_rminus_fast(t, q, pt + 1, qi, dx);
 #pragma unroll
     for (int a = 0; a < 6; ++a) dx[6 + a] = v[a] - pt[8 + a];
-    // u = (u_i + alpha k) + K dx
+    // u = (u_i + alpha k) + K dx; K dx in three independent partial sums per row
     T u[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      T kd = T(0);
+      T k0 = T(0), k1 = T(0), k2 = T(0);
 #pragma unroll
-      for (int col = 0; col < 12; ++col) kd += g[4 + col * 4 + a] * dx[col];
-      u[a] = (pt[14 + a] + alpha * g[a]) + kd;
+      for (int col = 0; col < 4; ++col) {
+        k0 += g[4 + col * 4 + a] * dx[col];
+        k1 += g[4 + (col + 4) * 4 + a] * dx[col + 4];
+        k2 += g[4 + (col + 8) * 4 + a] * dx[col + 8];
+      }
+      u[a] = (pt[14 + a] + alpha * g[a]) + ((k0 + k1) + k2);
     }
     T *o = out + (long)i * 18;
     o[0] = pt[0];
@@ -517,7 +698,15 @@ QILQR_HD void rollout_problem(const ModelConsts<T> &c, const T *traj, const T *g
     for (int a = 0; a < 6; ++a) o[8 + a] = v[a];
 #pragma unroll
     for (int a = 0; a < 4; ++a) o[14 + a] = u[a];
-    if (i + 1 < n) discrete_step(c, t, q, v, u);  // the reference's step after the last knot is discarded
+    if (i + 1 < n) {  // the reference's step after the last knot is computed and discarded
+      T acc[6], tau[6];
+      body_acceleration_fast(c, q, v, u, acc);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) tau[a] = c.dt * v[a];  // pose integrates with the OLD velocity
+      se3_rplus_fast(t, q, tau);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) v[a] = v[a] + c.dt * acc[a];
+    }
   }
 }
 

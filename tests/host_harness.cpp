@@ -50,6 +50,17 @@ void hh_rollout(const ModelConsts<double> *c, const double *traj, const double *
                 int n) {
   rollout_problem(*c, traj, gains, alpha, out, n);
 }
+// pose (-) pose and pose (+) tangent through the rollout's fast arithmetic; poses are [t ; q(w,x,y,z)]
+void hh_rminus_fast(const double *Y, const double *X, double *tau) {
+  const double qy[4] = {Y[4], Y[5], Y[6], Y[3]}, qx[4] = {X[4], X[5], X[6], X[3]};
+  se3_rminus_fast(Y, qy, X, qx, tau);
+}
+void hh_rplus_fast(const double *Tin, const double *tau, double *Tout) {
+  double t[3] = {Tin[0], Tin[1], Tin[2]}, q[4] = {Tin[4], Tin[5], Tin[6], Tin[3]};
+  se3_rplus_fast(t, q, tau);
+  Tout[0] = t[0]; Tout[1] = t[1]; Tout[2] = t[2];
+  Tout[3] = q[3]; Tout[4] = q[0]; Tout[5] = q[1]; Tout[6] = q[2];
+}
 // dense J_x (12x12) and J_u (12x4) rebuilt from a knot record through m_source()
 void hh_dense_jacobians(const ModelConsts<double> *c, const double *rec, double *Jx, double *Ju) {
   for (int r = 0; r < 12; ++r)

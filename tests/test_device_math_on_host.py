@@ -136,3 +136,65 @@ def test_backward_dataflow_matches_oracle(hh, seed, dense):
     g_ref, t_ref = s.backwards_pass(traj)
     np.testing.assert_allclose(terms, t_ref, rtol=1e-10)
     np.testing.assert_allclose(gains, g_ref, rtol=1e-9, atol=1e-10 * np.abs(g_ref).max())
+
+
+def _angles():
+    # straddle every branch threshold of the fast arithmetic: manif's 1e-10 switches, the series
+    # limits (s^2 <= 0.0625 <=> angle <= 0.5054; theta^2 <= 0.26 / 0.25), the w < 0 log branch, pi
+    out = [0.0, 1e-7, 0.99e-5, 1.01e-5, 1e-3, 0.1, 0.4999, 0.5001, 0.505, 0.506, 0.5098, 0.5100, 0.51, 1.0, 2.0,
+           3.0, np.pi - 1e-6, np.pi, 3.2, 4.0, 6.0]
+    return out
+
+
+def test_fast_rminus_matches_oracle_across_branches(hh):
+    r = np.random.default_rng(0)
+    for ang in _angles():
+        for _ in range(4):
+            ax = r.standard_normal(3)
+            ax /= np.linalg.norm(ax)
+            X = orc.se3_exp(np.concatenate([r.uniform(-2, 2, 3), r.uniform(-1.5, 1.5, 3)]))
+            Y = orc.se3_compose(X, orc.se3_exp(np.concatenate([r.uniform(-1, 1, 3), ax * ang])))
+            ref = orc.se3_log(orc.se3_compose(orc.se3_inverse(X), Y))
+            got = np.zeros(6)
+            hh.hh_rminus_fast(P(Y), P(X), P(got))
+            # (1 + cos)/(2 theta sin) is 0/0 at pi: manif's own formula loses digits there
+            tol = 1e-8 if abs(ang - np.pi) < 0.2 else 2e-13
+            np.testing.assert_allclose(got, ref, rtol=1e-12, atol=tol * max(1.0, np.abs(ref).max()), err_msg=str(ang))
+    X = orc.se3_exp(np.array([0.3, -1.0, 2.0, 0.7, -0.2, 1.1]))
+    got = np.ones(6)
+    hh.hh_rminus_fast(P(X), P(X), P(got))
+    np.testing.assert_array_equal(got, 0.0)  # x (-) x == 0 exactly (cost_test.cc:27-39)
+
+
+def test_fast_rplus_matches_oracle_across_branches(hh):
+    r = np.random.default_rng(1)
+    for ang in _angles():
+        for _ in range(4):
+            ax = r.standard_normal(3)
+            ax /= np.linalg.norm(ax)
+            X = orc.se3_exp(np.concatenate([r.uniform(-2, 2, 3), r.uniform(-1.5, 1.5, 3)]))
+            tau = np.concatenate([r.uniform(-1, 1, 3), ax * ang])
+            ref = orc.se3_compose(X, orc.se3_exp(tau))
+            got = np.zeros(7)
+            hh.hh_rplus_fast(P(X), P(tau), P(got))
+            # manif's closed forms (1 - cos)/th^2 and (th - sin)/th^3 cancel catastrophically just above
+            # their 1e-10 switch (relative error ~ 1e-16/th^2); the series used on the device do not
+            tol = 2e-13 + (4e-16 / ang if ang > 1e-5 else 0.0)
+            np.testing.assert_allclose(got, ref, rtol=0, atol=tol * max(1.0, np.abs(ref).max()), err_msg=str(ang))
+
+
+def test_rollout_near_nominal_matches_oracle(hh):
+    """rollouts of a converging solve: small relative rotations, i.e. the series branches"""
+    cfg = pb.config2(B=2, N=40)
+    c = consts(hh, cfg["model"], cfg["Q"], cfg["R"], cfg["dt"])
+    s = orc.OracleSolver(orc.model_params(**cfg["model"]), cfg["Q"], cfg["R"], cfg["desired"], cfg["dt"],
+                         orc.options(**cfg["options"]))
+    traj = cfg["init"][1]
+    for it in range(4):
+        gains, _ = s.backwards_pass(traj)
+        for alpha in (1.0, 0.5):
+            out = np.zeros_like(traj)
+            hh.hh_rollout(P(c), P(traj), P(gains), C.c_double(alpha), P(out), C.c_int(len(traj)))
+            ref = s.forward_sim(traj, gains, alpha)
+            np.testing.assert_allclose(out, ref, rtol=1e-10, atol=1e-11)
+        traj = s.forward_sim(traj, gains, 1.0)
