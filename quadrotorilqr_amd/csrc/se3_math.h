@@ -76,6 +76,9 @@ QILQR_HD void quat_to_R(const T q[4], T R[9]) {
 }
 template <typename T>
 QILQR_HD void quat_mul(const T a[4], const T b[4], T o[4]) {
+#if defined(__clang__)
+#pragma clang fp contract(off)  // conj(q) * q must give an exactly zero vector part (x (-) x == 0)
+#endif
   const T ax = a[0], ay = a[1], az = a[2], aw = a[3];
   const T bx = b[0], by = b[1], bz = b[2], bw = b[3];
   o[3] = aw * bw - ax * bx - ay * by - az * bz;

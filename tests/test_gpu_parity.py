@@ -188,7 +188,7 @@ def test_symmetric_fast_path_agrees_with_general_path():
     gf, tf = fast.backwards_pass(trajs)
     gg, tg = gen.backwards_pass(trajs)
     np.testing.assert_allclose(tf, tg, rtol=1e-11)
-    np.testing.assert_allclose(gf, gg, rtol=1e-9, atol=1e-11 * np.abs(gg).max())
+    np.testing.assert_allclose(gf, gg, rtol=1e-7, atol=1e-9 * np.abs(gg).max())
     of, og = fast.solve_batch(cfg["init"]), gen.solve_batch(cfg["init"])
     np.testing.assert_array_equal(of["iters"], og["iters"])
     np.testing.assert_allclose(of["cost"], og["cost"], rtol=1e-10)
@@ -283,15 +283,29 @@ def test_per_problem_desired_trajectories():
 
 # ------------------------------------------------------------------ failure paths
 def test_line_search_exhaustion():
-    # the demo at 200 knots exhausts the line search
-    cfg = pb.config1(20.0)
+    """ilqr.hh:191-193.  Made deterministic by asking for 10x the predicted reduction
+    (desired_reduction_frac = 10): no step can satisfy the Armijo test, so iteration 1 exhausts its
+    ls_max_iters trials in every implementation."""
+    cfg = pb.config2(B=5, N=20)
+    cfg["options"] = dict(cfg["options"], desired_reduction_frac=10.0, ls_max_iters=7)
     s = capi.from_config(cfg)
-    with pytest.raises(RuntimeError, match=r"Reached maximum number of line search iterations, 100\n"):
+    with pytest.raises(RuntimeError, match=r"Reached maximum number of line search iterations, 7\n"):
         s.solve(cfg["init"][0])
     out = s.solve_batch(cfg["init"])
-    ref = oracle_for(cfg).solve(cfg["init"][0])
-    assert out["status"][0] == capi.STATUS_LINE_SEARCH_FAILED == ref["status"]
-    assert out["n_fwd"][0] - out["iters"][0] >= 100 - 1
+    ref = oracle_for(cfg).solve_batch(cfg["init"])
+    assert (out["status"] == capi.STATUS_LINE_SEARCH_FAILED).all() and (ref["status"] == 3).all()
+    np.testing.assert_array_equal(out["iters"], 1)       # iteration 0 is taken unconditionally
+    np.testing.assert_array_equal(out["n_fwd"], 1 + 7)
+    np.testing.assert_array_equal(out["n_bwd"], 2)
+    # the trajectory handed back is the last accepted one (the reference throws instead)
+    np.testing.assert_allclose(out["traj"], ref["traj"], atol=1e-9)
+    np.testing.assert_allclose(out["cost"], ref["cost"], rtol=1e-10)
+    # stand-alone line_search reports the same
+    traj = s.forward_sim(cfg["init"], np.zeros((5, 20, 52)), 1.0)
+    cost = s.cost_trajectory(traj)
+    gains, terms = s.backwards_pass(traj)
+    ls = s.line_search(traj, cost, gains, terms)
+    assert (ls["status"] == capi.STATUS_LINE_SEARCH_FAILED).all()
 
 
 def test_longer_than_desired_is_index_error():
