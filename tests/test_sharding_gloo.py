@@ -1,0 +1,74 @@
+"""The N>1 path on CPU: two processes (gloo), contiguous shards of one batch, the single gather
+to rank 0.  The per-shard work here is a stand-in (a deterministic function of the shard's
+inputs) because the solver itself needs a GPU; what is checked is the sharding arithmetic, the
+shard-independence of the problem generator and the gather with ragged shards."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from quadrotorilqr_amd import problems as pb, sharding  # noqa: E402
+
+
+def test_shard_ranges_partition_the_batch():
+    for B in (1, 7, 8, 1024, 65536, 1001):
+        for world in (1, 2, 3, 8):
+            r = [sharding.shard_range(B, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [hi - lo for lo, hi in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_generator_is_shard_independent():
+    whole = pb.config2(B=37, N=5, seed=4)["init"]
+    lo, hi = sharding.shard_range(37, 1, 3)
+    part = pb.config2(B=hi - lo, N=5, seed=4, b0=lo)["init"]
+    np.testing.assert_array_equal(whole[lo:hi], part)
+
+
+def _worker(rank, world, port, B, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = sharding.shard_range(B, rank, world)
+    init = pb.config2(B=hi - lo, N=6, seed=4, b0=lo)["init"]
+    shard_out = torch.from_numpy(init * 2.0 + 1.0)            # stand-in for the shard's solve
+    shard_cost = torch.from_numpy(init[:, :, 1:4].sum(axis=(1, 2)))
+    sizes = [sharding.shard_range(B, k, world)[1] - sharding.shard_range(B, k, world)[0] for k in range(world)]
+    traj = sharding.gather_to_root(shard_out, sizes)
+    cost = sharding.gather_to_root(shard_cost, sizes)
+    if rank == 0:
+        q.put((traj.numpy(), cost.numpy()))
+    else:
+        assert traj is None and cost is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [10, 11])  # even and ragged shards
+def test_two_rank_gather_reassembles_the_batch(B):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    traj, cost = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    whole = pb.config2(B=B, N=6, seed=4)["init"]
+    np.testing.assert_array_equal(traj, whole * 2.0 + 1.0)
+    np.testing.assert_array_equal(cost, whole[:, :, 1:4].sum(axis=(1, 2)))
