@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--knots", type=int, default=100)
     ap.add_argument("--sync-every", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP events around the kernels (roofline = null)")
     args = ap.parse_args()
 
     import torch
@@ -60,7 +61,7 @@ def main():
 
     B, N = args.batch, args.knots
     cfg = pb.config2(B=B, N=N, seed=2, b0=rank * B)  # counter-based generator: shard-independent
-    solver = capi.from_config(cfg, device=dev.index, profile=True, sync_every=args.sync_every)
+    solver = capi.from_config(cfg, device=dev.index, profile=not args.no_profile, sync_every=args.sync_every)
 
     init = torch.from_numpy(cfg["init"]).to(dev)
     out_traj = torch.empty_like(init)
@@ -110,7 +111,7 @@ def main():
         }
         dom = max(kern, key=lambda k: kern[k]["ms"])
         kd = kern[dom]
-        sec = kd["ms"] * 1e-3
+        sec = max(kd["ms"], 1e-9) * 1e-3
         tflops = kd["flops"] / sec / 1e12
         gbs = kd["bytes"] / sec / 1e9
         roofline = {

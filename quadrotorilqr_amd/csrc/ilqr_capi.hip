@@ -49,6 +49,7 @@ struct qilqr_solver {
   qilqr_device_config dev;
   int n_desired = 0;
   bool symmetric = false;  // Q == Q^T and R == R^T exactly: transpose-free backward kernel
+  RecLayout layout;        // knot record layout chosen from the structure of Q
   double *d_desired = nullptr;  // shared desired trajectory
   // workspace
   long cap_B = 0, cap_n = 0;
@@ -117,10 +118,11 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
   free_workspace(s);
   const long cB = B > s->cap_B ? B : s->cap_B, cn = n > s->cap_n ? n : s->cap_n;
   BatchState &st = s->st;
+  st.layout = s->layout;
   int rc;
   for (int k = 0; k < 2; ++k) {
     if ((rc = dalloc(s, &st.traj[k], (size_t)cB * cn * 18))) return rc;
-    if ((rc = dalloc(s, &st.lin[k], (size_t)cB * cn * LIN_STRIDE))) return rc;
+    if ((rc = dalloc(s, &st.lin[k], (size_t)cB * cn * s->layout.stride))) return rc;
     if ((rc = dalloc(s, &st.knot_cost[k], (size_t)cB * cn))) return rc;
   }
   if ((rc = dalloc(s, &st.gains, (size_t)cB * cn * 52))) return rc;
@@ -298,6 +300,15 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   for (int i = 0; i < 4; ++i)
     for (int k = 0; k < i; ++k) s->symmetric = s->symmetric && (R[i * 4 + k] == R[k * 4 + i]);
   if (dc.force_general) s->symmetric = false;
+  {
+    bool qsym = true, ur0 = true;
+    for (int i = 0; i < 12; ++i)
+      for (int k = 0; k < 12; ++k) {
+        qsym = qsym && (Q[i * 12 + k] == Q[k * 12 + i]);
+        if (i < 6 && k >= 6) ur0 = ur0 && (Q[i * 12 + k] == 0.0);
+      }
+    s->layout = make_layout(qsym && !dc.force_general, ur0);
+  }
   s->n_desired = n_desired;
 
   hipError_t e = hipSetDevice(s->device);

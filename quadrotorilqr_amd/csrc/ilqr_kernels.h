@@ -30,7 +30,8 @@ struct SolveParams {
 // all device pointers; [B] unless noted
 struct BatchState {
   double *traj[2];       // [B][n][18]  current / candidate trajectories
-  double *lin[2];        // [B][n][LIN_STRIDE] knot records of traj[k]
+  double *lin[2];        // [B][n][layout.stride] knot records of traj[k]
+  RecLayout layout;
   double *knot_cost[2];  // [B][n]
   double *gains;         // [B][n][52]
   const double *desired; // [n_desired][18] shared, or [B][n][18]
@@ -73,9 +74,9 @@ __global__ __launch_bounds__(128) void k_linearize(ModelConsts<double> c, BatchS
   const int buf = st.cur[b] ^ which;
   const double *pt = st.traj[buf] + ((long)b * n + i) * 18;
   const double *pd = st.desired + (long)b * st.desired_stride + (long)i * 18;
-  double *rec = st.lin[buf] + ((long)b * n + i) * LIN_STRIDE;
-  linearize_knot(c, pt, pd, rec);
-  st.knot_cost[buf][(long)b * n + i] = rec[LIN_COST];
+  double *rec = st.lin[buf] + ((long)b * n + i) * st.layout.stride;
+  linearize_knot(c, st.layout, pt, pd, rec);
+  st.knot_cost[buf][(long)b * n + i] = rec[st.layout.off_cost];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -137,7 +138,8 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   if (!force && (fl & (F_ACTIVE | F_SEARCH)) != F_ACTIVE) return;  // wave-uniform
   const int lane = threadIdx.x;
   const int j = lane & 15, kk = lane >> 4;
-  const double *lin = st.lin[st.cur[b]] + (long)b * n * LIN_STRIDE;
+  const RecLayout L = st.layout;
+  const double *lin = st.lin[st.cur[b]] + (long)b * n * L.stride;
   double *gains = st.gains + (long)b * n * 52;
 
   constexpr int LD = 17;  // padded leading dimension: column reads of a row-major tile
@@ -153,8 +155,12 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   for (int kc = 0; kc < 3; ++kc) moff[kc] = m_source(4 * kc + kk, j, c.Bu, &mconst[kc]);
   // C_xx in accumulator layout: register r <-> row 4 r + kk, column j
   int coff[3];
+  double cconst[3];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) coff[r] = (j < 12) ? LIN_CXX + (4 * r + kk) * 12 + j : -1;
+  for (int r = 0; r < 3; ++r) {
+    cconst[r] = 0.0;
+    coff[r] = (j < 12) ? cxx_source(L, 4 * r + kk, j, c.Q, &cconst[r]) : -1;
+  }
   // register 3 <-> row 12 + kk: C_uu = 2 R (cost.hh:55) in columns 12..15
   const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] : 0.0;
 
@@ -165,23 +171,23 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   // software pipeline: the operands of knot i-1 are requested before the chain of knot i starts
   double m[3], cx[3], gcj;
   {
-    const double *rec = lin + (long)(n - 1) * LIN_STRIDE;
+    const double *rec = lin + (long)(n - 1) * L.stride;
 #pragma unroll
     for (int kc = 0; kc < 3; ++kc) m[kc] = (moff[kc] >= 0) ? rec[moff[kc]] : mconst[kc];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) cx[r] = (coff[r] >= 0) ? rec[coff[r]] : 0.0;
-    gcj = rec[LIN_G + j];
+    for (int r = 0; r < 3; ++r) cx[r] = (coff[r] >= 0) ? rec[coff[r]] : cconst[r];
+    gcj = rec[L.off_g + j];
   }
 
   for (int i = n - 1; i >= 0; --i) {
     double m_n[3], cx_n[3], gcj_n;
     {
-      const double *rec = lin + (long)(i > 0 ? i - 1 : 0) * LIN_STRIDE;
+      const double *rec = lin + (long)(i > 0 ? i - 1 : 0) * L.stride;
 #pragma unroll
       for (int kc = 0; kc < 3; ++kc) m_n[kc] = (moff[kc] >= 0) ? rec[moff[kc]] : mconst[kc];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) cx_n[r] = (coff[r] >= 0) ? rec[coff[r]] : 0.0;
-      gcj_n = rec[LIN_G + j];
+      for (int r = 0; r < 3; ++r) cx_n[r] = (coff[r] >= 0) ? rec[coff[r]] : cconst[r];
+      gcj_n = rec[L.off_g + j];
     }
 
     // T = V M

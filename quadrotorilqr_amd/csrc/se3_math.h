@@ -302,7 +302,9 @@ template <typename T>
 QILQR_HD void se3_rminus_fast(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T tau[6]);
 
 // ----------------------------------------------------------------- knot record layout
-// What k_linearize hands to k_backward for one knot (doubles):
+// What k_linearize hands to k_backward for one knot (doubles).  Only entries that are not
+// structurally constant are stored; the record is the dominant HBM traffic of the solver, so its
+// size is chosen per problem class (RecLayout, built once on the host):
 //   [  0.. 53] six 3x3 blocks of J_x, row-major:
 //              0: E^T            (rows 0-2 x cols 0-2 and rows 3-5 x cols 3-5)
 //              1: hat(-E^T p)E^T (rows 0-2 x cols 3-5)            Ad(Exp(tau)^-1)
@@ -310,15 +312,45 @@ QILQR_HD void se3_rminus_fast(const T ty[3], const T qy[4], const T tx[3], const
 //              3: dt Q(-tau)     (rows 0-2 x cols 9-11)
 //              4: -dt g hat(R^T e_z)                (rows 6-8 x cols 3-5)
 //              5: I - dt I^-1 (hat(w) I - hat(I w)) (rows 9-11 x cols 9-11)
-//   [ 54..197] C_xx (12x12 row-major)       cost.hh:52
-//   [198..213] C_x (12), C_u (4)            cost.hh:51,54
-//   [214]      knot cost                    cost.hh:47-48
-//   [215]      pad
+//   [off_cxx ..] C_xx = 2 J^T Q J (cost.hh:52), J = blkdiag(Jri, I6):
+//              general Q   : all 144 entries, row-major
+//              symmetric Q : upper-left 6x6 block packed upper-triangular (21), then the upper-right
+//                            6x6 block (36) unless Q[0:6,6:12] == 0 (then it is zero and not stored);
+//                            the lower-right block is the constant 2 Q[6:12,6:12]
+//   [off_g ..+15] C_x (12), C_u (4)         cost.hh:51,54
+//   [off_cost]    knot cost                 cost.hh:47-48
 constexpr int LIN_BLK = 0;
-constexpr int LIN_CXX = 54;
-constexpr int LIN_G = 198;
-constexpr int LIN_COST = 214;
-constexpr int LIN_STRIDE = 216;
+constexpr int LIN_MAX_STRIDE = 216;
+
+struct RecLayout {
+  int sym;      // Q == Q^T exactly
+  int ur_zero;  // sym and Q[0:6, 6:12] == 0
+  int off_cxx, off_g, off_cost, stride;
+};
+QILQR_HD RecLayout make_layout(bool sym, bool ur_zero) {
+  RecLayout L;
+  L.sym = sym ? 1 : 0;
+  L.ur_zero = (sym && ur_zero) ? 1 : 0;
+  L.off_cxx = 54;
+  const int ncxx = !sym ? 144 : (L.ur_zero ? 21 : 57);
+  L.off_g = L.off_cxx + ncxx;
+  L.off_cost = L.off_g + 16;
+  L.stride = (L.off_cost + 1 + 1) & ~1;  // even: records stay 16-byte aligned
+  return L;
+}
+QILQR_HD int sym6_index(int i, int j) {  // i <= j < 6, packed upper triangle, row-major
+  return i * 6 - (i * (i - 1)) / 2 + (j - i);
+}
+// where C_xx[row][col] (row, col < 12) lives in a record: offset, or -1 with *cst = the constant
+QILQR_HD int cxx_source(const RecLayout &L, int row, int col, const double *Q, double *cst) {
+  *cst = 0.0;
+  if (!L.sym) return L.off_cxx + row * 12 + col;
+  const int i = row < col ? row : col, j = row < col ? col : row;
+  if (j < 6) return L.off_cxx + sym6_index(i, j);
+  if (i < 6) return L.ur_zero ? -1 : L.off_cxx + 21 + i * 6 + (j - 6);
+  *cst = 2.0 * Q[row * 12 + col];
+  return -1;
+}
 
 // knot value of the cost only (cost.hh:36-48); pt/pd = 18-double knots
 template <typename T>
@@ -352,7 +384,7 @@ QILQR_HD T knot_cost(const ModelConsts<T> &c, const T *pt, const T *pd, T dx[12]
 // Full linearisation of one knot: dynamics Jacobian blocks (quadrotor_model.cc:33-49, 84-119,
 // 174-200, 266-276) and cost differentials (cost.hh:36-61), written to rec[LIN_STRIDE].
 template <typename T>
-QILQR_HD void linearize_knot(const ModelConsts<T> &c, const T *pt, const T *pd, T *rec) {
+QILQR_HD void linearize_knot(const ModelConsts<T> &c, const RecLayout &L, const T *pt, const T *pd, T *rec) {
   const T q[4] = {pt[5], pt[6], pt[7], pt[4]};
   const T *v = pt + 8;
   // ---- dynamics: tau = dt v ; E = Exp(tau) = (p, qe)
@@ -413,8 +445,7 @@ QILQR_HD void linearize_knot(const ModelConsts<T> &c, const T *pt, const T *pd, 
   // ---- cost: dx = x (-) x_d, J = blkdiag(Jri(tau_c), I6), Jri = [[a, b],[0, a]]
   T dx[12], du[4];
   const T cost = knot_cost(c, pt, pd, dx, du);
-  rec[LIN_COST] = cost;
-  rec[LIN_COST + 1] = T(0);
+  rec[L.off_cost] = cost;
   T Jri[36];
   {
     T Li[9], a[9], Qm[9], aq[9], b[9];
@@ -449,42 +480,76 @@ QILQR_HD void linearize_knot(const ModelConsts<T> &c, const T *pt, const T *pd, 
       T s = T(0);
 #pragma unroll
       for (int r = 0; r < 6; ++r) s += wq[r] * Jri[6 * r + j];
-      rec[LIN_G + j] = s;
+      rec[L.off_g + j] = s;
     }
 #pragma unroll
-    for (int j = 6; j < 12; ++j) rec[LIN_G + j] = wq[j];
+    for (int j = 6; j < 12; ++j) rec[L.off_g + j] = wq[j];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       T s = T(0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) s += (T(2) * du[i]) * c.R[i * 4 + j];
-      rec[LIN_G + 12 + j] = s;
+      rec[L.off_g + 12 + j] = s;
     }
   }
   // C_xx = 2 J^T Q J, column by column: P[:,j] = Q J[:,j], C_xx[:,j] = 2 J^T P[:,j]
-  for (int j = 0; j < 12; ++j) {
-    T P[12];
-    if (j < 6) {
+  if (!L.sym) {
+    for (int j = 0; j < 12; ++j) {
+      T P[12];
+      if (j < 6) {
 #pragma unroll
-      for (int r = 0; r < 12; ++r) {
+        for (int r = 0; r < 12; ++r) {
+          T s = T(0);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) s += c.Q[r * 12 + k] * Jri[6 * k + j];
+          P[r] = s;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 12; ++r) P[r] = c.Q[r * 12 + j];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        T s = T(0);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s += Jri[6 * r + i] * P[r];
+        rec[L.off_cxx + i * 12 + j] = T(2) * s;
+      }
+#pragma unroll
+      for (int i = 6; i < 12; ++i) rec[L.off_cxx + i * 12 + j] = T(2) * P[i];
+    }
+  } else {
+    // symmetric Q: only the upper triangle of the 6x6 pose block and (unless it vanishes) the
+    // pose x velocity block vary from knot to knot
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      T P[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
         T s = T(0);
 #pragma unroll
         for (int k = 0; k < 6; ++k) s += c.Q[r * 12 + k] * Jri[6 * k + j];
         P[r] = s;
       }
-    } else {
 #pragma unroll
-      for (int r = 0; r < 12; ++r) P[r] = c.Q[r * 12 + j];
+      for (int i = 0; i <= j; ++i) {
+        T s = T(0);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s += Jri[6 * r + i] * P[r];
+        rec[L.off_cxx + sym6_index(i, j)] = T(2) * s;
+      }
     }
+    if (!L.ur_zero) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      T s = T(0);
+      for (int j = 6; j < 12; ++j)
 #pragma unroll
-      for (int r = 0; r < 6; ++r) s += Jri[6 * r + i] * P[r];
-      rec[LIN_CXX + i * 12 + j] = T(2) * s;
+        for (int i = 0; i < 6; ++i) {
+          T s = T(0);
+#pragma unroll
+          for (int r = 0; r < 6; ++r) s += Jri[6 * r + i] * c.Q[r * 12 + j];
+          rec[L.off_cxx + 21 + i * 6 + (j - 6)] = T(2) * s;
+        }
     }
-#pragma unroll
-    for (int i = 6; i < 12; ++i) rec[LIN_CXX + i * 12 + j] = T(2) * P[i];
   }
 }
 

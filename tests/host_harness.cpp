@@ -41,10 +41,38 @@ int hh_make_consts(double mass, const double *inertia, double arm, double ttr, d
   return make_model_consts(mass, inertia, arm, ttr, g, Q, R, dt, out) ? 0 : 1;
 }
 int hh_consts_size() { return (int)sizeof(ModelConsts<double>); }
-int hh_lin_stride() { return LIN_STRIDE; }
+int hh_lin_stride() { return LIN_MAX_STRIDE; }
+// layout chosen exactly as qilqr_create does; out = {sym, ur_zero, off_cxx, off_g, off_cost, stride}
+void hh_layout(const ModelConsts<double> *c, int force_general, int *out) {
+  bool qsym = true, ur0 = true;
+  for (int i = 0; i < 12; ++i)
+    for (int k = 0; k < 12; ++k) {
+      qsym = qsym && (c->Q[i * 12 + k] == c->Q[k * 12 + i]);
+      if (i < 6 && k >= 6) ur0 = ur0 && (c->Q[i * 12 + k] == 0.0);
+    }
+  const RecLayout L = make_layout(qsym && !force_general, ur0);
+  out[0] = L.sym; out[1] = L.ur_zero; out[2] = L.off_cxx; out[3] = L.off_g; out[4] = L.off_cost; out[5] = L.stride;
+}
+static RecLayout layout_from(const int *v) {
+  RecLayout L;
+  L.sym = v[0]; L.ur_zero = v[1]; L.off_cxx = v[2]; L.off_g = v[3]; L.off_cost = v[4]; L.stride = v[5];
+  return L;
+}
+// dense C_xx (12x12) rebuilt from a record through cxx_source()
+void hh_dense_cxx(const ModelConsts<double> *c, const int *lay, const double *rec, double *Cxx) {
+  const RecLayout L = layout_from(lay);
+  for (int r = 0; r < 12; ++r)
+    for (int col = 0; col < 12; ++col) {
+      double cst;
+      const int off = cxx_source(L, r, col, c->Q, &cst);
+      Cxx[r * 12 + col] = off >= 0 ? rec[off] : cst;
+    }
+}
 
-void hh_linearize(const ModelConsts<double> *c, const double *traj, const double *desired, int n, double *lin) {
-  for (int i = 0; i < n; ++i) linearize_knot(*c, traj + i * 18, desired + i * 18, lin + (long)i * LIN_STRIDE);
+void hh_linearize(const ModelConsts<double> *c, const int *lay, const double *traj, const double *desired, int n,
+                  double *lin) {
+  const RecLayout L = layout_from(lay);
+  for (int i = 0; i < n; ++i) linearize_knot(*c, L, traj + i * 18, desired + i * 18, lin + (long)i * L.stride);
 }
 void hh_rollout(const ModelConsts<double> *c, const double *traj, const double *gains, double alpha, double *out,
                 int n) {
@@ -75,27 +103,32 @@ void hh_dense_jacobians(const ModelConsts<double> *c, const double *rec, double 
 
 // k_backward re-enacted lane by lane (same statements, loops over the 64 lanes between the
 // points where the kernel exchanges data)
-void hh_backward_emulated(const ModelConsts<double> *cp, const double *lin, int n, double *gains, double *terms) {
+void hh_backward_emulated(const ModelConsts<double> *cp, const int *lay, const double *lin, int n, double *gains,
+                          double *terms) {
   const ModelConsts<double> &c = *cp;
+  const RecLayout L = layout_from(lay);
   constexpr int LD = 17;
   double Vs[12 * LD] = {0}, Hs[16 * LD] = {0}, gs[16] = {0}, vxs[12] = {0};
   int moff[64][3], coff[64][3];
-  double mconst[64][3], cuu[64];
+  double mconst[64][3], cconst[64][3], cuu[64];
   double va[64][3] = {{0}}, vxl[64][3] = {{0}};
   double QuTk[64] = {0}, kTQuuk[64] = {0};
   for (int l = 0; l < 64; ++l) {
     const int j = l & 15, kk = l >> 4;
     for (int kc = 0; kc < 3; ++kc) moff[l][kc] = m_source(4 * kc + kk, j, c.Bu, &mconst[l][kc]);
-    for (int r = 0; r < 3; ++r) coff[l][r] = (j < 12) ? LIN_CXX + (4 * r + kk) * 12 + j : -1;
+    for (int r = 0; r < 3; ++r) {
+      cconst[l][r] = 0.0;
+      coff[l][r] = (j < 12) ? cxx_source(L, 4 * r + kk, j, c.Q, &cconst[l][r]) : -1;
+    }
     cuu[l] = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] : 0.0;
   }
   for (int i = n - 1; i >= 0; --i) {
-    const double *rec = lin + (long)i * LIN_STRIDE;
+    const double *rec = lin + (long)i * L.stride;
     double m[64][3], cx[64][3], gcj[64], T[64][4], H[64][4], part[64], ghat[64];
     for (int l = 0; l < 64; ++l) {
       for (int kc = 0; kc < 3; ++kc) m[l][kc] = moff[l][kc] >= 0 ? rec[moff[l][kc]] : mconst[l][kc];
-      for (int r = 0; r < 3; ++r) cx[l][r] = coff[l][r] >= 0 ? rec[coff[l][r]] : 0.0;
-      gcj[l] = rec[LIN_G + (l & 15)];
+      for (int r = 0; r < 3; ++r) cx[l][r] = coff[l][r] >= 0 ? rec[coff[l][r]] : cconst[l][r];
+      gcj[l] = rec[L.off_g + (l & 15)];
       for (int r = 0; r < 4; ++r) T[l][r] = 0.0;
     }
     double a[64], b[64];

@@ -42,12 +42,27 @@ def consts(hh, model, Q, R, dt):
     return buf
 
 
+def layout(hh, c, force_general=False):
+    lay = np.zeros(6, dtype=np.int32)
+    hh.hh_layout(P(c), C.c_int(int(force_general)), lay.ctypes.data_as(C.POINTER(C.c_int)))
+    return lay
+
+
+def IP(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
 def random_problem(seed, n=12, dense=False):
     r = np.random.default_rng(seed)
     A = r.uniform(-1, 1, (3, 3))
     model = dict(mass_kg=1.3, inertia=A @ A.T + 3 * np.eye(3), arm_length_m=0.7,
                  torque_to_thrust_ratio_m=0.2, g_mpss=9.81)
-    if dense:
+    if dense == "sym":
+        Q = r.uniform(-1, 1, (12, 12))
+        Q = Q @ Q.T + 12 * np.eye(12)                                      # dense, symmetric
+        R = r.uniform(-0.3, 0.3, (4, 4))
+        R = R + R.T + 2 * np.eye(4)
+    elif dense:
         Q = r.uniform(-1, 1, (12, 12))
         Q = Q @ Q.T + 12 * np.eye(12) + 0.3 * r.uniform(-1, 1, (12, 12))  # not symmetric
         R = r.uniform(-0.3, 0.3, (4, 4)) + 2 * np.eye(4)                   # not symmetric
@@ -64,15 +79,17 @@ def random_problem(seed, n=12, dense=False):
     return model, Q, R, rand_traj(), rand_traj()
 
 
-@pytest.mark.parametrize("seed,dense", [(1, False), (2, True), (3, True)])
+@pytest.mark.parametrize("seed,dense", [(1, False), (2, True), (3, True), (9, "sym")])
 def test_knot_records_match_oracle(hh, seed, dense):
     model, Q, R, traj, desired = random_problem(seed, dense=dense)
     dt = 0.1
     c = consts(hh, model, Q, R, dt)
     n = len(traj)
-    stride = hh.hh_lin_stride()
-    lin = np.zeros((n, stride))
-    hh.hh_linearize(P(c), P(traj), P(desired), C.c_int(n), P(lin))
+    lay = layout(hh, c)
+    assert list(lay[:2]) == {False: [1, 1], True: [0, 0], "sym": [1, 0]}[dense]
+    assert lay[5] == {False: 92, True: 216, "sym": 128}[dense]
+    lin = np.zeros((n, lay[5]))
+    hh.hh_linearize(P(c), IP(lay), P(traj), P(desired), C.c_int(n), P(lin))
     mp = orc.model_params(**model)
     for i in range(n):
         _, Jx, Ju = orc.discrete_dynamics(mp, traj[i, 1:14], traj[i, 14:18], dt, diffs=True)
@@ -81,11 +98,13 @@ def test_knot_records_match_oracle(hh, seed, dense):
         np.testing.assert_allclose(jx, Jx, rtol=1e-12, atol=1e-13)
         np.testing.assert_allclose(ju, Ju, rtol=1e-12, atol=1e-15)
         cost, D = orc.cost(Q, R, traj[i, 1:14], traj[i, 14:18], desired[i, 1:14], desired[i, 14:18], diffs=True)
-        np.testing.assert_allclose(lin[i, 214], cost, rtol=1e-13)
+        np.testing.assert_allclose(lin[i, lay[4]], cost, rtol=1e-13)
         scale = np.abs(D["xx"]).max()
-        np.testing.assert_allclose(lin[i, 54:198].reshape(12, 12), D["xx"], rtol=1e-11, atol=1e-12 * scale)
-        np.testing.assert_allclose(lin[i, 198:210], D["x"], rtol=1e-11, atol=1e-12 * np.abs(D["x"]).max())
-        np.testing.assert_allclose(lin[i, 210:214], D["u"], rtol=1e-12, atol=1e-13)
+        cxx = np.zeros((12, 12))
+        hh.hh_dense_cxx(P(c), IP(lay), P(lin[i]), P(cxx))
+        np.testing.assert_allclose(cxx, D["xx"], rtol=1e-11, atol=1e-12 * scale)
+        np.testing.assert_allclose(lin[i, lay[3]:lay[3] + 12], D["x"], rtol=1e-11, atol=1e-12 * np.abs(D["x"]).max())
+        np.testing.assert_allclose(lin[i, lay[3] + 12:lay[3] + 16], D["u"], rtol=1e-12, atol=1e-13)
 
 
 def test_knot_records_at_singular_points(hh):
@@ -95,10 +114,11 @@ def test_knot_records_at_singular_points(hh):
     traj = desired.copy()
     c = consts(hh, model, Q, R, 0.1)
     n = len(traj)
-    lin = np.zeros((n, hh.hh_lin_stride()))
-    hh.hh_linearize(P(c), P(traj), P(desired), C.c_int(n), P(lin))
+    lay = layout(hh, c)
+    lin = np.zeros((n, lay[5]))
+    hh.hh_linearize(P(c), IP(lay), P(traj), P(desired), C.c_int(n), P(lin))
     assert np.all(np.isfinite(lin))
-    np.testing.assert_array_equal(lin[:, 214], 0.0)  # cost_test.cc:27-39
+    np.testing.assert_array_equal(lin[:, lay[4]], 0.0)  # cost_test.cc:27-39
     mp = orc.model_params(**model)
     for i in (0, 15, 39):
         _, Jx, _ = orc.discrete_dynamics(mp, traj[i, 1:14], traj[i, 14:18], 0.1, diffs=True)
@@ -121,17 +141,18 @@ def test_rollout_matches_oracle(hh, seed, dense):
         np.testing.assert_allclose(out, ref, rtol=1e-10, atol=1e-10)
 
 
-@pytest.mark.parametrize("seed,dense", [(6, False), (7, True), (8, True)])
+@pytest.mark.parametrize("seed,dense", [(6, False), (7, True), (8, True), (10, "sym")])
 def test_backward_dataflow_matches_oracle(hh, seed, dense):
     """k_backward re-enacted on the CPU with the documented v_mfma_f64_16x16x4_f64 lane maps:
     proves the operand tables, the accumulator->operand hand-off and the gain layout."""
     model, Q, R, traj, desired = random_problem(seed, n=15, dense=dense)
     c = consts(hh, model, Q, R, 0.1)
     n = len(traj)
-    lin = np.zeros((n, hh.hh_lin_stride()))
-    hh.hh_linearize(P(c), P(traj), P(desired), C.c_int(n), P(lin))
+    lay = layout(hh, c)
+    lin = np.zeros((n, lay[5]))
+    hh.hh_linearize(P(c), IP(lay), P(traj), P(desired), C.c_int(n), P(lin))
     gains, terms = np.zeros((n, 52)), np.zeros(2)
-    hh.hh_backward_emulated(P(c), P(lin), C.c_int(n), P(gains), P(terms))
+    hh.hh_backward_emulated(P(c), IP(lay), P(lin), C.c_int(n), P(gains), P(terms))
     s = orc.OracleSolver(orc.model_params(**model), Q, R, desired, 0.1, orc.options())
     g_ref, t_ref = s.backwards_pass(traj)
     np.testing.assert_allclose(terms, t_ref, rtol=1e-10)
