@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--knots", type=int, default=100)
     ap.add_argument("--sync-every", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="HIP events around every kernel, not only the two candidates for dominant kernel")
+    ap.add_argument("--single-wave-rollout", action="store_true", help="diagnostic: k_rollout instead of k_rollout2")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP events around the kernels (roofline = null)")
     args = ap.parse_args()
 
@@ -61,7 +63,8 @@ def main():
 
     B, N = args.batch, args.knots
     cfg = pb.config2(B=B, N=N, seed=2, b0=rank * B)  # counter-based generator: shard-independent
-    solver = capi.from_config(cfg, device=dev.index, profile=not args.no_profile, sync_every=args.sync_every)
+    solver = capi.from_config(cfg, device=dev.index, profile=(0 if args.no_profile else (2 if args.profile_all else 1)), sync_every=args.sync_every,
+                              single_wave_rollout=args.single_wave_rollout)
 
     init = torch.from_numpy(cfg["init"]).to(dev)
     out_traj = torch.empty_like(init)

@@ -68,9 +68,10 @@ typedef struct {
 /* device-side configuration (no counterpart in the reference, which is CPU only) */
 typedef struct {
   int32_t device;   /* HIP device ordinal */
-  int32_t profile;  /* 1: bracket every kernel launch with HIP events (qilqr_profile_get) */
+  int32_t profile;  /* 0: off; 1: HIP events around k_backward and k_rollout only; 2: around every kernel */
   int32_t sync_every; /* host polls the active-problem counter every k outer iterations (>=1) */
   int32_t force_general; /* 1: use the general (non-symmetric-safe) backward kernel even when Q, R are symmetric */
+  int32_t single_wave_rollout; /* 1: one wavefront per 64 trajectories in the rollout instead of the cooperating pair */
 } qilqr_device_config;
 
 typedef struct qilqr_solver qilqr_solver;

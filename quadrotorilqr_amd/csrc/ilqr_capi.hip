@@ -71,6 +71,7 @@ struct Timed {
   EventPair *ep = nullptr;
   Timed(qilqr_solver *s_, int kind) : s(s_) {
     if (!s->dev.profile) return;
+    if (s->dev.profile == 1 && kind != K_BACKWARD && kind != K_ROLLOUT) return;
     if (s->events_used == s->events.size()) {
       EventPair e;
       if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
@@ -185,8 +186,12 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
 }
 int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
   Timed t(s, K_ROLLOUT);
-  hipLaunchKernelGGL(k_rollout, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->consts, s->st, (int)B, (int)n,
-                     need_flag);
+  if (s->dev.single_wave_rollout)
+    hipLaunchKernelGGL(k_rollout, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->consts, s->st, (int)B, (int)n,
+                       need_flag);
+  else
+    hipLaunchKernelGGL(k_rollout2, dim3(cdiv(B, 64)), dim3(128), 0, s->stream, s->consts, s->st, (int)B, (int)n,
+                       need_flag);
   return QILQR_OK;
 }
 int launch_accept(qilqr_solver *s, long B, long n, int ls_only) {
@@ -282,7 +287,7 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(QILQR_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
-  qilqr_device_config dc = {0, 0, 1, 0};
+  qilqr_device_config dc = {0, 0, 1, 0, 0};
   if (dev) dc = *dev;
   if (dc.device < 0 || dc.device >= ndev) return fail(QILQR_ERR_INVALID_ARG, "bad device ordinal");
   if (dc.sync_every < 1) dc.sync_every = 1;

@@ -356,6 +356,134 @@ __global__ __launch_bounds__(64) void k_rollout(ModelConsts<double> c, BatchStat
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_rollout2: the same rollout with TWO cooperating wavefronts per 64 trajectories (block = 128).
+// A single wavefront issues one fp64 instruction per ~9 cycles whatever the instruction-level
+// parallelism (profiles/microbench), so the serial per-knot chain is split into the two halves that
+// are independent inside one knot:
+//   wave Y (pose):     T_{i+1} = T_i Exp(dt v_i), then the pose part of x_{i+1} (-) xnom_{i+1}
+//   wave X (control):  rho_i = Jl^-1 td_i, u_i = u_nom + alpha k + K dx_i, v_{i+1} = v_i + dt a(q_i, v_i, u_i)
+// They trade 11 + 6 doubles per knot through LDS (double-buffered, one barrier per knot).  The
+// arithmetic is the same sequence of operations as rollout_problem: results are bit-identical.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchState st, int B, int n,
+                                                  int need_flag) {
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: X, 1: Y
+  const int b = blockIdx.x * 64 + lane;
+  const bool live = (b < B) && (!need_flag || (st.flags[b < B ? b : 0] & need_flag));
+  if (__ballot(live) == 0ull) return;  // same lanes -> same trajectories in both waves: block-uniform
+  const int bs = (b < B) ? b : (B - 1);
+  const int cur = st.cur[bs];
+  const double *traj = st.traj[cur] + (long)bs * n * 18;
+  const double *gains = st.gains + (long)bs * n * 52;
+  double *out = st.traj[cur ^ 1] + (long)bs * n * 18;
+  const double alpha = st.alpha[bs];
+
+  __shared__ double sh[2][17][64];  // [parity][0..3 q | 4..6 td | 7..9 th | 10 c | 11..16 v][lane]
+
+  double t[3] = {traj[1], traj[2], traj[3]};
+  double q[4] = {traj[5], traj[6], traj[7], traj[4]};
+  double v[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) v[a] = traj[8 + a];
+  double td[3] = {0, 0, 0}, th[3] = {0, 0, 0}, cj = 0.0;
+
+  if (role == 1) {
+    const double qn[4] = {traj[5], traj[6], traj[7], traj[4]};
+    se3_rminus_part1(t, q, traj + 1, qn, td, th, cj);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      sh[0][4 + a][lane] = td[a];
+      sh[0][7 + a][lane] = th[a];
+    }
+    sh[0][10][lane] = cj;
+    if (live) {
+      out[1] = t[0]; out[2] = t[1]; out[3] = t[2];
+      out[4] = q[3]; out[5] = q[0]; out[6] = q[1]; out[7] = q[2];
+    }
+  }
+  __syncthreads();
+  if (role == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      td[a] = sh[0][4 + a][lane];
+      th[a] = sh[0][7 + a][lane];
+    }
+    cj = sh[0][10][lane];
+  }
+
+  for (int i = 0; i < n; ++i) {
+    const int par = (i + 1) & 1;
+    const bool more = (i + 1 < n);
+    if (role == 0) {
+      const double *pt = traj + (long)i * 18;
+      const double *g = gains + (long)i * 52;
+      double dx[12];
+      se3_rminus_part2(td, th, cj, dx);
+      dx[3] = th[0]; dx[4] = th[1]; dx[5] = th[2];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) dx[6 + a] = v[a] - pt[8 + a];
+      double u[4];
+      control_law(pt, g, alpha, dx, u);
+      if (live) {
+        double *o = out + (long)i * 18;
+        o[0] = pt[0];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) o[8 + a] = v[a];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) o[14 + a] = u[a];
+      }
+      if (more) {
+        double acc[6];
+        body_acceleration_fast(c, q, v, u, acc);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          v[a] = v[a] + c.dt * acc[a];
+          sh[par][11 + a][lane] = v[a];
+        }
+      }
+    } else if (more) {
+      double tau[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) tau[a] = c.dt * v[a];  // pose integrates with the OLD velocity
+      se3_rplus_fast(t, q, tau);
+      const double *pn = traj + (long)(i + 1) * 18;
+      const double qn[4] = {pn[5], pn[6], pn[7], pn[4]};
+      se3_rminus_part1(t, q, pn + 1, qn, td, th, cj);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) sh[par][a][lane] = q[a];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        sh[par][4 + a][lane] = td[a];
+        sh[par][7 + a][lane] = th[a];
+      }
+      sh[par][10][lane] = cj;
+      if (live) {
+        double *o = out + (long)(i + 1) * 18;
+        o[1] = t[0]; o[2] = t[1]; o[3] = t[2];
+        o[4] = q[3]; o[5] = q[0]; o[6] = q[1]; o[7] = q[2];
+      }
+    }
+    __syncthreads();
+    if (more) {
+      if (role == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) q[a] = sh[par][a][lane];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          td[a] = sh[par][4 + a][lane];
+          th[a] = sh[par][7 + a][lane];
+        }
+        cj = sh[par][10][lane];
+      } else {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v[a] = sh[par][11 + a][lane];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_accept: thread b.  Cost of the candidate, acceptance, convergence (ilqr.hh:70-84, 174-194)
 // ---------------------------------------------------------------------------------------------
 __global__ void k_accept(SolveParams p, BatchState st, int B, int n, int ls_only) {

@@ -612,15 +612,17 @@ QILQR_HD void quat_rotate(const T q[4], const T v[3], T o[3]) {
   o[2] = v[2] + q[3] * t[2] + c[2];
 }
 
-// tau = Log(X^-1 Y), same value as se3_rminus
+// tau = Log(X^-1 Y), same value as se3_rminus, in two parts so that the rollout can run them in
+// two cooperating wavefronts: part 1 (pose -> td, theta, c) needs only poses; part 2 applies
+// Jl^-1(theta) to td.
 template <typename T>
-QILQR_HD void se3_rminus_fast(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T tau[6]) {
+QILQR_HD void se3_rminus_part1(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T td[3], T th[3], T &c) {
 #if defined(__clang__)
 #pragma clang fp contract(off)  // x (-) x must be exactly zero (cost_test.cc:27-39)
 #endif
   const T qc[4] = {-qx[0], -qx[1], -qx[2], qx[3]};
   const T d[3] = {ty[0] - tx[0], ty[1] - tx[1], ty[2] - tx[2]};
-  T td[3], qd[4];
+  T qd[4];
   quat_rotate(qc, d, td);
   quat_mul(qc, qy, qd);
   const T n = qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2] + qd[3] * qd[3];
@@ -643,7 +645,6 @@ QILQR_HD void se3_rminus_fast(const T ty[3], const T qy[4], const T tx[3], const
   }
   // so3_ljacinv(theta) t = t - theta x t / 2 + c theta x (theta x t), with its own switch on theta^2
   const T th2 = coeff * coeff * s2;
-  T c;
   if (!(th2 > Eps<T>::manif)) {
     c = T(0);
   } else if (th2 <= Series<T>::JINV_MAX) {
@@ -654,14 +655,25 @@ QILQR_HD void se3_rminus_fast(const T ty[3], const T qy[4], const T tx[3], const
     const T theta = sqrt(th2);
     c = T(1) / th2 - (T(1) + cos(theta)) / (T(2) * theta * sin(theta));
   }
-  const T th[3] = {qd[0] * coeff, qd[1] * coeff, qd[2] * coeff};
+  th[0] = qd[0] * coeff; th[1] = qd[1] * coeff; th[2] = qd[2] * coeff;
+}
+template <typename T>
+QILQR_HD void se3_rminus_part2(const T td[3], const T th[3], T c, T rho[3]) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
   T w1[3], w2[3];
   cross3(th, td, w1);
   cross3(th, w1, w2);
-  tau[0] = td[0] - T(0.5) * w1[0] + c * w2[0];
-  tau[1] = td[1] - T(0.5) * w1[1] + c * w2[1];
-  tau[2] = td[2] - T(0.5) * w1[2] + c * w2[2];
-  tau[3] = th[0]; tau[4] = th[1]; tau[5] = th[2];
+  rho[0] = td[0] - T(0.5) * w1[0] + c * w2[0];
+  rho[1] = td[1] - T(0.5) * w1[1] + c * w2[1];
+  rho[2] = td[2] - T(0.5) * w1[2] + c * w2[2];
+}
+template <typename T>
+QILQR_HD void se3_rminus_fast(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T tau[6]) {
+  T td[3], c;
+  se3_rminus_part1(ty, qy, tx, qx, td, tau + 3, c);
+  se3_rminus_part2(td, tau + 3, c, tau);
 }
 
 // (t, q) <- (t, q) * Exp(tau), same value as se3_rplus
@@ -727,6 +739,22 @@ QILQR_HD void body_acceleration_fast(const ModelConsts<T> &c, const T q[4], cons
   mat3_vec(c.inertia_inv, rhs, acc + 3);
 }
 
+// u = (u_i + alpha k) + K dx (ilqr.hh:158-161); K dx in three independent partial sums per row
+template <typename T>
+QILQR_HD void control_law(const T *pt, const T *g, T alpha, const T dx[12], T u[4]) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    T k0 = T(0), k1 = T(0), k2 = T(0);
+#pragma unroll
+    for (int col = 0; col < 4; ++col) {
+      k0 += g[4 + col * 4 + a] * dx[col];
+      k1 += g[4 + (col + 4) * 4 + a] * dx[col + 4];
+      k2 += g[4 + (col + 8) * 4 + a] * dx[col + 8];
+    }
+    u[a] = (pt[14 + a] + alpha * g[a]) + ((k0 + k1) + k2);
+  }
+}
+
 // closed-loop rollout of one problem (ilqr.hh:149-172).  traj/out are n x 18, gains n x 52.
 template <typename T>
 QILQR_HD void rollout_problem(const ModelConsts<T> &c, const T *traj, const T *gains, T alpha,
@@ -745,19 +773,8 @@ QILQR_HD void rollout_problem(const ModelConsts<T> &c, const T *traj, const T *g
     se3_rminus_fast(t, q, pt + 1, qi, dx);
 #pragma unroll
     for (int a = 0; a < 6; ++a) dx[6 + a] = v[a] - pt[8 + a];
-    // u = (u_i + alpha k) + K dx; K dx in three independent partial sums per row
     T u[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      T k0 = T(0), k1 = T(0), k2 = T(0);
-#pragma unroll
-      for (int col = 0; col < 4; ++col) {
-        k0 += g[4 + col * 4 + a] * dx[col];
-        k1 += g[4 + (col + 4) * 4 + a] * dx[col + 4];
-        k2 += g[4 + (col + 8) * 4 + a] * dx[col + 8];
-      }
-      u[a] = (pt[14 + a] + alpha * g[a]) + ((k0 + k1) + k2);
-    }
+    control_law(pt, g, alpha, dx, u);
     T *o = out + (long)i * 18;
     o[0] = pt[0];
     o[1] = t[0]; o[2] = t[1]; o[3] = t[2];
