@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -57,6 +58,8 @@ struct qilqr_solver {
   BatchState st{};
   std::vector<void *> allocs;
   int *h_counters = nullptr;  // pinned
+  double *io_aos = nullptr;         // device scratch in the plain [B][n][W] layout (W <= 52), for host I/O
+  double *desired_tiled = nullptr;  // per-problem desired trajectories, tiled (allocated on first use)
   // profiling
   std::vector<EventPair> events;
   size_t events_used = 0;
@@ -101,6 +104,8 @@ void free_workspace(qilqr_solver *s) {
   for (void *p : s->allocs) (void)hipFree(p);
   s->allocs.clear();
   s->cap_B = s->cap_n = 0;
+  s->io_aos = nullptr;
+  s->desired_tiled = nullptr;
 }
 
 template <typename T>
@@ -120,13 +125,16 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
   const long cB = B > s->cap_B ? B : s->cap_B, cn = n > s->cap_n ? n : s->cap_n;
   BatchState &st = s->st;
   st.layout = s->layout;
+  st.dbg_uniform = (getenv("QILQR_DBG_UNIFORM") != nullptr) ? 1 : 0;
   int rc;
   for (int k = 0; k < 2; ++k) {
-    if ((rc = dalloc(s, &st.traj[k], (size_t)cB * cn * 18))) return rc;
+    if ((rc = dalloc(s, &st.traj[k], (size_t)tiled_count(cB, cn, 18)))) return rc;
     if ((rc = dalloc(s, &st.lin[k], (size_t)cB * cn * s->layout.stride))) return rc;
-    if ((rc = dalloc(s, &st.knot_cost[k], (size_t)cB * cn))) return rc;
+    if ((rc = dalloc(s, &st.knot_cost[k], (size_t)tiled_count(cB, cn, 1)))) return rc;
   }
-  if ((rc = dalloc(s, &st.gains, (size_t)cB * cn * 52))) return rc;
+  if ((rc = dalloc(s, &st.gains, (size_t)tiled_count(cB, cn, 52)))) return rc;
+  if ((rc = dalloc(s, &s->io_aos, (size_t)cB * cn * 52))) return rc;
+  s->desired_tiled = nullptr;
   if ((rc = dalloc(s, &st.cur, cB))) return rc;
   if ((rc = dalloc(s, &st.cost, cB))) return rc;
   if ((rc = dalloc(s, &st.prev_cost, cB))) return rc;
@@ -153,7 +161,22 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
 
 inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
 
-// bind the desired trajectory (shared or per problem) and reset buffer selectors
+// plain [B][n][W] (device) -> tiled
+int to_tiled(qilqr_solver *s, const double *d_plain, double *tiled, long B, long n, int W) {
+  hipLaunchKernelGGL(k_retile, dim3(cdiv(B * n * W, 256)), dim3(256), 0, s->stream, d_plain, (double *)nullptr, tiled,
+                     tiled, (const int *)nullptr, 0, (int)B, (int)n, W, 1);
+  return QILQR_OK;
+}
+// tiled -> plain [B][n][W] (device); sel/flip choose between t0 and t1 per trajectory
+int from_tiled(qilqr_solver *s, double *d_plain, double *t0, double *t1, const int *sel, int flip, long B, long n,
+               int W) {
+  hipLaunchKernelGGL(k_retile, dim3(cdiv(B * n * W, 256)), dim3(256), 0, s->stream, (const double *)nullptr, d_plain,
+                     t0, t1, sel, flip, (int)B, (int)n, W, 0);
+  return QILQR_OK;
+}
+
+// bind the desired trajectory (shared, or per problem: plain device array, re-tiled here) and reset
+// the buffer selectors
 int begin_batch(qilqr_solver *s, long B, long n, const double *d_desired_batch) {
   if (B <= 0 || n <= 0) return fail(QILQR_ERR_INVALID_ARG, "B and n must be positive");
   if (!d_desired_batch && n > s->n_desired)
@@ -161,17 +184,37 @@ int begin_batch(qilqr_solver *s, long B, long n, const double *d_desired_batch) 
   HIP_TRY(hipSetDevice(s->device));
   int rc = ensure_workspace(s, B, n);
   if (rc) return rc;
-  s->st.desired = d_desired_batch ? d_desired_batch : s->d_desired;
-  s->st.desired_stride = d_desired_batch ? n * 18 : 0;
+  if (d_desired_batch) {
+    if (!s->desired_tiled && (rc = dalloc(s, &s->desired_tiled, (size_t)tiled_count(s->cap_B, s->cap_n, 18)))) return rc;
+    if ((rc = to_tiled(s, d_desired_batch, s->desired_tiled, B, n, 18))) return rc;
+    s->st.desired = s->desired_tiled;
+    s->st.desired_tiled = 1;
+  } else {
+    s->st.desired = s->d_desired;
+    s->st.desired_tiled = 0;
+  }
   HIP_TRY(hipMemsetAsync(s->st.cur, 0, sizeof(int) * B, s->stream));
   HIP_TRY(hipMemsetAsync(s->st.flags, 0, sizeof(int) * B, s->stream));
+  return QILQR_OK;
+}
+// host plain array -> device tiled buffer through the io scratch
+int upload_tiled(qilqr_solver *s, const double *h_plain, double *tiled, long B, long n, int W) {
+  HIP_TRY(hipMemcpyAsync(s->io_aos, h_plain, sizeof(double) * (size_t)B * n * W, hipMemcpyHostToDevice, s->stream));
+  return to_tiled(s, s->io_aos, tiled, B, n, W);
+}
+int download_tiled(qilqr_solver *s, double *h_plain, double *t0, double *t1, const int *sel, int flip, long B, long n,
+                   int W) {
+  int rc = from_tiled(s, s->io_aos, t0, t1, sel, flip, B, n, W);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(h_plain, s->io_aos, sizeof(double) * (size_t)B * n * W, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
   return QILQR_OK;
 }
 
 int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag) {
   Timed t(s, K_LINEARIZE);
-  hipLaunchKernelGGL(k_linearize, dim3(cdiv(B * n, 128)), dim3(128), 0, s->stream, s->consts, s->st, (int)B,
-                     (int)n, which, need_flag);
+  hipLaunchKernelGGL(k_linearize, dim3(cdiv(((B + 63) / 64) * 64 * n, 128)), dim3(128), 0, s->stream, s->consts,
+                     s->st, (int)B, (int)n, which, need_flag);
   return QILQR_OK;
 }
 int launch_backward(qilqr_solver *s, long B, long n, int force) {
@@ -383,8 +426,7 @@ int qilqr_solve_batch_device(qilqr_solver *s, const double *d_init, const double
   if (!s || !d_init) return fail(QILQR_ERR_INVALID_ARG, "null argument");
   int rc = begin_batch(s, B, n, d_desired_batch);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(s->st.traj[0], d_init, sizeof(double) * 18 * (size_t)B * n, hipMemcpyDeviceToDevice,
-                         s->stream));
+  if ((rc = to_tiled(s, d_init, s->st.traj[0], B, n, 18))) return rc;
   if ((rc = run_solve(s, B, n, s->dev.sync_every, [] { return QILQR_OK; }))) return rc;
   if ((rc = gather(s, B, n, d_out_traj, d_out_cost, d_out_status, d_out_iters, d_out_n_bwd, d_out_n_fwd)))
     return rc;
@@ -447,38 +489,39 @@ int qilqr_solve(qilqr_solver *s, const double *init, int32_t n, double *out_traj
   int rc;
   if ((rc = check_quaternions(init, n, "initial trajectory"))) return rc;
   if ((rc = begin_batch(s, 1, n, nullptr))) return rc;
-  const size_t tb = sizeof(double) * 18 * (size_t)n;
-  HIP_TRY(hipMemcpyAsync(s->st.traj[0], init, tb, hipMemcpyHostToDevice, s->stream));
+  if ((rc = upload_tiled(s, init, s->st.traj[0], 1, n, 18))) return rc;
   int seen = 0;
   const bool want_debug = s->options.populate_debug && debug_cap > 0 && (debug_cost || debug_trajs);
   auto capture = [&]() -> int {
     // ilqr.hh:78-80: one entry per completed forward pass (accepted iteration)
     if (!want_debug) return QILQR_OK;
-    int it = 0, cur = 0;
+    int it = 0;
     HIP_TRY(hipMemcpy(&it, s->st.iters, sizeof(int), hipMemcpyDeviceToHost));
     if (it > seen) {
-      HIP_TRY(hipMemcpy(&cur, s->st.cur, sizeof(int), hipMemcpyDeviceToHost));
       if (seen < debug_cap) {
         if (debug_cost) HIP_TRY(hipMemcpy(debug_cost + seen, s->st.cost, sizeof(double), hipMemcpyDeviceToHost));
-        if (debug_trajs) HIP_TRY(hipMemcpy(debug_trajs + (size_t)seen * 18 * n, s->st.traj[cur], tb, hipMemcpyDeviceToHost));
+        if (debug_trajs) {
+          int rc2 = download_tiled(s, debug_trajs + (size_t)seen * 18 * n, s->st.traj[0], s->st.traj[1], s->st.cur, 0, 1,
+                                   n, 18);
+          if (rc2) return rc2;
+        }
       }
       seen = it;
     }
     return QILQR_OK;
   };
   if ((rc = run_solve(s, 1, n, want_debug ? 1 : s->dev.sync_every, capture))) return rc;
-  int status = 0, iters = 0, cur = 0;
+  int status = 0, iters = 0;
   double cost = 0;
   HIP_TRY(hipMemcpy(&status, s->st.status, sizeof(int), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(&iters, s->st.iters, sizeof(int), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(&cur, s->st.cur, sizeof(int), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(&cost, s->st.cost, sizeof(double), hipMemcpyDeviceToHost));
   if (s->dev.profile) drain_events(s);
   if (n_debug) *n_debug = want_debug ? (seen < debug_cap ? seen : debug_cap) : 0;
   if (status == QILQR_STATUS_LINE_SEARCH_FAILED)
     return fail(QILQR_ERR_LINE_SEARCH, "Reached maximum number of line search iterations, " +
                                            std::to_string(s->options.ls_max_iters) + "\n");
-  HIP_TRY(hipMemcpy(out_traj, s->st.traj[cur], tb, hipMemcpyDeviceToHost));
+  if ((rc = download_tiled(s, out_traj, s->st.traj[0], s->st.traj[1], s->st.cur, 0, 1, n, 18))) return rc;
   if (out_cost) *out_cost = cost;
   if (out_status) *out_status = status;
   if (out_iters) *out_iters = iters;
@@ -489,7 +532,7 @@ int qilqr_cost_trajectory(qilqr_solver *s, const double *traj, int32_t B, int32_
   if (!s || !traj || !cost) return fail(QILQR_ERR_INVALID_ARG, "null argument");
   int rc = begin_batch(s, B, n, nullptr);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(s->st.traj[0], traj, sizeof(double) * 18 * (size_t)B * n, hipMemcpyHostToDevice, s->stream));
+  if ((rc = upload_tiled(s, traj, s->st.traj[0], B, n, 18))) return rc;
   if ((rc = launch_linearize(s, B, n, 0, 0))) return rc;
   hipLaunchKernelGGL(k_init, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->params, s->st, (int)B, (int)n);
   HIP_TRY(hipMemcpyAsync(cost, s->st.cost, sizeof(double) * B, hipMemcpyDeviceToHost, s->stream));
@@ -502,11 +545,11 @@ int qilqr_backwards_pass(qilqr_solver *s, const double *traj, int32_t B, int32_t
   if (!s || !traj || !gains || !terms) return fail(QILQR_ERR_INVALID_ARG, "null argument");
   int rc = begin_batch(s, B, n, nullptr);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(s->st.traj[0], traj, sizeof(double) * 18 * (size_t)B * n, hipMemcpyHostToDevice, s->stream));
+  if ((rc = upload_tiled(s, traj, s->st.traj[0], B, n, 18))) return rc;
   if ((rc = launch_linearize(s, B, n, 0, 0))) return rc;
   hipLaunchKernelGGL(k_init, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->params, s->st, (int)B, (int)n);
   if ((rc = launch_backward(s, B, n, 1))) return rc;
-  HIP_TRY(hipMemcpyAsync(gains, s->st.gains, sizeof(double) * 52 * (size_t)B * n, hipMemcpyDeviceToHost, s->stream));
+  if ((rc = download_tiled(s, gains, s->st.gains, s->st.gains, nullptr, 0, B, n, 52))) return rc;
   HIP_TRY(hipMemcpyAsync(terms, s->st.terms, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   HIP_TRY(hipGetLastError());
@@ -518,11 +561,11 @@ int qilqr_forward_sim(qilqr_solver *s, const double *traj, const double *gains, 
   if (!s || !traj || !gains || !alpha || !out_traj) return fail(QILQR_ERR_INVALID_ARG, "null argument");
   int rc = begin_batch(s, B, n, nullptr);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(s->st.traj[0], traj, sizeof(double) * 18 * (size_t)B * n, hipMemcpyHostToDevice, s->stream));
-  HIP_TRY(hipMemcpyAsync(s->st.gains, gains, sizeof(double) * 52 * (size_t)B * n, hipMemcpyHostToDevice, s->stream));
+  if ((rc = upload_tiled(s, traj, s->st.traj[0], B, n, 18))) return rc;
+  if ((rc = upload_tiled(s, gains, s->st.gains, B, n, 52))) return rc;
   HIP_TRY(hipMemcpyAsync(s->st.alpha, alpha, sizeof(double) * B, hipMemcpyHostToDevice, s->stream));
   if ((rc = launch_rollout(s, B, n, 0))) return rc;
-  HIP_TRY(hipMemcpyAsync(out_traj, s->st.traj[1], sizeof(double) * 18 * (size_t)B * n, hipMemcpyDeviceToHost, s->stream));
+  if ((rc = download_tiled(s, out_traj, s->st.traj[1], s->st.traj[1], nullptr, 0, B, n, 18))) return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
   HIP_TRY(hipGetLastError());
   return QILQR_OK;
@@ -537,8 +580,8 @@ int qilqr_line_search(qilqr_solver *s, const double *traj, const double *cost, c
   double *d_cost = nullptr, *d_terms = nullptr;
   HIP_TRY(hipMalloc((void **)&d_cost, sizeof(double) * B));
   HIP_TRY(hipMalloc((void **)&d_terms, sizeof(double) * 2 * B));
-  HIP_TRY(hipMemcpyAsync(s->st.traj[0], traj, sizeof(double) * 18 * (size_t)B * n, hipMemcpyHostToDevice, s->stream));
-  HIP_TRY(hipMemcpyAsync(s->st.gains, gains, sizeof(double) * 52 * (size_t)B * n, hipMemcpyHostToDevice, s->stream));
+  if ((rc = upload_tiled(s, traj, s->st.traj[0], B, n, 18))) return rc;
+  if ((rc = upload_tiled(s, gains, s->st.gains, B, n, 52))) return rc;
   HIP_TRY(hipMemcpyAsync(d_cost, cost, sizeof(double) * B, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(d_terms, terms, sizeof(double) * 2 * B, hipMemcpyHostToDevice, s->stream));
   hipLaunchKernelGGL(k_seed_search, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->st, (int)B, d_cost, d_terms);
@@ -562,16 +605,12 @@ int qilqr_line_search(qilqr_solver *s, const double *traj, const double *cost, c
   }
   HIP_TRY(hipStreamSynchronize(s->stream));
   // results: accepted candidates are traj[cur] (cur flipped); failures keep the input
-  std::vector<int> cur(B), status(B);
-  HIP_TRY(hipMemcpy(cur.data(), s->st.cur, sizeof(int) * B, hipMemcpyDeviceToHost));
+  std::vector<int> status(B);
   HIP_TRY(hipMemcpy(status.data(), s->st.status, sizeof(int) * B, hipMemcpyDeviceToHost));
   if (out_status) std::memcpy(out_status, status.data(), sizeof(int) * B);
   if (out_cost) HIP_TRY(hipMemcpy(out_cost, s->st.cost, sizeof(double) * B, hipMemcpyDeviceToHost));
   if (out_step) HIP_TRY(hipMemcpy(out_step, s->st.alpha, sizeof(double) * B, hipMemcpyDeviceToHost));
-  if (out_traj)
-    for (long b = 0; b < B; ++b)
-      HIP_TRY(hipMemcpy(out_traj + b * n * 18, s->st.traj[cur[b]] + b * n * 18, sizeof(double) * 18 * n,
-                        hipMemcpyDeviceToHost));
+  if (out_traj && (rc = download_tiled(s, out_traj, s->st.traj[0], s->st.traj[1], s->st.cur, 0, B, n, 18))) return rc;
   (void)hipFree(d_cost);
   (void)hipFree(d_terms);
   HIP_TRY(hipGetLastError());

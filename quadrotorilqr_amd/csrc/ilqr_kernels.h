@@ -29,13 +29,13 @@ struct SolveParams {
 
 // all device pointers; [B] unless noted
 struct BatchState {
-  double *traj[2];       // [B][n][18]  current / candidate trajectories
+  double *traj[2];       // TILED (se3_math.h) [tile][n][9][64][2]: current / candidate trajectories
   double *lin[2];        // [B][n][layout.stride] knot records of traj[k]
   RecLayout layout;
-  double *knot_cost[2];  // [B][n]
-  double *gains;         // [B][n][52]
-  const double *desired; // [n_desired][18] shared, or [B][n][18]
-  long desired_stride;   // 0 (shared) or n*18
+  double *knot_cost[2];  // [tile][n][64]
+  double *gains;         // TILED [tile][n][26][64][2]
+  const double *desired; // shared: plain [n_desired][18]; per problem: TILED like traj
+  int desired_tiled;     // 0 shared, 1 per problem
   int *cur;              // which of traj[] / lin[] is current
   double *cost;          // cost of the current trajectory ("new_cost", ilqr.hh:56)
   double *prev_cost;     // "cost" inside the iteration (ilqr.hh:61)
@@ -47,6 +47,7 @@ struct BatchState {
   int *counters;         // [0] trajectories still active after k_accept
   double *cost_hist;     // [B][hist_cap] or null
   int hist_cap;
+  int dbg_uniform;       // diagnostic only (QILQR_DBG_UNIFORM=1): every lane of a rollout wave reads one trajectory
 };
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -67,16 +68,22 @@ __device__ __forceinline__ double cost_reduction(double QuTk, double kTQuuk, dou
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void k_linearize(ModelConsts<double> c, BatchState st, int B, int n,
                                                    int which, int need_flag) {
+  // thread -> (tile, knot, lane): the 64 lanes of a wavefront read one knot of 64 consecutive trajectories
   const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= (long)B * n) return;
-  const int b = (int)(id / n), i = (int)(id % n);
+  const int lane = (int)(id & 63);
+  const long rest = id >> 6;
+  const int i = (int)(rest % n);
+  const long b = (rest / n) * 64 + lane;
+  if (b >= B) return;
   if (need_flag && !(st.flags[b] & need_flag)) return;
   const int buf = st.cur[b] ^ which;
-  const double *pt = st.traj[buf] + ((long)b * n + i) * 18;
-  const double *pd = st.desired + (long)b * st.desired_stride + (long)i * 18;
-  double *rec = st.lin[buf] + ((long)b * n + i) * st.layout.stride;
+  double pt[18], pd[18];
+  load_knot<true>(st.traj[buf] + knot_base<true>(b, n, 18), i, 18, pt);
+  if (st.desired_tiled) load_knot<true>(st.desired + knot_base<true>(b, n, 18), i, 18, pd);
+  else load_knot<false>(st.desired, i, 18, pd);
+  double *rec = st.lin[buf] + (b * n + i) * st.layout.stride;
   linearize_knot(c, st.layout, pt, pd, rec);
-  st.knot_cost[buf][(long)b * n + i] = rec[st.layout.off_cost];
+  st.knot_cost[buf][cost_index(b, i, n)] = rec[st.layout.off_cost];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -85,9 +92,9 @@ __global__ __launch_bounds__(128) void k_linearize(ModelConsts<double> c, BatchS
 __global__ void k_init(SolveParams p, BatchState st, int B, int n) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const double *kc = st.knot_cost[st.cur[b]] + (long)b * n;
+  const double *kc = st.knot_cost[st.cur[b]];
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += kc[i];
+  for (int i = 0; i < n; ++i) s += kc[cost_index(b, i, n)];
   st.cost[b] = s;
   st.prev_cost[b] = s;
   st.iters[b] = 0;
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   const int j = lane & 15, kk = lane >> 4;
   const RecLayout L = st.layout;
   const double *lin = st.lin[st.cur[b]] + (long)b * n * L.stride;
-  double *gains = st.gains + (long)b * n * 52;
+  double *gains = st.gains + knot_base<true>(b, n, 52);
 
   constexpr int LD = 17;  // padded leading dimension: column reads of a row-major tile
   __shared__ double Vs[SYM ? 1 : 12 * LD];
@@ -277,18 +284,14 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
     // A[j][kk] = -(K^T Quu)[j][kk], B[kk][j] = K[kk][j]
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(-sel4(mc, kk), sel4(kcol, kk), H, 0, 0, 0);
 
-    // gains of knot i: [k(4) | K column-major]; lane j < 12 owns column j, lane 12 owns k
-    if (kk == 0) {
-      double *g = gains + (long)i * 52;
-      if (j < 12) {
-        double2 *dst = reinterpret_cast<double2 *>(g + 4 + 4 * j);
-        dst[0] = make_double2(kcol[0], kcol[1]);
-        dst[1] = make_double2(kcol[2], kcol[3]);
-      } else if (j == 12) {
-        double2 *dst = reinterpret_cast<double2 *>(g);
-        dst[0] = make_double2(kff[0], kff[1]);
-        dst[1] = make_double2(kff[2], kff[3]);
-      }
+    // gains of knot i: [k(4) | K column-major]; lane j < 12 owns column j, lane 12 owns k.
+    // Tiled layout: element pair e/2 of this trajectory is one 16-byte slot.
+    if (kk == 0 && j <= 12) {
+      const int e0 = (j < 12) ? 4 + 4 * j : 0;
+      double2 *d0 = reinterpret_cast<double2 *>(gains + knot_elem<true>(i, e0, 52));
+      double2 *d1 = reinterpret_cast<double2 *>(gains + knot_elem<true>(i, e0 + 2, 52));
+      *d0 = (j < 12) ? make_double2(kcol[0], kcol[1]) : make_double2(kff[0], kff[1]);
+      *d1 = (j < 12) ? make_double2(kcol[2], kcol[3]) : make_double2(kff[2], kff[3]);
     }
     // hand V_xx, V_x to the next knot
     if constexpr (SYM) {
@@ -351,8 +354,8 @@ __global__ __launch_bounds__(64) void k_rollout(ModelConsts<double> c, BatchStat
   if (b >= B) return;
   if (need_flag && !(st.flags[b] & need_flag)) return;
   const int cur = st.cur[b];
-  rollout_problem(c, st.traj[cur] + (long)b * n * 18, st.gains + (long)b * n * 52, st.alpha[b],
-                  st.traj[cur ^ 1] + (long)b * n * 18, n);
+  rollout_problem<true>(c, st.traj[cur] + knot_base<true>(b, n, 18), st.gains + knot_base<true>(b, n, 52),
+                        st.alpha[b], st.traj[cur ^ 1] + knot_base<true>(b, n, 18), n);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -374,23 +377,26 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
   if (__ballot(live) == 0ull) return;  // same lanes -> same trajectories in both waves: block-uniform
   const int bs = (b < B) ? b : (B - 1);
   const int cur = st.cur[bs];
-  const double *traj = st.traj[cur] + (long)bs * n * 18;
-  const double *gains = st.gains + (long)bs * n * 52;
-  double *out = st.traj[cur ^ 1] + (long)bs * n * 18;
+  const int br = st.dbg_uniform ? blockIdx.x * 64 : bs;
+  const double *traj = st.traj[cur] + knot_base<true>(br, n, 18);
+  const double *gains = st.gains + knot_base<true>(br, n, 52);
+  double *out = st.traj[cur ^ 1] + knot_base<true>(bs, n, 18);
   const double alpha = st.alpha[bs];
 
   __shared__ double sh[2][17][64];  // [parity][0..3 q | 4..6 td | 7..9 th | 10 c | 11..16 v][lane]
 
-  double t[3] = {traj[1], traj[2], traj[3]};
-  double q[4] = {traj[5], traj[6], traj[7], traj[4]};
+  double pt[18];
+  load_knot<true>(traj, 0, 18, pt);
+  double t[3] = {pt[1], pt[2], pt[3]};
+  double q[4] = {pt[5], pt[6], pt[7], pt[4]};
   double v[6];
 #pragma unroll
-  for (int a = 0; a < 6; ++a) v[a] = traj[8 + a];
+  for (int a = 0; a < 6; ++a) v[a] = pt[8 + a];
   double td[3] = {0, 0, 0}, th[3] = {0, 0, 0}, cj = 0.0;
 
   if (role == 1) {
-    const double qn[4] = {traj[5], traj[6], traj[7], traj[4]};
-    se3_rminus_part1(t, q, traj + 1, qn, td, th, cj);
+    const double qn[4] = {pt[5], pt[6], pt[7], pt[4]};
+    se3_rminus_part1(t, q, pt + 1, qn, td, th, cj);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       sh[0][4 + a][lane] = td[a];
@@ -398,8 +404,9 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
     }
     sh[0][10][lane] = cj;
     if (live) {
-      out[1] = t[0]; out[2] = t[1]; out[3] = t[2];
-      out[4] = q[3]; out[5] = q[0]; out[6] = q[1]; out[7] = q[2];
+      const double po[8] = {0.0, t[0], t[1], t[2], q[3], q[0], q[1], q[2]};
+#pragma unroll
+      for (int e = 1; e < 8; ++e) out[knot_elem<true>(0, e, 18)] = po[e];
     }
   }
   __syncthreads();
@@ -416,8 +423,9 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
     const int par = (i + 1) & 1;
     const bool more = (i + 1 < n);
     if (role == 0) {
-      const double *pt = traj + (long)i * 18;
-      const double *g = gains + (long)i * 52;
+      double g[52];
+      load_knot<true>(traj, i, 18, pt);
+      load_knot<true>(gains, i, 52, g);
       double dx[12];
       se3_rminus_part2(td, th, cj, dx);
       dx[3] = th[0]; dx[4] = th[1]; dx[5] = th[2];
@@ -426,12 +434,11 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
       double u[4];
       control_law(pt, g, alpha, dx, u);
       if (live) {
-        double *o = out + (long)i * 18;
-        o[0] = pt[0];
+        out[knot_elem<true>(i, 0, 18)] = pt[0];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) o[8 + a] = v[a];
+        for (int a = 0; a < 6; ++a) out[knot_elem<true>(i, 8 + a, 18)] = v[a];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) o[14 + a] = u[a];
+        for (int a = 0; a < 4; ++a) out[knot_elem<true>(i, 14 + a, 18)] = u[a];
       }
       if (more) {
         double acc[6];
@@ -447,7 +454,9 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
 #pragma unroll
       for (int a = 0; a < 6; ++a) tau[a] = c.dt * v[a];  // pose integrates with the OLD velocity
       se3_rplus_fast(t, q, tau);
-      const double *pn = traj + (long)(i + 1) * 18;
+      double pn[8];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) pn[e] = traj[knot_elem<true>(i + 1, e, 18)];
       const double qn[4] = {pn[5], pn[6], pn[7], pn[4]};
       se3_rminus_part1(t, q, pn + 1, qn, td, th, cj);
 #pragma unroll
@@ -459,9 +468,9 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
       }
       sh[par][10][lane] = cj;
       if (live) {
-        double *o = out + (long)(i + 1) * 18;
-        o[1] = t[0]; o[2] = t[1]; o[3] = t[2];
-        o[4] = q[3]; o[5] = q[0]; o[6] = q[1]; o[7] = q[2];
+        const double po[8] = {0.0, t[0], t[1], t[2], q[3], q[0], q[1], q[2]};
+#pragma unroll
+        for (int e = 1; e < 8; ++e) out[knot_elem<true>(i + 1, e, 18)] = po[e];
       }
     }
     __syncthreads();
@@ -492,9 +501,9 @@ __global__ void k_accept(SolveParams p, BatchState st, int B, int n, int ls_only
   int fl = st.flags[b];
   if (fl & F_SEARCH) {
     const int cur = st.cur[b];
-    const double *kc = st.knot_cost[cur ^ 1] + (long)b * n;
+    const double *kc = st.knot_cost[cur ^ 1];
     double new_cost = 0.0;
-    for (int i = 0; i < n; ++i) new_cost += kc[i];
+    for (int i = 0; i < n; ++i) new_cost += kc[cost_index(b, i, n)];
     st.n_fwd[b] += 1;
     const int it = st.iters[b];
     const double cost = st.prev_cost[b];
@@ -540,22 +549,40 @@ __global__ void k_accept(SolveParams p, BatchState st, int B, int n, int ls_only
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_gather: results into caller buffers (any may be null)
+// k_gather: results into caller buffers in the plain [B][n][18] layout (any may be null)
 // ---------------------------------------------------------------------------------------------
 __global__ void k_gather(BatchState st, int B, int n, double *out_traj, double *out_cost, int *out_status,
                          int *out_iters, int *out_n_bwd, int *out_n_fwd) {
   const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long per = (long)n * 18;
   if (id >= (long)B * per) return;
-  const int b = (int)(id / per);
-  if (out_traj) out_traj[id] = st.traj[st.cur[b]][id];
-  if (id % per == 0) {
+  const long b = id / per;
+  const long r = id % per;
+  if (out_traj)
+    out_traj[id] = st.traj[st.cur[b]][knot_base<true>(b, n, 18) + knot_elem<true>(r / 18, (int)(r % 18), 18)];
+  if (r == 0) {
     if (out_cost) out_cost[b] = st.cost[b];
     if (out_status) out_status[b] = st.status[b];
     if (out_iters) out_iters[b] = st.iters[b];
     if (out_n_bwd) out_n_bwd[b] = st.n_bwd[b];
     if (out_n_fwd) out_n_fwd[b] = st.n_fwd[b];
   }
+}
+
+// plain [B][n][W] <-> tiled.  to_tiled = 1: plain -> tiled.  sel (optional): per-trajectory choice of
+// tiled buffer t0 / t1 (the current-trajectory selector), xor'ed with flip.
+__global__ void k_retile(const double *plain_in, double *plain_out, double *t0, double *t1, const int *sel,
+                         int flip, int B, int n, int W, int to_tiled) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per = (long)n * W;
+  if (id >= (long)B * per) return;
+  const long b = id / per;
+  const long r = id % per;
+  double *t = (sel && ((sel[b] ^ flip) & 1)) ? t1 : t0;
+  const long ti = (W == 18 ? knot_base<true>(b, n, 18) : knot_base<true>(b, n, 52)) +
+                  (W == 18 ? knot_elem<true>(r / W, (int)(r % W), 18) : knot_elem<true>(r / W, (int)(r % W), 52));
+  if (to_tiled) t[ti] = plain_in[id];
+  else plain_out[id] = t[ti];
 }
 
 // stand-alone line search support: seed per-problem scalars from caller data

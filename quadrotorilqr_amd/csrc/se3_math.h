@@ -29,6 +29,32 @@ struct Eps {
   static constexpr T manif = T(1e-10);  // manif Constants<double>::eps
 };
 
+// ----------------------------------------------------------------- batch layouts
+// Per-knot arrays that the lane-per-trajectory kernels touch (trajectories W = 18, gains W = 52,
+// knot costs W = 1) are stored "tiled": trajectories are grouped 64 at a time and, inside a tile,
+// the trajectory index is the fastest dimension in units of 16 bytes:
+//     [tile = b / 64][knot i][pair e / 2][lane = b % 64][e % 2]
+// so that the 64 lanes of a wavefront, each reading element pair (e, e+1) of ITS trajectory, touch
+// 1 KiB of consecutive memory (global_load_dwordx4, fully coalesced) instead of 64 separate cache
+// lines.  TILED = false is the plain [b][i][W] layout of the C ABI (and of the CPU harness).
+template <bool TILED>
+QILQR_HD long knot_base(long b, long n, int W) {
+  return TILED ? (b >> 6) * n * (W >> 1) * 128 + ((b & 63) << 1) : b * n * W;
+}
+template <bool TILED>
+QILQR_HD long knot_elem(long i, int e, int W) {
+  return TILED ? (i * (W >> 1) + (e >> 1)) * 128 + (e & 1) : i * W + e;
+}
+template <bool TILED, typename T>
+QILQR_HD void load_knot(const T *base, long i, int W, T *dst) {
+#pragma unroll
+  for (int e = 0; e < 52; ++e)
+    if (e < W) dst[e] = base[knot_elem<TILED>(i, e, W)];
+}
+QILQR_HD long tiled_count(long B, long n, int W) { return ((B + 63) >> 6) * 64 * n * W; }
+// knot costs: [tile][i][lane]
+QILQR_HD long cost_index(long b, long i, long n) { return ((b >> 6) * n + i) * 64 + (b & 63); }
+
 // ----------------------------------------------------------------- 3-vectors / 3x3 (row-major)
 template <typename T>
 QILQR_HD void skew3(const T a[3], T S[9]) {
@@ -755,18 +781,21 @@ QILQR_HD void control_law(const T *pt, const T *g, T alpha, const T dx[12], T u[
   }
 }
 
-// closed-loop rollout of one problem (ilqr.hh:149-172).  traj/out are n x 18, gains n x 52.
-template <typename T>
+// closed-loop rollout of one problem (ilqr.hh:149-172).  traj/gains/out point at this problem's
+// first element (knot_base) in the TILED or plain layout.
+template <bool TILED, typename T>
 QILQR_HD void rollout_problem(const ModelConsts<T> &c, const T *traj, const T *gains, T alpha,
                               T *out, int n) {
-  T t[3] = {traj[1], traj[2], traj[3]};
-  T q[4] = {traj[5], traj[6], traj[7], traj[4]};
+  T pt[18], g[52];
+  load_knot<TILED>(traj, 0, 18, pt);
+  T t[3] = {pt[1], pt[2], pt[3]};
+  T q[4] = {pt[5], pt[6], pt[7], pt[4]};
   T v[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) v[i] = traj[8 + i];
+  for (int i = 0; i < 6; ++i) v[i] = pt[8 + i];
   for (int i = 0; i < n; ++i) {
-    const T *pt = traj + (long)i * 18;
-    const T *g = gains + (long)i * 52;
+    load_knot<TILED>(traj, i, 18, pt);
+    load_knot<TILED>(gains, i, 52, g);
     // dx = state (-) x_i
     T dx[12];
     const T qi[4] = {pt[5], pt[6], pt[7], pt[4]};
@@ -775,14 +804,10 @@ QILQR_HD void rollout_problem(const ModelConsts<T> &c, const T *traj, const T *g
     for (int a = 0; a < 6; ++a) dx[6 + a] = v[a] - pt[8 + a];
     T u[4];
     control_law(pt, g, alpha, dx, u);
-    T *o = out + (long)i * 18;
-    o[0] = pt[0];
-    o[1] = t[0]; o[2] = t[1]; o[3] = t[2];
-    o[4] = q[3]; o[5] = q[0]; o[6] = q[1]; o[7] = q[2];
+    const T o[18] = {pt[0], t[0], t[1], t[2], q[3], q[0], q[1], q[2], v[0], v[1], v[2], v[3], v[4], v[5],
+                     u[0], u[1], u[2], u[3]};
 #pragma unroll
-    for (int a = 0; a < 6; ++a) o[8 + a] = v[a];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) o[14 + a] = u[a];
+    for (int e = 0; e < 18; ++e) out[knot_elem<TILED>(i, e, 18)] = o[e];
     if (i + 1 < n) {  // the reference's step after the last knot is computed and discarded
       T acc[6], tau[6];
       body_acceleration_fast(c, q, v, u, acc);

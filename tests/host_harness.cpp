@@ -76,7 +76,7 @@ void hh_linearize(const ModelConsts<double> *c, const int *lay, const double *tr
 }
 void hh_rollout(const ModelConsts<double> *c, const double *traj, const double *gains, double alpha, double *out,
                 int n) {
-  rollout_problem(*c, traj, gains, alpha, out, n);
+  rollout_problem<false>(*c, traj, gains, alpha, out, n);
 }
 // pose (-) pose and pose (+) tangent through the rollout's fast arithmetic; poses are [t ; q(w,x,y,z)]
 void hh_rminus_fast(const double *Y, const double *X, double *tau) {
@@ -88,6 +88,23 @@ void hh_rplus_fast(const double *Tin, const double *tau, double *Tout) {
   se3_rplus_fast(t, q, tau);
   Tout[0] = t[0]; Tout[1] = t[1]; Tout[2] = t[2];
   Tout[3] = q[3]; Tout[4] = q[0]; Tout[5] = q[1]; Tout[6] = q[2];
+}
+// the tiled layout's index arithmetic: scatter a plain [B][n][W] array into tiles, run the TILED
+// rollout on trajectory b, and hand back its output in the plain layout
+void hh_rollout_tiled(const ModelConsts<double> *c, const double *traj, const double *gains, const double *alpha,
+                      double *out, int B, int n) {
+  std::vector<double> tt(tiled_count(B, n, 18)), tg(tiled_count(B, n, 52)), to(tiled_count(B, n, 18));
+  for (long b = 0; b < B; ++b)
+    for (long i = 0; i < n; ++i) {
+      for (int e = 0; e < 18; ++e) tt[knot_base<true>(b, n, 18) + knot_elem<true>(i, e, 18)] = traj[(b * n + i) * 18 + e];
+      for (int e = 0; e < 52; ++e) tg[knot_base<true>(b, n, 52) + knot_elem<true>(i, e, 52)] = gains[(b * n + i) * 52 + e];
+    }
+  for (long b = 0; b < B; ++b)
+    rollout_problem<true>(*c, tt.data() + knot_base<true>(b, n, 18), tg.data() + knot_base<true>(b, n, 52), alpha[b],
+                          to.data() + knot_base<true>(b, n, 18), n);
+  for (long b = 0; b < B; ++b)
+    for (long i = 0; i < n; ++i)
+      for (int e = 0; e < 18; ++e) out[(b * n + i) * 18 + e] = to[knot_base<true>(b, n, 18) + knot_elem<true>(i, e, 18)];
 }
 // dense J_x (12x12) and J_u (12x4) rebuilt from a knot record through m_source()
 void hh_dense_jacobians(const ModelConsts<double> *c, const double *rec, double *Jx, double *Ju) {

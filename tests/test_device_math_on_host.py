@@ -219,3 +219,21 @@ def test_rollout_near_nominal_matches_oracle(hh):
             ref = s.forward_sim(traj, gains, alpha)
             np.testing.assert_allclose(out, ref, rtol=1e-10, atol=1e-11)
         traj = s.forward_sim(traj, gains, 1.0)
+
+
+def test_tiled_layout_rollout_equals_plain_layout(hh):
+    """the [tile][knot][pair][lane][2] indexing used on the device, exercised on the CPU"""
+    for B, n in [(1, 5), (64, 3), (70, 9), (130, 2)]:
+        cfg = pb.config2(B=B, N=n, seed=11)
+        c = consts(hh, cfg["model"], cfg["Q"], cfg["R"], cfg["dt"])
+        r = np.random.default_rng(B)
+        traj = cfg["init"] + 0.1 * r.standard_normal(cfg["init"].shape) * (np.arange(18) >= 8)
+        gains = 0.05 * r.uniform(-1, 1, (B, n, 52))
+        alpha = 0.5 ** r.integers(0, 3, B).astype(float)
+        out_t = np.zeros_like(traj)
+        hh.hh_rollout_tiled(P(c), P(traj), P(gains), P(alpha), P(out_t), C.c_int(B), C.c_int(n))
+        for b in range(B):
+            out = np.zeros((n, 18))
+            hh.hh_rollout(P(c), P(np.ascontiguousarray(traj[b])), P(np.ascontiguousarray(gains[b])),
+                          C.c_double(alpha[b]), P(out), C.c_int(n))
+            np.testing.assert_array_equal(out_t[b], out)
