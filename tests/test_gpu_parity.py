@@ -195,8 +195,9 @@ def test_symmetric_fast_path_agrees_with_general_path():
     np.testing.assert_allclose(of["traj"], og["traj"], atol=1e-7)
 
 
-def test_two_wave_rollout_is_bit_identical_to_single_wave():
-    """k_rollout2 (pose wave + control wave) performs the same operations as k_rollout"""
+def test_two_wave_rollout_matches_single_wave():
+    """k_rollout2 (pose wave + control wave) performs the same operations as k_rollout; the compiler
+    may contract multiply-adds differently in the two kernels, so agreement is to rounding (1e-12)"""
     for B, n in [(70, 33), (5, 1), (64, 2)]:
         cfg = pb.config2(B=B, N=n, seed=7)
         two = capi.from_config(cfg)
@@ -206,10 +207,11 @@ def test_two_wave_rollout_is_bit_identical_to_single_wave():
         alpha = 0.5 ** r.integers(0, 4, B)
         trajs = cfg["init"] + 0.0
         trajs[:, :, 8:14] += 0.3 * r.standard_normal((B, n, 6))
-        np.testing.assert_array_equal(two.forward_sim(trajs, gains, alpha), one.forward_sim(trajs, gains, alpha))
+        np.testing.assert_allclose(two.forward_sim(trajs, gains, alpha), one.forward_sim(trajs, gains, alpha),
+                                   rtol=1e-12, atol=1e-12)
     cfg = pb.config2(B=96, N=40)
     a, b = capi.from_config(cfg).solve_batch(cfg["init"]), capi.from_config(cfg, single_wave_rollout=True).solve_batch(cfg["init"])
-    np.testing.assert_array_equal(a["traj"], b["traj"])
+    np.testing.assert_allclose(a["traj"], b["traj"], atol=1e-8)
     np.testing.assert_array_equal(a["iters"], b["iters"])
 
 
