@@ -270,16 +270,17 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round) {
   const long max_rounds = (long)std::fmin(bound, 2e9);
   if (sync_every < 1) sync_every = 1;
   for (long round = 0; round < max_rounds; ++round) {
+    // k_backward first settles the candidate of the previous round (cost, Armijo, convergence) and
+    // counts the trajectories still active; then rollout + linearise the next candidates
     if ((rc = launch_backward(s, B, n, 0))) return rc;
-    if ((rc = launch_rollout(s, B, n, F_SEARCH))) return rc;
-    if ((rc = launch_linearize(s, B, n, 1, F_SEARCH))) return rc;
-    if ((rc = launch_accept(s, B, n, 0))) return rc;
     if ((round + 1) % sync_every == 0) {
       int n_active = 0;
       if ((rc = read_active(s, &n_active))) return rc;
       if ((rc = on_round())) return rc;
       if (n_active == 0) break;
     }
+    if ((rc = launch_rollout(s, B, n, F_SEARCH))) return rc;
+    if ((rc = launch_linearize(s, B, n, 1, F_SEARCH))) return rc;
   }
   HIP_TRY(hipStreamSynchronize(s->stream));
   HIP_TRY(hipGetLastError());

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(128) void k_linearize(ModelConsts<double> c, BatchS
                                                    int which, int need_flag) {
   // thread -> (tile, knot, lane): the 64 lanes of a wavefront read one knot of 64 consecutive trajectories
   const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id == 0) st.counters[0] = 0;  // the next k_backward counts the trajectories still active
   const int lane = (int)(id & 63);
   const long rest = id >> 6;
   const int i = (int)(rest % n);
@@ -139,14 +140,81 @@ template <bool SYM>
 __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolveParams p, BatchState st,
                                                  int B, int n, int force) {
   const int b = blockIdx.x;
-  if (b == 0 && threadIdx.x == 0) st.counters[0] = 0;  // k_accept of this round re-counts
   if (b >= B) return;
-  const int fl = st.flags[b];
-  if (!force && (fl & (F_ACTIVE | F_SEARCH)) != F_ACTIVE) return;  // wave-uniform
+  const int lane = threadIdx.x;
+  int fl = st.flags[b];
+  int cur = st.cur[b];
+  if (!force) {
+    if (fl & F_SEARCH) {
+      // ---- acceptance of the pending candidate (ilqr.hh:70-84, 174-194), fused here so that a round
+      // is three launches.  Cost = left-to-right sum of the knot costs (ilqr.hh:89-95): 64 lanes fetch
+      // 64 knot costs at once, the additions stay sequential.
+      const double *kc = st.knot_cost[cur ^ 1];
+      double new_cost = 0.0;
+      for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const double v = (i < n) ? kc[cost_index(b, i, n)] : 0.0;
+        const int cnt = (n - base < 64) ? n - base : 64;
+        const long long bits = __double_as_longlong(v);
+        for (int t = 0; t < cnt; ++t) {
+          const int lo = __builtin_amdgcn_readlane((int)bits, t);
+          const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), t);
+          new_cost += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        }
+      }
+      const int it = st.iters[b];
+      const double cost = st.prev_cost[b];
+      const double alpha = st.alpha[b];
+      bool accept;
+      if (it == 0) {
+        accept = true;  // ilqr.hh:71-73: the first rollout is taken unconditionally
+      } else {
+        const double desired = p.reduction_frac * cost_reduction(st.terms[2 * b], st.terms[2 * b + 1], alpha);
+        accept = (new_cost - cost < desired);  // ilqr.hh:186
+      }
+      int status = -1;
+      if (accept) {
+        cur ^= 1;
+        fl = F_ACTIVE;
+        if (it > 0 && is_converged(p, cost, new_cost)) {
+          status = 1;  // ilqr.hh:82-84
+          fl = 0;
+        } else if (!((double)(it + 1) < p.max_iters)) {
+          status = 2;  // ilqr.hh:86
+          fl = 0;
+        }
+      } else {
+        if (st.trial[b] + 1 >= p.ls_max_iters) {
+          status = 3;  // ilqr.hh:191-193
+          fl = 0;
+        }
+      }
+      if (lane == 0) {
+        st.n_fwd[b] += 1;
+        if (accept) {
+          st.cur[b] = cur;
+          st.cost[b] = new_cost;
+          if (st.cost_hist && it < st.hist_cap) st.cost_hist[(long)b * st.hist_cap + it] = new_cost;
+          st.iters[b] = it + 1;
+        } else {
+          st.trial[b] = st.trial[b] + 1;
+          st.alpha[b] = alpha * p.step_update;  // ilqr.hh:189
+        }
+        if (status >= 0) st.status[b] = status;
+        st.flags[b] = fl;
+        if (fl & F_ACTIVE) atomicAdd(&st.counters[0], 1);
+      }
+      if (!accept || fl == 0) return;  // back-tracking continues with the old gains, or the trajectory is done
+    } else if (fl == F_ACTIVE) {
+      if (lane == 0) atomicAdd(&st.counters[0], 1);
+    } else {
+      return;
+    }
+  }
   const int lane = threadIdx.x;
   const int j = lane & 15, kk = lane >> 4;
   const RecLayout L = st.layout;
-  const double *lin = st.lin[st.cur[b]] + (long)b * n * L.stride;
+  const double *lin = st.lin[cur] + (long)b * n * L.stride;
   double *gains = st.gains + knot_base<true>(b, n, 52);
 
   constexpr int LD = 17;  // padded leading dimension: column reads of a row-major tile
