@@ -211,7 +211,6 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
       return;
     }
   }
-  const int lane = threadIdx.x;
   const int j = lane & 15, kk = lane >> 4;
   const RecLayout L = st.layout;
   const double *lin = st.lin[cur] + (long)b * n * L.stride;
