@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
     ap.add_argument("--knots", type=int, default=100)
-    ap.add_argument("--sync-every", type=int, default=1)
+    ap.add_argument("--sync-every", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="HIP events around every kernel, not only the two candidates for dominant kernel")
     ap.add_argument("--single-wave-rollout", action="store_true", help="diagnostic: k_rollout instead of k_rollout2")

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Runs the non-headline BASELINE.json configurations at full size on the GPU box and prints one
+JSON line per configuration (wall time of qilqr_solve_batch_device with inputs resident in HBM,
+status histogram, pass counts).  Usage: python profiles/run_configs.py [config4shard] [config5] [big]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quadrotorilqr_amd import capi, problems as pb  # noqa: E402
+
+
+def run(name, cfg, reps=2):
+    dev = torch.device("cuda", 0)
+    B, N = cfg["init"].shape[:2]
+    s = capi.from_config(cfg, sync_every=2)
+    init = torch.from_numpy(cfg["init"]).to(dev)
+    out = torch.empty_like(init)
+    cost = torch.empty(B, dtype=torch.float64, device=dev)
+    ints = [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(4)]
+    best = 1e30
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        s.solve_batch_device(init, out, cost, *ints)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t)
+    st, it, nb, nf = (x.cpu().numpy() for x in ints)
+    print(json.dumps({"config": name, "B": B, "N": N, "seconds": best, "solves_per_s": B / best,
+                      "knot_steps_per_s": float((nb.sum() + nf.sum()) * N / best),
+                      "status_counts": np.bincount(st, minlength=4).tolist(), "iters_mean": float(it.mean()),
+                      "iters_max": int(it.max()), "n_bwd_mean": float(nb.mean()), "n_fwd_mean": float(nf.mean())}))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["config4shard", "config5"]
+    if "config4shard" in which:  # one rank's shard of configs[3]: 8192 problems, 100 knots, seed 4
+        run("configs[3] shard of one GPU (B=8192, N=100, seed 4)", pb.config2(B=8192, N=100, seed=4))
+    if "config5" in which:
+        a, b = pb.config5()
+        run("configs[4] half A: model A hover (B=2048, N=500)", a, reps=1)
+        run("configs[4] half B: demo box-climb, random starts (B=2048, N=500)", b, reps=1)
+    if "big" in which:
+        run("B=65536, N=100, model A (whole configs[3] on one GPU)", pb.config2(B=65536, N=100, seed=4), reps=1)

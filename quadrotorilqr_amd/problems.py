@@ -158,3 +158,18 @@ def config1(horizon_s=10.0):
     desired = box_climb_desired(horizon_s)
     return dict(model=MODEL_D, Q=Q_DEMO, R=R_DEMO, dt=DT_DEMO, options=dict(OPTIONS_DEMO),
                 desired=desired, init=desired[None].copy())
+
+
+def config5(B=4096, N=500, seed=5):
+    """BASELINE.json configs[4]: long-horizon stress.  Two halves that need two solver handles
+    (different model and desired trajectory): (a) model A hover with random starts -- well posed;
+    (b) the demo's box-climb stretched to N knots with random starts -- the unchecked first full step
+    (ilqr.hh:71-73) usually diverges at this horizon, so line-search exhaustion and max-iteration
+    exits are expected.  Graded on per-problem status and on parity where the oracle converges."""
+    half = B // 2
+    a = config2(B=half, N=N, seed=seed)
+    desired = box_climb_desired(N * DT_DEMO)[:N]
+    init = random_start_batch(np.arange(half, B), desired, seed)
+    b = dict(model=MODEL_D, Q=Q_DEMO, R=R_DEMO, dt=DT_DEMO, options=dict(OPTIONS_DEMO, populate_debug=False),
+             desired=desired, init=init)
+    return a, b
