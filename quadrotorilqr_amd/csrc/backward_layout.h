@@ -46,4 +46,31 @@ QILQR_HD int m_source(int row, int col, const double *Bu, double *cst) {
   return LIN_BLK + blk * 9 + rr * 3 + cc;
 }
 
+// Constant operand table (device memory, built once per solver): entries that do not change from
+// knot to knot are read through the same unconditional loads as the record entries, so that the
+// loads of knot i-1 can be issued before the chain of knot i and nothing selects on their result.
+//   [0] = 0, [1] = 1, [2..49] = J_u (12x4), [50..193] = 2 Q (12x12)
+constexpr int CTAB_ZERO = 0, CTAB_ONE = 1, CTAB_BU = 2, CTAB_2Q = 50, CTAB_SIZE = 194;
+QILQR_HD void build_ctab(const double *Bu, const double *Q, double *tab) {
+  tab[CTAB_ZERO] = 0.0;
+  tab[CTAB_ONE] = 1.0;
+  for (int i = 0; i < 48; ++i) tab[CTAB_BU + i] = Bu[i];
+  for (int i = 0; i < 144; ++i) tab[CTAB_2Q + i] = 2.0 * Q[i];
+}
+// like m_source, but constants are returned as an index into the table: -1 - index
+QILQR_HD int m_source_tab(int row, int col) {
+  if (col >= 12) return -1 - (CTAB_BU + row * 4 + (col - 12));
+  double cst;
+  const int off = m_source(row, col, nullptr, &cst);
+  if (off >= 0) return off;
+  return -1 - (cst == 1.0 ? CTAB_ONE : CTAB_ZERO);
+}
+QILQR_HD int cxx_source_tab(const RecLayout &L, int row, int col) {
+  if (!L.sym) return L.off_cxx + row * 12 + col;
+  const int i = row < col ? row : col, j = row < col ? col : row;
+  if (j < 6) return L.off_cxx + sym6_index(i, j);
+  if (i < 6) return L.ur_zero ? -1 - CTAB_ZERO : L.off_cxx + 21 + i * 6 + (j - 6);
+  return -1 - (CTAB_2Q + row * 12 + col);
+}
+
 }  // namespace qilqr

@@ -52,6 +52,7 @@ struct qilqr_solver {
   bool symmetric = false;  // Q == Q^T and R == R^T exactly: transpose-free backward kernel
   RecLayout layout;        // knot record layout chosen from the structure of Q
   double *d_desired = nullptr;  // shared desired trajectory
+  double *d_ctab = nullptr;     // constant operand table of k_backward
   // workspace
   long cap_B = 0, cap_n = 0;
   int hist_cap = 0;
@@ -125,6 +126,7 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
   const long cB = B > s->cap_B ? B : s->cap_B, cn = n > s->cap_n ? n : s->cap_n;
   BatchState &st = s->st;
   st.layout = s->layout;
+  st.ctab = s->d_ctab;
   st.dbg_uniform = (getenv("QILQR_DBG_UNIFORM") != nullptr) ? 1 : 0;
   int rc;
   for (int k = 0; k < 2; ++k) {
@@ -147,6 +149,11 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
   if ((rc = dalloc(s, &st.n_bwd, cB))) return rc;
   if ((rc = dalloc(s, &st.n_fwd, cB))) return rc;
   if ((rc = dalloc(s, &st.counters, 4))) return rc;
+#ifdef QILQR_STAMPS
+  if ((rc = dalloc(s, &st.stamps, 8 * cB))) return rc;
+#else
+  st.stamps = nullptr;
+#endif
   st.cost_hist = nullptr;
   st.hist_cap = 0;
   if (want_hist > 0) {
@@ -366,6 +373,12 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   if (e == hipSuccess && n_desired > 0)
     e = hipMemcpy(s->d_desired, desired, sizeof(double) * 18 * n_desired, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_counters, sizeof(int) * 4, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctab, sizeof(double) * CTAB_SIZE);
+  if (e == hipSuccess) {
+    double tab[CTAB_SIZE];
+    build_ctab(s->consts.Bu, s->consts.Q, tab);
+    e = hipMemcpy(s->d_ctab, tab, sizeof(tab), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     const int rc = fail(QILQR_ERR_HIP, std::string("qilqr_create: ") + hipGetErrorString(e));
     qilqr_destroy(s);
@@ -385,6 +398,7 @@ void qilqr_destroy(qilqr_solver *s) {
     (void)hipEventDestroy(e.b);
   }
   if (s->d_desired) (void)hipFree(s->d_desired);
+  if (s->d_ctab) (void)hipFree(s->d_ctab);
   if (s->h_counters) (void)hipHostFree(s->h_counters);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -617,5 +631,15 @@ int qilqr_line_search(qilqr_solver *s, const double *traj, const double *cost, c
   HIP_TRY(hipGetLastError());
   return QILQR_OK;
 }
+
+#ifdef QILQR_STAMPS
+// diagnostic build only: per-trajectory section cycle sums of the last k_backward launch
+int qilqr_debug_stamps(qilqr_solver *s, unsigned long long *out, int32_t B) {
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpy(out, s->st.stamps, sizeof(unsigned long long) * 8 * B, hipMemcpyDeviceToHost));
+  return QILQR_OK;
+}
+#endif
 
 }  // extern "C"

@@ -47,10 +47,30 @@ struct BatchState {
   int *counters;         // [0] trajectories still active after k_accept
   double *cost_hist;     // [B][hist_cap] or null
   int hist_cap;
+  const double *ctab;    // constant operand table (backward_layout.h)
+  unsigned long long *stamps;  // diagnostic build only (-DQILQR_STAMPS): [B][8] cycle sums per section of k_backward
   int dbg_uniform;       // diagnostic only (QILQR_DBG_UNIFORM=1): every lane of a rollout wave reads one trajectory
 };
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+#ifdef QILQR_STAMPS
+// In-kernel section timing for a separate diagnostic build (cdna_hip_programming.md section 7): one
+// s_memtime per section boundary, sums kept per wavefront, written to a buffer nothing else reads.
+#define QSTAMP(slot)                                                                   \
+  do {                                                                                 \
+    unsigned long long _t;                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");        \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    stamp_sum[slot] += _t - stamp_prev;                                                \
+    stamp_prev = _t;                                                                   \
+  } while (0)
+#define QKEEP(x) asm volatile("" ::"v"(x))
+#else
+#define QSTAMP(slot) do { } while (0)
+#define QKEEP(x) do { } while (0)
+#endif
 
 __device__ __forceinline__ bool is_converged(const SolveParams &p, double cost, double new_cost) {
   // ilqr.hh:196-205 (cost == 0 gives NaN < rtol == false and falls through to atol)
@@ -130,6 +150,21 @@ __device__ __forceinline__ double bcast_lane(double x, int src) {
   const int lo = __builtin_amdgcn_readlane((int)v, src);
   const int hi = __builtin_amdgcn_readlane((int)(v >> 32), src);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// x + (x of the lane 16 / 32 positions away): the two butterfly steps of a sum over the four 16-lane
+// rows, with v_permlane16_swap / v_permlane32_swap (VALU, no LDS round trip)
+__device__ __forceinline__ double xor16_sum(double x) {
+  const unsigned lo = (unsigned)__double_as_longlong(x), hi = (unsigned)(__double_as_longlong(x) >> 32);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __longlong_as_double(((long long)b[0] << 32) | a[0]) + __longlong_as_double(((long long)b[1] << 32) | a[1]);
+}
+__device__ __forceinline__ double xor32_sum(double x) {
+  const unsigned lo = (unsigned)__double_as_longlong(x), hi = (unsigned)(__double_as_longlong(x) >> 32);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __longlong_as_double(((long long)b[0] << 32) | a[0]) + __longlong_as_double(((long long)b[1] << 32) | a[1]);
 }
 
 // SYM = true: Q and R are exactly symmetric, so V_xx and H are symmetric to rounding and the
@@ -222,18 +257,23 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   __shared__ double gs[SYM ? 1 : 16];
   __shared__ double vxs[SYM ? 1 : 12];
 
-  // where this lane's three elements of M = [J_x | J_u] live in a knot record
-  int moff[3];
-  double mconst[3];
+  // Seven operands per lane and knot: three elements of M = [J_x | J_u] (rows kk, 4+kk, 8+kk of
+  // column j), three of C_xx (accumulator layout: register r <-> row 4 r + kk, column j) and one of
+  // [C_x ; C_u].  Each is either an entry of the knot record (pointer walks back one record per knot)
+  // or a constant (pointer into the constant table, step 0): the loads are unconditional.
+  const double *op[7];
+  long step[7];
+  {
+    const double *last = lin + (long)(n - 1) * L.stride;
 #pragma unroll
-  for (int kc = 0; kc < 3; ++kc) moff[kc] = m_source(4 * kc + kk, j, c.Bu, &mconst[kc]);
-  // C_xx in accumulator layout: register r <-> row 4 r + kk, column j
-  int coff[3];
-  double cconst[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    cconst[r] = 0.0;
-    coff[r] = (j < 12) ? cxx_source(L, 4 * r + kk, j, c.Q, &cconst[r]) : -1;
+    for (int k = 0; k < 7; ++k) {
+      int src;
+      if (k < 3) src = m_source_tab(4 * k + kk, j);
+      else if (k < 6) src = (j < 12) ? cxx_source_tab(L, 4 * (k - 3) + kk, j) : -1 - CTAB_ZERO;
+      else src = L.off_g + j;
+      op[k] = (src >= 0) ? last + src : st.ctab + (-1 - src);
+      step[k] = (src >= 0) ? (long)L.stride : 0;
+    }
   }
   // register 3 <-> row 12 + kk: C_uu = 2 R (cost.hh:55) in columns 12..15
   const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] : 0.0;
@@ -244,42 +284,46 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
 
   // software pipeline: the operands of knot i-1 are requested before the chain of knot i starts
   double m[3], cx[3], gcj;
-  {
-    const double *rec = lin + (long)(n - 1) * L.stride;
-#pragma unroll
-    for (int kc = 0; kc < 3; ++kc) m[kc] = (moff[kc] >= 0) ? rec[moff[kc]] : mconst[kc];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) cx[r] = (coff[r] >= 0) ? rec[coff[r]] : cconst[r];
-    gcj = rec[L.off_g + j];
-  }
+  m[0] = *op[0]; m[1] = *op[1]; m[2] = *op[2];
+  cx[0] = *op[3]; cx[1] = *op[4]; cx[2] = *op[5];
+  gcj = *op[6];
 
+#ifdef QILQR_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
   for (int i = n - 1; i >= 0; --i) {
     double m_n[3], cx_n[3], gcj_n;
-    {
-      const double *rec = lin + (long)(i > 0 ? i - 1 : 0) * L.stride;
+    if (i > 0) {
 #pragma unroll
-      for (int kc = 0; kc < 3; ++kc) m_n[kc] = (moff[kc] >= 0) ? rec[moff[kc]] : mconst[kc];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) cx_n[r] = (coff[r] >= 0) ? rec[coff[r]] : cconst[r];
-      gcj_n = rec[L.off_g + j];
+      for (int k = 0; k < 7; ++k) op[k] -= step[k];
     }
-
+    m_n[0] = *op[0]; m_n[1] = *op[1]; m_n[2] = *op[2];
+    cx_n[0] = *op[3]; cx_n[1] = *op[4]; cx_n[2] = *op[5];
+    gcj_n = *op[6];
+    QSTAMP(0);  // prefetch issue
     // T = V M
     d4 T = {0.0, 0.0, 0.0, 0.0};
     T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0], m[0], T, 0, 0, 0);
     T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1], m[1], T, 0, 0, 0);
     T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2], m[2], T, 0, 0, 0);
+    QKEEP(T[0]); QKEEP(T[3]);
+    QSTAMP(1);  // T = V M (3 MFMA) complete
     // H = blkdiag(C_xx, C_uu) + M^T T   (ilqr.hh:118-124 in one tile)
     d4 H = {cx[0], cx[1], cx[2], cuu};
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
+    QKEEP(H[0]); QKEEP(H[3]);
+    QSTAMP(2);  // H (3 MFMA) complete
     // [Q_x ; Q_u] = [C_x ; C_u] + M^T V_x
     double part = m[0] * vxl[0] + m[1] * vxl[1] + m[2] * vxl[2];
-    part += __shfl_xor(part, 16);
-    part += __shfl_xor(part, 32);
+    part = xor16_sum(part);
+    part = xor32_sum(part);
     const double ghat = gcj + part;
 
+    QKEEP(ghat);
+    QSTAMP(3);  // gradient
     // every lane: Q_uu (4x4), Q_u; lane column j < 12: its row of Q_xu
     double Quu[16], Qu[4], rhs[4];
     if constexpr (SYM) {
@@ -305,6 +349,8 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
         rhs[a] = (j < 12) ? Hs[j * LD + 12 + a] : 0.0;
       }
     }
+    QKEEP(Quu[15]); QKEEP(Quu[0]); QKEEP(Qu[3]); QKEEP(rhs[3]); QKEEP(rhs[0]);
+    QSTAMP(4);  // broadcast of Q_uu, Q_u, right-hand sides
     // LDL^T of the lower triangle of Q_uu (the reference: Eigen LDLT, ilqr.hh:126; no pivoting here)
     const double i0 = rcp_nr(Quu[0]);
     const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
@@ -318,6 +364,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
     const double l32 = c32 * i2;
     const double d3 = Quu[15] - l30 * Quu[12] - l31 * c31 - l32 * c32;
     const double i3 = rcp_nr(d3);
+    QKEEP(i3); QKEEP(l32); QKEEP(l31);
     double kcol[4], kff[4];
     {
       // K[:, j] = -Quu^-1 Q_xu[j, :]^T ; k = -Quu^-1 Q_u   (ilqr.hh:127-128)
@@ -332,6 +379,8 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
       x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
       kff[0] = -x0; kff[1] = -x1; kff[2] = -x2; kff[3] = -x3;
     }
+    QKEEP(kcol[0]); QKEEP(kcol[3]); QKEEP(kff[0]); QKEEP(kff[3]);
+    QSTAMP(5);  // factorisation + two solves
     // (K^T Quu)[j][:], then V_x = Q_x - (K^T Quu) k   (ilqr.hh:132)
     double mc[4];
 #pragma unroll
@@ -347,6 +396,8 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
         s += (kff[0] * Quu[bb] + kff[1] * Quu[4 + bb] + kff[2] * Quu[8 + bb] + kff[3] * Quu[12 + bb]) * kff[bb];
       kTQuuk += s;
     }
+    QKEEP(mc[3]); QKEEP(vx); QKEEP(QuTk); QKEEP(kTQuuk);
+    QSTAMP(6);  // K^T Quu, V_x, reduction terms
     // V_xx = Q_xx - (K^T Quu) K   (ilqr.hh:133): one more MFMA on the same accumulator,
     // A[j][kk] = -(K^T Quu)[j][kk], B[kk][j] = K[kk][j]
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(-sel4(mc, kk), sel4(kcol, kk), H, 0, 0, 0);
@@ -387,8 +438,14 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
       cx[kc] = cx_n[kc];
     }
     gcj = gcj_n;
+    QKEEP(va[0]); QKEEP(vxl[2]);
+    QSTAMP(7);  // V_xx MFMA, gain stores, hand-off
   }
 
+#ifdef QILQR_STAMPS
+  if (lane == 0 && st.stamps)
+    for (int k = 0; k < 8; ++k) st.stamps[(long)b * 8 + k] = stamp_sum[k];
+#endif
   if (lane == 0) {
     st.terms[2 * b] = QuTk;
     st.terms[2 * b + 1] = kTQuuk;

@@ -58,6 +58,26 @@ static RecLayout layout_from(const int *v) {
   L.sym = v[0]; L.ur_zero = v[1]; L.off_cxx = v[2]; L.off_g = v[3]; L.off_cost = v[4]; L.stride = v[5];
   return L;
 }
+// the table-indexed operand sources of k_backward against the value-returning ones; returns mismatches
+int hh_check_operand_tables(const ModelConsts<double> *c, const int *lay) {
+  const RecLayout L = layout_from(lay);
+  double tab[CTAB_SIZE];
+  build_ctab(c->Bu, c->Q, tab);
+  int bad = 0;
+  for (int r = 0; r < 12; ++r) {
+    for (int col = 0; col < 16; ++col) {
+      double cst;
+      const int a = m_source(r, col, c->Bu, &cst), b = m_source_tab(r, col);
+      if (a >= 0 ? (a != b) : (b >= 0 || tab[-1 - b] != cst)) ++bad;
+    }
+    for (int col = 0; col < 12; ++col) {
+      double cst;
+      const int a = cxx_source(L, r, col, c->Q, &cst), b = cxx_source_tab(L, r, col);
+      if (a >= 0 ? (a != b) : (b >= 0 || tab[-1 - b] != cst)) ++bad;
+    }
+  }
+  return bad;
+}
 // dense C_xx (12x12) rebuilt from a record through cxx_source()
 void hh_dense_cxx(const ModelConsts<double> *c, const int *lay, const double *rec, double *Cxx) {
   const RecLayout L = layout_from(lay);

@@ -88,6 +88,7 @@ def test_knot_records_match_oracle(hh, seed, dense):
     lay = layout(hh, c)
     assert list(lay[:2]) == {False: [1, 1], True: [0, 0], "sym": [1, 0]}[dense]
     assert lay[5] == {False: 92, True: 216, "sym": 128}[dense]
+    assert hh.hh_check_operand_tables(P(c), IP(lay)) == 0
     lin = np.zeros((n, lay[5]))
     hh.hh_linearize(P(c), IP(lay), P(traj), P(desired), C.c_int(n), P(lin))
     mp = orc.model_params(**model)
