@@ -149,6 +149,7 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
   if ((rc = dalloc(s, &st.n_bwd, cB))) return rc;
   if ((rc = dalloc(s, &st.n_fwd, cB))) return rc;
   if ((rc = dalloc(s, &st.counters, 4))) return rc;
+  if ((rc = dalloc(s, &st.dump, 4 * cB))) return rc;
 #ifdef QILQR_STAMPS
   if ((rc = dalloc(s, &st.stamps, 8 * cB))) return rc;
 #else

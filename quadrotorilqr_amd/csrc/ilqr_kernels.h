@@ -48,11 +48,17 @@ struct BatchState {
   double *cost_hist;     // [B][hist_cap] or null
   int hist_cap;
   const double *ctab;    // constant operand table (backward_layout.h)
+  double *dump;          // [B][4] write-only sink for the lanes of k_backward that own no gain entry
   unsigned long long *stamps;  // diagnostic build only (-DQILQR_STAMPS): [B][8] cycle sums per section of k_backward
   int dbg_uniform;       // diagnostic only (QILQR_DBG_UNIFORM=1): every lane of a rollout wave reads one trajectory
 };
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+// explicit global address space: a pointer selected between two buffers is otherwise 'generic' and
+// becomes flat_load (out-of-order return, forces vmcnt(0) + lgkmcnt(0) waits)
+typedef const double __attribute__((address_space(1))) *gcptr;
+typedef double dv2 __attribute__((ext_vector_type(2)));
+typedef dv2 __attribute__((address_space(1))) *gptr2;
 
 #ifdef QILQR_STAMPS
 // In-kernel section timing for a separate diagnostic build (cdna_hip_programming.md section 7): one
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   // column j), three of C_xx (accumulator layout: register r <-> row 4 r + kk, column j) and one of
   // [C_x ; C_u].  Each is either an entry of the knot record (pointer walks back one record per knot)
   // or a constant (pointer into the constant table, step 0): the loads are unconditional.
-  const double *op[7];
+  gcptr op[7];
   long step[7];
   {
     const double *last = lin + (long)(n - 1) * L.stride;
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
       if (k < 3) src = m_source_tab(4 * k + kk, j);
       else if (k < 6) src = (j < 12) ? cxx_source_tab(L, 4 * (k - 3) + kk, j) : -1 - CTAB_ZERO;
       else src = L.off_g + j;
-      op[k] = (src >= 0) ? last + src : st.ctab + (-1 - src);
+      op[k] = (gcptr)((src >= 0) ? last + src : st.ctab + (-1 - src));
       step[k] = (src >= 0) ? (long)L.stride : 0;
     }
   }
@@ -404,12 +410,18 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
 
     // gains of knot i: [k(4) | K column-major]; lane j < 12 owns column j, lane 12 owns k.
     // Tiled layout: element pair e/2 of this trajectory is one 16-byte slot.
-    if (kk == 0 && j <= 12) {
+    // Every lane stores (lanes that own nothing write zeros to a per-trajectory dump slot): no branch
+    // around the stores, so the wait for the next knot's operands is an exact vmcnt(2), not vmcnt(0).
+    {
+      const bool owner = (kk == 0 && j <= 12);
       const int e0 = (j < 12) ? 4 + 4 * j : 0;
-      double2 *d0 = reinterpret_cast<double2 *>(gains + knot_elem<true>(i, e0, 52));
-      double2 *d1 = reinterpret_cast<double2 *>(gains + knot_elem<true>(i, e0 + 2, 52));
-      *d0 = (j < 12) ? make_double2(kcol[0], kcol[1]) : make_double2(kff[0], kff[1]);
-      *d1 = (j < 12) ? make_double2(kcol[2], kcol[3]) : make_double2(kff[2], kff[3]);
+      gptr2 d0 = (gptr2)(owner ? gains + knot_elem<true>(i, e0, 52) : st.dump + 4 * (long)b);
+      gptr2 d1 = (gptr2)(owner ? gains + knot_elem<true>(i, e0 + 2, 52) : st.dump + 4 * (long)b + 2);
+      const double s0 = (j < 12) ? kcol[0] : kff[0], s1 = (j < 12) ? kcol[1] : kff[1];
+      const double s2 = (j < 12) ? kcol[2] : kff[2], s3 = (j < 12) ? kcol[3] : kff[3];
+      const dv2 w0 = {owner ? s0 : 0.0, owner ? s1 : 0.0}, w1 = {owner ? s2 : 0.0, owner ? s3 : 0.0};
+      *d0 = w0;
+      *d1 = w1;
     }
     // hand V_xx, V_x to the next knot
     if constexpr (SYM) {
