@@ -258,6 +258,8 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   double *gains = st.gains + knot_base<true>(b, n, 52);
 
   constexpr int LD = 17;  // padded leading dimension: column reads of a row-major tile
+  __shared__ double Ls[SYM ? 4 * LD : 1];  // SYM: register 3 of every lane, [kk][j] (rows 12..15 of H)
+  __shared__ double Lg[SYM ? 16 : 1];      // SYM: [Q_x ; Q_u]
   __shared__ double Vs[SYM ? 1 : 12 * LD];
   __shared__ double Hs[SYM ? 1 : 16 * LD];
   __shared__ double gs[SYM ? 1 : 16];
@@ -281,6 +283,13 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
       step[k] = (src >= 0) ? (long)L.stride : 0;
     }
   }
+  // gain slots of this lane for knot n-1, walked back one knot per iteration (tiled layout: one
+  // 16-byte slot per element pair); lanes that own nothing point at the dump slot with step 0
+  const bool gowner = (kk == 0 && j <= 12);
+  const int ge0 = (j < 12) ? 4 + 4 * j : 0;
+  gptr2 gdst0 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0, 52) : st.dump + 4 * (long)b);
+  gptr2 gdst1 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0 + 2, 52) : st.dump + 4 * (long)b + 2);
+  const long gstep = gowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
   // register 3 <-> row 12 + kk: C_uu = 2 R (cost.hh:55) in columns 12..15
   const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] : 0.0;
 
@@ -333,15 +342,24 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
     // every lane: Q_uu (4x4), Q_u; lane column j < 12: its row of Q_xu
     double Quu[16], Qu[4], rhs[4];
     if constexpr (SYM) {
+      // rows 12..15 of H (register 3) and the gradient through one small LDS tile: 2 stores per lane,
+      // then broadcast reads (same address in every lane) for Q_uu and Q_u and a column read for the
+      // right-hand side.  Q_xu[j][a] = Q_ux[a][j] by symmetry, so the tile also holds the right-hand sides.
+      Ls[kk * LD + j] = H[3];
+      Lg[j] = ghat;
+      __syncthreads();
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb) Quu[a * 4 + bb] = bcast_lane(H[3], 12 + bb + 16 * a);
-        Qu[a] = bcast_lane(ghat, 12 + a);
-        // Q_xu[j][a] = Q_ux[a][j] (symmetry) sits in register 3 of lane (j, kk = a)
-        const double r = __shfl(H[3], j + 16 * a);
-        rhs[a] = (j < 12) ? r : 0.0;
+        for (int bb = 0; bb < 4; ++bb) Quu[a * 4 + bb] = Ls[a * LD + 12 + bb];
+        Qu[a] = Lg[12 + a];
       }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const double r = Ls[a * LD + j];
+        rhs[a] = (j < 12) ? r : ((j == 12) ? Qu[a] : 0.0);  // lane 12 solves for the feed-forward k
+      }
+      __syncthreads();  // the tile is rewritten by the next knot
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) Hs[(4 * r + kk) * LD + j] = H[r];
@@ -373,56 +391,46 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
     QKEEP(i3); QKEEP(l32); QKEEP(l31);
     double kcol[4], kff[4];
     {
-      // K[:, j] = -Quu^-1 Q_xu[j, :]^T ; k = -Quu^-1 Q_u   (ilqr.hh:127-128)
-      double y0 = rhs[0], y1 = rhs[1] - l10 * y0, y2 = rhs[2] - l20 * y0 - l21 * y1,
-             y3 = rhs[3] - l30 * y0 - l31 * y1 - l32 * y2;
-      double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
-             x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
+      // one right-hand side per lane: K[:, j] = -Quu^-1 Q_xu[j, :]^T in lanes j < 12 and
+      // k = -Quu^-1 Q_u in lane 12   (ilqr.hh:127-128); k is then broadcast
+      const double y0 = rhs[0], y1 = rhs[1] - l10 * y0, y2 = rhs[2] - l20 * y0 - l21 * y1,
+                   y3 = rhs[3] - l30 * y0 - l31 * y1 - l32 * y2;
+      const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
+                   x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
       kcol[0] = -x0; kcol[1] = -x1; kcol[2] = -x2; kcol[3] = -x3;
-      y0 = Qu[0]; y1 = Qu[1] - l10 * y0; y2 = Qu[2] - l20 * y0 - l21 * y1;
-      y3 = Qu[3] - l30 * y0 - l31 * y1 - l32 * y2;
-      x3 = y3 * i3; x2 = y2 * i2 - l32 * x3; x1 = y1 * i1 - l21 * x2 - l31 * x3;
-      x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
-      kff[0] = -x0; kff[1] = -x1; kff[2] = -x2; kff[3] = -x3;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) kff[a] = bcast_lane(kcol[a], 12);
     }
     QKEEP(kcol[0]); QKEEP(kcol[3]); QKEEP(kff[0]); QKEEP(kff[3]);
-    QSTAMP(5);  // factorisation + two solves
+    QSTAMP(5);  // factorisation + solve
+    // gains of knot i: [k(4) | K column-major]; lane j < 12 owns column j, lane 12 owns k.
+    // Every lane stores (lanes that own nothing write zeros to a per-trajectory dump slot): no branch
+    // around the stores, so the wait for the next knot's operands is an exact vmcnt(2), not vmcnt(0).
+    {
+      const bool owner = (kk == 0 && j <= 12);
+      const dv2 w0 = {owner ? kcol[0] : 0.0, owner ? kcol[1] : 0.0}, w1 = {owner ? kcol[2] : 0.0, owner ? kcol[3] : 0.0};
+      *gdst0 = w0;
+      *gdst1 = w1;
+      gdst0 -= gstep;
+      gdst1 -= gstep;
+    }
     // (K^T Quu)[j][:], then V_x = Q_x - (K^T Quu) k   (ilqr.hh:132)
     double mc[4];
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb)
       mc[bb] = kcol[0] * Quu[bb] + kcol[1] * Quu[4 + bb] + kcol[2] * Quu[8 + bb] + kcol[3] * Quu[12 + bb];
     const double vx = ghat - (mc[0] * kff[0] + mc[1] * kff[1] + mc[2] * kff[2] + mc[3] * kff[3]);
-    // expected cost reduction terms (ilqr.hh:136-140), identical in every lane
-    QuTk += Qu[0] * kff[0] + Qu[1] * kff[1] + Qu[2] * kff[2] + Qu[3] * kff[3];
-    {
-      double s = 0.0;
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb)
-        s += (kff[0] * Quu[bb] + kff[1] * Quu[4 + bb] + kff[2] * Quu[8 + bb] + kff[3] * Quu[12 + bb]) * kff[bb];
-      kTQuuk += s;
-    }
+    // expected cost reduction terms (ilqr.hh:136-140): in lane 12 the right-hand side is Q_u and the
+    // solution is k, so Q_u^T k = rhs . kcol and k^T Quu k = (K^T Quu) . kcol there; every lane
+    // accumulates its own column's value and lane 12's sums are read after the loop
+    QuTk += rhs[0] * kcol[0] + rhs[1] * kcol[1] + rhs[2] * kcol[2] + rhs[3] * kcol[3];
+    kTQuuk += mc[0] * kcol[0] + mc[1] * kcol[1] + mc[2] * kcol[2] + mc[3] * kcol[3];
     QKEEP(mc[3]); QKEEP(vx); QKEEP(QuTk); QKEEP(kTQuuk);
     QSTAMP(6);  // K^T Quu, V_x, reduction terms
     // V_xx = Q_xx - (K^T Quu) K   (ilqr.hh:133): one more MFMA on the same accumulator,
     // A[j][kk] = -(K^T Quu)[j][kk], B[kk][j] = K[kk][j]
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(-sel4(mc, kk), sel4(kcol, kk), H, 0, 0, 0);
 
-    // gains of knot i: [k(4) | K column-major]; lane j < 12 owns column j, lane 12 owns k.
-    // Tiled layout: element pair e/2 of this trajectory is one 16-byte slot.
-    // Every lane stores (lanes that own nothing write zeros to a per-trajectory dump slot): no branch
-    // around the stores, so the wait for the next knot's operands is an exact vmcnt(2), not vmcnt(0).
-    {
-      const bool owner = (kk == 0 && j <= 12);
-      const int e0 = (j < 12) ? 4 + 4 * j : 0;
-      gptr2 d0 = (gptr2)(owner ? gains + knot_elem<true>(i, e0, 52) : st.dump + 4 * (long)b);
-      gptr2 d1 = (gptr2)(owner ? gains + knot_elem<true>(i, e0 + 2, 52) : st.dump + 4 * (long)b + 2);
-      const double s0 = (j < 12) ? kcol[0] : kff[0], s1 = (j < 12) ? kcol[1] : kff[1];
-      const double s2 = (j < 12) ? kcol[2] : kff[2], s3 = (j < 12) ? kcol[3] : kff[3];
-      const dv2 w0 = {owner ? s0 : 0.0, owner ? s1 : 0.0}, w1 = {owner ? s2 : 0.0, owner ? s3 : 0.0};
-      *d0 = w0;
-      *d1 = w1;
-    }
     // hand V_xx, V_x to the next knot
     if constexpr (SYM) {
 #pragma unroll
@@ -458,6 +466,8 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   if (lane == 0 && st.stamps)
     for (int k = 0; k < 8; ++k) st.stamps[(long)b * 8 + k] = stamp_sum[k];
 #endif
+  QuTk = bcast_lane(QuTk, 12);
+  kTQuuk = bcast_lane(kTQuuk, 12);
   if (lane == 0) {
     st.terms[2 * b] = QuTk;
     st.terms[2 * b + 1] = kTQuuk;

@@ -190,14 +190,14 @@ void hh_backward_emulated(const ModelConsts<double> *cp, const int *lay, const d
       for (int r = 0; r < 4; ++r) Hs[(4 * r + kk) * LD + j] = H[l][r];
       if (kk == 0) gs[j] = ghat[l];
     }
-    double aop[64], bop[64], vx[64];
+    double aop[64], bop[64], vx[64], kcol_all[64][4], mc_all[64][4], Quu_l[16] = {0};
     for (int l = 0; l < 64; ++l) {
       const int j = l & 15, kk = l >> 4;
       double Quu[16], Qu[4], rhs[4];
       for (int aa = 0; aa < 4; ++aa) {
         for (int bb = 0; bb < 4; ++bb) Quu[aa * 4 + bb] = Hs[(12 + aa) * LD + 12 + bb];
         Qu[aa] = gs[12 + aa];
-        rhs[aa] = (j < 12) ? Hs[j * LD + 12 + aa] : 0.0;
+        rhs[aa] = (j < 12) ? Hs[j * LD + 12 + aa] : ((j == 12) ? Qu[aa] : 0.0);  // lane 12 solves for k
       }
       const double i0 = 1.0 / Quu[0];
       const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
@@ -211,32 +211,30 @@ void hh_backward_emulated(const ModelConsts<double> *cp, const int *lay, const d
       const double l32 = c32 * i2;
       const double d3 = Quu[15] - l30 * Quu[12] - l31 * c31 - l32 * c32;
       const double i3 = 1.0 / d3;
-      double kcol[4], kff[4];
-      double y0 = rhs[0], y1 = rhs[1] - l10 * y0, y2 = rhs[2] - l20 * y0 - l21 * y1,
-             y3 = rhs[3] - l30 * y0 - l31 * y1 - l32 * y2;
-      double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
-             x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
-      kcol[0] = -x0; kcol[1] = -x1; kcol[2] = -x2; kcol[3] = -x3;
-      y0 = Qu[0]; y1 = Qu[1] - l10 * y0; y2 = Qu[2] - l20 * y0 - l21 * y1;
-      y3 = Qu[3] - l30 * y0 - l31 * y1 - l32 * y2;
-      x3 = y3 * i3; x2 = y2 * i2 - l32 * x3; x1 = y1 * i1 - l21 * x2 - l31 * x3;
-      x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
-      kff[0] = -x0; kff[1] = -x1; kff[2] = -x2; kff[3] = -x3;
-      double mc[4];
+      const double y0 = rhs[0], y1 = rhs[1] - l10 * y0, y2 = rhs[2] - l20 * y0 - l21 * y1,
+                   y3 = rhs[3] - l30 * y0 - l31 * y1 - l32 * y2;
+      const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
+                   x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
+      kcol_all[l][0] = -x0; kcol_all[l][1] = -x1; kcol_all[l][2] = -x2; kcol_all[l][3] = -x3;
       for (int bb = 0; bb < 4; ++bb)
-        mc[bb] = kcol[0] * Quu[bb] + kcol[1] * Quu[4 + bb] + kcol[2] * Quu[8 + bb] + kcol[3] * Quu[12 + bb];
+        mc_all[l][bb] = kcol_all[l][0] * Quu[bb] + kcol_all[l][1] * Quu[4 + bb] + kcol_all[l][2] * Quu[8 + bb] +
+                        kcol_all[l][3] * Quu[12 + bb];
+      QuTk[l] += rhs[0] * kcol_all[l][0] + rhs[1] * kcol_all[l][1] + rhs[2] * kcol_all[l][2] + rhs[3] * kcol_all[l][3];
+      kTQuuk[l] += mc_all[l][0] * kcol_all[l][0] + mc_all[l][1] * kcol_all[l][1] + mc_all[l][2] * kcol_all[l][2] +
+                   mc_all[l][3] * kcol_all[l][3];
+      (void)Quu_l;
+      (void)kk;
+    }
+    for (int l = 0; l < 64; ++l) {
+      const int j = l & 15, kk = l >> 4;
+      const double *kcol = kcol_all[l], *mc = mc_all[l], *kff = kcol_all[12];  // k broadcast from lane 12
       vx[l] = ghat[l] - (mc[0] * kff[0] + mc[1] * kff[1] + mc[2] * kff[2] + mc[3] * kff[3]);
-      QuTk[l] += Qu[0] * kff[0] + Qu[1] * kff[1] + Qu[2] * kff[2] + Qu[3] * kff[3];
-      double s = 0.0;
-      for (int bb = 0; bb < 4; ++bb)
-        s += (kff[0] * Quu[bb] + kff[1] * Quu[4 + bb] + kff[2] * Quu[8 + bb] + kff[3] * Quu[12 + bb]) * kff[bb];
-      kTQuuk[l] += s;
       aop[l] = -mc[kk];
       bop[l] = kcol[kk];
       if (kk == 0) {
         double *g = gains + (long)i * 52;
         if (j < 12) for (int aa = 0; aa < 4; ++aa) g[4 + 4 * j + aa] = kcol[aa];
-        else if (j == 12) for (int aa = 0; aa < 4; ++aa) g[aa] = kff[aa];
+        else if (j == 12) for (int aa = 0; aa < 4; ++aa) g[aa] = kcol[aa];
       }
     }
     mfma_f64_16x16x4(aop, bop, H);
@@ -255,8 +253,8 @@ void hh_backward_emulated(const ModelConsts<double> *cp, const int *lay, const d
       }
     }
   }
-  terms[0] = QuTk[0];
-  terms[1] = kTQuuk[0];
+  terms[0] = QuTk[12];  // lane 12 owns the feed-forward column
+  terms[1] = kTQuuk[12];
 }
 
 }  // extern "C"
