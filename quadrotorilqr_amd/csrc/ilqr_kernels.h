@@ -173,6 +173,22 @@ __device__ __forceinline__ double xor32_sum(double x) {
   return __longlong_as_double(((long long)b[0] << 32) | a[0]) + __longlong_as_double(((long long)b[1] << 32) | a[1]);
 }
 
+// r[a] = value of x in the lane of the same column and row a (a = 0..3), for every lane: three
+// permlane swaps per dword instead of four ds_bpermute round trips
+__device__ __forceinline__ void gather_rows(double x, double r[4]) {
+  const unsigned lo = (unsigned)__double_as_longlong(x), hi = (unsigned)(__double_as_longlong(x) >> 32);
+  const auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);  // {x0,x0,x2,x2}, {x1,x1,x3,x3}
+  const auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const auto la = __builtin_amdgcn_permlane32_swap(l16[0], l16[0], false, false);  // x0 everywhere, x2 everywhere
+  const auto ha = __builtin_amdgcn_permlane32_swap(h16[0], h16[0], false, false);
+  const auto lb = __builtin_amdgcn_permlane32_swap(l16[1], l16[1], false, false);  // x1, x3
+  const auto hb = __builtin_amdgcn_permlane32_swap(h16[1], h16[1], false, false);
+  r[0] = __longlong_as_double(((long long)ha[0] << 32) | la[0]);
+  r[1] = __longlong_as_double(((long long)hb[0] << 32) | lb[0]);
+  r[2] = __longlong_as_double(((long long)ha[1] << 32) | la[1]);
+  r[3] = __longlong_as_double(((long long)hb[1] << 32) | lb[1]);
+}
+
 // SYM = true: Q and R are exactly symmetric, so V_xx and H are symmetric to rounding and the
 // accumulator tile can be reused as the next knot's A operand without a transpose; no LDS and no
 // barrier remain in the loop (Q_uu/Q_u are broadcast with v_readlane, the right-hand sides with
@@ -258,8 +274,6 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   double *gains = st.gains + knot_base<true>(b, n, 52);
 
   constexpr int LD = 17;  // padded leading dimension: column reads of a row-major tile
-  __shared__ double Ls[SYM ? 4 * LD : 1];  // SYM: register 3 of every lane, [kk][j] (rows 12..15 of H)
-  __shared__ double Lg[SYM ? 16 : 1];      // SYM: [Q_x ; Q_u]
   __shared__ double Vs[SYM ? 1 : 12 * LD];
   __shared__ double Hs[SYM ? 1 : 16 * LD];
   __shared__ double gs[SYM ? 1 : 16];
@@ -342,24 +356,23 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
     // every lane: Q_uu (4x4), Q_u; lane column j < 12: its row of Q_xu
     double Quu[16], Qu[4], rhs[4];
     if constexpr (SYM) {
-      // rows 12..15 of H (register 3) and the gradient through one small LDS tile: 2 stores per lane,
-      // then broadcast reads (same address in every lane) for Q_uu and Q_u and a column read for the
-      // right-hand side.  Q_xu[j][a] = Q_ux[a][j] by symmetry, so the tile also holds the right-hand sides.
-      Ls[kk * LD + j] = H[3];
-      Lg[j] = ghat;
-      __syncthreads();
+      // rows 12..15 of H live in register 3: lane (j, kk) holds H[12 + kk][j].  Gather the four rows
+      // of each column into every lane (permlane swaps): column j < 12 is the right-hand side
+      // Q_xu[j][:] (= Q_ux[:][j] by symmetry), columns 12..15 are Q_uu, broadcast with v_readlane
+      // (lower triangle only; Q_uu is symmetric here).
+      double col[4];
+      gather_rows(H[3], col);
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb) Quu[a * 4 + bb] = Ls[a * LD + 12 + bb];
-        Qu[a] = Lg[12 + a];
+        for (int bb = 0; bb <= a; ++bb) {
+          Quu[a * 4 + bb] = bcast_lane(col[a], 12 + bb);
+          Quu[bb * 4 + a] = Quu[a * 4 + bb];
+        }
+        Qu[a] = bcast_lane(ghat, 12 + a);
       }
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const double r = Ls[a * LD + j];
-        rhs[a] = (j < 12) ? r : ((j == 12) ? Qu[a] : 0.0);  // lane 12 solves for the feed-forward k
-      }
-      __syncthreads();  // the tile is rewritten by the next knot
+      for (int a = 0; a < 4; ++a) rhs[a] = (j < 12) ? col[a] : ((j == 12) ? Qu[a] : 0.0);  // lane 12: feed-forward
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) Hs[(4 * r + kk) * LD + j] = H[r];
@@ -370,7 +383,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb) Quu[a * 4 + bb] = Hs[(12 + a) * LD + 12 + bb];
         Qu[a] = gs[12 + a];
-        rhs[a] = (j < 12) ? Hs[j * LD + 12 + a] : 0.0;
+        rhs[a] = (j < 12) ? Hs[j * LD + 12 + a] : ((j == 12) ? gs[12 + a] : 0.0);  // lane 12: feed-forward
       }
     }
     QKEEP(Quu[15]); QKEEP(Quu[0]); QKEEP(Qu[3]); QKEEP(rhs[3]); QKEEP(rhs[0]);
