@@ -578,22 +578,36 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
     cj = sh[0][10][lane];
   }
 
-  for (int i = 0; i < n; ++i) {
+  // Operands of the NEXT knot are requested before the current knot's chain starts and consumed one
+  // iteration later (two register sets, loop unrolled by two so that no copies are needed): wave X
+  // prefetches the nominal knot and the 52 gains, wave Y the nominal pose.
+  double ptA[18], ptB[18], gA[52], gB[52], pnA[8], pnB[8];
+  if (role == 0) {
+    load_knot<true>(traj, 0, 18, ptA);
+    load_knot<true>(gains, 0, 52, gA);
+  } else if (n > 1) {
+#pragma unroll
+    for (int e = 1; e < 8; ++e) pnA[e] = traj[knot_elem<true>(1, e, 18)];
+  }
+
+  auto knot = [&](int i, double (&ptc)[18], double (&gc)[52], double (&ptn)[18], double (&gn)[52], double (&pnc)[8],
+                  double (&pnn)[8]) {
     const int par = (i + 1) & 1;
     const bool more = (i + 1 < n);
     if (role == 0) {
-      double g[52];
-      load_knot<true>(traj, i, 18, pt);
-      load_knot<true>(gains, i, 52, g);
+      if (more) {
+        load_knot<true>(traj, i + 1, 18, ptn);
+        load_knot<true>(gains, i + 1, 52, gn);
+      }
       double dx[12];
       se3_rminus_part2(td, th, cj, dx);
       dx[3] = th[0]; dx[4] = th[1]; dx[5] = th[2];
 #pragma unroll
-      for (int a = 0; a < 6; ++a) dx[6 + a] = v[a] - pt[8 + a];
+      for (int a = 0; a < 6; ++a) dx[6 + a] = v[a] - ptc[8 + a];
       double u[4];
-      control_law(pt, g, alpha, dx, u);
+      control_law(ptc, gc, alpha, dx, u);
       if (live) {
-        out[knot_elem<true>(i, 0, 18)] = pt[0];
+        out[knot_elem<true>(i, 0, 18)] = ptc[0];
 #pragma unroll
         for (int a = 0; a < 6; ++a) out[knot_elem<true>(i, 8 + a, 18)] = v[a];
 #pragma unroll
@@ -609,15 +623,16 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
         }
       }
     } else if (more) {
+      if (i + 2 < n) {
+#pragma unroll
+        for (int e = 1; e < 8; ++e) pnn[e] = traj[knot_elem<true>(i + 2, e, 18)];
+      }
       double tau[6];
 #pragma unroll
       for (int a = 0; a < 6; ++a) tau[a] = c.dt * v[a];  // pose integrates with the OLD velocity
       se3_rplus_fast(t, q, tau);
-      double pn[8];
-#pragma unroll
-      for (int e = 1; e < 8; ++e) pn[e] = traj[knot_elem<true>(i + 1, e, 18)];
-      const double qn[4] = {pn[5], pn[6], pn[7], pn[4]};
-      se3_rminus_part1(t, q, pn + 1, qn, td, th, cj);
+      const double qn[4] = {pnc[5], pnc[6], pnc[7], pnc[4]};
+      se3_rminus_part1(t, q, pnc + 1, qn, td, th, cj);
 #pragma unroll
       for (int a = 0; a < 4; ++a) sh[par][a][lane] = q[a];
 #pragma unroll
@@ -648,6 +663,10 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
         for (int a = 0; a < 6; ++a) v[a] = sh[par][11 + a][lane];
       }
     }
+  };
+  for (int i = 0; i < n; i += 2) {
+    knot(i, ptA, gA, ptB, gB, pnA, pnB);
+    if (i + 1 < n) knot(i + 1, ptB, gB, ptA, gA, pnB, pnA);
   }
 }
 
