@@ -590,6 +590,10 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
     for (int e = 1; e < 8; ++e) pnA[e] = traj[knot_elem<true>(1, e, 18)];
   }
 
+#ifdef QILQR_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
   auto knot = [&](int i, double (&ptc)[18], double (&gc)[52], double (&ptn)[18], double (&gn)[52], double (&pnc)[8],
                   double (&pnn)[8]) {
     const int par = (i + 1) & 1;
@@ -599,13 +603,18 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
         load_knot<true>(traj, i + 1, 18, ptn);
         load_knot<true>(gains, i + 1, 52, gn);
       }
+      QSTAMP(0);  // X: prefetch issue
       double dx[12];
       se3_rminus_part2(td, th, cj, dx);
       dx[3] = th[0]; dx[4] = th[1]; dx[5] = th[2];
 #pragma unroll
       for (int a = 0; a < 6; ++a) dx[6 + a] = v[a] - ptc[8 + a];
+      QKEEP(dx[0]); QKEEP(dx[11]);
+      QSTAMP(1);  // X: rho = Jl^-1 td, dx
       double u[4];
       control_law(ptc, gc, alpha, dx, u);
+      QKEEP(u[0]); QKEEP(u[3]);
+      QSTAMP(2);  // X: control law (waits for this knot's operands)
       if (live) {
         out[knot_elem<true>(i, 0, 18)] = ptc[0];
 #pragma unroll
@@ -613,6 +622,7 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
 #pragma unroll
         for (int a = 0; a < 4; ++a) out[knot_elem<true>(i, 14 + a, 18)] = u[a];
       }
+      QSTAMP(3);  // X: stores
       if (more) {
         double acc[6];
         body_acceleration_fast(c, q, v, u, acc);
@@ -622,6 +632,7 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
           sh[par][11 + a][lane] = v[a];
         }
       }
+      QSTAMP(4);  // X: acceleration, velocity update, LDS write
     } else if (more) {
       if (i + 2 < n) {
 #pragma unroll
@@ -630,9 +641,14 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
       double tau[6];
 #pragma unroll
       for (int a = 0; a < 6; ++a) tau[a] = c.dt * v[a];  // pose integrates with the OLD velocity
+      QSTAMP(0);  // Y: prefetch issue
       se3_rplus_fast(t, q, tau);
+      QKEEP(q[0]); QKEEP(t[0]);
+      QSTAMP(1);  // Y: T <- T Exp(dt v)
       const double qn[4] = {pnc[5], pnc[6], pnc[7], pnc[4]};
       se3_rminus_part1(t, q, pnc + 1, qn, td, th, cj);
+      QKEEP(td[0]); QKEEP(th[0]); QKEEP(cj);
+      QSTAMP(2);  // Y: pose part of x (-) xnom (waits for the nominal pose)
 #pragma unroll
       for (int a = 0; a < 4; ++a) sh[par][a][lane] = q[a];
 #pragma unroll
@@ -663,11 +679,17 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
         for (int a = 0; a < 6; ++a) v[a] = sh[par][11 + a][lane];
       }
     }
+    QKEEP(v[0]); QKEEP(q[0]); QKEEP(cj);
+    QSTAMP(6);  // LDS read of the partner's results
   };
   for (int i = 0; i < n; i += 2) {
     knot(i, ptA, gA, ptB, gB, pnA, pnB);
     if (i + 1 < n) knot(i + 1, ptB, gB, ptA, gA, pnB, pnA);
   }
+#ifdef QILQR_STAMPS
+  if (lane == 0 && st.stamps)
+    for (int k = 0; k < 8; ++k) st.stamps[((long)blockIdx.x * 2 + role) * 8 + k] = stamp_sum[k];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
