@@ -237,7 +237,9 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
 }
 int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
   Timed t(s, K_ROLLOUT);
-  if (s->dev.single_wave_rollout)
+  // the cooperating pair shortens one trajectory's chain; with more tiles than the chip has room for
+  // pairs (1 pair per SIMD at 256 VGPRs) the single-wave form gives the higher throughput
+  if (s->dev.single_wave_rollout || B > 16384)
     hipLaunchKernelGGL(k_rollout, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->consts, s->st, (int)B, (int)n,
                        need_flag);
   else
