@@ -51,8 +51,10 @@ struct qilqr_solver {
   int n_desired = 0;
   bool symmetric = false;  // Q == Q^T and R == R^T exactly: transpose-free backward kernel
   RecLayout layout;        // knot record layout chosen from the structure of Q
-  double *d_desired = nullptr;  // shared desired trajectory
-  double *d_ctab = nullptr;     // constant operand table of k_backward
+  void *d_desired = nullptr;    // shared desired trajectory, storage precision
+  void *d_ctab = nullptr;       // constant operand table of k_backward, storage precision
+  bool f32 = false;             // mixed-precision mode (qilqr_device_config.precision == 1)
+  ModelConsts<float> constsf;   // the model constants for the fp32 lane-local kernels
   // workspace
   long cap_B = 0, cap_n = 0;
   int hist_cap = 0;
@@ -60,7 +62,7 @@ struct qilqr_solver {
   std::vector<void *> allocs;
   int *h_counters = nullptr;  // pinned
   double *io_aos = nullptr;         // device scratch in the plain [B][n][W] layout (W <= 52), for host I/O
-  double *desired_tiled = nullptr;  // per-problem desired trajectories, tiled (allocated on first use)
+  void *desired_tiled = nullptr;    // per-problem desired trajectories, tiled (allocated on first use)
   // profiling
   std::vector<EventPair> events;
   size_t events_used = 0;
@@ -119,6 +121,13 @@ int dalloc(qilqr_solver *s, T **p, size_t count) {
   return QILQR_OK;
 }
 
+int dalloc_s(qilqr_solver *s, void **p, size_t count) {  // count elements of the storage type
+  char *q = nullptr;
+  int rc = dalloc(s, &q, count * (s->f32 ? sizeof(float) : sizeof(double)));
+  *p = q;
+  return rc;
+}
+
 int ensure_workspace(qilqr_solver *s, long B, long n) {
   const int want_hist = s->options.populate_debug ? (int)std::fmin(std::fmax(s->params.max_iters, 0.0), 1e6) : 0;
   if (B <= s->cap_B && n <= s->cap_n && want_hist <= s->hist_cap) return QILQR_OK;
@@ -130,11 +139,11 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
   st.dbg_uniform = (getenv("QILQR_DBG_UNIFORM") != nullptr) ? 1 : 0;
   int rc;
   for (int k = 0; k < 2; ++k) {
-    if ((rc = dalloc(s, &st.traj[k], (size_t)tiled_count(cB, cn, 18)))) return rc;
-    if ((rc = dalloc(s, &st.lin[k], (size_t)cB * cn * s->layout.stride))) return rc;
+    if ((rc = dalloc_s(s, &st.traj[k], (size_t)tiled_count(cB, cn, 18)))) return rc;
+    if ((rc = dalloc_s(s, &st.lin[k], (size_t)cB * cn * s->layout.stride))) return rc;
     if ((rc = dalloc(s, &st.knot_cost[k], (size_t)tiled_count(cB, cn, 1)))) return rc;
   }
-  if ((rc = dalloc(s, &st.gains, (size_t)tiled_count(cB, cn, 52)))) return rc;
+  if ((rc = dalloc_s(s, &st.gains, (size_t)tiled_count(cB, cn, 52)))) return rc;
   if ((rc = dalloc(s, &s->io_aos, (size_t)cB * cn * 52))) return rc;
   s->desired_tiled = nullptr;
   if ((rc = dalloc(s, &st.cur, cB))) return rc;
@@ -149,7 +158,7 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
   if ((rc = dalloc(s, &st.n_bwd, cB))) return rc;
   if ((rc = dalloc(s, &st.n_fwd, cB))) return rc;
   if ((rc = dalloc(s, &st.counters, 4))) return rc;
-  if ((rc = dalloc(s, &st.dump, 4 * cB))) return rc;
+  if ((rc = dalloc_s(s, &st.dump, 4 * cB))) return rc;
 #ifdef QILQR_STAMPS
   if ((rc = dalloc(s, &st.stamps, 8 * cB))) return rc;
 #else
@@ -169,17 +178,24 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
 
 inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
 
-// plain [B][n][W] (device) -> tiled
-int to_tiled(qilqr_solver *s, const double *d_plain, double *tiled, long B, long n, int W) {
-  hipLaunchKernelGGL(k_retile, dim3(cdiv(B * n * W, 256)), dim3(256), 0, s->stream, d_plain, (double *)nullptr, tiled,
-                     tiled, (const int *)nullptr, 0, (int)B, (int)n, W, 1);
+// plain [B][n][W] fp64 (device) -> tiled, storage precision
+int to_tiled(qilqr_solver *s, const double *d_plain, void *tiled, long B, long n, int W) {
+  if (s->f32)
+    hipLaunchKernelGGL(k_retile<float>, dim3(cdiv(B * n * W, 256)), dim3(256), 0, s->stream, d_plain, (double *)nullptr,
+                       (float *)tiled, (float *)tiled, (const int *)nullptr, 0, (int)B, (int)n, W, 1);
+  else
+    hipLaunchKernelGGL(k_retile<double>, dim3(cdiv(B * n * W, 256)), dim3(256), 0, s->stream, d_plain,
+                       (double *)nullptr, (double *)tiled, (double *)tiled, (const int *)nullptr, 0, (int)B, (int)n, W, 1);
   return QILQR_OK;
 }
-// tiled -> plain [B][n][W] (device); sel/flip choose between t0 and t1 per trajectory
-int from_tiled(qilqr_solver *s, double *d_plain, double *t0, double *t1, const int *sel, int flip, long B, long n,
-               int W) {
-  hipLaunchKernelGGL(k_retile, dim3(cdiv(B * n * W, 256)), dim3(256), 0, s->stream, (const double *)nullptr, d_plain,
-                     t0, t1, sel, flip, (int)B, (int)n, W, 0);
+// tiled -> plain [B][n][W] fp64 (device); sel/flip choose between t0 and t1 per trajectory
+int from_tiled(qilqr_solver *s, double *d_plain, void *t0, void *t1, const int *sel, int flip, long B, long n, int W) {
+  if (s->f32)
+    hipLaunchKernelGGL(k_retile<float>, dim3(cdiv(B * n * W, 256)), dim3(256), 0, s->stream, (const double *)nullptr,
+                       d_plain, (float *)t0, (float *)t1, sel, flip, (int)B, (int)n, W, 0);
+  else
+    hipLaunchKernelGGL(k_retile<double>, dim3(cdiv(B * n * W, 256)), dim3(256), 0, s->stream, (const double *)nullptr,
+                       d_plain, (double *)t0, (double *)t1, sel, flip, (int)B, (int)n, W, 0);
   return QILQR_OK;
 }
 
@@ -193,7 +209,7 @@ int begin_batch(qilqr_solver *s, long B, long n, const double *d_desired_batch) 
   int rc = ensure_workspace(s, B, n);
   if (rc) return rc;
   if (d_desired_batch) {
-    if (!s->desired_tiled && (rc = dalloc(s, &s->desired_tiled, (size_t)tiled_count(s->cap_B, s->cap_n, 18)))) return rc;
+    if (!s->desired_tiled && (rc = dalloc_s(s, &s->desired_tiled, (size_t)tiled_count(s->cap_B, s->cap_n, 18)))) return rc;
     if ((rc = to_tiled(s, d_desired_batch, s->desired_tiled, B, n, 18))) return rc;
     s->st.desired = s->desired_tiled;
     s->st.desired_tiled = 1;
@@ -206,11 +222,11 @@ int begin_batch(qilqr_solver *s, long B, long n, const double *d_desired_batch) 
   return QILQR_OK;
 }
 // host plain array -> device tiled buffer through the io scratch
-int upload_tiled(qilqr_solver *s, const double *h_plain, double *tiled, long B, long n, int W) {
+int upload_tiled(qilqr_solver *s, const double *h_plain, void *tiled, long B, long n, int W) {
   HIP_TRY(hipMemcpyAsync(s->io_aos, h_plain, sizeof(double) * (size_t)B * n * W, hipMemcpyHostToDevice, s->stream));
   return to_tiled(s, s->io_aos, tiled, B, n, W);
 }
-int download_tiled(qilqr_solver *s, double *h_plain, double *t0, double *t1, const int *sel, int flip, long B, long n,
+int download_tiled(qilqr_solver *s, double *h_plain, void *t0, void *t1, const int *sel, int flip, long B, long n,
                    int W) {
   int rc = from_tiled(s, s->io_aos, t0, t1, sel, flip, B, n, W);
   if (rc) return rc;
@@ -221,30 +237,49 @@ int download_tiled(qilqr_solver *s, double *h_plain, double *t0, double *t1, con
 
 int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag) {
   Timed t(s, K_LINEARIZE);
-  hipLaunchKernelGGL(k_linearize, dim3(cdiv(((B + 63) / 64) * 64 * n, 128)), dim3(128), 0, s->stream, s->consts,
-                     s->st, (int)B, (int)n, which, need_flag);
+  const dim3 grid(cdiv(((B + 63) / 64) * 64 * n, 128));
+  if (s->f32)
+    hipLaunchKernelGGL(k_linearize<float>, grid, dim3(128), 0, s->stream, s->constsf, s->st, (int)B, (int)n, which,
+                       need_flag);
+  else
+    hipLaunchKernelGGL(k_linearize<double>, grid, dim3(128), 0, s->stream, s->consts, s->st, (int)B, (int)n, which,
+                       need_flag);
   return QILQR_OK;
 }
 int launch_backward(qilqr_solver *s, long B, long n, int force) {
   Timed t(s, K_BACKWARD);
-  if (s->symmetric)
-    hipLaunchKernelGGL(k_backward<true>, dim3((unsigned)B), dim3(64), 0, s->stream, s->consts, s->params, s->st,
-                       (int)B, (int)n, force);
-  else
-    hipLaunchKernelGGL(k_backward<false>, dim3((unsigned)B), dim3(64), 0, s->stream, s->consts, s->params, s->st,
-                       (int)B, (int)n, force);
+#define QILQR_LAUNCH_BWD(SYM, S)                                                                              \
+  hipLaunchKernelGGL((k_backward<SYM, S>), dim3((unsigned)B), dim3(64), 0, s->stream, s->consts, s->params, s->st, \
+                     (int)B, (int)n, force)
+  if (s->symmetric) {
+    if (s->f32) QILQR_LAUNCH_BWD(true, float);
+    else QILQR_LAUNCH_BWD(true, double);
+  } else {
+    if (s->f32) QILQR_LAUNCH_BWD(false, float);
+    else QILQR_LAUNCH_BWD(false, double);
+  }
+#undef QILQR_LAUNCH_BWD
   return QILQR_OK;
 }
 int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
   Timed t(s, K_ROLLOUT);
   // the cooperating pair shortens one trajectory's chain; with more tiles than the chip has room for
   // pairs (1 pair per SIMD at 256 VGPRs) the single-wave form gives the higher throughput
-  if (s->dev.single_wave_rollout || B > 16384)
-    hipLaunchKernelGGL(k_rollout, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->consts, s->st, (int)B, (int)n,
-                       need_flag);
-  else
-    hipLaunchKernelGGL(k_rollout2, dim3(cdiv(B, 64)), dim3(128), 0, s->stream, s->consts, s->st, (int)B, (int)n,
-                       need_flag);
+  if (s->dev.single_wave_rollout || B > 16384) {
+    if (s->f32)
+      hipLaunchKernelGGL(k_rollout<float>, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->constsf, s->st, (int)B, (int)n,
+                         need_flag);
+    else
+      hipLaunchKernelGGL(k_rollout<double>, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->consts, s->st, (int)B, (int)n,
+                         need_flag);
+  } else {
+    if (s->f32)
+      hipLaunchKernelGGL(k_rollout2<float>, dim3(cdiv(B, 64)), dim3(128), 0, s->stream, s->constsf, s->st, (int)B,
+                         (int)n, need_flag);
+    else
+      hipLaunchKernelGGL(k_rollout2<double>, dim3(cdiv(B, 64)), dim3(128), 0, s->stream, s->consts, s->st, (int)B,
+                         (int)n, need_flag);
+  }
   return QILQR_OK;
 }
 int launch_accept(qilqr_solver *s, long B, long n, int ls_only) {
@@ -300,8 +335,12 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round) {
 int gather(qilqr_solver *s, long B, long n, double *d_traj, double *d_cost, int *d_status, int *d_iters,
            int *d_bwd, int *d_fwd) {
   Timed t(s, K_OTHER);
-  hipLaunchKernelGGL(k_gather, dim3(cdiv(B * n * 18, 256)), dim3(256), 0, s->stream, s->st, (int)B, (int)n,
-                     d_traj, d_cost, d_status, d_iters, d_bwd, d_fwd);
+  if (s->f32)
+    hipLaunchKernelGGL(k_gather<float>, dim3(cdiv(B * n * 18, 256)), dim3(256), 0, s->stream, s->st, (int)B, (int)n,
+                       d_traj, d_cost, d_status, d_iters, d_bwd, d_fwd);
+  else
+    hipLaunchKernelGGL(k_gather<double>, dim3(cdiv(B * n * 18, 256)), dim3(256), 0, s->stream, s->st, (int)B, (int)n,
+                       d_traj, d_cost, d_status, d_iters, d_bwd, d_fwd);
   return QILQR_OK;
 }
 
@@ -341,7 +380,7 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(QILQR_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
-  qilqr_device_config dc = {0, 0, 1, 0, 0};
+  qilqr_device_config dc = {0, 0, 1, 0, 0, 0};
   if (dev) dc = *dev;
   if (dc.device < 0 || dc.device >= ndev) return fail(QILQR_ERR_INVALID_ARG, "bad device ordinal");
   if (dc.sync_every < 1) dc.sync_every = 1;
@@ -353,6 +392,8 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   s->params = SolveParams{options->step_update, options->desired_reduction_frac, options->rtol, options->atol,
                           options->max_iters, options->ls_max_iters};
   s->consts = mc;
+  s->f32 = (dc.precision == 1);
+  convert_consts(mc, s->constsf);
   s->symmetric = true;
   for (int i = 0; i < 12; ++i)
     for (int k = 0; k < i; ++k) s->symmetric = s->symmetric && (Q[i * 12 + k] == Q[k * 12 + i]);
@@ -372,15 +413,25 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
 
   hipError_t e = hipSetDevice(s->device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipMalloc((void **)&s->d_desired, sizeof(double) * 18 * (n_desired > 0 ? n_desired : 1));
-  if (e == hipSuccess && n_desired > 0)
-    e = hipMemcpy(s->d_desired, desired, sizeof(double) * 18 * n_desired, hipMemcpyHostToDevice);
+  const size_t es = s->f32 ? sizeof(float) : sizeof(double);
+  if (e == hipSuccess) e = hipMalloc(&s->d_desired, es * 18 * (n_desired > 0 ? n_desired : 1));
+  if (e == hipSuccess && n_desired > 0) {
+    if (s->f32) {
+      std::vector<float> tmp((size_t)18 * n_desired);
+      for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = (float)desired[i];
+      e = hipMemcpy(s->d_desired, tmp.data(), es * tmp.size(), hipMemcpyHostToDevice);
+    } else {
+      e = hipMemcpy(s->d_desired, desired, es * 18 * n_desired, hipMemcpyHostToDevice);
+    }
+  }
   if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_counters, sizeof(int) * 4, hipHostMallocDefault);
-  if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctab, sizeof(double) * CTAB_SIZE);
+  if (e == hipSuccess) e = hipMalloc(&s->d_ctab, es * CTAB_SIZE);
   if (e == hipSuccess) {
     double tab[CTAB_SIZE];
+    float tabf[CTAB_SIZE];
     build_ctab(s->consts.Bu, s->consts.Q, tab);
-    e = hipMemcpy(s->d_ctab, tab, sizeof(tab), hipMemcpyHostToDevice);
+    for (int i = 0; i < CTAB_SIZE; ++i) tabf[i] = (float)tab[i];
+    e = hipMemcpy(s->d_ctab, s->f32 ? (const void *)tabf : (const void *)tab, es * CTAB_SIZE, hipMemcpyHostToDevice);
   }
   if (e != hipSuccess) {
     const int rc = fail(QILQR_ERR_HIP, std::string("qilqr_create: ") + hipGetErrorString(e));

@@ -29,12 +29,14 @@ struct SolveParams {
 
 // all device pointers; [B] unless noted
 struct BatchState {
-  double *traj[2];       // TILED (se3_math.h) [tile][n][9][64][2]: current / candidate trajectories
-  double *lin[2];        // [B][n][layout.stride] knot records of traj[k]
+  // Buffers whose element type S is the solver's storage precision (double, or float in the
+  // mixed-precision mode): kernels are instantiated on S and cast.
+  void *traj[2];         // TILED (se3_math.h) [tile][n][9][64][2]: current / candidate trajectories
+  void *lin[2];          // [B][n][layout.stride] knot records of traj[k]
   RecLayout layout;
   double *knot_cost[2];  // [tile][n][64]
-  double *gains;         // TILED [tile][n][26][64][2]
-  const double *desired; // shared: plain [n_desired][18]; per problem: TILED like traj
+  void *gains;           // TILED [tile][n][26][64][2]
+  const void *desired;   // shared: plain [n_desired][18]; per problem: TILED like traj
   int desired_tiled;     // 0 shared, 1 per problem
   int *cur;              // which of traj[] / lin[] is current
   double *cost;          // cost of the current trajectory ("new_cost", ilqr.hh:56)
@@ -47,8 +49,8 @@ struct BatchState {
   int *counters;         // [0] trajectories still active after k_accept
   double *cost_hist;     // [B][hist_cap] or null
   int hist_cap;
-  const double *ctab;    // constant operand table (backward_layout.h)
-  double *dump;          // [B][4] write-only sink for the lanes of k_backward that own no gain entry
+  const void *ctab;      // constant operand table (backward_layout.h)
+  void *dump;            // [B][4] write-only sink for the lanes of k_backward that own no gain entry
   unsigned long long *stamps;  // diagnostic build only (-DQILQR_STAMPS): [B][8] cycle sums per section of k_backward
   int dbg_uniform;       // diagnostic only (QILQR_DBG_UNIFORM=1): every lane of a rollout wave reads one trajectory
 };
@@ -56,9 +58,12 @@ struct BatchState {
 typedef double d4 __attribute__((ext_vector_type(4)));
 // explicit global address space: a pointer selected between two buffers is otherwise 'generic' and
 // becomes flat_load (out-of-order return, forces vmcnt(0) + lgkmcnt(0) waits)
-typedef const double __attribute__((address_space(1))) *gcptr;
-typedef double dv2 __attribute__((ext_vector_type(2)));
-typedef dv2 __attribute__((address_space(1))) *gptr2;
+template <typename S>
+struct GA {  // global address space views of storage type S
+  typedef const S __attribute__((address_space(1))) *cptr;
+  typedef S v2 __attribute__((ext_vector_type(2)));
+  typedef v2 __attribute__((address_space(1))) *ptr2;
+};
 
 #ifdef QILQR_STAMPS
 // In-kernel section timing for a separate diagnostic build (cdna_hip_programming.md section 7): one
@@ -92,8 +97,9 @@ __device__ __forceinline__ double cost_reduction(double QuTk, double kTQuuk, dou
 // k_linearize: thread (b, i).  which = 0: trajectory traj[cur[b]], 1: candidate traj[cur[b]^1].
 // need_flag: only problems whose flags contain it (0 = all).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_linearize(ModelConsts<double> c, BatchState st, int B, int n,
-                                                   int which, int need_flag) {
+template <typename S>
+__global__ __launch_bounds__(128) void k_linearize(ModelConsts<S> c, BatchState st, int B, int n, int which,
+                                                   int need_flag) {
   // thread -> (tile, knot, lane): the 64 lanes of a wavefront read one knot of 64 consecutive trajectories
   const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (id == 0) st.counters[0] = 0;  // the next k_backward counts the trajectories still active
@@ -104,13 +110,13 @@ __global__ __launch_bounds__(128) void k_linearize(ModelConsts<double> c, BatchS
   if (b >= B) return;
   if (need_flag && !(st.flags[b] & need_flag)) return;
   const int buf = st.cur[b] ^ which;
-  double pt[18], pd[18];
-  load_knot<true>(st.traj[buf] + knot_base<true>(b, n, 18), i, 18, pt);
-  if (st.desired_tiled) load_knot<true>(st.desired + knot_base<true>(b, n, 18), i, 18, pd);
-  else load_knot<false>(st.desired, i, 18, pd);
-  double *rec = st.lin[buf] + (b * n + i) * st.layout.stride;
+  S pt[18], pd[18];
+  load_knot<true>((const S *)st.traj[buf] + knot_base<true>(b, n, 18), i, 18, pt);
+  if (st.desired_tiled) load_knot<true>((const S *)st.desired + knot_base<true>(b, n, 18), i, 18, pd);
+  else load_knot<false>((const S *)st.desired, i, 18, pd);
+  S *rec = (S *)st.lin[buf] + (b * n + i) * st.layout.stride;
   linearize_knot(c, st.layout, pt, pd, rec);
-  st.knot_cost[buf][cost_index(b, i, n)] = rec[st.layout.off_cost];
+  st.knot_cost[buf][cost_index(b, i, n)] = (double)rec[st.layout.off_cost];  // summed in fp64 (k_init / k_backward)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -193,7 +199,7 @@ __device__ __forceinline__ void gather_rows(double x, double r[4]) {
 // accumulator tile can be reused as the next knot's A operand without a transpose; no LDS and no
 // barrier remain in the loop (Q_uu/Q_u are broadcast with v_readlane, the right-hand sides with
 // ds_bpermute).  SYM = false: general weights, hand-offs go through padded LDS tiles.
-template <bool SYM>
+template <bool SYM, typename S>
 __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolveParams p, BatchState st,
                                                  int B, int n, int force) {
   const int b = blockIdx.x;
@@ -270,8 +276,10 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   }
   const int j = lane & 15, kk = lane >> 4;
   const RecLayout L = st.layout;
-  const double *lin = st.lin[cur] + (long)b * n * L.stride;
-  double *gains = st.gains + knot_base<true>(b, n, 52);
+  // the recursion itself is always fp64 (fp64 MFMA); S is only the type of the records read and of
+  // the gains written
+  const S *lin = (const S *)st.lin[cur] + (long)b * n * L.stride;
+  S *gains = (S *)st.gains + knot_base<true>(b, n, 52);
 
   constexpr int LD = 17;  // padded leading dimension: column reads of a row-major tile
   __shared__ double Vs[SYM ? 1 : 12 * LD];
@@ -283,17 +291,17 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   // column j), three of C_xx (accumulator layout: register r <-> row 4 r + kk, column j) and one of
   // [C_x ; C_u].  Each is either an entry of the knot record (pointer walks back one record per knot)
   // or a constant (pointer into the constant table, step 0): the loads are unconditional.
-  gcptr op[7];
+  typename GA<S>::cptr op[7];
   long step[7];
   {
-    const double *last = lin + (long)(n - 1) * L.stride;
+    const S *last = lin + (long)(n - 1) * L.stride;
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
       int src;
       if (k < 3) src = m_source_tab(4 * k + kk, j);
       else if (k < 6) src = (j < 12) ? cxx_source_tab(L, 4 * (k - 3) + kk, j) : -1 - CTAB_ZERO;
       else src = L.off_g + j;
-      op[k] = (gcptr)((src >= 0) ? last + src : st.ctab + (-1 - src));
+      op[k] = (typename GA<S>::cptr)((src >= 0) ? last + src : (const S *)st.ctab + (-1 - src));
       step[k] = (src >= 0) ? (long)L.stride : 0;
     }
   }
@@ -301,8 +309,10 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   // 16-byte slot per element pair); lanes that own nothing point at the dump slot with step 0
   const bool gowner = (kk == 0 && j <= 12);
   const int ge0 = (j < 12) ? 4 + 4 * j : 0;
-  gptr2 gdst0 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0, 52) : st.dump + 4 * (long)b);
-  gptr2 gdst1 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0 + 2, 52) : st.dump + 4 * (long)b + 2);
+  typedef typename GA<S>::ptr2 gptr2;
+  typedef typename GA<S>::v2 sv2;
+  gptr2 gdst0 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0, 52) : (S *)st.dump + 4 * (long)b);
+  gptr2 gdst1 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0 + 2, 52) : (S *)st.dump + 4 * (long)b + 2);
   const long gstep = gowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
   // register 3 <-> row 12 + kk: C_uu = 2 R (cost.hh:55) in columns 12..15
   const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] : 0.0;
@@ -313,23 +323,22 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
 
   // software pipeline: the operands of knot i-1 are requested before the chain of knot i starts
   double m[3], cx[3], gcj;
-  m[0] = *op[0]; m[1] = *op[1]; m[2] = *op[2];
-  cx[0] = *op[3]; cx[1] = *op[4]; cx[2] = *op[5];
-  gcj = *op[6];
+  m[0] = (double)*op[0]; m[1] = (double)*op[1]; m[2] = (double)*op[2];
+  cx[0] = (double)*op[3]; cx[1] = (double)*op[4]; cx[2] = (double)*op[5];
+  gcj = (double)*op[6];
 
 #ifdef QILQR_STAMPS
   unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
   for (int i = n - 1; i >= 0; --i) {
-    double m_n[3], cx_n[3], gcj_n;
     if (i > 0) {
 #pragma unroll
       for (int k = 0; k < 7; ++k) op[k] -= step[k];
     }
-    m_n[0] = *op[0]; m_n[1] = *op[1]; m_n[2] = *op[2];
-    cx_n[0] = *op[3]; cx_n[1] = *op[4]; cx_n[2] = *op[5];
-    gcj_n = *op[6];
+    // (loaded in storage precision, converted where first used, so that the conversion does not wait
+    // on the load at the top of the loop)
+    const S m_s0 = *op[0], m_s1 = *op[1], m_s2 = *op[2], cx_s0 = *op[3], cx_s1 = *op[4], cx_s2 = *op[5], g_s = *op[6];
     QSTAMP(0);  // prefetch issue
     // T = V M
     d4 T = {0.0, 0.0, 0.0, 0.0};
@@ -421,7 +430,8 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
     // around the stores, so the wait for the next knot's operands is an exact vmcnt(2), not vmcnt(0).
     {
       const bool owner = (kk == 0 && j <= 12);
-      const dv2 w0 = {owner ? kcol[0] : 0.0, owner ? kcol[1] : 0.0}, w1 = {owner ? kcol[2] : 0.0, owner ? kcol[3] : 0.0};
+      const sv2 w0 = {(S)(owner ? kcol[0] : 0.0), (S)(owner ? kcol[1] : 0.0)},
+                w1 = {(S)(owner ? kcol[2] : 0.0), (S)(owner ? kcol[3] : 0.0)};
       *gdst0 = w0;
       *gdst1 = w1;
       gdst0 -= gstep;
@@ -465,12 +475,9 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
         vxl[kc] = vxs[4 * kc + kk];
       }
     }
-#pragma unroll
-    for (int kc = 0; kc < 3; ++kc) {
-      m[kc] = m_n[kc];
-      cx[kc] = cx_n[kc];
-    }
-    gcj = gcj_n;
+    m[0] = (double)m_s0; m[1] = (double)m_s1; m[2] = (double)m_s2;
+    cx[0] = (double)cx_s0; cx[1] = (double)cx_s1; cx[2] = (double)cx_s2;
+    gcj = (double)g_s;
     QKEEP(va[0]); QKEEP(vxl[2]);
     QSTAMP(7);  // V_xx MFMA, gain stores, hand-off
   }
@@ -507,14 +514,16 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
 // ---------------------------------------------------------------------------------------------
 // k_rollout: thread b.  traj[cur] + gains + alpha -> traj[cur ^ 1]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_rollout(ModelConsts<double> c, BatchState st, int B, int n,
+template <typename S>
+__global__ __launch_bounds__(64) void k_rollout(ModelConsts<S> c, BatchState st, int B, int n,
                                                 int need_flag) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   if (need_flag && !(st.flags[b] & need_flag)) return;
   const int cur = st.cur[b];
-  rollout_problem<true>(c, st.traj[cur] + knot_base<true>(b, n, 18), st.gains + knot_base<true>(b, n, 52),
-                        st.alpha[b], st.traj[cur ^ 1] + knot_base<true>(b, n, 18), n);
+  rollout_problem<true>(c, (const S *)st.traj[cur] + knot_base<true>(b, n, 18),
+                        (const S *)st.gains + knot_base<true>(b, n, 52), (S)st.alpha[b],
+                        (S *)st.traj[cur ^ 1] + knot_base<true>(b, n, 18), n);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -527,7 +536,8 @@ __global__ __launch_bounds__(64) void k_rollout(ModelConsts<double> c, BatchStat
 // They trade 11 + 6 doubles per knot through LDS (double-buffered, one barrier per knot).  The
 // arithmetic is the same sequence of operations as rollout_problem: results are bit-identical.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchState st, int B, int n,
+template <typename S>
+__global__ __launch_bounds__(128) void k_rollout2(ModelConsts<S> c, BatchState st, int B, int n,
                                                   int need_flag) {
   const int lane = threadIdx.x & 63;
   const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: X, 1: Y
@@ -537,24 +547,24 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
   const int bs = (b < B) ? b : (B - 1);
   const int cur = st.cur[bs];
   const int br = st.dbg_uniform ? blockIdx.x * 64 : bs;
-  const double *traj = st.traj[cur] + knot_base<true>(br, n, 18);
-  const double *gains = st.gains + knot_base<true>(br, n, 52);
-  double *out = st.traj[cur ^ 1] + knot_base<true>(bs, n, 18);
-  const double alpha = st.alpha[bs];
+  const S *traj = (const S *)st.traj[cur] + knot_base<true>(br, n, 18);
+  const S *gains = (const S *)st.gains + knot_base<true>(br, n, 52);
+  S *out = (S *)st.traj[cur ^ 1] + knot_base<true>(bs, n, 18);
+  const S alpha = (S)st.alpha[bs];
 
-  __shared__ double sh[2][17][64];  // [parity][0..3 q | 4..6 td | 7..9 th | 10 c | 11..16 v][lane]
+  __shared__ S sh[2][17][64];  // [parity][0..3 q | 4..6 td | 7..9 th | 10 c | 11..16 v][lane]
 
-  double pt[18];
+  S pt[18];
   load_knot<true>(traj, 0, 18, pt);
-  double t[3] = {pt[1], pt[2], pt[3]};
-  double q[4] = {pt[5], pt[6], pt[7], pt[4]};
-  double v[6];
+  S t[3] = {pt[1], pt[2], pt[3]};
+  S q[4] = {pt[5], pt[6], pt[7], pt[4]};
+  S v[6];
 #pragma unroll
   for (int a = 0; a < 6; ++a) v[a] = pt[8 + a];
-  double td[3] = {0, 0, 0}, th[3] = {0, 0, 0}, cj = 0.0;
+  S td[3] = {0, 0, 0}, th[3] = {0, 0, 0}, cj = 0;
 
   if (role == 1) {
-    const double qn[4] = {pt[5], pt[6], pt[7], pt[4]};
+    const S qn[4] = {pt[5], pt[6], pt[7], pt[4]};
     se3_rminus_part1(t, q, pt + 1, qn, td, th, cj);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -563,7 +573,7 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
     }
     sh[0][10][lane] = cj;
     if (live) {
-      const double po[8] = {0.0, t[0], t[1], t[2], q[3], q[0], q[1], q[2]};
+      const S po[8] = {0, t[0], t[1], t[2], q[3], q[0], q[1], q[2]};
 #pragma unroll
       for (int e = 1; e < 8; ++e) out[knot_elem<true>(0, e, 18)] = po[e];
     }
@@ -581,7 +591,7 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
   // Operands of the NEXT knot are requested before the current knot's chain starts and consumed one
   // iteration later (two register sets, loop unrolled by two so that no copies are needed): wave X
   // prefetches the nominal knot and the 52 gains, wave Y the nominal pose.
-  double ptA[18], ptB[18], gA[52], gB[52], pnA[8], pnB[8];
+  S ptA[18], ptB[18], gA[52], gB[52], pnA[8], pnB[8];
   if (role == 0) {
     load_knot<true>(traj, 0, 18, ptA);
     load_knot<true>(gains, 0, 52, gA);
@@ -594,8 +604,7 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
   unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
-  auto knot = [&](int i, double (&ptc)[18], double (&gc)[52], double (&ptn)[18], double (&gn)[52], double (&pnc)[8],
-                  double (&pnn)[8]) {
+  auto knot = [&](int i, S (&ptc)[18], S (&gc)[52], S (&ptn)[18], S (&gn)[52], S (&pnc)[8], S (&pnn)[8]) {
     const int par = (i + 1) & 1;
     const bool more = (i + 1 < n);
     if (role == 0) {
@@ -604,14 +613,14 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
         load_knot<true>(gains, i + 1, 52, gn);
       }
       QSTAMP(0);  // X: prefetch issue
-      double dx[12];
+      S dx[12];
       se3_rminus_part2(td, th, cj, dx);
       dx[3] = th[0]; dx[4] = th[1]; dx[5] = th[2];
 #pragma unroll
       for (int a = 0; a < 6; ++a) dx[6 + a] = v[a] - ptc[8 + a];
       QKEEP(dx[0]); QKEEP(dx[11]);
       QSTAMP(1);  // X: rho = Jl^-1 td, dx
-      double u[4];
+      S u[4];
       control_law(ptc, gc, alpha, dx, u);
       QKEEP(u[0]); QKEEP(u[3]);
       QSTAMP(2);  // X: control law (waits for this knot's operands)
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
       }
       QSTAMP(3);  // X: stores
       if (more) {
-        double acc[6];
+        S acc[6];
         body_acceleration_fast(c, q, v, u, acc);
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
@@ -638,14 +647,14 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
 #pragma unroll
         for (int e = 1; e < 8; ++e) pnn[e] = traj[knot_elem<true>(i + 2, e, 18)];
       }
-      double tau[6];
+      S tau[6];
 #pragma unroll
       for (int a = 0; a < 6; ++a) tau[a] = c.dt * v[a];  // pose integrates with the OLD velocity
       QSTAMP(0);  // Y: prefetch issue
       se3_rplus_fast(t, q, tau);
       QKEEP(q[0]); QKEEP(t[0]);
       QSTAMP(1);  // Y: T <- T Exp(dt v)
-      const double qn[4] = {pnc[5], pnc[6], pnc[7], pnc[4]};
+      const S qn[4] = {pnc[5], pnc[6], pnc[7], pnc[4]};
       se3_rminus_part1(t, q, pnc + 1, qn, td, th, cj);
       QKEEP(td[0]); QKEEP(th[0]); QKEEP(cj);
       QSTAMP(2);  // Y: pose part of x (-) xnom (waits for the nominal pose)
@@ -658,7 +667,7 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<double> c, BatchSt
       }
       sh[par][10][lane] = cj;
       if (live) {
-        const double po[8] = {0.0, t[0], t[1], t[2], q[3], q[0], q[1], q[2]};
+        const S po[8] = {0, t[0], t[1], t[2], q[3], q[0], q[1], q[2]};
 #pragma unroll
         for (int e = 1; e < 8; ++e) out[knot_elem<true>(i + 1, e, 18)] = po[e];
       }
@@ -751,6 +760,7 @@ __global__ void k_accept(SolveParams p, BatchState st, int B, int n, int ls_only
 // ---------------------------------------------------------------------------------------------
 // k_gather: results into caller buffers in the plain [B][n][18] layout (any may be null)
 // ---------------------------------------------------------------------------------------------
+template <typename S>
 __global__ void k_gather(BatchState st, int B, int n, double *out_traj, double *out_cost, int *out_status,
                          int *out_iters, int *out_n_bwd, int *out_n_fwd) {
   const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -759,7 +769,7 @@ __global__ void k_gather(BatchState st, int B, int n, double *out_traj, double *
   const long b = id / per;
   const long r = id % per;
   if (out_traj)
-    out_traj[id] = st.traj[st.cur[b]][knot_base<true>(b, n, 18) + knot_elem<true>(r / 18, (int)(r % 18), 18)];
+    out_traj[id] = (double)((const S *)st.traj[st.cur[b]])[knot_base<true>(b, n, 18) + knot_elem<true>(r / 18, (int)(r % 18), 18)];
   if (r == 0) {
     if (out_cost) out_cost[b] = st.cost[b];
     if (out_status) out_status[b] = st.status[b];
@@ -771,18 +781,19 @@ __global__ void k_gather(BatchState st, int B, int n, double *out_traj, double *
 
 // plain [B][n][W] <-> tiled.  to_tiled = 1: plain -> tiled.  sel (optional): per-trajectory choice of
 // tiled buffer t0 / t1 (the current-trajectory selector), xor'ed with flip.
-__global__ void k_retile(const double *plain_in, double *plain_out, double *t0, double *t1, const int *sel,
+template <typename S>
+__global__ void k_retile(const double *plain_in, double *plain_out, S *t0, S *t1, const int *sel,
                          int flip, int B, int n, int W, int to_tiled) {
   const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long per = (long)n * W;
   if (id >= (long)B * per) return;
   const long b = id / per;
   const long r = id % per;
-  double *t = (sel && ((sel[b] ^ flip) & 1)) ? t1 : t0;
+  S *t = (sel && ((sel[b] ^ flip) & 1)) ? t1 : t0;
   const long ti = (W == 18 ? knot_base<true>(b, n, 18) : knot_base<true>(b, n, 52)) +
                   (W == 18 ? knot_elem<true>(r / W, (int)(r % W), 18) : knot_elem<true>(r / W, (int)(r % W), 52));
-  if (to_tiled) t[ti] = plain_in[id];
-  else plain_out[id] = t[ti];
+  if (to_tiled) t[ti] = (S)plain_in[id];
+  else plain_out[id] = (double)t[ti];
 }
 
 // stand-alone line search support: seed per-problem scalars from caller data

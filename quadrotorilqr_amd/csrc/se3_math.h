@@ -28,6 +28,10 @@ template <typename T>
 struct Eps {
   static constexpr T manif = T(1e-10);  // manif Constants<double>::eps
 };
+template <>
+struct Eps<float> {
+  static constexpr float manif = 1e-6f;  // manif Constants<float>::eps (+: recollection of upstream)
+};
 
 // ----------------------------------------------------------------- batch layouts
 // Per-knot arrays that the lane-per-trajectory kernels touch (trajectories W = 18, gains W = 52,
@@ -283,6 +287,17 @@ struct ModelConsts {
   T Q[144];
   T R[16];
 };
+
+// the same constants in another precision (mixed-precision mode: lane-local kernels run in float)
+template <typename T, typename U>
+QILQR_HD void convert_consts(const ModelConsts<U> &a, ModelConsts<T> &b) {
+  b.dt = (T)a.dt; b.mass = (T)a.mass; b.g = (T)a.g;
+  for (int i = 0; i < 9; ++i) { b.inertia[i] = (T)a.inertia[i]; b.inertia_inv[i] = (T)a.inertia_inv[i]; }
+  for (int i = 0; i < 12; ++i) b.arms[i] = (T)a.arms[i];
+  for (int i = 0; i < 48; ++i) b.Bu[i] = (T)a.Bu[i];
+  for (int i = 0; i < 144; ++i) b.Q[i] = (T)a.Q[i];
+  for (int i = 0; i < 16; ++i) b.R[i] = (T)a.R[i];
+}
 
 // continuous dynamics (quadrotor_model.cc:65-78) -> body acceleration (6)
 template <typename T>

@@ -173,3 +173,12 @@ def config5(B=4096, N=500, seed=5):
     b = dict(model=MODEL_D, Q=Q_DEMO, R=R_DEMO, dt=DT_DEMO, options=dict(OPTIONS_DEMO, populate_debug=False),
              desired=desired, init=init)
     return a, b
+
+
+def config3(B=8192, N=200, seed=3):
+    """BASELINE.json configs[2]: as config 2 with 200 knots, fp32 (mixed precision: fp32 storage and
+    lane-local arithmetic, fp64 Riccati recursion, fp64 cost sums / Armijo / convergence), and the
+    convergence tolerances fp32 can reach: conv(1e-5, 1e-5, 100)."""
+    cfg = config2(B=B, N=N, seed=seed)
+    cfg["options"] = dict(cfg["options"], rtol=1e-5, atol=1e-5)
+    return cfg

@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(capi.Model) == 13 * 8
     assert C.sizeof(capi.Options) == 56      # 2 doubles, int32 + pad, 3 doubles, int32 + pad
     assert capi.Options.rtol.offset == 24 and capi.Options.populate_debug.offset == 48
-    assert C.sizeof(capi.DeviceConfig) == 20
+    assert C.sizeof(capi.DeviceConfig) == 24
     assert C.sizeof(capi.Profile) == 64
 
 

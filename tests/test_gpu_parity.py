@@ -423,3 +423,30 @@ def test_config5_long_horizon_stress_reduced():
     np.testing.assert_allclose(sb.cost_trajectory(ob["traj"]), ob["cost"], rtol=1e-12)
     # both implementations end in the same cost regime (orders of magnitude below the first rollout)
     assert np.all(np.abs(np.log10(ob["cost"] / rb["cost"])) < 1.0)
+
+
+# ------------------------------------------------------------------ BASELINE.json configs[2]: fp32
+def test_config3_mixed_precision_reduced():
+    """fp32 storage + fp32 rollout / linearisation, fp64 Riccati recursion and fp64 cost arithmetic,
+    against the fp64 oracle with the same (fp32-reachable) tolerances.  Stated fp32 bar:
+    final cost within 1e-3 relative, trajectory within 1e-2; exit paths must be convergence exits."""
+    cfg = pb.config3(B=64, N=200)
+    s32 = capi.from_config(cfg, precision="f32")
+    out = s32.solve_batch(cfg["init"])
+    ref = oracle_for(cfg).solve_batch(cfg["init"], n_threads=8)
+    assert np.isin(out["status"], [0, 1]).all() and np.isin(ref["status"], [0, 1]).all()
+    np.testing.assert_allclose(out["cost"], ref["cost"], rtol=1e-3)
+    np.testing.assert_allclose(out["traj"], ref["traj"], atol=1e-2)
+    assert np.abs(out["iters"].astype(int) - ref["iters"]).max() <= 3
+    # the fp64 mode on the same problem and tolerances is tight
+    o64 = capi.from_config(cfg).solve_batch(cfg["init"])
+    np.testing.assert_array_equal(o64["iters"], ref["iters"])
+    np.testing.assert_allclose(o64["cost"], ref["cost"], rtol=1e-9)
+    # per-pass agreement of the fp32 kernels with the fp64 ones
+    s64 = capi.from_config(cfg)
+    tr = s64.forward_sim(cfg["init"], np.zeros((64, 200, 52)), 1.0)
+    np.testing.assert_allclose(s32.cost_trajectory(tr), s64.cost_trajectory(tr), rtol=2e-5)
+    g32, t32 = s32.backwards_pass(tr)
+    g64, t64 = s64.backwards_pass(tr)
+    np.testing.assert_allclose(t32, t64, rtol=2e-3)
+    np.testing.assert_allclose(g32, g64, rtol=0, atol=2e-4 * np.abs(g64).max())
