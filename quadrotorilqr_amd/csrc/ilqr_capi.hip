@@ -265,13 +265,20 @@ int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
   Timed t(s, K_ROLLOUT);
   // the cooperating pair shortens one trajectory's chain; with more tiles than the chip has room for
   // pairs (1 pair per SIMD at 256 VGPRs) the single-wave form gives the higher throughput
-  if (s->dev.single_wave_rollout || B > 16384) {
+  if (s->dev.single_wave_rollout == 1 || B > 16384) {
     if (s->f32)
       hipLaunchKernelGGL(k_rollout<float>, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->constsf, s->st, (int)B, (int)n,
                          need_flag);
     else
       hipLaunchKernelGGL(k_rollout<double>, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->consts, s->st, (int)B, (int)n,
                          need_flag);
+  } else if (s->dev.single_wave_rollout == 2) {
+    if (s->f32)
+      hipLaunchKernelGGL(k_rollout3<float>, dim3(cdiv(B, 64)), dim3(192), 0, s->stream, s->constsf, s->st, (int)B,
+                         (int)n, need_flag);
+    else
+      hipLaunchKernelGGL(k_rollout3<double>, dim3(cdiv(B, 64)), dim3(192), 0, s->stream, s->consts, s->st, (int)B,
+                         (int)n, need_flag);
   } else {
     if (s->f32)
       hipLaunchKernelGGL(k_rollout2<float>, dim3(cdiv(B, 64)), dim3(128), 0, s->stream, s->constsf, s->st, (int)B,

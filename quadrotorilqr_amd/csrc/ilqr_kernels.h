@@ -702,6 +702,214 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<S> c, BatchState s
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_rollout3: k_rollout2 plus a LOADER wavefront (block = 192).  In k_rollout2 the control wave spends
+// a third of every knot issuing the 35 sixteen-byte loads of the next knot's nominal point and gains
+// (profiles/microbench/rollout_stamps.py).  Here wave L streams those operands two knots ahead
+// through registers into a double-buffered LDS image (same [pair][lane] order as the tiled global
+// layout, so its stores and the consumers' reads are conflict-free), and the nominal pose that the
+// pose wave needs one knot earlier into a second small image.  Waves X and Y read LDS only.
+//   iteration i:  L: issue loads of knot i+2 (+ pose of knot i+3); write knot i+1 -> bx[(i+1)&1],
+//                    pose of knot i+2 -> by[(i+2)&1]
+//                 X: operands of knot i from bx[i&1];  Y: nominal pose of knot i+1 from by[(i+1)&1]
+//   one barrier per knot.  Same arithmetic as k_rollout / k_rollout2.
+// ---------------------------------------------------------------------------------------------
+template <typename S>
+__global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState st, int B, int n, int need_flag) {
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: X, 1: Y, 2: L
+  const int b = blockIdx.x * 64 + lane;
+  const bool live = (b < B) && (!need_flag || (st.flags[b < B ? b : 0] & need_flag));
+  if (__ballot(live) == 0ull) return;  // identical in the three waves: block-uniform
+  const int bs = (b < B) ? b : (B - 1);
+  const int cur = st.cur[bs];
+  const S *traj = (const S *)st.traj[cur] + knot_base<true>(bs, n, 18);
+  const S *gains = (const S *)st.gains + knot_base<true>(bs, n, 52);
+  S *out = (S *)st.traj[cur ^ 1] + knot_base<true>(bs, n, 18);
+
+  typedef S sv2 __attribute__((ext_vector_type(2)));
+  __shared__ sv2 bx[2][35][64];  // [parity][pair: 0..8 nominal knot, 9..34 gains][lane]
+  __shared__ sv2 by[2][4][64];   // [parity][pair 0..3 of the nominal knot = time, t, q][lane]
+  __shared__ S sh[2][17][64];    // X <-> Y exchange, as in k_rollout2
+
+  // Each role runs its own loop (so that the register allocator sees three disjoint live ranges);
+  // all three execute exactly 1 + n barriers.
+  if (role == 2) {
+    // ------------------------------------------------------------------ L: loader
+    const sv2 *tp = reinterpret_cast<const sv2 *>(traj);   // pair k of knot i: tp[(i * 9 + k) * 64]
+    const sv2 *gp = reinterpret_cast<const sv2 *>(gains);  //                   gp[(i * 26 + k) * 64]
+    sv2 ra[35], rb[35], pa[4], pb[4];
+    auto load_ops = [&](int k, sv2 (&r)[35]) {
+      if (k < n) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) r[e] = tp[((long)k * 9 + e) * 64];
+#pragma unroll
+        for (int e = 0; e < 26; ++e) r[9 + e] = gp[((long)k * 26 + e) * 64];
+      }
+    };
+    auto load_pose = [&](int k, sv2 (&r)[4]) {
+      if (k < n) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = tp[((long)k * 9 + e) * 64];
+      }
+    };
+    load_ops(0, ra);
+    load_pose(1, pa);
+#pragma unroll
+    for (int e = 0; e < 35; ++e) bx[0][e][lane] = ra[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) by[1][e][lane] = pa[e];
+    load_ops(1, ra);   // written during iteration 0
+    load_pose(2, pa);  // written during iteration 0
+    __syncthreads();
+    auto knot = [&](int i, sv2 (&rc)[35], sv2 (&rn)[35], sv2 (&pc)[4], sv2 (&pn)[4]) {
+      load_ops(i + 2, rn);   // consumed by X at iteration i + 2
+      load_pose(i + 3, pn);  // consumed by Y at iteration i + 2
+      if (i + 1 < n) {
+#pragma unroll
+        for (int e = 0; e < 35; ++e) bx[(i + 1) & 1][e][lane] = rc[e];  // knot i + 1
+      }
+      if (i + 2 < n) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) by[i & 1][e][lane] = pc[e];  // nominal pose of knot i + 2
+      }
+      __syncthreads();
+    };
+    for (int i = 0; i < n; i += 2) {
+      knot(i, ra, rb, pa, pb);
+      if (i + 1 < n) knot(i + 1, rb, ra, pb, pa);
+    }
+    return;
+  }
+
+  S t[3], q[4], v[6], td[3] = {0, 0, 0}, th[3] = {0, 0, 0}, cj = 0;
+  {
+    S p0[18];
+    load_knot<true>(traj, 0, 18, p0);
+    t[0] = p0[1]; t[1] = p0[2]; t[2] = p0[3];
+    q[0] = p0[5]; q[1] = p0[6]; q[2] = p0[7]; q[3] = p0[4];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) v[a] = p0[8 + a];
+    if (role == 1) {
+      const S qn[4] = {p0[5], p0[6], p0[7], p0[4]};
+      se3_rminus_part1(t, q, p0 + 1, qn, td, th, cj);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        sh[0][4 + a][lane] = td[a];
+        sh[0][7 + a][lane] = th[a];
+      }
+      sh[0][10][lane] = cj;
+      if (live) {
+        const S po[8] = {0, t[0], t[1], t[2], q[3], q[0], q[1], q[2]};
+#pragma unroll
+        for (int e = 1; e < 8; ++e) out[knot_elem<true>(0, e, 18)] = po[e];
+      }
+    }
+  }
+  __syncthreads();
+
+  if (role == 0) {
+    // ------------------------------------------------------------------ X: control + velocity
+    const S alpha = (S)st.alpha[bs];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      td[a] = sh[0][4 + a][lane];
+      th[a] = sh[0][7 + a][lane];
+    }
+    cj = sh[0][10][lane];
+    for (int i = 0; i < n; ++i) {
+      const int par = (i + 1) & 1;
+      const bool more = (i + 1 < n);
+      S pt[18], g[52];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        const sv2 w = bx[i & 1][e][lane];
+        pt[2 * e] = w[0];
+        pt[2 * e + 1] = w[1];
+      }
+#pragma unroll
+      for (int e = 0; e < 26; ++e) {
+        const sv2 w = bx[i & 1][9 + e][lane];
+        g[2 * e] = w[0];
+        g[2 * e + 1] = w[1];
+      }
+      S dx[12];
+      se3_rminus_part2(td, th, cj, dx);
+      dx[3] = th[0]; dx[4] = th[1]; dx[5] = th[2];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) dx[6 + a] = v[a] - pt[8 + a];
+      S u[4];
+      control_law(pt, g, alpha, dx, u);
+      if (live) {
+        out[knot_elem<true>(i, 0, 18)] = pt[0];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) out[knot_elem<true>(i, 8 + a, 18)] = v[a];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) out[knot_elem<true>(i, 14 + a, 18)] = u[a];
+      }
+      if (more) {
+        S acc[6];
+        body_acceleration_fast(c, q, v, u, acc);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          v[a] = v[a] + c.dt * acc[a];
+          sh[par][11 + a][lane] = v[a];
+        }
+      }
+      __syncthreads();
+      if (more) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) q[a] = sh[par][a][lane];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          td[a] = sh[par][4 + a][lane];
+          th[a] = sh[par][7 + a][lane];
+        }
+        cj = sh[par][10][lane];
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------ Y: pose
+    for (int i = 0; i < n; ++i) {
+      const int par = (i + 1) & 1;
+      const bool more = (i + 1 < n);
+      if (more) {
+        S pnm[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const sv2 w = by[par][e][lane];  // nominal pose of knot i + 1
+          pnm[2 * e] = w[0];
+          pnm[2 * e + 1] = w[1];
+        }
+        S tau[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) tau[a] = c.dt * v[a];  // pose integrates with the OLD velocity
+        se3_rplus_fast(t, q, tau);
+        const S qn[4] = {pnm[5], pnm[6], pnm[7], pnm[4]};
+        se3_rminus_part1(t, q, pnm + 1, qn, td, th, cj);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) sh[par][a][lane] = q[a];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          sh[par][4 + a][lane] = td[a];
+          sh[par][7 + a][lane] = th[a];
+        }
+        sh[par][10][lane] = cj;
+        if (live) {
+          const S po[8] = {0, t[0], t[1], t[2], q[3], q[0], q[1], q[2]};
+#pragma unroll
+          for (int e = 1; e < 8; ++e) out[knot_elem<true>(i + 1, e, 18)] = po[e];
+        }
+      }
+      __syncthreads();
+      if (more) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v[a] = sh[par][11 + a][lane];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_accept: thread b.  Cost of the candidate, acceptance, convergence (ilqr.hh:70-84, 174-194)
 // ---------------------------------------------------------------------------------------------
 __global__ void k_accept(SolveParams p, BatchState st, int B, int n, int ls_only) {

@@ -209,10 +209,16 @@ def test_two_wave_rollout_matches_single_wave():
         trajs[:, :, 8:14] += 0.3 * r.standard_normal((B, n, 6))
         np.testing.assert_allclose(two.forward_sim(trajs, gains, alpha), one.forward_sim(trajs, gains, alpha),
                                    rtol=1e-12, atol=1e-12)
+        three = capi.from_config(cfg, single_wave_rollout=2)   # pair + loader wave (k_rollout3)
+        np.testing.assert_allclose(three.forward_sim(trajs, gains, alpha), one.forward_sim(trajs, gains, alpha),
+                                   rtol=1e-12, atol=1e-12)
     cfg = pb.config2(B=96, N=40)
     a, b = capi.from_config(cfg).solve_batch(cfg["init"]), capi.from_config(cfg, single_wave_rollout=True).solve_batch(cfg["init"])
     np.testing.assert_allclose(a["traj"], b["traj"], atol=1e-8)
     np.testing.assert_array_equal(a["iters"], b["iters"])
+    c3 = capi.from_config(cfg, single_wave_rollout=2).solve_batch(cfg["init"])
+    np.testing.assert_allclose(c3["traj"], b["traj"], atol=1e-8)
+    np.testing.assert_array_equal(c3["iters"], b["iters"])
 
 
 # ------------------------------------------------------------------ full solves
