@@ -71,8 +71,9 @@ typedef struct {
   int32_t profile;  /* 0: off; 1: HIP events around k_backward and k_rollout only; 2: around every kernel */
   int32_t sync_every; /* host polls the active-problem counter every k outer iterations (>=1) */
   int32_t force_general; /* 1: use the general (non-symmetric-safe) backward kernel even when Q, R are symmetric */
-  int32_t single_wave_rollout; /* rollout kernel: 0 = pose wave + control wave per 64 trajectories (k_rollout2),
-                                  1 = one wavefront (k_rollout), 2 = pair + loader wave (k_rollout3) */
+  int32_t single_wave_rollout; /* rollout kernel: 0 (default) or 2 = pose wave + control wave + loader wave per 64
+                                  trajectories (k_rollout3); 1 = one wavefront (k_rollout, always used above 16384
+                                  trajectories); 3 = pose wave + control wave without loader (k_rollout2) */
   int32_t precision; /* 0: fp64 everywhere (reference parity).  1: mixed: trajectories, gains and knot records
                         stored in fp32, rollout and linearisation computed in fp32, Riccati recursion on the fp64
                         matrix core, cost sums / Armijo / convergence tests in fp64 (BASELINE.json configs[2]) */

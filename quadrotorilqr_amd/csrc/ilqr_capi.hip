@@ -272,7 +272,7 @@ int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
     else
       hipLaunchKernelGGL(k_rollout<double>, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->consts, s->st, (int)B, (int)n,
                          need_flag);
-  } else if (s->dev.single_wave_rollout == 2) {
+  } else if (s->dev.single_wave_rollout != 3) {
     if (s->f32)
       hipLaunchKernelGGL(k_rollout3<float>, dim3(cdiv(B, 64)), dim3(192), 0, s->stream, s->constsf, s->st, (int)B,
                          (int)n, need_flag);

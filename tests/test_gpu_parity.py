@@ -200,8 +200,8 @@ def test_two_wave_rollout_matches_single_wave():
     may contract multiply-adds differently in the two kernels, so agreement is to rounding (1e-12)"""
     for B, n in [(70, 33), (5, 1), (64, 2)]:
         cfg = pb.config2(B=B, N=n, seed=7)
-        two = capi.from_config(cfg)
-        one = capi.from_config(cfg, single_wave_rollout=True)
+        two = capi.from_config(cfg, single_wave_rollout=3)   # pose wave + control wave (k_rollout2)
+        one = capi.from_config(cfg, single_wave_rollout=1)   # one wave (k_rollout)
         r = np.random.default_rng(B)
         gains = 0.05 * r.uniform(-1, 1, (B, n, 52))
         alpha = 0.5 ** r.integers(0, 4, B)
