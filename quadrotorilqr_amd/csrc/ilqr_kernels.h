@@ -450,17 +450,21 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
     kTQuuk += mc[0] * kcol[0] + mc[1] * kcol[1] + mc[2] * kcol[2] + mc[3] * kcol[3];
     QKEEP(mc[3]); QKEEP(vx); QKEEP(QuTk); QKEEP(kTQuuk);
     QSTAMP(6);  // K^T Quu, V_x, reduction terms
+    if constexpr (SYM) {
+#pragma unroll
+      for (int kc = 0; kc < 3; ++kc) vxl[kc] = __shfl(vx, 4 * kc + kk);  // V_x[r] lives in lanes with j == r
+    }
     // V_xx = Q_xx - (K^T Quu) K   (ilqr.hh:133): one more MFMA on the same accumulator,
     // A[j][kk] = -(K^T Quu)[j][kk], B[kk][j] = K[kk][j]
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(-sel4(mc, kk), sel4(kcol, kk), H, 0, 0, 0);
 
     // hand V_xx, V_x to the next knot
     if constexpr (SYM) {
+      // V symmetric: the accumulator tile IS the next A operand.  Lanes j >= 12 hold Q_xu / Q_uu
+      // leftovers there, i.e. rows 12..15 of the A operand, which only reach rows 12..15 of T
+      // (register 3), and those are never used: no masking needed.
 #pragma unroll
-      for (int kc = 0; kc < 3; ++kc) {
-        va[kc] = (j < 12) ? H[kc] : 0.0;       // V symmetric: accumulator layout == A-operand layout
-        vxl[kc] = __shfl(vx, 4 * kc + kk);     // V_x[r] lives in lanes with j == r
-      }
+      for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
     } else {
       // accumulator layout -> A-operand layout through LDS (a transpose)
       if (j < 12) {
