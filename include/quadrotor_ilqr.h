@@ -69,7 +69,8 @@ typedef struct {
 typedef struct {
   int32_t device;   /* HIP device ordinal */
   int32_t profile;  /* 0: off; 1: HIP events around k_backward and k_rollout only; 2: around every kernel */
-  int32_t sync_every; /* host polls the active-problem counter every k outer iterations (>=1) */
+  int32_t sync_every; /* 1: the host waits for every round's count of active trajectories; k > 1: it reads the
+                         count k rounds late, i.e. keeps the stream k rounds ahead of the device (k <= 6) */
   int32_t force_general; /* 1: use the general (non-symmetric-safe) backward kernel even when Q, R are symmetric */
   int32_t single_wave_rollout; /* rollout kernel: 0 (default) or 2 = pose wave + control wave + loader wave per 64
                                   trajectories (k_rollout3); 1 = one wavefront (k_rollout, always used above 16384
@@ -138,6 +139,13 @@ int qilqr_forward_sim(qilqr_solver *s, const double *traj, const double *gains,
 int qilqr_line_search(qilqr_solver *s, const double *traj, const double *cost, const double *gains,
                       const double *terms, int32_t B, int32_t n, double *out_traj,
                       double *out_cost, double *out_step, int32_t *out_status);
+
+/* Cost history of the last batch solve (options.populate_debug = 1): hist is B x cap, row b holds
+ * new_cost after each completed forward pass of problem b (what ILQRDebug.cost would hold, ilqr.hh:78-80;
+ * trajectories are only captured by the single-problem qilqr_solve), unused entries are NaN.
+ * cap = the largest number of entries any problem can have (= min(max_iters, 1e6)); returned in *out_cap
+ * when hist is NULL. */
+int qilqr_cost_history(qilqr_solver *s, int32_t B, double *hist, int32_t cap, int32_t *out_cap);
 
 /* profiling (HIP events on the solver's stream) */
 int qilqr_profile_reset(qilqr_solver *s);

@@ -34,7 +34,7 @@ STATUS_LINE_SEARCH_FAILED = 3
 EXPORTS = (
     "qilqr_create", "qilqr_destroy", "qilqr_last_error", "qilqr_solve", "qilqr_solve_batch",
     "qilqr_solve_batch_device", "qilqr_cost_trajectory", "qilqr_backwards_pass", "qilqr_forward_sim",
-    "qilqr_line_search", "qilqr_profile_reset", "qilqr_profile_get", "qilqr_device", "qilqr_stream",
+    "qilqr_line_search", "qilqr_cost_history", "qilqr_profile_reset", "qilqr_profile_get", "qilqr_device", "qilqr_stream",
     "qilqr_abi_version",
 )
 
@@ -240,6 +240,17 @@ class QuadrotorILQRBatch:
         if rc:
             _raise(rc)
         return dict(traj=out, cost=oc, step=step, status=st)
+
+    def cost_history(self, B):
+        """(B, cap) array: cost after every completed forward pass of the last batch solve (NaN padded);
+        needs options['populate_debug']"""
+        cap = C.c_int32()
+        load().qilqr_cost_history(self._h, C.c_int32(B), None, C.c_int32(0), C.byref(cap))
+        hist = np.zeros((B, max(cap.value, 1)))
+        rc = load().qilqr_cost_history(self._h, C.c_int32(B), _p(hist), C.c_int32(hist.shape[1]), C.byref(cap))
+        if rc:
+            _raise(rc)
+        return hist
 
     # ---- profiling
     def profile_reset(self):

@@ -60,7 +60,8 @@ struct qilqr_solver {
   int hist_cap = 0;
   BatchState st{};
   std::vector<void *> allocs;
-  int *h_counters = nullptr;  // pinned
+  int *h_counters = nullptr;  // pinned, 16 slots
+  hipEvent_t poll_ev[8] = {};  // one per in-flight poll of the active counter
   double *io_aos = nullptr;         // device scratch in the plain [B][n][W] layout (W <= 52), for host I/O
   void *desired_tiled = nullptr;    // per-problem desired trajectories, tiled (allocated on first use)
   // profiling
@@ -320,16 +321,22 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round) {
   // a trajectory needs at most max_iters backward passes and max_iters * ls_max_iters trials
   const double bound = (std::fmin(s->params.max_iters, 1e7) + 1.0) * ((double)std::max(s->params.ls_max_iters, 1) + 1.0);
   const long max_rounds = (long)std::fmin(bound, 2e9);
-  if (sync_every < 1) sync_every = 1;
+  // The count of still-active trajectories is copied to pinned memory after every k_backward and
+  // looked at `lag` rounds later, so the host keeps the stream `lag` rounds ahead of the device and
+  // the GPU never waits for a host round trip.  Rounds enqueued past the end find nothing to do.
+  const int lag = (sync_every > 1) ? std::min(sync_every, 6) : 0;
   for (long round = 0; round < max_rounds; ++round) {
     // k_backward first settles the candidate of the previous round (cost, Armijo, convergence) and
     // counts the trajectories still active; then rollout + linearise the next candidates
     if ((rc = launch_backward(s, B, n, 0))) return rc;
-    if ((round + 1) % sync_every == 0) {
-      int n_active = 0;
-      if ((rc = read_active(s, &n_active))) return rc;
-      if ((rc = on_round())) return rc;
-      if (n_active == 0) break;
+    const int slot = (int)(round % 8);
+    HIP_TRY(hipMemcpyAsync(&s->h_counters[slot], s->st.counters, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipEventRecord(s->poll_ev[slot], s->stream));
+    if (round >= lag) {
+      const int old = (int)((round - lag) % 8);
+      HIP_TRY(hipEventSynchronize(s->poll_ev[old]));
+      if (lag == 0 && (rc = on_round())) return rc;
+      if (s->h_counters[old] == 0) break;
     }
     if ((rc = launch_rollout(s, B, n, F_SEARCH))) return rc;
     if ((rc = launch_linearize(s, B, n, 1, F_SEARCH))) return rc;
@@ -431,7 +438,8 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
       e = hipMemcpy(s->d_desired, desired, es * 18 * n_desired, hipMemcpyHostToDevice);
     }
   }
-  if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_counters, sizeof(int) * 4, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_counters, sizeof(int) * 16, hipHostMallocDefault);
+  for (int k = 0; k < 8 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&s->poll_ev[k], hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc(&s->d_ctab, es * CTAB_SIZE);
   if (e == hipSuccess) {
     double tab[CTAB_SIZE];
@@ -461,12 +469,33 @@ void qilqr_destroy(qilqr_solver *s) {
   if (s->d_desired) (void)hipFree(s->d_desired);
   if (s->d_ctab) (void)hipFree(s->d_ctab);
   if (s->h_counters) (void)hipHostFree(s->h_counters);
+  for (int k = 0; k < 8; ++k)
+    if (s->poll_ev[k]) (void)hipEventDestroy(s->poll_ev[k]);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
 
 int qilqr_device(const qilqr_solver *s) { return s ? s->device : -1; }
 void *qilqr_stream(const qilqr_solver *s) { return s ? (void *)s->stream : nullptr; }
+
+int qilqr_cost_history(qilqr_solver *s, int32_t B, double *hist, int32_t cap, int32_t *out_cap) {
+  if (!s) return fail(QILQR_ERR_INVALID_ARG, "null solver");
+  if (out_cap) *out_cap = s->hist_cap;
+  if (!hist) return QILQR_OK;
+  if (!s->options.populate_debug || !s->st.cost_hist || s->hist_cap <= 0)
+    return fail(QILQR_ERR_INVALID_ARG, "cost history needs options.populate_debug");
+  if (B <= 0 || B > s->cap_B || cap < s->hist_cap) return fail(QILQR_ERR_INVALID_ARG, "bad B or cap");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  std::vector<double> tmp((size_t)B * s->hist_cap);
+  std::vector<int> iters(B);
+  HIP_TRY(hipMemcpy(tmp.data(), s->st.cost_hist, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(iters.data(), s->st.iters, sizeof(int) * B, hipMemcpyDeviceToHost));
+  for (long b = 0; b < B; ++b)
+    for (int k = 0; k < cap; ++k)
+      hist[b * cap + k] = (k < iters[b] && k < s->hist_cap) ? tmp[b * s->hist_cap + k] : std::nan("");
+  return QILQR_OK;
+}
 
 int qilqr_profile_reset(qilqr_solver *s) {
   if (!s) return fail(QILQR_ERR_INVALID_ARG, "null solver");

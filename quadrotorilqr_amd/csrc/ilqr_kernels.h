@@ -205,8 +205,14 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   const int b = blockIdx.x;
   if (b >= B) return;
   const int lane = threadIdx.x;
+  // all per-trajectory scalars are requested at once (independent loads), not one after the other
+  // behind the branches that use them
   int fl = st.flags[b];
   int cur = st.cur[b];
+  const int it0 = st.iters[b];
+  const int trial0 = st.trial[b];
+  const double prev_cost0 = st.prev_cost[b], alpha0 = st.alpha[b];
+  const double term0 = st.terms[2 * b], term1 = st.terms[2 * b + 1];
   if (!force) {
     if (fl & F_SEARCH) {
       // ---- acceptance of the pending candidate (ilqr.hh:70-84, 174-194), fused here so that a round
@@ -225,14 +231,14 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
           new_cost += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
         }
       }
-      const int it = st.iters[b];
-      const double cost = st.prev_cost[b];
-      const double alpha = st.alpha[b];
+      const int it = it0;
+      const double cost = prev_cost0;
+      const double alpha = alpha0;
       bool accept;
       if (it == 0) {
         accept = true;  // ilqr.hh:71-73: the first rollout is taken unconditionally
       } else {
-        const double desired = p.reduction_frac * cost_reduction(st.terms[2 * b], st.terms[2 * b + 1], alpha);
+        const double desired = p.reduction_frac * cost_reduction(term0, term1, alpha);
         accept = (new_cost - cost < desired);  // ilqr.hh:186
       }
       int status = -1;
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
           fl = 0;
         }
       } else {
-        if (st.trial[b] + 1 >= p.ls_max_iters) {
+        if (trial0 + 1 >= p.ls_max_iters) {
           status = 3;  // ilqr.hh:191-193
           fl = 0;
         }
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
           if (st.cost_hist && it < st.hist_cap) st.cost_hist[(long)b * st.hist_cap + it] = new_cost;
           st.iters[b] = it + 1;
         } else {
-          st.trial[b] = st.trial[b] + 1;
+          st.trial[b] = trial0 + 1;
           st.alpha[b] = alpha * p.step_update;  // ilqr.hh:189
         }
         if (status >= 0) st.status[b] = status;

@@ -295,6 +295,22 @@ def test_dense_coupled_weights_solve():
     np.testing.assert_allclose(out["traj"], ref["traj"], atol=1e-6)
 
 
+def test_batch_cost_history_matches_oracle():
+    """ILQRDebug for batches: the cost after every completed forward pass"""
+    cfg = pb.config2(B=12, N=60)
+    cfg["options"] = dict(cfg["options"], populate_debug=True)
+    s = capi.from_config(cfg)
+    out = s.solve_batch(cfg["init"])
+    hist = s.cost_history(12)
+    ref = oracle_for(cfg)
+    for b in range(12):
+        r = ref.solve(cfg["init"][b])
+        k = out["iters"][b]
+        assert k == r["iters"] and np.isnan(hist[b, k:]).all()
+        np.testing.assert_allclose(hist[b, :k], r["cost_hist"], rtol=1e-8)
+        assert hist[b, k - 1] == out["cost"][b]
+
+
 def test_per_problem_desired_trajectories():
     cfg = pb.config2(B=6, N=30)
     r = np.random.default_rng(5)
