@@ -143,7 +143,7 @@ def main():
         }
         # ---- CPU baseline: the oracle on this host's cores, bounded sample of the same workload
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             from oracle import oracle as orc
             cores = max(1, min(os.cpu_count() or 1, 64))
             sample = min(B, max(64, 24 * cores))

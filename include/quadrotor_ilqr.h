@@ -80,6 +80,8 @@ typedef struct {
                         matrix core, cost sums / Armijo / convergence tests in fp64 (BASELINE.json configs[2]) */
 } qilqr_device_config;
 
+/* A handle owns its device workspace and stream: use it from one thread at a time (different handles are
+ * independent; the reference's ILQR object is const and re-entrant). */
 typedef struct qilqr_solver qilqr_solver;
 
 /* per-kernel device time accumulated since the last reset (profile = 1) */
