@@ -497,3 +497,34 @@ def test_config3_mixed_precision_reduced():
     g64, t64 = s64.backwards_pass(tr)
     np.testing.assert_allclose(t32, t64, rtol=2e-3)
     np.testing.assert_allclose(g32, g64, rtol=0, atol=1e-3 * np.abs(g64).max())
+
+
+# ------------------------------------------------------------------ randomised parity sweep
+@pytest.mark.parametrize("seed", range(8))
+def test_randomised_models_and_horizons_match_oracle(seed):
+    """Random physical parameters (mass, SPD inertia, arm, rotor torque ratio, gravity), time step,
+    horizon, diagonal weights and option values; random SE(3) starts towards a random hover pose."""
+    r = np.random.default_rng(1000 + seed)
+    A = r.uniform(-0.3, 0.3, (3, 3))
+    model = dict(mass_kg=r.uniform(0.5, 3.0), inertia=A @ A.T + np.diag(r.uniform(0.5, 2.0, 3)),
+                 arm_length_m=r.uniform(0.2, 1.2), torque_to_thrust_ratio_m=r.uniform(0.05, 0.5),
+                 g_mpss=r.uniform(3.0, 12.0))
+    n = int(r.integers(5, 90))
+    dt = float(r.uniform(0.02, 0.12))
+    B = int(r.integers(1, 40))
+    Q = np.diag(np.concatenate([r.uniform(10, 200, 6), r.uniform(0.5, 5, 6)]))
+    R = np.diag(r.uniform(0.5, 3.0, 4))
+    desired = pb.hover_desired(n, dt, model["mass_kg"] * model["g_mpss"] / 4.0)
+    desired[:, 1:8] = orc.se3_exp(np.concatenate([r.uniform(-1, 1, 3), r.uniform(-0.3, 0.3, 3)]))
+    init = pb.random_start_batch(np.arange(B), desired, 77 + seed, pos_m=0.8, ang_rad=0.6, vel_sigma=0.4)
+    opts = dict(step_update=float(r.choice([0.5, 0.3, 0.7])), desired_reduction_frac=float(r.choice([0.5, 0.1, 0.01])),
+                ls_max_iters=int(r.integers(5, 40)), rtol=1e-10, atol=1e-10, max_iters=int(r.integers(3, 60)),
+                populate_debug=False)
+    cfg = dict(model=model, Q=Q, R=R, dt=dt, options=opts, desired=desired, init=init)
+    out = capi.from_config(cfg).solve_batch(init)
+    ref = oracle_for(cfg).solve_batch(init, n_threads=8)
+    np.testing.assert_array_equal(out["status"], ref["status"])
+    np.testing.assert_array_equal(out["iters"], ref["iters"])
+    np.testing.assert_array_equal(out["n_fwd"], ref["n_fwd"])
+    np.testing.assert_allclose(out["cost"], ref["cost"], rtol=1e-8)
+    np.testing.assert_allclose(out["traj"], ref["traj"], atol=1e-6)
