@@ -137,7 +137,6 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
   BatchState &st = s->st;
   st.layout = s->layout;
   st.ctab = s->d_ctab;
-  st.dbg_uniform = (getenv("QILQR_DBG_UNIFORM") != nullptr) ? 1 : 0;
   int rc;
   for (int k = 0; k < 2; ++k) {
     if ((rc = dalloc_s(s, &st.traj[k], (size_t)tiled_count(cB, cn, 18)))) return rc;

@@ -52,7 +52,6 @@ struct BatchState {
   const void *ctab;      // constant operand table (backward_layout.h)
   void *dump;            // [B][4] write-only sink for the lanes of k_backward that own no gain entry
   unsigned long long *stamps;  // diagnostic build only (-DQILQR_STAMPS): [B][8] cycle sums per section of k_backward
-  int dbg_uniform;       // diagnostic only (QILQR_DBG_UNIFORM=1): every lane of a rollout wave reads one trajectory
 };
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -556,7 +555,7 @@ __global__ __launch_bounds__(128) void k_rollout2(ModelConsts<S> c, BatchState s
   if (__ballot(live) == 0ull) return;  // same lanes -> same trajectories in both waves: block-uniform
   const int bs = (b < B) ? b : (B - 1);
   const int cur = st.cur[bs];
-  const int br = st.dbg_uniform ? blockIdx.x * 64 : bs;
+  const int br = bs;
   const S *traj = (const S *)st.traj[cur] + knot_base<true>(br, n, 18);
   const S *gains = (const S *)st.gains + knot_base<true>(br, n, 52);
   S *out = (S *)st.traj[cur ^ 1] + knot_base<true>(bs, n, 18);
