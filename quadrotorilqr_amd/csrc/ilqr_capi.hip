@@ -237,7 +237,7 @@ int download_tiled(qilqr_solver *s, double *h_plain, void *t0, void *t1, const i
 
 int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag) {
   Timed t(s, K_LINEARIZE);
-  const dim3 grid(cdiv(((B + 63) / 64) * 64 * n, 128));
+  const dim3 grid(cdiv(2 * ((B + 63) / 64) * 64 * n, 128));  // dynamics half + cost half
   if (s->f32)
     hipLaunchKernelGGL(k_linearize<float>, grid, dim3(128), 0, s->stream, s->constsf, s->st, (int)B, (int)n, which,
                        need_flag);

@@ -93,15 +93,24 @@ __device__ __forceinline__ double cost_reduction(double QuTk, double kTQuuk, dou
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_linearize: thread (b, i).  which = 0: trajectory traj[cur[b]], 1: candidate traj[cur[b]^1].
+// k_linearize: two threads per (b, i), in different wavefronts: one writes the dynamics Jacobian
+// blocks of the knot record, the other the cost differentials and the knot cost (the kernel is bound
+// by its instruction count, and the two halves share nothing but the knot they read).
+// which = 0: trajectory traj[cur[b]], 1: candidate traj[cur[b]^1].
 // need_flag: only problems whose flags contain it (0 = all).
 // ---------------------------------------------------------------------------------------------
+#ifndef QILQR_LIN_WAVES
+#define QILQR_LIN_WAVES 4  // register budget of k_linearize in waves per SIMD (2, 3, 4 measured equal)
+#endif
 template <typename S>
-__global__ __launch_bounds__(128) void k_linearize(ModelConsts<S> c, BatchState st, int B, int n, int which,
-                                                   int need_flag) {
-  // thread -> (tile, knot, lane): the 64 lanes of a wavefront read one knot of 64 consecutive trajectories
-  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(QILQR_LIN_WAVES, QILQR_LIN_WAVES))) void
+k_linearize(ModelConsts<S> c, BatchState st, int B, int n, int which, int need_flag) {
+  // thread -> (half, tile, knot, lane): the 64 lanes of a wavefront read one knot of 64 consecutive trajectories
+  long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (id == 0) st.counters[0] = 0;  // the next k_backward counts the trajectories still active
+  const long per_half = (long)((B + 63) / 64) * n * 64;
+  const bool cost_half = id >= per_half;
+  if (cost_half) id -= per_half;
   const int lane = (int)(id & 63);
   const long rest = id >> 6;
   const int i = (int)(rest % n);
@@ -109,13 +118,18 @@ __global__ __launch_bounds__(128) void k_linearize(ModelConsts<S> c, BatchState 
   if (b >= B) return;
   if (need_flag && !(st.flags[b] & need_flag)) return;
   const int buf = st.cur[b] ^ which;
-  S pt[18], pd[18];
+  S pt[18];
   load_knot<true>((const S *)st.traj[buf] + knot_base<true>(b, n, 18), i, 18, pt);
+  S *rec = (S *)st.lin[buf] + (b * n + i) * st.layout.stride;
+  if (!cost_half) {
+    linearize_dynamics(c, pt, rec);
+    return;
+  }
+  S pd[18];
   if (st.desired_tiled) load_knot<true>((const S *)st.desired + knot_base<true>(b, n, 18), i, 18, pd);
   else load_knot<false>((const S *)st.desired, i, 18, pd);
-  S *rec = (S *)st.lin[buf] + (b * n + i) * st.layout.stride;
-  linearize_knot(c, st.layout, pt, pd, rec);
-  st.knot_cost[buf][cost_index(b, i, n)] = (double)rec[st.layout.off_cost];  // summed in fp64 (k_init / k_backward)
+  const S cost = linearize_cost(c, st.layout, pt, pd, rec);
+  st.knot_cost[buf][cost_index(b, i, n)] = (double)cost;  // summed in fp64 (k_init / k_backward)
 }
 
 // ---------------------------------------------------------------------------------------------

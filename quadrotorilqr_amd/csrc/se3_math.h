@@ -341,6 +341,98 @@ QILQR_HD void discrete_step(const ModelConsts<T> &c, T t[3], T q[4], T v[6], con
 
 template <typename T>
 QILQR_HD void se3_rminus_fast(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T tau[6]);
+template <typename T>
+struct Series;
+template <typename T>
+QILQR_HD T poly8(const T c[8], T x);
+
+// ----------------------------------------------------------------- matrices for the linearisation
+// The same Jacobians as so3_ljac / so3_ljacinv / se3_fillQ, formed without 3x3 matrix products from
+//   hat(a) hat(b) = b a^T - (a.b) I ,   W^2 = th th^T - |th|^2 I
+// and with the series of the scalar coefficients for moderate angles (manif's theta^2 <= 1e-10
+// branches kept).  k_linearize is bound by its instruction count; this is a third of it.
+template <typename T>
+QILQR_HD void so3_sym_part(const T th[3], T th2, T coef, T J[9]) {  // J += coef (th th^T - th2 I)
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) J[3 * i + j] += coef * (th[i] * th[j] - ((i == j) ? th2 : T(0)));
+}
+template <typename T>
+QILQR_HD void so3_ljac_fast(const T th[3], T J[9]) {  // I + a W + b W^2
+  const T th2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2];
+  T a, b;
+  if (!(th2 > Eps<T>::manif)) {
+    a = T(0.5); b = T(0);
+  } else if (th2 <= Series<T>::EXP_MAX) {
+    a = poly8(Series<T>::jac_a, th2);
+    b = poly8(Series<T>::jac_b, th2);
+  } else {
+    const T theta = sqrt(th2);
+    a = (T(1) - cos(theta)) / th2;
+    b = (theta - sin(theta)) / (th2 * theta);
+  }
+  skew3(th, J);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) J[i] *= a;
+  J[0] += 1; J[4] += 1; J[8] += 1;
+  so3_sym_part(th, th2, b, J);
+}
+template <typename T>
+QILQR_HD void so3_ljacinv_fast(const T th[3], T J[9]) {  // I - W/2 + c W^2
+  const T th2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2];
+  T c;
+  if (!(th2 > Eps<T>::manif)) {
+    c = T(0);
+  } else if (th2 <= Series<T>::JINV_MAX) {
+    c = poly8(Series<T>::jinv_c, th2);
+  } else {
+    const T theta = sqrt(th2);
+    c = T(1) / th2 - (T(1) + cos(theta)) / (T(2) * theta * sin(theta));
+  }
+  skew3(th, J);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) J[i] *= T(-0.5);
+  J[0] += 1; J[4] += 1; J[8] += 1;
+  so3_sym_part(th, th2, c, J);
+}
+// Q(rho, th) = V/2 + B (rho th^T + th rho^T) - 2 B s I - (B + C) s W - C (n th^T - th n^T) + 2 D s W^2,
+// s = th.rho, n = th x rho  (Barfoot eq. 102 with the products of skew matrices written out)
+template <typename T>
+QILQR_HD void se3_fillQ_fast(const T rho[3], const T th[3], T Qm[9]) {
+  const T th2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2];
+  T B, C, D;
+  if (!(th2 > Eps<T>::manif)) {
+    B = T(1. / 6.) - th2 / T(120);
+    C = T(-1. / 24.) + th2 / T(720);
+    D = T(-1. / 120.);
+  } else if (th2 <= Series<T>::EXP_MAX) {
+    B = poly8(Series<T>::jac_b, th2);
+    C = poly8(Series<T>::fillq_C, th2);
+    D = poly8(Series<T>::fillq_D, th2);
+  } else {
+    const T theta = sqrt(th2);
+    const T s = sin(theta), co = cos(theta);
+    B = (theta - s) / (th2 * theta);
+    C = (T(1) - th2 / T(2) - co) / (th2 * th2);
+    D = T(0.5) * (C - T(3) * (theta - s - th2 * theta / T(6)) / (th2 * th2 * theta));
+  }
+  const T s = th[0] * rho[0] + th[1] * rho[1] + th[2] * rho[2];
+  T n[3], V[9], W[9];
+  cross3(th, rho, n);
+  skew3(rho, V);
+  skew3(th, W);
+  const T cw = -(B + C) * s, cd = T(2) * D * s, ci = T(-2) * B * s;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      T q = T(0.5) * V[3 * i + j] + B * (rho[i] * th[j] + th[i] * rho[j]) + cw * W[3 * i + j] -
+            C * (n[i] * th[j] - th[i] * n[j]) + cd * (th[i] * th[j]);
+      if (i == j) q += ci - cd * th2;
+      Qm[3 * i + j] = q;
+    }
+}
 
 // ----------------------------------------------------------------- knot record layout
 // What k_linearize hands to k_backward for one knot (doubles).  Only entries that are not
@@ -422,10 +514,10 @@ QILQR_HD T knot_cost(const ModelConsts<T> &c, const T *pt, const T *pd, T dx[12]
   return cx + cu;
 }
 
-// Full linearisation of one knot: dynamics Jacobian blocks (quadrotor_model.cc:33-49, 84-119,
-// 174-200, 266-276) and cost differentials (cost.hh:36-61), written to rec[LIN_STRIDE].
+// Linearisation of one knot in two independent halves (k_linearize runs them in different lanes).
+// Dynamics: the six Jacobian blocks of quadrotor_model.cc:33-49, 84-119, 174-200, 266-276.
 template <typename T>
-QILQR_HD void linearize_knot(const ModelConsts<T> &c, const RecLayout &L, const T *pt, const T *pd, T *rec) {
+QILQR_HD void linearize_dynamics(const ModelConsts<T> &c, const T *pt, T *rec) {
   const T q[4] = {pt[5], pt[6], pt[7], pt[4]};
   const T *v = pt + 8;
   // ---- dynamics: tau = dt v ; E = Exp(tau) = (p, qe)
@@ -434,7 +526,7 @@ QILQR_HD void linearize_knot(const ModelConsts<T> &c, const RecLayout &L, const 
   for (int i = 0; i < 6; ++i) tau[i] = c.dt * v[i];
   {
     T Jl[9], p[3], qe[4];
-    so3_ljac(tau + 3, Jl);
+    so3_ljac_fast(tau + 3, Jl);
     mat3_vec(Jl, tau, p);
     so3_exp(tau + 3, qe);
     // Ad(E^-1) = [[Rc, hat(ti) Rc],[0, Rc]],  Rc = R(qe*), ti = -Rc p
@@ -452,7 +544,7 @@ QILQR_HD void linearize_knot(const ModelConsts<T> &c, const RecLayout &L, const 
     }
     // dt * rjac(tau) = dt [[Jr, Q(-tau)],[0, Jr]],  Jr = Jl^T
     T nrho[3] = {-tau[0], -tau[1], -tau[2]}, nth[3] = {-tau[3], -tau[4], -tau[5]}, Qm[9];
-    se3_fillQ(nrho, nth, Qm);
+    se3_fillQ_fast(nrho, nth, Qm);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -483,6 +575,11 @@ QILQR_HD void linearize_knot(const ModelConsts<T> &c, const RecLayout &L, const 
 #pragma unroll
     for (int i = 0; i < 9; ++i) rec[LIN_BLK + 45 + i] = ((i % 4 == 0) ? T(1) : T(0)) + c.dt * (-S[i]);
   }
+}
+
+// Cost: value and differentials of cost.hh:36-61; returns the knot cost.
+template <typename T>
+QILQR_HD T linearize_cost(const ModelConsts<T> &c, const RecLayout &L, const T *pt, const T *pd, T *rec) {
   // ---- cost: dx = x (-) x_d, J = blkdiag(Jri(tau_c), I6), Jri = [[a, b],[0, a]]
   T dx[12], du[4];
   const T cost = knot_cost(c, pt, pd, dx, du);
@@ -490,10 +587,10 @@ QILQR_HD void linearize_knot(const ModelConsts<T> &c, const RecLayout &L, const 
   T Jri[36];
   {
     T Li[9], a[9], Qm[9], aq[9], b[9];
-    so3_ljacinv(dx + 3, Li);
+    so3_ljacinv_fast(dx + 3, Li);
     transpose3(Li, a);  // rjacinv = ljacinv^T
     T nrho[3] = {-dx[0], -dx[1], -dx[2]}, nth[3] = {-dx[3], -dx[4], -dx[5]};
-    se3_fillQ(nrho, nth, Qm);
+    se3_fillQ_fast(nrho, nth, Qm);
     mat3_mul(a, Qm, aq);
     mat3_mul(aq, a, b);
 #pragma unroll
@@ -592,6 +689,12 @@ QILQR_HD void linearize_knot(const ModelConsts<T> &c, const RecLayout &L, const 
         }
     }
   }
+  return cost;
+}
+template <typename T>
+QILQR_HD void linearize_knot(const ModelConsts<T> &c, const RecLayout &L, const T *pt, const T *pd, T *rec) {
+  linearize_dynamics(c, pt, rec);
+  linearize_cost(c, L, pt, pd, rec);
 }
 
 // ----------------------------------------------------------------- rollout arithmetic
@@ -627,6 +730,14 @@ struct Series {
   static constexpr T jac_b[8] = {0.16666666666666666, -0.008333333333333333, 0.0001984126984126984,
                                  -2.7557319223985893e-06, 2.505210838544172e-08, -1.6059043836821613e-10,
                                  7.647163731819816e-13, -2.8114572543455206e-15};  // (th - sin th)/th^3
+  // Barfoot Q-block coefficients C = (1 - x/2 - cos th)/x^2 and D = (C - 3 (th - sin th - th^3/6)/th^5)/2
+  // in x = theta^2 (B is jac_b), valid for x <= EXP_MAX
+  static constexpr T fillq_C[8] = {-0.041666666666666664, 0.001388888888888889, -2.48015873015873e-05,
+                                   2.755731922398589e-07, -2.08767569878681e-09, 1.1470745597729725e-11,
+                                   -4.779477332387385e-14, 1.5619206968586225e-16};
+  static constexpr T fillq_D[8] = {-0.008333333333333333, 0.0003968253968253968, -8.267195767195768e-06,
+                                   1.0020843354176688e-07, -8.029521918410807e-10, 4.58829823909189e-12,
+                                   -1.9680200780418645e-14, 6.576508197299464e-17};
   // asin(s)/s in y = s^2, valid for y <= LOG_MAX
   static constexpr T LOG_MAX = T(0.0625);
   static constexpr T asin_lo[8] = {1.0, 0.16666666666666666, 0.075, 0.044642857142857144,

@@ -108,6 +108,50 @@ def test_knot_records_match_oracle(hh, seed, dense):
         np.testing.assert_allclose(lin[i, lay[3] + 12:lay[3] + 16], D["u"], rtol=1e-12, atol=1e-13)
 
 
+def test_knot_records_across_series_branches(hh):
+    # the linearisation's Jacobian coefficients switch between manif's small-angle constants
+    # (theta^2 <= 1e-10), power series (theta^2 <= 0.25 / 0.26) and the closed forms: sweep the step
+    # rotation dt*omega and the orientation error across all of them
+    model, Q, R = pb.MODEL_D, pb.Q_DEMO, pb.R_DEMO
+    dt = 0.1
+    c = consts(hh, model, Q, R, dt)
+    lay = layout(hh, c)
+    mp = orc.model_params(**model)
+    r = np.random.default_rng(5)
+    angles = [0.0, 1e-7, 9e-6, 1.1e-5, 1e-3, 0.05, 0.3, 0.499, 0.501, 0.509, 0.511, 0.8, 2.0, 3.0]
+    for ang in angles:
+        ax = r.normal(size=3); ax /= np.linalg.norm(ax)
+        ax2 = r.normal(size=3); ax2 /= np.linalg.norm(ax2)
+        des = np.zeros((1, 18)); tr = np.zeros((1, 18))
+        des[0, 1:8] = orc.se3_exp(np.concatenate([r.uniform(-1, 1, 3), r.uniform(-1, 1, 3)]))
+        des[0, 8:14] = r.uniform(-1, 1, 6)
+        des[0, 14:18] = r.uniform(0, 5, 4)
+        err = np.concatenate([r.uniform(-1, 1, 3), ang * ax])
+        tr[0, 1:8] = orc.se3_compose(des[0, 1:8], orc.se3_exp(err))
+        tr[0, 8:11] = r.uniform(-2, 2, 3)
+        tr[0, 11:14] = ang / dt * ax2
+        tr[0, 14:18] = r.uniform(0, 5, 4)
+        lin = np.zeros((1, lay[5]))
+        hh.hh_linearize(P(c), IP(lay), P(tr), P(des), C.c_int(1), P(lin))
+        _, Jx, Ju = orc.discrete_dynamics(mp, tr[0, 1:14], tr[0, 14:18], dt, diffs=True)
+        jx, ju = np.zeros((12, 12)), np.zeros((12, 4))
+        hh.hh_dense_jacobians(P(c), P(lin[0]), P(jx), P(ju))
+        # Just above theta^2 = 1e-10 the reference's closed forms cancel: (1 - cos th)/th^2 carries ~1e-16/th^2
+        # relative error and the Q-block's (1 - th^2/2 - cos th)/th^4 an ABSOLUTE error ~1e-16/th^4 (thousands at
+        # th = 1.1e-5), which the th^2 |rho| factors it multiplies reduce to ~1e-16/th^2 in the Jacobian.  The
+        # series used here do not cancel, so that noise of the reference is the tolerance.
+        noise = 1e-12 + (2e-16 / ang ** 2 if ang > 1e-5 else 0.0)
+        np.testing.assert_allclose(jx, Jx, rtol=1e-12, atol=noise, err_msg=f"angle {ang}")
+        cost, D = orc.cost(Q, R, tr[0, 1:14], tr[0, 14:18], des[0, 1:14], des[0, 14:18], diffs=True)
+        np.testing.assert_allclose(lin[0, lay[4]], cost, rtol=1e-12, atol=1e-25)
+        cxx = np.zeros((12, 12))
+        hh.hh_dense_cxx(P(c), IP(lay), P(lin[0]), P(cxx))
+        scale = np.abs(D["xx"]).max()
+        np.testing.assert_allclose(cxx, D["xx"], rtol=1e-11, atol=noise * scale, err_msg=f"angle {ang}")
+        np.testing.assert_allclose(lin[0, lay[3]:lay[3] + 12], D["x"], rtol=1e-11,
+                                   atol=noise * max(np.abs(D["x"]).max(), 1e-300), err_msg=f"angle {ang}")
+
+
 def test_knot_records_at_singular_points(hh):
     # desired roll = pi (w = 0 branch of Log), zero rotation rate (small-angle Exp), zero error
     model, Q, R = pb.MODEL_D, pb.Q_DEMO, pb.R_DEMO
