@@ -159,7 +159,8 @@ __global__ void k_init(SolveParams p, BatchState st, int B, int n) {
 // force = 1: run on every trajectory, no convergence test (the stand-alone backwards_pass API).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double sel4(const double v[4], int kk) {
-  return kk == 0 ? v[0] : (kk == 1 ? v[1] : (kk == 2 ? v[2] : v[3]));
+  const double lo = (kk & 1) ? v[1] : v[0], hi = (kk & 1) ? v[3] : v[2];
+  return (kk & 2) ? hi : lo;
 }
 // 1/x to fp64 accuracy (not correctly rounded): hardware estimate + two Newton steps; half the
 // dependent depth of the IEEE division sequence, which matters on the per-knot serial chain
@@ -400,7 +401,8 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
         Qu[a] = bcast_lane(ghat, 12 + a);
       }
 #pragma unroll
-      for (int a = 0; a < 4; ++a) rhs[a] = (j < 12) ? col[a] : ((j == 12) ? Qu[a] : 0.0);  // lane 12: feed-forward
+      // lane 12: feed-forward.  Lanes 13..15 solve against a column of Q_uu itself; nobody reads them.
+      for (int a = 0; a < 4; ++a) rhs[a] = (j == 12) ? Qu[a] : col[a];
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) Hs[(4 * r + kk) * LD + j] = H[r];
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
     const double d3 = Quu[15] - l30 * Quu[12] - l31 * c31 - l32 * c32;
     const double i3 = rcp_nr(d3);
     QKEEP(i3); QKEEP(l32); QKEEP(l31);
-    double kcol[4], kff[4];
+    double kcol[4];
     {
       // one right-hand side per lane: K[:, j] = -Quu^-1 Q_xu[j, :]^T in lanes j < 12 and
       // k = -Quu^-1 Q_u in lane 12   (ilqr.hh:127-128); k is then broadcast
@@ -439,43 +441,55 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
       const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
                    x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
       kcol[0] = -x0; kcol[1] = -x1; kcol[2] = -x2; kcol[3] = -x3;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) kff[a] = bcast_lane(kcol[a], 12);
     }
-    QKEEP(kcol[0]); QKEEP(kcol[3]); QKEEP(kff[0]); QKEEP(kff[3]);
+    QKEEP(kcol[0]); QKEEP(kcol[3]);
     QSTAMP(5);  // factorisation + solve
     // gains of knot i: [k(4) | K column-major]; lane j < 12 owns column j, lane 12 owns k.
-    // Every lane stores (lanes that own nothing write zeros to a per-trajectory dump slot): no branch
-    // around the stores, so the wait for the next knot's operands is an exact vmcnt(2), not vmcnt(0).
+    // Every lane stores (lanes that own nothing write whatever they hold to a per-trajectory dump slot
+    // nobody reads): no branch around the stores, so the wait for the next knot's operands is an exact
+    // vmcnt(2), not vmcnt(0), and no select in front of them.
     {
-      const bool owner = (kk == 0 && j <= 12);
-      const sv2 w0 = {(S)(owner ? kcol[0] : 0.0), (S)(owner ? kcol[1] : 0.0)},
-                w1 = {(S)(owner ? kcol[2] : 0.0), (S)(owner ? kcol[3] : 0.0)};
+      const sv2 w0 = {(S)kcol[0], (S)kcol[1]}, w1 = {(S)kcol[2], (S)kcol[3]};
       *gdst0 = w0;
       *gdst1 = w1;
       gdst0 -= gstep;
       gdst1 -= gstep;
     }
-    // (K^T Quu)[j][:], then V_x = Q_x - (K^T Quu) k   (ilqr.hh:132)
-    double mc[4];
-#pragma unroll
-    for (int bb = 0; bb < 4; ++bb)
-      mc[bb] = kcol[0] * Quu[bb] + kcol[1] * Quu[4 + bb] + kcol[2] * Quu[8 + bb] + kcol[3] * Quu[12 + bb];
-    const double vx = ghat - (mc[0] * kff[0] + mc[1] * kff[1] + mc[2] * kff[2] + mc[3] * kff[3]);
     // expected cost reduction terms (ilqr.hh:136-140): in lane 12 the right-hand side is Q_u and the
-    // solution is k, so Q_u^T k = rhs . kcol and k^T Quu k = (K^T Quu) . kcol there; every lane
-    // accumulates its own column's value and lane 12's sums are read after the loop
+    // solution is k, so Q_u^T k = rhs . kcol there; every lane accumulates its own column's value and
+    // lane 12's sum is read after the loop
     QuTk += rhs[0] * kcol[0] + rhs[1] * kcol[1] + rhs[2] * kcol[2] + rhs[3] * kcol[3];
-    kTQuuk += mc[0] * kcol[0] + mc[1] * kcol[1] + mc[2] * kcol[2] + mc[3] * kcol[3];
-    QKEEP(mc[3]); QKEEP(vx); QKEEP(QuTk); QKEEP(kTQuuk);
-    QSTAMP(6);  // K^T Quu, V_x, reduction terms
+    double vx;
     if constexpr (SYM) {
+      // With Q_uu symmetric and K = -Quu^-1 Q_ux, k = -Quu^-1 Q_u, the reference's updates
+      //   V_x = Q_x - K^T Quu k,  V_xx = Q_xx - K^T Quu K,  k^T Quu k      (ilqr.hh:132-133, 139)
+      // are, term by term,  Q_x + K^T Q_u,  Q_xx + Q_xu K,  -Q_u^T k  (they differ from the reference's
+      // evaluation by the residual of the 4x4 solve, ~ cond(Quu) eps).  That removes the product
+      // K^T Quu (16 FMA per lane) from the serial chain, and the A operand of the update
+      //   A[j][kk] = Q_xu[j][kk] = H[12 + kk][j]
+      // is accumulator register 3 as it stands.
+      vx = ghat + (kcol[0] * Qu[0] + kcol[1] * Qu[1] + kcol[2] * Qu[2] + kcol[3] * Qu[3]);
+      QKEEP(vx); QKEEP(QuTk);
+      QSTAMP(6);  // V_x, reduction term
 #pragma unroll
       for (int kc = 0; kc < 3; ++kc) vxl[kc] = __shfl(vx, 4 * kc + kk);  // V_x[r] lives in lanes with j == r
+      H = __builtin_amdgcn_mfma_f64_16x16x4f64(H[3], sel4(kcol, kk), H, 0, 0, 0);
+    } else {
+      // (K^T Quu)[j][:], then V_x = Q_x - (K^T Quu) k   (ilqr.hh:132)
+      double mc[4], kff[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) kff[a] = bcast_lane(kcol[a], 12);
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb)
+        mc[bb] = kcol[0] * Quu[bb] + kcol[1] * Quu[4 + bb] + kcol[2] * Quu[8 + bb] + kcol[3] * Quu[12 + bb];
+      vx = ghat - (mc[0] * kff[0] + mc[1] * kff[1] + mc[2] * kff[2] + mc[3] * kff[3]);
+      kTQuuk += mc[0] * kcol[0] + mc[1] * kcol[1] + mc[2] * kcol[2] + mc[3] * kcol[3];
+      QKEEP(mc[3]); QKEEP(vx); QKEEP(QuTk); QKEEP(kTQuuk);
+      QSTAMP(6);  // K^T Quu, V_x, reduction terms
+      // V_xx = Q_xx - (K^T Quu) K   (ilqr.hh:133): one more MFMA on the same accumulator,
+      // A[j][kk] = -(K^T Quu)[j][kk], B[kk][j] = K[kk][j]
+      H = __builtin_amdgcn_mfma_f64_16x16x4f64(-sel4(mc, kk), sel4(kcol, kk), H, 0, 0, 0);
     }
-    // V_xx = Q_xx - (K^T Quu) K   (ilqr.hh:133): one more MFMA on the same accumulator,
-    // A[j][kk] = -(K^T Quu)[j][kk], B[kk][j] = K[kk][j]
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(-sel4(mc, kk), sel4(kcol, kk), H, 0, 0, 0);
 
     // hand V_xx, V_x to the next knot
     if constexpr (SYM) {
@@ -510,7 +524,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
     for (int k = 0; k < 8; ++k) st.stamps[(long)b * 8 + k] = stamp_sum[k];
 #endif
   QuTk = bcast_lane(QuTk, 12);
-  kTQuuk = bcast_lane(kTQuuk, 12);
+  kTQuuk = SYM ? -QuTk : bcast_lane(kTQuuk, 12);
   if (lane == 0) {
     st.terms[2 * b] = QuTk;
     st.terms[2 * b + 1] = kTQuuk;

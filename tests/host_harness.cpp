@@ -139,9 +139,10 @@ void hh_dense_jacobians(const ModelConsts<double> *c, const double *rec, double 
 }
 
 // k_backward re-enacted lane by lane (same statements, loops over the 64 lanes between the
-// points where the kernel exchanges data)
+// points where the kernel exchanges data).  sym = 1: the SYM = true instantiation (accumulator tile
+// reused as A operand, V_x / V_xx / k^T Quu k in their Q_xu forms), sym = 0: the general one.
 void hh_backward_emulated(const ModelConsts<double> *cp, const int *lay, const double *lin, int n, double *gains,
-                          double *terms) {
+                          double *terms, int sym) {
   const ModelConsts<double> &c = *cp;
   const RecLayout L = layout_from(lay);
   constexpr int LD = 17;
@@ -197,7 +198,8 @@ void hh_backward_emulated(const ModelConsts<double> *cp, const int *lay, const d
       for (int aa = 0; aa < 4; ++aa) {
         for (int bb = 0; bb < 4; ++bb) Quu[aa * 4 + bb] = Hs[(12 + aa) * LD + 12 + bb];
         Qu[aa] = gs[12 + aa];
-        rhs[aa] = (j < 12) ? Hs[j * LD + 12 + aa] : ((j == 12) ? Qu[aa] : 0.0);  // lane 12 solves for k
+        if (sym) rhs[aa] = (j == 12) ? Qu[aa] : Hs[(12 + aa) * LD + j];  // col[aa] = H[12 + aa][j]
+        else rhs[aa] = (j < 12) ? Hs[j * LD + 12 + aa] : ((j == 12) ? Qu[aa] : 0.0);  // lane 12 solves for k
       }
       const double i0 = 1.0 / Quu[0];
       const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
@@ -228,8 +230,13 @@ void hh_backward_emulated(const ModelConsts<double> *cp, const int *lay, const d
     for (int l = 0; l < 64; ++l) {
       const int j = l & 15, kk = l >> 4;
       const double *kcol = kcol_all[l], *mc = mc_all[l], *kff = kcol_all[12];  // k broadcast from lane 12
-      vx[l] = ghat[l] - (mc[0] * kff[0] + mc[1] * kff[1] + mc[2] * kff[2] + mc[3] * kff[3]);
-      aop[l] = -mc[kk];
+      if (sym) {
+        vx[l] = ghat[l] + (kcol[0] * gs[12] + kcol[1] * gs[13] + kcol[2] * gs[14] + kcol[3] * gs[15]);
+        aop[l] = H[l][3];
+      } else {
+        vx[l] = ghat[l] - (mc[0] * kff[0] + mc[1] * kff[1] + mc[2] * kff[2] + mc[3] * kff[3]);
+        aop[l] = -mc[kk];
+      }
       bop[l] = kcol[kk];
       if (kk == 0) {
         double *g = gains + (long)i * 52;
@@ -248,13 +255,14 @@ void hh_backward_emulated(const ModelConsts<double> *cp, const int *lay, const d
     for (int l = 0; l < 64; ++l) {
       const int j = l & 15, kk = l >> 4;
       for (int kc = 0; kc < 3; ++kc) {
-        va[l][kc] = (j < 12) ? Vs[j * LD + 4 * kc + kk] : 0.0;
+        if (sym) va[l][kc] = H[l][kc];  // no transpose: V symmetric to rounding
+        else va[l][kc] = (j < 12) ? Vs[j * LD + 4 * kc + kk] : 0.0;
         vxl[l][kc] = vxs[4 * kc + kk];
       }
     }
   }
   terms[0] = QuTk[12];  // lane 12 owns the feed-forward column
-  terms[1] = kTQuuk[12];
+  terms[1] = sym ? -QuTk[12] : kTQuuk[12];
 }
 
 }  // extern "C"

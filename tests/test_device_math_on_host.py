@@ -186,10 +186,12 @@ def test_rollout_matches_oracle(hh, seed, dense):
         np.testing.assert_allclose(out, ref, rtol=1e-10, atol=1e-10)
 
 
-@pytest.mark.parametrize("seed,dense", [(6, False), (7, True), (8, True), (10, "sym")])
-def test_backward_dataflow_matches_oracle(hh, seed, dense):
+@pytest.mark.parametrize("seed,dense,sym", [(6, False, 1), (6, False, 0), (7, True, 0), (8, True, 0), (10, "sym", 1),
+                                             (10, "sym", 0)])
+def test_backward_dataflow_matches_oracle(hh, seed, dense, sym):
     """k_backward re-enacted on the CPU with the documented v_mfma_f64_16x16x4_f64 lane maps:
-    proves the operand tables, the accumulator->operand hand-off and the gain layout."""
+    proves the operand tables, the accumulator->operand hand-off and the gain layout.  sym = 1 is the
+    instantiation for symmetric weights (V_x, V_xx, k^T Quu k in their Q_xu forms), sym = 0 the general one."""
     model, Q, R, traj, desired = random_problem(seed, n=15, dense=dense)
     c = consts(hh, model, Q, R, 0.1)
     n = len(traj)
@@ -197,7 +199,7 @@ def test_backward_dataflow_matches_oracle(hh, seed, dense):
     lin = np.zeros((n, lay[5]))
     hh.hh_linearize(P(c), IP(lay), P(traj), P(desired), C.c_int(n), P(lin))
     gains, terms = np.zeros((n, 52)), np.zeros(2)
-    hh.hh_backward_emulated(P(c), IP(lay), P(lin), C.c_int(n), P(gains), P(terms))
+    hh.hh_backward_emulated(P(c), IP(lay), P(lin), C.c_int(n), P(gains), P(terms), C.c_int(sym))
     s = orc.OracleSolver(orc.model_params(**model), Q, R, desired, 0.1, orc.options())
     g_ref, t_ref = s.backwards_pass(traj)
     np.testing.assert_allclose(terms, t_ref, rtol=1e-10)
