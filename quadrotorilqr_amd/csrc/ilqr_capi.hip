@@ -61,7 +61,7 @@ struct qilqr_solver {
   BatchState st{};
   std::vector<void *> allocs;
   int *h_counters = nullptr;  // pinned, 16 slots
-  hipEvent_t poll_ev[8] = {};  // one per in-flight poll of the active counter
+  unsigned long long *h_active = nullptr;  // pinned + mapped, 8 words written by k_linearize (BatchState::host_active)
   double *io_aos = nullptr;         // device scratch in the plain [B][n][W] layout (W <= 52), for host I/O
   void *desired_tiled = nullptr;    // per-problem desired trajectories, tiled (allocated on first use)
   // profiling
@@ -235,15 +235,15 @@ int download_tiled(qilqr_solver *s, double *h_plain, void *t0, void *t1, const i
   return QILQR_OK;
 }
 
-int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag) {
+int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag, int round = -1) {
   Timed t(s, K_LINEARIZE);
   const dim3 grid(cdiv(2 * ((B + 63) / 64) * 64 * n, 128));  // dynamics half + cost half
   if (s->f32)
     hipLaunchKernelGGL(k_linearize<float>, grid, dim3(128), 0, s->stream, s->constsf, s->st, (int)B, (int)n, which,
-                       need_flag);
+                       need_flag, round);
   else
     hipLaunchKernelGGL(k_linearize<double>, grid, dim3(128), 0, s->stream, s->consts, s->st, (int)B, (int)n, which,
-                       need_flag);
+                       need_flag, round);
   return QILQR_OK;
 }
 int launch_backward(qilqr_solver *s, long B, long n, int force) {
@@ -320,25 +320,52 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round) {
   // a trajectory needs at most max_iters backward passes and max_iters * ls_max_iters trials
   const double bound = (std::fmin(s->params.max_iters, 1e7) + 1.0) * ((double)std::max(s->params.ls_max_iters, 1) + 1.0);
   const long max_rounds = (long)std::fmin(bound, 2e9);
-  // The count of still-active trajectories is copied to pinned memory after every k_backward and
-  // looked at `lag` rounds later, so the host keeps the stream `lag` rounds ahead of the device and
-  // the GPU never waits for a host round trip.  Rounds enqueued past the end find nothing to do.
   const int lag = (sync_every > 1) ? std::min(sync_every, 6) : 0;
-  for (long round = 0; round < max_rounds; ++round) {
-    // k_backward first settles the candidate of the previous round (cost, Armijo, convergence) and
-    // counts the trajectories still active; then rollout + linearise the next candidates
-    if ((rc = launch_backward(s, B, n, 0))) return rc;
-    const int slot = (int)(round % 8);
-    HIP_TRY(hipMemcpyAsync(&s->h_counters[slot], s->st.counters, sizeof(int), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipEventRecord(s->poll_ev[slot], s->stream));
-    if (round >= lag) {
-      const int old = (int)((round - lag) % 8);
-      HIP_TRY(hipEventSynchronize(s->poll_ev[old]));
-      if (lag == 0 && (rc = on_round())) return rc;
-      if (s->h_counters[old] == 0) break;
+  if (lag == 0) {
+    // Synchronous rounds (debug capture): the host reads the count after every k_backward.
+    for (long round = 0; round < max_rounds; ++round) {
+      // k_backward first settles the candidate of the previous round (cost, Armijo, convergence) and
+      // counts the trajectories still active; then rollout + linearise the next candidates
+      if ((rc = launch_backward(s, B, n, 0))) return rc;
+      int active = 0;
+      if ((rc = read_active(s, &active))) return rc;
+      if ((rc = on_round())) return rc;
+      if (active == 0) break;
+      if ((rc = launch_rollout(s, B, n, F_SEARCH))) return rc;
+      if ((rc = launch_linearize(s, B, n, 1, F_SEARCH))) return rc;
     }
-    if ((rc = launch_rollout(s, B, n, F_SEARCH))) return rc;
-    if ((rc = launch_linearize(s, B, n, 1, F_SEARCH))) return rc;
+  } else {
+    // Free-running rounds: three kernels per round and nothing else on the stream.  k_linearize hands
+    // the count of still-active trajectories to the host through pinned memory, tagged with its round;
+    // the host looks at the count `lag` rounds late, i.e. keeps the stream `lag` rounds ahead of the
+    // device, so the GPU never waits for a host round trip.  Rounds enqueued past the end find nothing
+    // to do.
+    for (int k = 0; k < 8; ++k) s->h_active[k] = 0;
+    for (long round = 0; round < max_rounds; ++round) {
+      if ((rc = launch_backward(s, B, n, 0))) return rc;
+      if ((rc = launch_rollout(s, B, n, F_SEARCH))) return rc;
+      if ((rc = launch_linearize(s, B, n, 1, F_SEARCH, (int)(round & 0x3fffffff)))) return rc;
+      if (round >= lag) {
+        const long old = round - lag;
+        const unsigned tag = (unsigned)((old & 0x3fffffff) + 1);
+        unsigned long long v;
+        for (long spins = 0;; ++spins) {
+          v = __atomic_load_n(&s->h_active[old & 7], __ATOMIC_ACQUIRE);
+          if ((unsigned)(v >> 32) == tag) break;
+          if ((spins & 1023) == 1023) {
+            // never spin on a dead stream: a drained or failed stream without the tag is an error
+            const hipError_t q = hipStreamQuery(s->stream);
+            if (q != hipErrorNotReady) {
+              v = __atomic_load_n(&s->h_active[old & 7], __ATOMIC_ACQUIRE);
+              if ((unsigned)(v >> 32) == tag) break;
+              return fail(QILQR_ERR_HIP, std::string("a round never reported its active count: ") + hipGetErrorString(q));
+            }
+          }
+          __builtin_ia32_pause();
+        }
+        if ((unsigned)v == 0) break;
+      }
+    }
   }
   HIP_TRY(hipStreamSynchronize(s->stream));
   HIP_TRY(hipGetLastError());
@@ -438,7 +465,12 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
     }
   }
   if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_counters, sizeof(int) * 16, hipHostMallocDefault);
-  for (int k = 0; k < 8 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&s->poll_ev[k], hipEventDisableTiming);
+  if (e == hipSuccess)
+    e = hipHostMalloc((void **)&s->h_active, sizeof(unsigned long long) * 8, hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) {
+    for (int k = 0; k < 8; ++k) s->h_active[k] = 0;
+    e = hipHostGetDevicePointer((void **)&s->st.host_active, s->h_active, 0);
+  }
   if (e == hipSuccess) e = hipMalloc(&s->d_ctab, es * CTAB_SIZE);
   if (e == hipSuccess) {
     double tab[CTAB_SIZE];
@@ -468,8 +500,7 @@ void qilqr_destroy(qilqr_solver *s) {
   if (s->d_desired) (void)hipFree(s->d_desired);
   if (s->d_ctab) (void)hipFree(s->d_ctab);
   if (s->h_counters) (void)hipHostFree(s->h_counters);
-  for (int k = 0; k < 8; ++k)
-    if (s->poll_ev[k]) (void)hipEventDestroy(s->poll_ev[k]);
+  if (s->h_active) (void)hipHostFree(s->h_active);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }

@@ -46,7 +46,8 @@ struct BatchState {
   int *trial;
   int *flags;
   int *status, *iters, *n_bwd, *n_fwd;
-  int *counters;         // [0] trajectories still active after k_accept
+  int *counters;         // [0] trajectories still active, counted by k_backward
+  unsigned long long *host_active;  // pinned host memory, 8 words: (round + 1) << 32 | active count (k_linearize)
   double *cost_hist;     // [B][hist_cap] or null
   int hist_cap;
   const void *ctab;      // constant operand table (backward_layout.h)
@@ -97,17 +98,25 @@ __device__ __forceinline__ double cost_reduction(double QuTk, double kTQuuk, dou
 // blocks of the knot record, the other the cost differentials and the knot cost (the kernel is bound
 // by its instruction count, and the two halves share nothing but the knot they read).
 // which = 0: trajectory traj[cur[b]], 1: candidate traj[cur[b]^1].
-// need_flag: only problems whose flags contain it (0 = all).
+// need_flag: only problems whose flags contain it (0 = all).  round >= 0: publish the active count.
 // ---------------------------------------------------------------------------------------------
 #ifndef QILQR_LIN_WAVES
 #define QILQR_LIN_WAVES 4  // register budget of k_linearize in waves per SIMD (2, 3, 4 measured equal)
 #endif
 template <typename S>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(QILQR_LIN_WAVES, QILQR_LIN_WAVES))) void
-k_linearize(ModelConsts<S> c, BatchState st, int B, int n, int which, int need_flag) {
+k_linearize(ModelConsts<S> c, BatchState st, int B, int n, int which, int need_flag, int round) {
   // thread -> (half, tile, knot, lane): the 64 lanes of a wavefront read one knot of 64 consecutive trajectories
   long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id == 0) st.counters[0] = 0;  // the next k_backward counts the trajectories still active
+  if (id == 0) {
+    // hand the count of trajectories still active after this round's k_backward to the host: one
+    // system-scope store into pinned memory, tagged with the round (no copy kernel, no event on the stream)
+    if (round >= 0)
+      __hip_atomic_store(&st.host_active[round & 7],
+                         ((unsigned long long)(unsigned)(round + 1) << 32) | (unsigned)st.counters[0], __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    st.counters[0] = 0;  // the next k_backward counts again
+  }
   const long per_half = (long)((B + 63) / 64) * n * 64;
   const bool cost_half = id >= per_half;
   if (cost_half) id -= per_half;
@@ -209,9 +218,26 @@ __device__ __forceinline__ void gather_rows(double x, double r[4]) {
   r[3] = __longlong_as_double(((long long)hb[1] << 32) | lb[1]);
 }
 
+// value of x in lane SRC of the caller's own row of 16 lanes (DPP row_newbcast: one v_mov_b64_dpp, no trip
+// through the scalar registers)
+template <int SRC>
+__device__ __forceinline__ double row_bcast(double x) {
+  return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + SRC, 0xf, 0xf, false);
+}
+template <int A>
+__device__ __forceinline__ void bcast_quu_row(const double col[4], double ghat, double Quu[16], double Qu[4]) {
+  // row A of the lower triangle of Q_uu and Q_u[A]; the four rows of 16 lanes hold identical copies of
+  // col[] and ghat in their lanes 12..15, so a broadcast inside each row reaches the whole wave
+  Quu[A * 4 + 0] = row_bcast<12>(col[A]);
+  if constexpr (A >= 1) Quu[A * 4 + 1] = row_bcast<13>(col[A]);
+  if constexpr (A >= 2) Quu[A * 4 + 2] = row_bcast<14>(col[A]);
+  if constexpr (A >= 3) Quu[A * 4 + 3] = row_bcast<15>(col[A]);
+  Qu[A] = row_bcast<12 + A>(ghat);
+}
+
 // SYM = true: Q and R are exactly symmetric, so V_xx and H are symmetric to rounding and the
 // accumulator tile can be reused as the next knot's A operand without a transpose; no LDS and no
-// barrier remain in the loop (Q_uu/Q_u are broadcast with v_readlane, the right-hand sides with
+// barrier remain in the loop (Q_uu/Q_u are broadcast with DPP row broadcasts, the right-hand sides with
 // ds_bpermute).  SYM = false: general weights, hand-offs go through padded LDS tiles.
 template <bool SYM, typename S>
 __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolveParams p, BatchState st,
@@ -387,19 +413,18 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
     if constexpr (SYM) {
       // rows 12..15 of H live in register 3: lane (j, kk) holds H[12 + kk][j].  Gather the four rows
       // of each column into every lane (permlane swaps): column j < 12 is the right-hand side
-      // Q_xu[j][:] (= Q_ux[:][j] by symmetry), columns 12..15 are Q_uu, broadcast with v_readlane
+      // Q_xu[j][:] (= Q_ux[:][j] by symmetry), columns 12..15 are Q_uu, broadcast inside each row of 16 lanes
       // (lower triangle only; Q_uu is symmetric here).
       double col[4];
       gather_rows(H[3], col);
+      bcast_quu_row<0>(col, ghat, Quu, Qu);
+      bcast_quu_row<1>(col, ghat, Quu, Qu);
+      bcast_quu_row<2>(col, ghat, Quu, Qu);
+      bcast_quu_row<3>(col, ghat, Quu, Qu);
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int bb = 0; bb <= a; ++bb) {
-          Quu[a * 4 + bb] = bcast_lane(col[a], 12 + bb);
-          Quu[bb * 4 + a] = Quu[a * 4 + bb];
-        }
-        Qu[a] = bcast_lane(ghat, 12 + a);
-      }
+        for (int bb = a + 1; bb < 4; ++bb) Quu[a * 4 + bb] = Quu[bb * 4 + a];
 #pragma unroll
       // lane 12: feed-forward.  Lanes 13..15 solve against a column of Q_uu itself; nobody reads them.
       for (int a = 0; a < 4; ++a) rhs[a] = (j == 12) ? Qu[a] : col[a];
