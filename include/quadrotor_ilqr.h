@@ -68,7 +68,8 @@ typedef struct {
 /* device-side configuration (no counterpart in the reference, which is CPU only) */
 typedef struct {
   int32_t device;   /* HIP device ordinal */
-  int32_t profile;  /* 0: off; 1: HIP events around k_backward and k_rollout only; 2: around every kernel */
+  int32_t profile;  /* start/stop HIP events attached to kernel dispatches.  0: off; 1: k_backward and k_rollout;
+                       2: every kernel; 3: k_backward only; 4: k_rollout only */
   int32_t sync_every; /* 1: the host waits for every round's count of active trajectories; k > 1: it reads the
                          count k rounds late, i.e. keeps the stream k rounds ahead of the device (k <= 6) */
   int32_t force_general; /* 1: use the general (non-symmetric-safe) backward kernel even when Q, R are symmetric */
@@ -84,7 +85,7 @@ typedef struct {
  * independent; the reference's ILQR object is const and re-entrant). */
 typedef struct qilqr_solver qilqr_solver;
 
-/* per-kernel device time accumulated since the last reset (profile = 1) */
+/* per-kernel device time accumulated since the last reset (kernels not selected by `profile` stay at 0) */
 typedef struct {
   double backward_ms;  int32_t backward_launches;
   double rollout_ms;   int32_t rollout_launches;
@@ -152,6 +153,8 @@ int qilqr_cost_history(qilqr_solver *s, int32_t B, double *hist, int32_t cap, in
 /* profiling (HIP events on the solver's stream) */
 int qilqr_profile_reset(qilqr_solver *s);
 int qilqr_profile_get(qilqr_solver *s, qilqr_profile *out);
+/* change qilqr_device_config.profile of a live solver (drains the stream, resets the accumulated times) */
+int qilqr_profile_mode(qilqr_solver *s, int32_t mode);
 
 /* device the solver is bound to, and the HIP stream it launches on (hipStream_t as void*) */
 int qilqr_device(const qilqr_solver *s);

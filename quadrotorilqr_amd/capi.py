@@ -34,7 +34,8 @@ STATUS_LINE_SEARCH_FAILED = 3
 EXPORTS = (
     "qilqr_create", "qilqr_destroy", "qilqr_last_error", "qilqr_solve", "qilqr_solve_batch",
     "qilqr_solve_batch_device", "qilqr_cost_trajectory", "qilqr_backwards_pass", "qilqr_forward_sim",
-    "qilqr_line_search", "qilqr_cost_history", "qilqr_profile_reset", "qilqr_profile_get", "qilqr_device", "qilqr_stream",
+    "qilqr_line_search", "qilqr_cost_history", "qilqr_profile_reset", "qilqr_profile_get", "qilqr_profile_mode",
+    "qilqr_device", "qilqr_stream",
     "qilqr_abi_version",
 )
 
@@ -255,6 +256,12 @@ class QuadrotorILQRBatch:
     # ---- profiling
     def profile_reset(self):
         rc = load().qilqr_profile_reset(self._h)
+        if rc:
+            _raise(rc)
+
+    def profile_mode(self, mode):
+        """0 off, 1 k_backward + k_rollout, 2 every kernel, 3 k_backward only, 4 k_rollout only"""
+        rc = load().qilqr_profile_mode(self._h, C.c_int32(int(mode)))
         if rc:
             _raise(rc)
 

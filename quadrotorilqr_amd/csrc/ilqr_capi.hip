@@ -1,6 +1,7 @@
 // ilqr_capi.hip -- host side of libquadrotor_ilqr.so: the C ABI of include/quadrotor_ilqr.h
 // over the HIP kernels of ilqr_kernels.h.  C++ because the reference's host side is C++
 // (src/quadrotor_ilqr_binding.cc, src/ilqr.hh); no exceptions cross the ABI.
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -73,25 +74,30 @@ struct qilqr_solver {
 
 namespace {
 
-struct Timed {
-  qilqr_solver *s;
-  EventPair *ep = nullptr;
-  Timed(qilqr_solver *s_, int kind) : s(s_) {
-    if (!s->dev.profile) return;
-    if (s->dev.profile == 1 && kind != K_BACKWARD && kind != K_ROLLOUT) return;
-    if (s->events_used == s->events.size()) {
-      EventPair e;
-      if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
-      s->events.push_back(e);
-    }
-    ep = &s->events[s->events_used++];
-    ep->kind = kind;
-    (void)hipEventRecord(ep->a, s->stream);
+// Slot for the start/stop events of one launch, or null when this kind of kernel is not being timed.
+EventPair *timing_slot(qilqr_solver *s, int kind) {
+  if (!s->dev.profile) return nullptr;
+  if (s->dev.profile == 1 && kind != K_BACKWARD && kind != K_ROLLOUT) return nullptr;
+  if (s->dev.profile == 3 && kind != K_BACKWARD) return nullptr;
+  if (s->dev.profile == 4 && kind != K_ROLLOUT) return nullptr;
+  if (s->events_used == s->events.size()) {
+    EventPair e;
+    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return nullptr;
+    s->events.push_back(e);
   }
-  ~Timed() {
-    if (ep) (void)hipEventRecord(ep->b, s->stream);
-  }
-};
+  EventPair *ep = &s->events[s->events_used++];
+  ep->kind = kind;
+  return ep;
+}
+// Every kernel goes through here.  A timed launch hands its start/stop events to the dispatch itself
+// (hipExtLaunchKernelGGL): the timestamps are the kernel's own begin and end, and no extra barrier
+// packet enters the stream, so profiling does not stretch the round it measures.
+template <typename... P, typename... Args>
+void launch(qilqr_solver *s, int kind, void (*kernel)(P...), dim3 grid, dim3 block, Args... args) {
+  EventPair *ep = timing_slot(s, kind);
+  hipExtLaunchKernelGGL(kernel, grid, block, 0, s->stream, ep ? ep->a : nullptr, ep ? ep->b : nullptr, 0,
+                        static_cast<P>(args)...);  // arguments converted to the kernel's own parameter types
+}
 
 void drain_events(qilqr_solver *s) {
   for (size_t i = 0; i < s->events_used; ++i) {
@@ -181,20 +187,20 @@ inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
 // plain [B][n][W] fp64 (device) -> tiled, storage precision
 int to_tiled(qilqr_solver *s, const double *d_plain, void *tiled, long B, long n, int W) {
   if (s->f32)
-    hipLaunchKernelGGL(k_retile<float>, dim3(cdiv(B * n * W, 256)), dim3(256), 0, s->stream, d_plain, (double *)nullptr,
+    launch(s, K_OTHER, k_retile<float>, dim3(cdiv(B * n * W, 256)), dim3(256), d_plain, (double *)nullptr,
                        (float *)tiled, (float *)tiled, (const int *)nullptr, 0, (int)B, (int)n, W, 1);
   else
-    hipLaunchKernelGGL(k_retile<double>, dim3(cdiv(B * n * W, 256)), dim3(256), 0, s->stream, d_plain,
+    launch(s, K_OTHER, k_retile<double>, dim3(cdiv(B * n * W, 256)), dim3(256), d_plain,
                        (double *)nullptr, (double *)tiled, (double *)tiled, (const int *)nullptr, 0, (int)B, (int)n, W, 1);
   return QILQR_OK;
 }
 // tiled -> plain [B][n][W] fp64 (device); sel/flip choose between t0 and t1 per trajectory
 int from_tiled(qilqr_solver *s, double *d_plain, void *t0, void *t1, const int *sel, int flip, long B, long n, int W) {
   if (s->f32)
-    hipLaunchKernelGGL(k_retile<float>, dim3(cdiv(B * n * W, 256)), dim3(256), 0, s->stream, (const double *)nullptr,
+    launch(s, K_OTHER, k_retile<float>, dim3(cdiv(B * n * W, 256)), dim3(256), (const double *)nullptr,
                        d_plain, (float *)t0, (float *)t1, sel, flip, (int)B, (int)n, W, 0);
   else
-    hipLaunchKernelGGL(k_retile<double>, dim3(cdiv(B * n * W, 256)), dim3(256), 0, s->stream, (const double *)nullptr,
+    launch(s, K_OTHER, k_retile<double>, dim3(cdiv(B * n * W, 256)), dim3(256), (const double *)nullptr,
                        d_plain, (double *)t0, (double *)t1, sel, flip, (int)B, (int)n, W, 0);
   return QILQR_OK;
 }
@@ -236,20 +242,18 @@ int download_tiled(qilqr_solver *s, double *h_plain, void *t0, void *t1, const i
 }
 
 int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag, int round = -1) {
-  Timed t(s, K_LINEARIZE);
   const dim3 grid(cdiv(2 * ((B + 63) / 64) * 64 * n, 128));  // dynamics half + cost half
   if (s->f32)
-    hipLaunchKernelGGL(k_linearize<float>, grid, dim3(128), 0, s->stream, s->constsf, s->st, (int)B, (int)n, which,
+    launch(s, K_LINEARIZE, k_linearize<float>, grid, dim3(128), s->constsf, s->st, (int)B, (int)n, which,
                        need_flag, round);
   else
-    hipLaunchKernelGGL(k_linearize<double>, grid, dim3(128), 0, s->stream, s->consts, s->st, (int)B, (int)n, which,
+    launch(s, K_LINEARIZE, k_linearize<double>, grid, dim3(128), s->consts, s->st, (int)B, (int)n, which,
                        need_flag, round);
   return QILQR_OK;
 }
 int launch_backward(qilqr_solver *s, long B, long n, int force) {
-  Timed t(s, K_BACKWARD);
 #define QILQR_LAUNCH_BWD(SYM, S)                                                                              \
-  hipLaunchKernelGGL((k_backward<SYM, S>), dim3((unsigned)B), dim3(64), 0, s->stream, s->consts, s->params, s->st, \
+  launch(s, K_BACKWARD, (k_backward<SYM, S>), dim3((unsigned)B), dim3(64), s->consts, s->params, s->st, \
                      (int)B, (int)n, force)
   if (s->symmetric) {
     if (s->f32) QILQR_LAUNCH_BWD(true, float);
@@ -262,36 +266,34 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
   return QILQR_OK;
 }
 int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
-  Timed t(s, K_ROLLOUT);
   // the cooperating pair shortens one trajectory's chain; with more tiles than the chip has room for
   // pairs (1 pair per SIMD at 256 VGPRs) the single-wave form gives the higher throughput
   if (s->dev.single_wave_rollout == 1 || B > 16384) {
     if (s->f32)
-      hipLaunchKernelGGL(k_rollout<float>, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->constsf, s->st, (int)B, (int)n,
+      launch(s, K_ROLLOUT, k_rollout<float>, dim3(cdiv(B, 64)), dim3(64), s->constsf, s->st, (int)B, (int)n,
                          need_flag);
     else
-      hipLaunchKernelGGL(k_rollout<double>, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->consts, s->st, (int)B, (int)n,
+      launch(s, K_ROLLOUT, k_rollout<double>, dim3(cdiv(B, 64)), dim3(64), s->consts, s->st, (int)B, (int)n,
                          need_flag);
   } else if (s->dev.single_wave_rollout != 3) {
     if (s->f32)
-      hipLaunchKernelGGL(k_rollout3<float>, dim3(cdiv(B, 64)), dim3(192), 0, s->stream, s->constsf, s->st, (int)B,
+      launch(s, K_ROLLOUT, k_rollout3<float>, dim3(cdiv(B, 64)), dim3(192), s->constsf, s->st, (int)B,
                          (int)n, need_flag);
     else
-      hipLaunchKernelGGL(k_rollout3<double>, dim3(cdiv(B, 64)), dim3(192), 0, s->stream, s->consts, s->st, (int)B,
+      launch(s, K_ROLLOUT, k_rollout3<double>, dim3(cdiv(B, 64)), dim3(192), s->consts, s->st, (int)B,
                          (int)n, need_flag);
   } else {
     if (s->f32)
-      hipLaunchKernelGGL(k_rollout2<float>, dim3(cdiv(B, 64)), dim3(128), 0, s->stream, s->constsf, s->st, (int)B,
+      launch(s, K_ROLLOUT, k_rollout2<float>, dim3(cdiv(B, 64)), dim3(128), s->constsf, s->st, (int)B,
                          (int)n, need_flag);
     else
-      hipLaunchKernelGGL(k_rollout2<double>, dim3(cdiv(B, 64)), dim3(128), 0, s->stream, s->consts, s->st, (int)B,
+      launch(s, K_ROLLOUT, k_rollout2<double>, dim3(cdiv(B, 64)), dim3(128), s->consts, s->st, (int)B,
                          (int)n, need_flag);
   }
   return QILQR_OK;
 }
 int launch_accept(qilqr_solver *s, long B, long n, int ls_only) {
-  Timed t(s, K_OTHER);
-  hipLaunchKernelGGL(k_accept, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->params, s->st, (int)B, (int)n,
+  launch(s, K_OTHER, k_accept, dim3(cdiv(B, 64)), dim3(64), s->params, s->st, (int)B, (int)n,
                      ls_only);
   return QILQR_OK;
 }
@@ -310,8 +312,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round) {
   int rc;
   if ((rc = launch_linearize(s, B, n, 0, 0))) return rc;
   {
-    Timed t(s, K_OTHER);
-    hipLaunchKernelGGL(k_init, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->params, s->st, (int)B, (int)n);
+    launch(s, K_OTHER, k_init, dim3(cdiv(B, 64)), dim3(64), s->params, s->st, (int)B, (int)n);
   }
   if (!(0.0 < s->params.max_iters)) {
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -374,12 +375,11 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round) {
 
 int gather(qilqr_solver *s, long B, long n, double *d_traj, double *d_cost, int *d_status, int *d_iters,
            int *d_bwd, int *d_fwd) {
-  Timed t(s, K_OTHER);
   if (s->f32)
-    hipLaunchKernelGGL(k_gather<float>, dim3(cdiv(B * n * 18, 256)), dim3(256), 0, s->stream, s->st, (int)B, (int)n,
+    launch(s, K_OTHER, k_gather<float>, dim3(cdiv(B * n * 18, 256)), dim3(256), s->st, (int)B, (int)n,
                        d_traj, d_cost, d_status, d_iters, d_bwd, d_fwd);
   else
-    hipLaunchKernelGGL(k_gather<double>, dim3(cdiv(B * n * 18, 256)), dim3(256), 0, s->stream, s->st, (int)B, (int)n,
+    launch(s, K_OTHER, k_gather<double>, dim3(cdiv(B * n * 18, 256)), dim3(256), s->st, (int)B, (int)n,
                        d_traj, d_cost, d_status, d_iters, d_bwd, d_fwd);
   return QILQR_OK;
 }
@@ -539,6 +539,15 @@ int qilqr_profile_reset(qilqr_solver *s) {
   return QILQR_OK;
 }
 
+int qilqr_profile_mode(qilqr_solver *s, int32_t mode) {
+  if (!s) return fail(QILQR_ERR_INVALID_ARG, "null solver");
+  if (mode < 0 || mode > 4) return fail(QILQR_ERR_INVALID_ARG, "profile mode must be 0..4");
+  int rc = qilqr_profile_reset(s);
+  if (rc) return rc;
+  s->dev.profile = mode;
+  return QILQR_OK;
+}
+
 int qilqr_profile_get(qilqr_solver *s, qilqr_profile *out) {
   if (!s || !out) return fail(QILQR_ERR_INVALID_ARG, "null argument");
   HIP_TRY(hipSetDevice(s->device));
@@ -669,7 +678,7 @@ int qilqr_cost_trajectory(qilqr_solver *s, const double *traj, int32_t B, int32_
   if (rc) return rc;
   if ((rc = upload_tiled(s, traj, s->st.traj[0], B, n, 18))) return rc;
   if ((rc = launch_linearize(s, B, n, 0, 0))) return rc;
-  hipLaunchKernelGGL(k_init, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->params, s->st, (int)B, (int)n);
+  launch(s, K_OTHER, k_init, dim3(cdiv(B, 64)), dim3(64), s->params, s->st, (int)B, (int)n);
   HIP_TRY(hipMemcpyAsync(cost, s->st.cost, sizeof(double) * B, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   HIP_TRY(hipGetLastError());
@@ -682,7 +691,7 @@ int qilqr_backwards_pass(qilqr_solver *s, const double *traj, int32_t B, int32_t
   if (rc) return rc;
   if ((rc = upload_tiled(s, traj, s->st.traj[0], B, n, 18))) return rc;
   if ((rc = launch_linearize(s, B, n, 0, 0))) return rc;
-  hipLaunchKernelGGL(k_init, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->params, s->st, (int)B, (int)n);
+  launch(s, K_OTHER, k_init, dim3(cdiv(B, 64)), dim3(64), s->params, s->st, (int)B, (int)n);
   if ((rc = launch_backward(s, B, n, 1))) return rc;
   if ((rc = download_tiled(s, gains, s->st.gains, s->st.gains, nullptr, 0, B, n, 52))) return rc;
   HIP_TRY(hipMemcpyAsync(terms, s->st.terms, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, s->stream));
@@ -719,7 +728,7 @@ int qilqr_line_search(qilqr_solver *s, const double *traj, const double *cost, c
   if ((rc = upload_tiled(s, gains, s->st.gains, B, n, 52))) return rc;
   HIP_TRY(hipMemcpyAsync(d_cost, cost, sizeof(double) * B, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(d_terms, terms, sizeof(double) * 2 * B, hipMemcpyHostToDevice, s->stream));
-  hipLaunchKernelGGL(k_seed_search, dim3(cdiv(B, 64)), dim3(64), 0, s->stream, s->st, (int)B, d_cost, d_terms);
+  launch(s, K_OTHER, k_seed_search, dim3(cdiv(B, 64)), dim3(64), s->st, (int)B, d_cost, d_terms);
   if (s->params.ls_max_iters <= 0) {
     // ilqr.hh:178: the loop body never runs, the reference throws at once
     std::vector<int> st3(B, QILQR_STATUS_LINE_SEARCH_FAILED);
