@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-knot cycle shares of the two roles of k_rollout2 (separate -DQILQR_STAMPS build)."""
+"""Diagnostic: per-knot cycle shares of the three roles of k_rollout3 (separate -DQILQR_STAMPS build)."""
 import ctypes as C
 import os
 import sys
@@ -26,12 +26,13 @@ print("mode:", mode)
 out = np.zeros((B, 8), dtype=np.uint64)
 capi.load().qilqr_debug_stamps(s._h, out.ctypes.data_as(C.c_void_p), C.c_int32(B))
 blocks = B // 64
-st = out.reshape(-1)[: blocks * 16].reshape(blocks, 2, 8).astype(np.float64)
-names = {0: ["prefetch issue", "rho, dx", "control law (operand wait)", "stores", "acceleration, v, LDS write", "barrier wait", "LDS read", "-"],
-         1: ["prefetch issue", "T <- T Exp(dt v)", "pose part of (-) (operand wait)", "-", "LDS write + stores", "barrier wait", "LDS read", "-"]}
-for role in (0, 1):
+st = out.reshape(-1)[: blocks * 24].reshape(blocks, 3, 8).astype(np.float64)
+names = {0: ["operands from LDS", "rho, dx", "control law", "-", "stores, acceleration, v, LDS write", "barrier wait", "LDS read", "-"],
+         1: ["nominal pose from LDS", "T <- T Exp(dt v)", "pose part of (-)", "-", "LDS write + stores", "barrier wait", "LDS read", "-"],
+         2: ["load issue", "wait for loads, LDS writes", "-", "-", "-", "barrier wait", "-", "-"]}
+for role in (0, 1, 2):
     med = np.median(st[:, role, :], axis=0) / N
-    print("wave", "X (control)" if role == 0 else "Y (pose)", " total %.0f cycles/knot" % med.sum())
+    print("wave", ["X (control)", "Y (pose)", "L (loader)"][role], " total %.0f cycles/knot" % med.sum())
     for n_, m in zip(names[role], med):
         if m > 0:
             print(f"   {n_:34s} {m:8.0f}  {100 * m / med.sum():5.1f} %")

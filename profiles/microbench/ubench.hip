@@ -97,7 +97,7 @@ void run(const char *name, int per_iter, int blocks) {
 }
 
 int main() {
-  for (int blocks : {16, 1024, 8192}) {
+  for (int blocks : {16, 1024, 2048, 3072, 4096, 8192}) {
     run<0>("fma_f64 dependent", 8, blocks);
     run<1>("fma_f64 8 independent", 8, blocks);
     run<11>("add_f64 8 independent", 8, blocks);

@@ -68,8 +68,8 @@ QILQR_HD int m_source_tab(int row, int col) {
 QILQR_HD int cxx_source_tab(const RecLayout &L, int row, int col) {
   if (!L.sym) return L.off_cxx + row * 12 + col;
   const int i = row < col ? row : col, j = row < col ? col : row;
-  if (j < 6) return L.off_cxx + sym6_index(i, j);
-  if (i < 6) return L.ur_zero ? -1 - CTAB_ZERO : L.off_cxx + 21 + i * 6 + (j - 6);
+  if (j < 6) return L.off_cxx + symrow_index(!L.ur_zero, i, j);
+  if (i < 6) return L.ur_zero ? -1 - CTAB_ZERO : L.off_cxx + symrow_index(true, i, j);
   return -1 - (CTAB_2Q + row * 12 + col);
 }
 

@@ -54,6 +54,7 @@ struct qilqr_solver {
   RecLayout layout;        // knot record layout chosen from the structure of Q
   void *d_desired = nullptr;    // shared desired trajectory, storage precision
   void *d_ctab = nullptr;       // constant operand table of k_backward, storage precision
+  void *d_consts = nullptr;     // the model constants in device memory (k_linearize reads them where it uses them)
   bool f32 = false;             // mixed-precision mode (qilqr_device_config.precision == 1)
   ModelConsts<float> constsf;   // the model constants for the fp32 lane-local kernels
   // workspace
@@ -146,7 +147,7 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
   int rc;
   for (int k = 0; k < 2; ++k) {
     if ((rc = dalloc_s(s, &st.traj[k], (size_t)tiled_count(cB, cn, 18)))) return rc;
-    if ((rc = dalloc_s(s, &st.lin[k], (size_t)cB * cn * s->layout.stride))) return rc;
+    if ((rc = dalloc_s(s, &st.lin[k], (size_t)rec_count(cB, cn, s->layout.stride)))) return rc;
     if ((rc = dalloc(s, &st.knot_cost[k], (size_t)tiled_count(cB, cn, 1)))) return rc;
   }
   if ((rc = dalloc_s(s, &st.gains, (size_t)tiled_count(cB, cn, 52)))) return rc;
@@ -243,12 +244,17 @@ int download_tiled(qilqr_solver *s, double *h_plain, void *t0, void *t1, const i
 
 int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag, int round = -1) {
   const dim3 grid(cdiv(2 * ((B + 63) / 64) * 64 * n, 128));  // dynamics half + cost half
-  if (s->f32)
-    launch(s, K_LINEARIZE, k_linearize<float>, grid, dim3(128), s->constsf, s->st, (int)B, (int)n, which,
-                       need_flag, round);
-  else
-    launch(s, K_LINEARIZE, k_linearize<double>, grid, dim3(128), s->consts, s->st, (int)B, (int)n, which,
-                       need_flag, round);
+#define QILQR_LAUNCH_LIN(S, LK, CONSTS, DCONSTS) \
+  launch(s, K_LINEARIZE, k_linearize<S, LK>, grid, dim3(128), CONSTS, DCONSTS, s->st, (int)B, (int)n, which, need_flag, round)
+  switch (layout_kind(s->layout) + (s->f32 ? 3 : 0)) {
+    case 0: QILQR_LAUNCH_LIN(double, 0, s->consts, (const ModelConsts<double> *)s->d_consts); break;
+    case 1: QILQR_LAUNCH_LIN(double, 1, s->consts, (const ModelConsts<double> *)s->d_consts); break;
+    case 2: QILQR_LAUNCH_LIN(double, 2, s->consts, (const ModelConsts<double> *)s->d_consts); break;
+    case 3: QILQR_LAUNCH_LIN(float, 0, s->constsf, (const ModelConsts<float> *)s->d_consts); break;
+    case 4: QILQR_LAUNCH_LIN(float, 1, s->constsf, (const ModelConsts<float> *)s->d_consts); break;
+    default: QILQR_LAUNCH_LIN(float, 2, s->constsf, (const ModelConsts<float> *)s->d_consts); break;
+  }
+#undef QILQR_LAUNCH_LIN
   return QILQR_OK;
 }
 int launch_backward(qilqr_solver *s, long B, long n, int force) {
@@ -471,6 +477,10 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
     for (int k = 0; k < 8; ++k) s->h_active[k] = 0;
     e = hipHostGetDevicePointer((void **)&s->st.host_active, s->h_active, 0);
   }
+  if (e == hipSuccess) e = hipMalloc(&s->d_consts, s->f32 ? sizeof(ModelConsts<float>) : sizeof(ModelConsts<double>));
+  if (e == hipSuccess)
+    e = s->f32 ? hipMemcpy(s->d_consts, &s->constsf, sizeof(ModelConsts<float>), hipMemcpyHostToDevice)
+               : hipMemcpy(s->d_consts, &s->consts, sizeof(ModelConsts<double>), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&s->d_ctab, es * CTAB_SIZE);
   if (e == hipSuccess) {
     double tab[CTAB_SIZE];
@@ -499,6 +509,7 @@ void qilqr_destroy(qilqr_solver *s) {
   }
   if (s->d_desired) (void)hipFree(s->d_desired);
   if (s->d_ctab) (void)hipFree(s->d_ctab);
+  if (s->d_consts) (void)hipFree(s->d_consts);
   if (s->h_counters) (void)hipHostFree(s->h_counters);
   if (s->h_active) (void)hipHostFree(s->h_active);
   if (s->stream) (void)hipStreamDestroy(s->stream);

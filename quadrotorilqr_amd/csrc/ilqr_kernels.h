@@ -32,7 +32,7 @@ struct BatchState {
   // Buffers whose element type S is the solver's storage precision (double, or float in the
   // mixed-precision mode): kernels are instantiated on S and cast.
   void *traj[2];         // TILED (se3_math.h) [tile][n][9][64][2]: current / candidate trajectories
-  void *lin[2];          // [B][n][layout.stride] knot records of traj[k]
+  void *lin[2];          // [B][n][layout.stride] knot records of traj[k] (se3_math.h, rec_base / rec_elem)
   RecLayout layout;
   double *knot_cost[2];  // [tile][n][64]
   void *gains;           // TILED [tile][n][26][64][2]
@@ -99,15 +99,37 @@ __device__ __forceinline__ double cost_reduction(double QuTk, double kTQuuk, dou
 // by its instruction count, and the two halves share nothing but the knot they read).
 // which = 0: trajectory traj[cur[b]], 1: candidate traj[cur[b]^1].
 // need_flag: only problems whose flags contain it (0 = all).  round >= 0: publish the active count.
+// LK: layout kind of the records (se3_math.h, layout_kind).
 // ---------------------------------------------------------------------------------------------
 #ifndef QILQR_LIN_WAVES
-#define QILQR_LIN_WAVES 4  // register budget of k_linearize in waves per SIMD (2, 3, 4 measured equal)
+#define QILQR_LIN_WAVES 4  // register budget of k_linearize in waves per SIMD (3 avoids its few spills but the next k_backward then runs 3% slower)
 #endif
-template <typename S>
+template <typename S, int LK>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(QILQR_LIN_WAVES, QILQR_LIN_WAVES))) void
-k_linearize(ModelConsts<S> c, BatchState st, int B, int n, int which, int need_flag, int round) {
-  // thread -> (half, tile, knot, lane): the 64 lanes of a wavefront read one knot of 64 consecutive trajectories
+k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState st, int B, int n, int which,
+            int need_flag, int round) {
+  // The weights Q (144) and R (16) are more constants than a wave has scalar registers: the block keeps
+  // them in LDS (filled from the device copy *cp) and the cost half reads them row by row where it uses
+  // them; everything else comes from the by-value copy c.
+  __shared__ S qr[160];
+  for (int k = threadIdx.x; k < 160; k += blockDim.x) qr[k] = (k < 144) ? cp->Q[k] : cp->R[k - 144];
+  // thread -> (half, tile, knot, lane): the 64 lanes of a wavefront hold one knot of 64 consecutive trajectories
   long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+#ifdef QILQR_STAMPS
+  unsigned long long lin_t0, lin_r0;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(lin_t0), "=s"(lin_r0)::"memory");
+  const long lin_wave = id >> 6;
+  auto lin_stamp = [&](int half, double keep) {
+    unsigned long long t1, r1;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) : "v"(keep) : "memory");
+    if ((id & 63) == 0 && st.stamps && lin_wave < 2048) {
+      st.stamps[lin_wave * 4 + 0] = lin_r0;
+      st.stamps[lin_wave * 4 + 1] = r1;
+      st.stamps[lin_wave * 4 + 2] = t1 - lin_t0;
+      st.stamps[lin_wave * 4 + 3] = half;
+    }
+  };
+#endif
   if (id == 0) {
     // hand the count of trajectories still active after this round's k_backward to the host: one
     // system-scope store into pinned memory, tagged with the round (no copy kernel, no event on the stream)
@@ -117,9 +139,11 @@ k_linearize(ModelConsts<S> c, BatchState st, int B, int n, int which, int need_f
                          __HIP_MEMORY_SCOPE_SYSTEM);
     st.counters[0] = 0;  // the next k_backward counts again
   }
+  __syncthreads();  // qr is filled
   const long per_half = (long)((B + 63) / 64) * n * 64;
   const bool cost_half = id >= per_half;
   if (cost_half) id -= per_half;
+  if (id >= per_half) return;  // grid padding (whole wavefronts)
   const int lane = (int)(id & 63);
   const long rest = id >> 6;
   const int i = (int)(rest % n);
@@ -129,16 +153,22 @@ k_linearize(ModelConsts<S> c, BatchState st, int B, int n, int which, int need_f
   const int buf = st.cur[b] ^ which;
   S pt[18];
   load_knot<true>((const S *)st.traj[buf] + knot_base<true>(b, n, 18), i, 18, pt);
-  S *rec = (S *)st.lin[buf] + (b * n + i) * st.layout.stride;
+  const PlainRecWriter<S> w{(S *)st.lin[buf] + rec_base(b, n, st.layout.stride) + rec_elem(i, 0, st.layout.stride)};
   if (!cost_half) {
-    linearize_dynamics(c, pt, rec);
+    linearize_dynamics(c, pt, w);
+#ifdef QILQR_STAMPS
+    lin_stamp(0, (double)pt[0]);
+#endif
     return;
   }
   S pd[18];
   if (st.desired_tiled) load_knot<true>((const S *)st.desired + knot_base<true>(b, n, 18), i, 18, pd);
   else load_knot<false>((const S *)st.desired, i, 18, pd);
-  const S cost = linearize_cost(c, st.layout, pt, pd, rec);
+  const S cost = linearize_cost<LK>(qr, qr + 144, pt, pd, w);
   st.knot_cost[buf][cost_index(b, i, n)] = (double)cost;  // summed in fp64 (k_init / k_backward)
+#ifdef QILQR_STAMPS
+  lin_stamp(1, (double)cost);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -324,7 +354,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   const RecLayout L = st.layout;
   // the recursion itself is always fp64 (fp64 MFMA); S is only the type of the records read and of
   // the gains written
-  const S *lin = (const S *)st.lin[cur] + (long)b * n * L.stride;
+  const S *lin = (const S *)st.lin[cur] + rec_base(b, n, L.stride);
   S *gains = (S *)st.gains + knot_base<true>(b, n, 52);
 
   constexpr int LD = 17;  // padded leading dimension: column reads of a row-major tile
@@ -340,15 +370,15 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   typename GA<S>::cptr op[7];
   long step[7];
   {
-    const S *last = lin + (long)(n - 1) * L.stride;
+    const long knot_step = rec_elem(1, 0, L.stride) - rec_elem(0, 0, L.stride);  // one knot back
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
       int src;
       if (k < 3) src = m_source_tab(4 * k + kk, j);
       else if (k < 6) src = (j < 12) ? cxx_source_tab(L, 4 * (k - 3) + kk, j) : -1 - CTAB_ZERO;
       else src = L.off_g + j;
-      op[k] = (typename GA<S>::cptr)((src >= 0) ? last + src : (const S *)st.ctab + (-1 - src));
-      step[k] = (src >= 0) ? (long)L.stride : 0;
+      op[k] = (typename GA<S>::cptr)((src >= 0) ? lin + rec_elem(n - 1, src, L.stride) : (const S *)st.ctab + (-1 - src));
+      step[k] = (src >= 0) ? knot_step : 0;
     }
   }
   // gain slots of this lane for knot n-1, walked back one knot per iteration (tiled layout: one
@@ -782,6 +812,13 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
   const int b = blockIdx.x * 64 + lane;
   const bool live = (b < B) && (!need_flag || (st.flags[b < B ? b : 0] & need_flag));
   if (__ballot(live) == 0ull) return;  // identical in the three waves: block-uniform
+#ifdef QILQR_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  auto stamp_flush = [&]() {
+    if (lane == 0 && st.stamps)
+      for (int k = 0; k < 8; ++k) st.stamps[((long)blockIdx.x * 3 + role) * 8 + k] = stamp_sum[k];
+  };
+#endif
   const int bs = (b < B) ? b : (B - 1);
   const int cur = st.cur[bs];
   const S *traj = (const S *)st.traj[cur] + knot_base<true>(bs, n, 18);
@@ -823,9 +860,13 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
     load_ops(1, ra);   // written during iteration 0
     load_pose(2, pa);  // written during iteration 0
     __syncthreads();
+#ifdef QILQR_STAMPS
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
     auto knot = [&](int i, sv2 (&rc)[35], sv2 (&rn)[35], sv2 (&pc)[4], sv2 (&pn)[4]) {
       load_ops(i + 2, rn);   // consumed by X at iteration i + 2
       load_pose(i + 3, pn);  // consumed by Y at iteration i + 2
+      QSTAMP(0);  // L: load issue
       if (i + 1 < n) {
 #pragma unroll
         for (int e = 0; e < 35; ++e) bx[(i + 1) & 1][e][lane] = rc[e];  // knot i + 1
@@ -834,12 +875,17 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
 #pragma unroll
         for (int e = 0; e < 4; ++e) by[i & 1][e][lane] = pc[e];  // nominal pose of knot i + 2
       }
+      QSTAMP(1);  // L: wait for the loads of the previous iteration, LDS writes
       __syncthreads();
+      QSTAMP(5);  // L: barrier
     };
     for (int i = 0; i < n; i += 2) {
       knot(i, ra, rb, pa, pb);
       if (i + 1 < n) knot(i + 1, rb, ra, pb, pa);
     }
+#ifdef QILQR_STAMPS
+    stamp_flush();
+#endif
     return;
   }
 
@@ -878,6 +924,9 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
       th[a] = sh[0][7 + a][lane];
     }
     cj = sh[0][10][lane];
+#ifdef QILQR_STAMPS
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
     for (int i = 0; i < n; ++i) {
       const int par = (i + 1) & 1;
       const bool more = (i + 1 < n);
@@ -894,13 +943,19 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
         g[2 * e] = w[0];
         g[2 * e + 1] = w[1];
       }
+      QKEEP(pt[17]); QKEEP(g[51]); QKEEP(g[0]);
+      QSTAMP(0);  // X: operands from LDS
       S dx[12];
       se3_rminus_part2(td, th, cj, dx);
       dx[3] = th[0]; dx[4] = th[1]; dx[5] = th[2];
 #pragma unroll
       for (int a = 0; a < 6; ++a) dx[6 + a] = v[a] - pt[8 + a];
+      QKEEP(dx[0]); QKEEP(dx[11]);
+      QSTAMP(1);  // X: rho = Jl^-1 td, dx
       S u[4];
       control_law(pt, g, alpha, dx, u);
+      QKEEP(u[0]); QKEEP(u[3]);
+      QSTAMP(2);  // X: control law
       if (live) {
         out[knot_elem<true>(i, 0, 18)] = pt[0];
 #pragma unroll
@@ -917,7 +972,9 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
           sh[par][11 + a][lane] = v[a];
         }
       }
+      QSTAMP(4);  // X: stores, acceleration, velocity update, LDS write
       __syncthreads();
+      QSTAMP(5);  // X: barrier
       if (more) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) q[a] = sh[par][a][lane];
@@ -928,9 +985,14 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
         }
         cj = sh[par][10][lane];
       }
+      QKEEP(cj); QKEEP(q[0]);
+      QSTAMP(6);  // X: LDS read of Y's results
     }
   } else {
     // ------------------------------------------------------------------ Y: pose
+#ifdef QILQR_STAMPS
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
     for (int i = 0; i < n; ++i) {
       const int par = (i + 1) & 1;
       const bool more = (i + 1 < n);
@@ -945,9 +1007,15 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
         S tau[6];
 #pragma unroll
         for (int a = 0; a < 6; ++a) tau[a] = c.dt * v[a];  // pose integrates with the OLD velocity
+        QKEEP(pnm[7]);
+        QSTAMP(0);  // Y: nominal pose from LDS
         se3_rplus_fast(t, q, tau);
+        QKEEP(t[0]); QKEEP(q[3]);
+        QSTAMP(1);  // Y: T <- T Exp(dt v)
         const S qn[4] = {pnm[5], pnm[6], pnm[7], pnm[4]};
         se3_rminus_part1(t, q, pnm + 1, qn, td, th, cj);
+        QKEEP(td[0]); QKEEP(th[2]); QKEEP(cj);
+        QSTAMP(2);  // Y: pose part of x (-) xnom
 #pragma unroll
         for (int a = 0; a < 4; ++a) sh[par][a][lane] = q[a];
 #pragma unroll
@@ -962,13 +1030,20 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
           for (int e = 1; e < 8; ++e) out[knot_elem<true>(i + 1, e, 18)] = po[e];
         }
       }
+      QSTAMP(4);  // Y: LDS write, stores
       __syncthreads();
+      QSTAMP(5);  // Y: barrier
       if (more) {
 #pragma unroll
         for (int a = 0; a < 6; ++a) v[a] = sh[par][11 + a][lane];
       }
+      QKEEP(v[5]);
+      QSTAMP(6);  // Y: LDS read of X's results
     }
   }
+#ifdef QILQR_STAMPS
+  stamp_flush();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

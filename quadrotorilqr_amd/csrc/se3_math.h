@@ -22,6 +22,21 @@
 
 #include <math.h>
 
+// Keeps the instruction scheduler from hoisting every scalar load of the weight matrices to the top of
+// a function (more constants than scalar registers: they would be spilled lane by lane).
+// QILQR_REFETCH(): what was read from memory before this point is read again after it rather than kept in
+// registers (the weights are used in several passes; keeping all of them live spills).
+// QILQR_PIN(x): x is computed here, not sunk to its first use (which would leave its operands live).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define QILQR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define QILQR_REFETCH() asm volatile("" ::: "memory")
+#define QILQR_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define QILQR_SCHED_FENCE() do { } while (0)
+#define QILQR_REFETCH() do { } while (0)
+#define QILQR_PIN(x) do { } while (0)
+#endif
+
 namespace qilqr {
 
 template <typename T>
@@ -447,8 +462,9 @@ QILQR_HD void se3_fillQ_fast(const T rho[3], const T th[3], T Qm[9]) {
 //              5: I - dt I^-1 (hat(w) I - hat(I w)) (rows 9-11 x cols 9-11)
 //   [off_cxx ..] C_xx = 2 J^T Q J (cost.hh:52), J = blkdiag(Jri, I6):
 //              general Q   : all 144 entries, row-major
-//              symmetric Q : upper-left 6x6 block packed upper-triangular (21), then the upper-right
-//                            6x6 block (36) unless Q[0:6,6:12] == 0 (then it is zero and not stored);
+//              symmetric Q : rows 0..5, each from its diagonal entry to column 5 (upper triangle of the
+//                            pose block, 21) plus columns 6..11 (pose x velocity block, 36) unless
+//                            Q[0:6,6:12] == 0 (then that block is zero and not stored);
 //                            the lower-right block is the constant 2 Q[6:12,6:12]
 //   [off_g ..+15] C_x (12), C_u (4)         cost.hh:51,54
 //   [off_cost]    knot cost                 cost.hh:47-48
@@ -460,8 +476,8 @@ struct RecLayout {
   int ur_zero;  // sym and Q[0:6, 6:12] == 0
   int off_cxx, off_g, off_cost, stride;
 };
-QILQR_HD RecLayout make_layout(bool sym, bool ur_zero) {
-  RecLayout L;
+QILQR_HD constexpr RecLayout make_layout(bool sym, bool ur_zero) {
+  RecLayout L{};
   L.sym = sym ? 1 : 0;
   L.ur_zero = (sym && ur_zero) ? 1 : 0;
   L.off_cxx = 54;
@@ -471,7 +487,26 @@ QILQR_HD RecLayout make_layout(bool sym, bool ur_zero) {
   L.stride = (L.off_cost + 1 + 1) & ~1;  // even: records stay 16-byte aligned
   return L;
 }
-QILQR_HD int sym6_index(int i, int j) {  // i <= j < 6, packed upper triangle, row-major
+// Device layout of the knot records: [b][knot i][stride], one contiguous record per knot.
+// (A layout with the 64 trajectories of a tile interleaved in 128-byte chunks, written out coalesced
+// through LDS, was measured: k_linearize is bound by the bytes it writes, not by how they are
+// addressed, and the padding such a layout needs made both it and k_backward slower.)
+QILQR_HD long rec_base(long b, long n, int stride) { return b * n * stride; }
+QILQR_HD long rec_elem(long i, int k, int stride) { return i * stride + k; }
+QILQR_HD long rec_count(long B, long n, int stride) { return B * n * stride; }
+// The linearisation hands its entries to a writer: put(k, v) stores entry k of the record.
+template <typename T>
+struct PlainRecWriter {
+  T *rec;
+  QILQR_HD void put(int k, T v) const { rec[k] = v; }  // (non-temporal stores here are 6x slower: the L2 must merge them)
+};
+// symmetric layouts, rows i < 6 of C_xx in order of production: row i holds its part of the upper triangle
+// of the pose block (columns i..5) and, when the pose x velocity block is stored, its six entries of that
+QILQR_HD constexpr int symrow_index(bool with_pv, int i, int j) {  // i < 6, i <= j < (with_pv ? 12 : 6)
+  const int w = with_pv ? 12 : 6;
+  return i * w - (i * (i - 1)) / 2 + (j - i);
+}
+QILQR_HD constexpr int sym6_index(int i, int j) {  // i <= j < 6, packed upper triangle, row-major
   return i * 6 - (i * (i - 1)) / 2 + (j - i);
 }
 // where C_xx[row][col] (row, col < 12) lives in a record: offset, or -1 with *cst = the constant
@@ -479,15 +514,19 @@ QILQR_HD int cxx_source(const RecLayout &L, int row, int col, const double *Q, d
   *cst = 0.0;
   if (!L.sym) return L.off_cxx + row * 12 + col;
   const int i = row < col ? row : col, j = row < col ? col : row;
-  if (j < 6) return L.off_cxx + sym6_index(i, j);
-  if (i < 6) return L.ur_zero ? -1 : L.off_cxx + 21 + i * 6 + (j - 6);
+  if (j < 6) return L.off_cxx + symrow_index(!L.ur_zero, i, j);
+  if (i < 6) return L.ur_zero ? -1 : L.off_cxx + symrow_index(true, i, j);
   *cst = 2.0 * Q[row * 12 + col];
   return -1;
 }
 
-// knot value of the cost only (cost.hh:36-48); pt/pd = 18-double knots
-template <typename T>
-QILQR_HD T knot_cost(const ModelConsts<T> &c, const T *pt, const T *pd, T dx[12], T du[4]) {
+// knot value of the cost (cost.hh:36-48); pt/pd = 18-double knots.  Also returns the row vectors
+// sq = dx^T Q and sr = du^T R, which the differentials reuse (C_x = 2 sq J, C_u = 2 sr).
+// Q (12x12) and R (4x4) are read row by row through pointers (k_linearize keeps them in LDS).
+// BLOCKDIAG: Q's pose x velocity blocks are exactly zero, their products are skipped (adding exact
+// zeros changes nothing for finite dx).
+template <bool BLOCKDIAG, typename T>
+QILQR_HD T knot_cost(const T *Q, const T *R, const T *pt, const T *pd, T dx[12], T du[4], T sq[12], T sr[4]) {
   const T qx[4] = {pt[5], pt[6], pt[7], pt[4]};
   const T qd[4] = {pd[5], pd[6], pd[7], pd[4]};
   se3_rminus_fast(pt + 1, qx, pd + 1, qd, dx);  // x (-) x_d; exactly zero at zero error
@@ -495,29 +534,38 @@ QILQR_HD T knot_cost(const ModelConsts<T> &c, const T *pt, const T *pd, T dx[12]
   for (int i = 0; i < 6; ++i) dx[6 + i] = pt[8 + i] - pd[8 + i];
 #pragma unroll
   for (int i = 0; i < 4; ++i) du[i] = pt[14 + i] - pd[14 + i];
+  // sq[j] = sum_i dx[i] Q[i][j], i ascending for every j
+#pragma unroll
+  for (int j = 0; j < 12; ++j) sq[j] = T(0);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int j0 = BLOCKDIAG ? (i < 6 ? 0 : 6) : 0, j1 = BLOCKDIAG ? j0 + 6 : 12;
+#pragma unroll
+    for (int j = 0; j < 12; ++j)
+      if (j >= j0 && j < j1) sq[j] += dx[i] * Q[i * 12 + j];
+    if ((i & 1) == 1) QILQR_SCHED_FENCE();  // two rows of weights in flight, not all twelve
+  }
+#pragma unroll
+  for (int j = 0; j < 12; ++j) QILQR_PIN(sq[j]);
   T cx = T(0);
 #pragma unroll
-  for (int j = 0; j < 12; ++j) {
-    T s = T(0);
+  for (int j = 0; j < 12; ++j) cx += sq[j] * dx[j];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) s += dx[i] * c.Q[i * 12 + j];
-    cx += s * dx[j];
-  }
+  for (int j = 0; j < 4; ++j) sr[j] = T(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sr[j] += du[i] * R[i * 4 + j];
   T cu = T(0);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    T s = T(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s += du[i] * c.R[i * 4 + j];
-    cu += s * du[j];
-  }
+  for (int j = 0; j < 4; ++j) cu += sr[j] * du[j];
   return cx + cu;
 }
 
 // Linearisation of one knot in two independent halves (k_linearize runs them in different lanes).
 // Dynamics: the six Jacobian blocks of quadrotor_model.cc:33-49, 84-119, 174-200, 266-276.
-template <typename T>
-QILQR_HD void linearize_dynamics(const ModelConsts<T> &c, const T *pt, T *rec) {
+template <typename T, typename W>
+QILQR_HD void linearize_dynamics(const ModelConsts<T> &c, const T *pt, W &w) {
   const T q[4] = {pt[5], pt[6], pt[7], pt[4]};
   const T *v = pt + 8;
   // ---- dynamics: tau = dt v ; E = Exp(tau) = (p, qe)
@@ -538,20 +586,18 @@ QILQR_HD void linearize_dynamics(const ModelConsts<T> &c, const T *pt, T *rec) {
     skew3(ti, S);
     mat3_mul(S, Rc, SR);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      rec[LIN_BLK + 0 + i] = Rc[i];
-      rec[LIN_BLK + 9 + i] = SR[i];
-    }
+    for (int i = 0; i < 9; ++i) w.put(LIN_BLK + 0 + i, Rc[i]);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w.put(LIN_BLK + 9 + i, SR[i]);
     // dt * rjac(tau) = dt [[Jr, Q(-tau)],[0, Jr]],  Jr = Jl^T
     T nrho[3] = {-tau[0], -tau[1], -tau[2]}, nth[3] = {-tau[3], -tau[4], -tau[5]}, Qm[9];
     se3_fillQ_fast(nrho, nth, Qm);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        rec[LIN_BLK + 18 + 3 * i + j] = Jl[3 * j + i] * c.dt;
-        rec[LIN_BLK + 27 + 3 * i + j] = Qm[3 * i + j] * c.dt;
-      }
+      for (int j = 0; j < 3; ++j) w.put(LIN_BLK + 18 + 3 * i + j, Jl[3 * j + i] * c.dt);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w.put(LIN_BLK + 27 + i, Qm[i] * c.dt);
   }
   {
     // d(lin acc)/d(rot) = -g hat(R^T e_z), scaled by dt
@@ -561,140 +607,155 @@ QILQR_HD void linearize_dynamics(const ModelConsts<T> &c, const T *pt, T *rec) {
     T H[9];
     skew3(rz, H);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) rec[LIN_BLK + 36 + i] = c.dt * (-c.g * H[i]);
+    for (int i = 0; i < 9; ++i) w.put(LIN_BLK + 36 + i, c.dt * (-c.g * H[i]));
     // d(ang acc)/d(omega) = -I^-1 (hat(w) I - hat(I w)); block = I + dt * that
-    const T *w = v + 3;
+    const T *om = v + 3;
     T Wh[9], WI[9], Iw[3], IwH[9], Jd[9], S[9];
-    skew3(w, Wh);
+    skew3(om, Wh);
     mat3_mul(Wh, c.inertia, WI);
-    mat3_vec(c.inertia, w, Iw);
+    mat3_vec(c.inertia, om, Iw);
     skew3(Iw, IwH);
 #pragma unroll
     for (int i = 0; i < 9; ++i) Jd[i] = WI[i] - IwH[i];
     mat3_mul(c.inertia_inv, Jd, S);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) rec[LIN_BLK + 45 + i] = ((i % 4 == 0) ? T(1) : T(0)) + c.dt * (-S[i]);
+    for (int i = 0; i < 9; ++i) w.put(LIN_BLK + 45 + i, ((i % 4 == 0) ? T(1) : T(0)) + c.dt * (-S[i]));
   }
 }
 
 // Cost: value and differentials of cost.hh:36-61; returns the knot cost.
-template <typename T>
-QILQR_HD T linearize_cost(const ModelConsts<T> &c, const RecLayout &L, const T *pt, const T *pd, T *rec) {
-  // ---- cost: dx = x (-) x_d, J = blkdiag(Jri(tau_c), I6), Jri = [[a, b],[0, a]]
-  T dx[12], du[4];
-  const T cost = knot_cost(c, pt, pd, dx, du);
-  rec[L.off_cost] = cost;
-  T Jri[36];
+// LK = layout kind of the record, a compile-time choice (one kernel instantiation each, so that no weight
+// is loaded on two sides of a run-time branch): 0 general Q, 1 symmetric Q, 2 symmetric Q with zero
+// pose x velocity blocks.
+QILQR_HD constexpr int layout_kind(const RecLayout &L) { return !L.sym ? 0 : (L.ur_zero ? 2 : 1); }
+template <int LK, typename T, typename W>
+QILQR_HD T linearize_cost(const T *Q, const T *R, const T *pt, const T *pd, W &w) {
+  constexpr RecLayout L = make_layout(LK > 0, LK == 2);
+  // ---- cost: dx = x (-) x_d, J = blkdiag(Jri(tau_c), I6), Jri = [[a, -b],[0, a]] (3x3 blocks)
+  T dx[12], du[4], sq[12], sr[4];
+  const T cost = knot_cost<LK == 2>(Q, R, pt, pd, dx, du, sq, sr);
+  T a[9], nb[9];  // Jri blocks: a = rjacinv of the rotation, nb = -a Q(-tau) a
   {
-    T Li[9], a[9], Qm[9], aq[9], b[9];
+    T Li[9], Qm[9], aq[9];
     so3_ljacinv_fast(dx + 3, Li);
     transpose3(Li, a);  // rjacinv = ljacinv^T
     T nrho[3] = {-dx[0], -dx[1], -dx[2]}, nth[3] = {-dx[3], -dx[4], -dx[5]};
     se3_fillQ_fast(nrho, nth, Qm);
     mat3_mul(a, Qm, aq);
-    mat3_mul(aq, a, b);
+    mat3_mul(aq, a, nb);
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        Jri[6 * i + j] = a[3 * i + j];
-        Jri[6 * i + 3 + j] = -b[3 * i + j];
-        Jri[6 * (3 + i) + j] = T(0);
-        Jri[6 * (3 + i) + 3 + j] = a[3 * i + j];
-      }
+    for (int i = 0; i < 9; ++i) nb[i] = -nb[i];
   }
-  // C_x = ((2 dx^T) Q) J ; C_u = (2 du^T) R
+  // column j of Jri: rows 0..2 = a[:, j] (j < 3) or nb[:, j - 3]; rows 3..5 = 0 (j < 3) or a[:, j - 3].
+  // The structural zeros are skipped below (they would only add exact zeros).
+  // C_x = 2 (dx^T Q) J ; C_u = 2 du^T R
   {
-    T wq[12];
+    T gx[6];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      T s = T(0);
+    for (int j = 0; j < 3; ++j) {
+      T s = T(0), v = T(0);
 #pragma unroll
-      for (int i = 0; i < 12; ++i) s += (T(2) * dx[i]) * c.Q[i * 12 + j];
-      wq[j] = s;
+      for (int r = 0; r < 3; ++r) {
+        s += (T(2) * sq[r]) * a[3 * r + j];
+        v += (T(2) * sq[r]) * nb[3 * r + j];
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) v += (T(2) * sq[3 + r]) * a[3 * r + j];
+      gx[j] = s;
+      gx[3 + j] = v;
     }
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      T s = T(0);
+    for (int j = 0; j < 6; ++j) w.put(L.off_g + j, gx[j]);
 #pragma unroll
-      for (int r = 0; r < 6; ++r) s += wq[r] * Jri[6 * r + j];
-      rec[L.off_g + j] = s;
-    }
+    for (int j = 6; j < 12; ++j) w.put(L.off_g + j, T(2) * sq[j]);
 #pragma unroll
-    for (int j = 6; j < 12; ++j) rec[L.off_g + j] = wq[j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      T s = T(0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) s += (T(2) * du[i]) * c.R[i * 4 + j];
-      rec[L.off_g + 12 + j] = s;
-    }
+    for (int j = 0; j < 4; ++j) w.put(L.off_g + 12 + j, T(2) * sr[j]);
   }
-  // C_xx = 2 J^T Q J, column by column: P[:,j] = Q J[:,j], C_xx[:,j] = 2 J^T P[:,j]
-  if (!L.sym) {
-    for (int j = 0; j < 12; ++j) {
-      T P[12];
-      if (j < 6) {
+  w.put(L.off_cost, cost);
+  // C_xx = 2 (J^T Q) J, row by row (the order the record wants, and the association Eigen uses):
+  //   wrow[k] = (J^T Q)[i][k] = sum_r J[r][i] Q[r][k],   C_xx[i][j] = 2 sum_k wrow[k] J[k][j]
+  // with column c of Jri: rows 0..2 = a[:, c] (c < 3) or nb[:, c - 3]; rows 3..5 = 0 (c < 3) or a[:, c - 3].
+  constexpr int NK = (LK == 2) ? 6 : 12;  // columns of Q that matter for the rows i < 6
+  auto jtq_row = [&](int i, T wrow[12]) {
+    QILQR_REFETCH();
 #pragma unroll
-        for (int r = 0; r < 12; ++r) {
-          T s = T(0);
+    for (int k = 0; k < NK; ++k) {
+      T s = T(0);
+      if (i < 3) {
 #pragma unroll
-          for (int k = 0; k < 6; ++k) s += c.Q[r * 12 + k] * Jri[6 * k + j];
-          P[r] = s;
-        }
+        for (int r = 0; r < 3; ++r) s += a[3 * r + i] * Q[r * 12 + k];
       } else {
 #pragma unroll
-        for (int r = 0; r < 12; ++r) P[r] = c.Q[r * 12 + j];
+        for (int r = 0; r < 3; ++r) s += nb[3 * r + (i - 3)] * Q[r * 12 + k];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) s += a[3 * r + (i - 3)] * Q[(3 + r) * 12 + k];
       }
+      wrow[k] = s;
+    }
+    QILQR_SCHED_FENCE();
+  };
+  auto times_jri = [&](const T *row, int j) {  // sum_k row[k] Jri[k][j], k < 6
+    T s = T(0);
+    if (j < 3) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        T s = T(0);
+      for (int k = 0; k < 3; ++k) s += row[k] * a[3 * k + j];
+    } else {
 #pragma unroll
-        for (int r = 0; r < 6; ++r) s += Jri[6 * r + i] * P[r];
-        rec[L.off_cxx + i * 12 + j] = T(2) * s;
-      }
+      for (int k = 0; k < 3; ++k) s += row[k] * nb[3 * k + (j - 3)];
 #pragma unroll
-      for (int i = 6; i < 12; ++i) rec[L.off_cxx + i * 12 + j] = T(2) * P[i];
+      for (int k = 0; k < 3; ++k) s += row[3 + k] * a[3 * k + (j - 3)];
+    }
+    return s;
+  };
+  if constexpr (LK == 0) {
+    // dense 12x12, row-major: [[J^T Qpp J, J^T Qpv],[Qvp J, Qvv]]
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      T wrow[12];
+      jtq_row(i, wrow);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) w.put(L.off_cxx + i * 12 + j, T(2) * times_jri(wrow, j));
+#pragma unroll
+      for (int j = 6; j < 12; ++j) w.put(L.off_cxx + i * 12 + j, T(2) * wrow[j]);
+    }
+#pragma unroll
+    for (int i = 6; i < 12; ++i) {
+      T qrow[12];
+      QILQR_REFETCH();
+#pragma unroll
+      for (int k = 0; k < 12; ++k) qrow[k] = Q[i * 12 + k];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) w.put(L.off_cxx + i * 12 + j, T(2) * times_jri(qrow, j));
+#pragma unroll
+      for (int j = 6; j < 12; ++j) w.put(L.off_cxx + i * 12 + j, T(2) * qrow[j]);
+      QILQR_SCHED_FENCE();
     }
   } else {
     // symmetric Q: only the upper triangle of the 6x6 pose block and (unless it vanishes) the
     // pose x velocity block vary from knot to knot
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      T P[6];
+    for (int i = 0; i < 6; ++i) {
+      T wrow[12];
+      jtq_row(i, wrow);
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        T s = T(0);
+      for (int j = i; j < 6; ++j) w.put(L.off_cxx + symrow_index(LK == 1, i, j), T(2) * times_jri(wrow, j));
+      if constexpr (LK == 1) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) s += c.Q[r * 12 + k] * Jri[6 * k + j];
-        P[r] = s;
+        for (int j = 6; j < 12; ++j) w.put(L.off_cxx + symrow_index(true, i, j), T(2) * wrow[j]);
       }
-#pragma unroll
-      for (int i = 0; i <= j; ++i) {
-        T s = T(0);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) s += Jri[6 * r + i] * P[r];
-        rec[L.off_cxx + sym6_index(i, j)] = T(2) * s;
-      }
-    }
-    if (!L.ur_zero) {
-#pragma unroll
-      for (int j = 6; j < 12; ++j)
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          T s = T(0);
-#pragma unroll
-          for (int r = 0; r < 6; ++r) s += Jri[6 * r + i] * c.Q[r * 12 + j];
-          rec[L.off_cxx + 21 + i * 6 + (j - 6)] = T(2) * s;
-        }
     }
   }
   return cost;
 }
 template <typename T>
 QILQR_HD void linearize_knot(const ModelConsts<T> &c, const RecLayout &L, const T *pt, const T *pd, T *rec) {
-  linearize_dynamics(c, pt, rec);
-  linearize_cost(c, L, pt, pd, rec);
+  PlainRecWriter<T> w{rec};
+  linearize_dynamics(c, pt, w);
+  switch (layout_kind(L)) {
+    case 0: linearize_cost<0>(c.Q, c.R, pt, pd, w); break;
+    case 1: linearize_cost<1>(c.Q, c.R, pt, pd, w); break;
+    default: linearize_cost<2>(c.Q, c.R, pt, pd, w); break;
+  }
 }
 
 // ----------------------------------------------------------------- rollout arithmetic
