@@ -72,7 +72,9 @@ typedef struct {
                        2: every kernel; 3: k_backward only; 4: k_rollout only */
   int32_t sync_every; /* 1: the host waits for every round's count of active trajectories; k > 1: it reads the
                          count k rounds late, i.e. keeps the stream k rounds ahead of the device (k <= 6) */
-  int32_t force_general; /* 1: use the general (non-symmetric-safe) backward kernel even when Q, R are symmetric */
+  int32_t force_general; /* backward kernel.  0: by the weights and the batch (symmetric Q, R and B <= 8192: k_backward2, two
+                            wavefronts per trajectory); 1: the general kernel even when Q, R are symmetric; 2: the one-wavefront
+                            kernel for symmetric weights (k_backward<true>) */
   int32_t single_wave_rollout; /* rollout kernel: 0 (default) or 2 = pose wave + control wave + loader wave per 64
                                   trajectories (k_rollout3); 1 = one wavefront (k_rollout, always used above 16384
                                   trajectories); 3 = pose wave + control wave without loader (k_rollout2) */

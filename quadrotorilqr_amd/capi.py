@@ -138,7 +138,7 @@ class QuadrotorILQRBatch:
         o.populate_debug = int(bool(options.get("populate_debug", False)))
         self.options = dict(options)
         self.desired = _d(desired).reshape(-1, KNOT)
-        dc = DeviceConfig(int(device), int(profile), int(sync_every), int(bool(force_general)),
+        dc = DeviceConfig(int(device), int(profile), int(sync_every), int(force_general),
                           int(single_wave_rollout), {"f64": 0, "f32": 1}[precision])
         self._h = C.c_void_p()
         rc = lib.qilqr_create(C.byref(m), _p(Q), _p(R), _p(self.desired), C.c_int32(len(self.desired)),

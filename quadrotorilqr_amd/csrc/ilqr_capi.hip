@@ -261,7 +261,17 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
 #define QILQR_LAUNCH_BWD(SYM, S)                                                                              \
   launch(s, K_BACKWARD, (k_backward<SYM, S>), dim3((unsigned)B), dim3(64), s->consts, s->params, s->st, \
                      (int)B, (int)n, force)
-  if (s->symmetric) {
+  if (s->symmetric && s->dev.force_general != 2 && B <= 8192) {
+    // two cooperating wavefronts per trajectory (matrix recursion / gradient recursion + operand streaming):
+    // shortens one trajectory's chain; above ~8 trajectories per SIMD the chip is bound by the matrix pipe and
+    // the one-wavefront kernel gives 2% more throughput
+    if (s->f32)
+      launch(s, K_BACKWARD, k_backward2<float>, dim3((unsigned)B), dim3(128), s->consts, s->params, s->st, (int)B, (int)n,
+             force);
+    else
+      launch(s, K_BACKWARD, k_backward2<double>, dim3((unsigned)B), dim3(128), s->consts, s->params, s->st, (int)B,
+             (int)n, force);
+  } else if (s->symmetric) {
     if (s->f32) QILQR_LAUNCH_BWD(true, float);
     else QILQR_LAUNCH_BWD(true, double);
   } else {
@@ -445,7 +455,7 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
     for (int k = 0; k < i; ++k) s->symmetric = s->symmetric && (Q[i * 12 + k] == Q[k * 12 + i]);
   for (int i = 0; i < 4; ++i)
     for (int k = 0; k < i; ++k) s->symmetric = s->symmetric && (R[i * 4 + k] == R[k * 4 + i]);
-  if (dc.force_general) s->symmetric = false;
+  if (dc.force_general == 1) s->symmetric = false;
   {
     bool qsym = true, ur0 = true;
     for (int i = 0; i < 12; ++i)
@@ -453,7 +463,7 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
         qsym = qsym && (Q[i * 12 + k] == Q[k * 12 + i]);
         if (i < 6 && k >= 6) ur0 = ur0 && (Q[i * 12 + k] == 0.0);
       }
-    s->layout = make_layout(qsym && !dc.force_general, ur0);
+    s->layout = make_layout(qsym && dc.force_general != 1, ur0);
   }
   s->n_desired = n_desired;
 

@@ -604,6 +604,309 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_backward2: the recursion for symmetric weights with TWO cooperating wavefronts per trajectory
+// (block = 128).  The value gradient V_x never feeds back into V_xx, so its part of every knot is
+// taken off the serial chain of the matrix recursion:
+//   wave M (matrix):   T = V M, H = C + M^T T, LDL^T of Q_uu, K = -Quu^-1 Q_ux, V_xx = Q_xx + Q_xu K;
+//                      stores K; hands K and the LDL^T factors to G through LDS
+//   wave G (gradient): one knot behind.  [Q_x ; Q_u] = [C_x ; C_u] + M^T V_x, k = -Quu^-1 Q_u with
+//                      M's factors, V_x = Q_x + K^T Q_u, Q_u^T k; stores k.  It also streams the knot
+//                      records from HBM into a three-deep LDS ring (two coalesced loads per knot), from
+//                      which both waves take their operands (M one knot ahead, into registers).
+// Interval I_i (between two barriers) for i = n-1 .. 0:
+//   M: knot i (operands in registers); reads knot i-1's operands from ring[(i-1) % 3]; writes K_i, factors_i
+//   G: gradient step of knot i+1 (ring[(i+1) % 3], kf[(i+1) & 1]); then record i-2 -> ring[(i-2) % 3];
+//      then issues the loads of record i-3
+// Same arithmetic as k_backward<true>: the gains are bit-identical.
+// ---------------------------------------------------------------------------------------------
+constexpr int BW2_REC = 128;                   // doubles reserved for a record (symmetric layouts: stride <= 128)
+constexpr int BW2_BUF = BW2_REC + CTAB_SIZE;   // one ring slot: record, then the constant operand table
+template <typename S>
+__global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n,
+                                                   int force) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: M, 1: G
+  // ---- settle the pending candidate (ilqr.hh:70-84, 174-194).  Both waves take the decision from the
+  // same global data; wave G's lane 0 applies it after a barrier (nobody reads those words afterwards).
+  int fl = st.flags[b];
+  int cur = st.cur[b];
+  const int it0 = st.iters[b];
+  const int trial0 = st.trial[b];
+  const double prev_cost0 = st.prev_cost[b], alpha0 = st.alpha[b];
+  const double term0 = st.terms[2 * b], term1 = st.terms[2 * b + 1];
+  double cost_now = st.cost[b];
+  bool settle = false, accept = false, count_active = false;
+  int status = -1;
+  double new_cost = 0.0;
+  if (!force) {
+    if (fl & F_SEARCH) {
+      settle = true;
+      const double *kc = st.knot_cost[cur ^ 1];
+      for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const double v = (i < n) ? kc[cost_index(b, i, n)] : 0.0;
+        const int cnt = (n - base < 64) ? n - base : 64;
+        const long long bits = __double_as_longlong(v);
+        for (int t = 0; t < cnt; ++t) {
+          const int lo = __builtin_amdgcn_readlane((int)bits, t);
+          const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), t);
+          new_cost += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        }
+      }
+      if (it0 == 0) {
+        accept = true;  // ilqr.hh:71-73
+      } else {
+        const double desired = p.reduction_frac * cost_reduction(term0, term1, alpha0);
+        accept = (new_cost - prev_cost0 < desired);  // ilqr.hh:186
+      }
+      if (accept) {
+        cur ^= 1;
+        fl = F_ACTIVE;
+        cost_now = new_cost;
+        if (it0 > 0 && is_converged(p, prev_cost0, new_cost)) {
+          status = 1;  // ilqr.hh:82-84
+          fl = 0;
+        } else if (!((double)(it0 + 1) < p.max_iters)) {
+          status = 2;  // ilqr.hh:86
+          fl = 0;
+        }
+      } else if (trial0 + 1 >= p.ls_max_iters) {
+        status = 3;  // ilqr.hh:191-193
+        fl = 0;
+      }
+      count_active = (fl & F_ACTIVE) != 0;
+    } else if (fl == F_ACTIVE) {
+      count_active = true;
+    } else {
+      return;  // both waves
+    }
+  }
+  const bool run = force || !settle || (accept && fl != 0);
+  const int iters_now = (settle && accept) ? it0 + 1 : it0;
+  __syncthreads();
+  if (role == 1 && lane == 0) {
+    if (settle) {
+      st.n_fwd[b] += 1;
+      if (accept) {
+        st.cur[b] = cur;
+        st.cost[b] = new_cost;
+        if (st.cost_hist && it0 < st.hist_cap) st.cost_hist[(long)b * st.hist_cap + it0] = new_cost;
+        st.iters[b] = it0 + 1;
+      } else {
+        st.trial[b] = trial0 + 1;
+        st.alpha[b] = alpha0 * p.step_update;  // ilqr.hh:189
+      }
+      if (status >= 0) st.status[b] = status;
+      st.flags[b] = fl;
+    }
+    if (count_active) atomicAdd(&st.counters[0], 1);
+  }
+  if (!run) return;  // back-tracking continues with the old gains, or the trajectory is done
+
+  const int j = lane & 15, kk = lane >> 4;
+  const RecLayout L = st.layout;
+  const S *lin = (const S *)st.lin[cur] + rec_base(b, n, L.stride);
+  S *gains = (S *)st.gains + knot_base<true>(b, n, 52);
+  __shared__ double ring[3][BW2_BUF];
+  __shared__ double kf[2][80];  // [0..63] K, column j at [4 j ..]; [64..73] l10 l20 l30 l21 l31 l32 1/d0..1/d3
+  // operand offsets inside a ring slot: record entries, or entries of the constant table behind the record
+  int off[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    int src;
+    if (k < 3) src = m_source_tab(4 * k + kk, j);
+    else if (k < 6) src = (j < 12) ? cxx_source_tab(L, 4 * (k - 3) + kk, j) : -1 - CTAB_ZERO;
+    else src = L.off_g + j;
+    off[k] = (src >= 0) ? src : BW2_REC + (-1 - src);
+  }
+  for (int t = threadIdx.x; t < CTAB_SIZE; t += 128) {
+    const double v = (double)((const S *)st.ctab)[t];
+    ring[0][BW2_REC + t] = v;
+    ring[1][BW2_REC + t] = v;
+    ring[2][BW2_REC + t] = v;
+  }
+  typedef typename GA<S>::cptr gptr;
+  const int tail = (L.stride - 65 < lane) ? L.stride - 65 : lane;  // second load: elements 64 .. stride-1, clamped
+
+  if (role == 1) {
+    // ------------------------------------------------------------------ G: records + gradient
+    auto rec_ptr = [&](int i) { return (gptr)(lin + rec_elem(i, 0, L.stride)); };
+    S r0 = 0, r1 = 0;
+    {
+      gptr q1 = rec_ptr(n - 1);
+      const S a0 = q1[lane], a1 = q1[64 + tail];
+      ring[(n - 1) % 3][lane] = (double)a0;
+      ring[(n - 1) % 3][64 + lane] = (double)a1;
+      if (n >= 2) {
+        gptr q2 = rec_ptr(n - 2);
+        const S b0 = q2[lane], b1 = q2[64 + tail];
+        ring[(n - 2) % 3][lane] = (double)b0;
+        ring[(n - 2) % 3][64 + lane] = (double)b1;
+      }
+      if (n >= 3) {
+        gptr q3 = rec_ptr(n - 3);
+        r0 = q3[lane];
+        r1 = q3[64 + tail];
+      }
+    }
+    __syncthreads();
+    double vxl[3] = {0.0, 0.0, 0.0};  // V_x[4 kc + kk]
+    double QuTk = 0.0;
+    typedef typename GA<S>::v2 sv2;
+    typedef typename GA<S>::ptr2 gptr2;
+    gptr2 kdst = (gptr2)(gains + knot_elem<true>(n - 1, 0, 52));  // k of knot n-1; lanes other than 0 use the dump slot
+    const long kstep = (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2;
+    gptr2 kdst0 = (lane == 0) ? kdst : (gptr2)((S *)st.dump + 4 * (long)b);
+    gptr2 kdst1 = (lane == 0) ? kdst + 64 : (gptr2)((S *)st.dump + 4 * (long)b + 2);
+    const long kst = (lane == 0) ? kstep : 0;
+    auto gradient_step = [&](int q) {
+      const double *buf = ring[q % 3];
+      const double *f = kf[q & 1];
+      const double m0 = buf[off[0]], m1 = buf[off[1]], m2 = buf[off[2]], gcj = buf[off[6]];
+      double part = m0 * vxl[0] + m1 * vxl[1] + m2 * vxl[2];
+      part = xor16_sum(part);
+      part = xor32_sum(part);
+      const double ghat = gcj + part;  // [Q_x ; Q_u][j]
+      const double Qu0 = row_bcast<12>(ghat), Qu1 = row_bcast<13>(ghat), Qu2 = row_bcast<14>(ghat),
+                   Qu3 = row_bcast<15>(ghat);
+      const double l10 = f[64], l20 = f[65], l30 = f[66], l21 = f[67], l31 = f[68], l32 = f[69], i0 = f[70],
+                   i1 = f[71], i2 = f[72], i3 = f[73];
+      const double y0 = Qu0, y1 = Qu1 - l10 * y0, y2 = Qu2 - l20 * y0 - l21 * y1,
+                   y3 = Qu3 - l30 * y0 - l31 * y1 - l32 * y2;
+      const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
+                   x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
+      const double k0 = -x0, k1 = -x1, k2 = -x2, k3 = -x3;  // feed-forward (ilqr.hh:128), in every lane
+      const sv2 w0 = {(S)k0, (S)k1}, w1 = {(S)k2, (S)k3};
+      *kdst0 = w0;
+      *kdst1 = w1;
+      kdst0 -= kst;
+      kdst1 -= kst;
+      const double c0 = f[4 * j], c1 = f[4 * j + 1], c2 = f[4 * j + 2], c3 = f[4 * j + 3];  // K[:, j]
+      const double vx = ghat + (c0 * Qu0 + c1 * Qu1 + c2 * Qu2 + c3 * Qu3);  // V_x = Q_x + K^T Q_u
+      QuTk += Qu0 * k0 + Qu1 * k1 + Qu2 * k2 + Qu3 * k3;
+#pragma unroll
+      for (int kc = 0; kc < 3; ++kc) vxl[kc] = __shfl(vx, 4 * kc + kk);
+    };
+    for (int i = n - 1; i >= 0; --i) {
+      if (i + 1 <= n - 1) gradient_step(i + 1);
+      if (i - 2 >= 0) {
+        ring[(i - 2) % 3][lane] = (double)r0;
+        ring[(i - 2) % 3][64 + lane] = (double)r1;
+      }
+      if (i - 3 >= 0) {
+        gptr q = rec_ptr(i - 3);
+        r0 = q[lane];
+        r1 = q[64 + tail];
+      }
+      __syncthreads();
+    }
+    gradient_step(0);
+    if (lane == 0) {
+      st.terms[2 * b] = QuTk;
+      st.terms[2 * b + 1] = -QuTk;  // k^T Quu k = -Q_u^T k for the exact solve (see k_backward)
+      st.n_bwd[b] += 1;
+      if (!force) {
+        st.prev_cost[b] = cost_now;  // ilqr.hh:61
+        if (iters_now > 0 && is_converged(p, cost_now, cost_now + cost_reduction(QuTk, -QuTk, 1.0))) {
+          st.status[b] = 0;  // ilqr.hh:66-68
+          st.flags[b] = 0;
+        } else if (iters_now > 0 && p.ls_max_iters <= 0) {
+          st.status[b] = 3;  // line_search with no trial allowed throws at once
+          st.flags[b] = 0;
+        } else {
+          st.alpha[b] = 1.0;
+          st.trial[b] = 0;
+          st.flags[b] = F_ACTIVE | F_SEARCH;
+        }
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- M: matrix recursion
+  const bool gowner = (kk == 0 && j < 12);
+  const int ge0 = 4 + 4 * j;
+  typedef typename GA<S>::ptr2 gptr2;
+  typedef typename GA<S>::v2 sv2;
+  gptr2 gdst0 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0, 52) : (S *)st.dump + 4 * (long)b);
+  gptr2 gdst1 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0 + 2, 52) : (S *)st.dump + 4 * (long)b + 2);
+  const long gstep = gowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
+  const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] : 0.0;  // register 3 <-> row 12 + kk: C_uu = 2 R
+  double va[3] = {0.0, 0.0, 0.0};  // V_xx[j][4 kc + kk]  (A operand)
+  __syncthreads();  // ring[(n-1) % 3], ring[(n-2) % 3] and the constant tables are filled
+  double m[3], cx[3];
+  {
+    const double *buf = ring[(n - 1) % 3];
+    m[0] = buf[off[0]]; m[1] = buf[off[1]]; m[2] = buf[off[2]];
+    cx[0] = buf[off[3]]; cx[1] = buf[off[4]]; cx[2] = buf[off[5]];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    // operands of knot i-1, for the next iteration (the slot was filled during the previous interval)
+    const double *nb = ring[(i > 0 ? i - 1 : 0) % 3];
+    const double m_n0 = nb[off[0]], m_n1 = nb[off[1]], m_n2 = nb[off[2]], cx_n0 = nb[off[3]], cx_n1 = nb[off[4]],
+                 cx_n2 = nb[off[5]];
+    d4 T = {0.0, 0.0, 0.0, 0.0};
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0], m[0], T, 0, 0, 0);
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1], m[1], T, 0, 0, 0);
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2], m[2], T, 0, 0, 0);
+    d4 H = {cx[0], cx[1], cx[2], cuu};
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
+    double Quu[16], Qu_unused[4], col[4];
+    gather_rows(H[3], col);
+    bcast_quu_row<0>(col, 0.0, Quu, Qu_unused);
+    bcast_quu_row<1>(col, 0.0, Quu, Qu_unused);
+    bcast_quu_row<2>(col, 0.0, Quu, Qu_unused);
+    bcast_quu_row<3>(col, 0.0, Quu, Qu_unused);
+    // LDL^T of the lower triangle of Q_uu (ilqr.hh:126), as in k_backward
+    const double i0 = rcp_nr(Quu[0]);
+    const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
+    const double d1 = Quu[5] - l10 * Quu[4];
+    const double i1 = rcp_nr(d1);
+    const double c21 = Quu[9] - l20 * Quu[4], c31 = Quu[13] - l30 * Quu[4];
+    const double l21 = c21 * i1, l31 = c31 * i1;
+    const double d2 = Quu[10] - l20 * Quu[8] - l21 * c21;
+    const double i2 = rcp_nr(d2);
+    const double c32 = Quu[14] - l30 * Quu[8] - l31 * c21;
+    const double l32 = c32 * i2;
+    const double d3 = Quu[15] - l30 * Quu[12] - l31 * c31 - l32 * c32;
+    const double i3 = rcp_nr(d3);
+    double kcol[4];
+    {
+      const double y0 = col[0], y1 = col[1] - l10 * y0, y2 = col[2] - l20 * y0 - l21 * y1,
+                   y3 = col[3] - l30 * y0 - l31 * y1 - l32 * y2;
+      const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
+                   x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
+      kcol[0] = -x0; kcol[1] = -x1; kcol[2] = -x2; kcol[3] = -x3;  // K[:, j] (ilqr.hh:127)
+    }
+    {
+      const sv2 w0 = {(S)kcol[0], (S)kcol[1]}, w1 = {(S)kcol[2], (S)kcol[3]};
+      *gdst0 = w0;
+      *gdst1 = w1;
+      gdst0 -= gstep;
+      gdst1 -= gstep;
+    }
+    // hand K and the factors to G (the four lanes of a column hold the same K[:, j]: same address, same data)
+    double *f = kf[i & 1];
+    f[4 * j] = kcol[0]; f[4 * j + 1] = kcol[1]; f[4 * j + 2] = kcol[2]; f[4 * j + 3] = kcol[3];
+    if (lane == 0) {
+      f[64] = l10; f[65] = l20; f[66] = l30; f[67] = l21; f[68] = l31; f[69] = l32;
+      f[70] = i0; f[71] = i1; f[72] = i2; f[73] = i3;
+    }
+    // V_xx = Q_xx + Q_xu K: A[j][kk] = Q_xu[j][kk] = H[12 + kk][j] is accumulator register 3
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(H[3], sel4(kcol, kk), H, 0, 0, 0);
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
+    m[0] = m_n0; m[1] = m_n1; m[2] = m_n2;
+    cx[0] = cx_n0; cx[1] = cx_n1; cx[2] = cx_n2;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_rollout: thread b.  traj[cur] + gains + alpha -> traj[cur ^ 1]
 // ---------------------------------------------------------------------------------------------
 template <typename S>

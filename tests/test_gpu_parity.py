@@ -195,6 +195,33 @@ def test_symmetric_fast_path_agrees_with_general_path():
     np.testing.assert_allclose(of["traj"], og["traj"], atol=1e-7)
 
 
+def test_two_wave_backward_matches_single_wave():
+    """k_backward2 (matrix wave + gradient wave, operands streamed through LDS) performs the operations of
+    k_backward<SYM> with the gradient recursion moved to its own wavefront: same gains and terms to rounding
+    (the compiler may contract multiply-adds differently), same solves.  Horizons 1, 2, 3 exercise the
+    start-up of the three-deep record ring; the dense symmetric weights the 128-entry record."""
+    r = np.random.default_rng(11)
+    Qd = r.uniform(-1, 1, (12, 12)); Qd = Qd @ Qd.T + 12 * np.eye(12)
+    Rd = r.uniform(-0.3, 0.3, (4, 4)); Rd = Rd + Rd.T + 2 * np.eye(4)
+    for B, n, dense, prec in [(33, 60, False, "f64"), (5, 1, False, "f64"), (7, 2, False, "f64"), (9, 3, False, "f64"),
+                              (6, 4, True, "f64"), (20, 37, True, "f64"), (16, 50, False, "f32")]:
+        cfg = pb.config2(B=B, N=n, seed=3)
+        if dense:
+            cfg["Q"], cfg["R"] = Qd, Rd
+        two = capi.from_config(cfg, precision=prec)
+        one = capi.from_config(cfg, precision=prec, force_general=2)
+        trajs = two.forward_sim(cfg["init"], np.zeros((B, n, 52)), 1.0)
+        g2, t2 = two.backwards_pass(trajs)
+        g1, t1 = one.backwards_pass(trajs)
+        np.testing.assert_allclose(t2, t1, rtol=1e-12, atol=1e-300)
+        np.testing.assert_allclose(g2, g1, rtol=1e-11, atol=1e-13 * max(np.abs(g1).max(), 1e-300))
+        o2, o1 = two.solve_batch(cfg["init"]), one.solve_batch(cfg["init"])
+        np.testing.assert_array_equal(o2["status"], o1["status"])
+        np.testing.assert_array_equal(o2["iters"], o1["iters"])
+        np.testing.assert_array_equal(o2["n_fwd"], o1["n_fwd"])
+        np.testing.assert_allclose(o2["cost"], o1["cost"], rtol=1e-9 if prec == "f64" else 1e-4)
+
+
 def test_two_wave_rollout_matches_single_wave():
     """k_rollout2 (pose wave + control wave) performs the same operations as k_rollout; the compiler
     may contract multiply-adds differently in the two kernels, so agreement is to rounding (1e-12)"""
