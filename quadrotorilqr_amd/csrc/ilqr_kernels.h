@@ -842,25 +842,36 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
     m[0] = buf[off[0]]; m[1] = buf[off[1]]; m[2] = buf[off[2]];
     cx[0] = buf[off[3]]; cx[1] = buf[off[4]]; cx[2] = buf[off[5]];
   }
+#ifdef QILQR_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
   for (int i = n - 1; i >= 0; --i) {
     // operands of knot i-1, for the next iteration (the slot was filled during the previous interval)
     const double *nb = ring[(i > 0 ? i - 1 : 0) % 3];
     const double m_n0 = nb[off[0]], m_n1 = nb[off[1]], m_n2 = nb[off[2]], cx_n0 = nb[off[3]], cx_n1 = nb[off[4]],
                  cx_n2 = nb[off[5]];
+    QSTAMP(0);  // operand reads issued
     d4 T = {0.0, 0.0, 0.0, 0.0};
     T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0], m[0], T, 0, 0, 0);
     T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1], m[1], T, 0, 0, 0);
     T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2], m[2], T, 0, 0, 0);
+    QKEEP(T[0]); QKEEP(T[3]);
+    QSTAMP(1);  // T = V M
     d4 H = {cx[0], cx[1], cx[2], cuu};
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
+    QKEEP(H[0]); QKEEP(H[3]);
+    QSTAMP(2);  // H
     double Quu[16], Qu_unused[4], col[4];
     gather_rows(H[3], col);
     bcast_quu_row<0>(col, 0.0, Quu, Qu_unused);
     bcast_quu_row<1>(col, 0.0, Quu, Qu_unused);
     bcast_quu_row<2>(col, 0.0, Quu, Qu_unused);
     bcast_quu_row<3>(col, 0.0, Quu, Qu_unused);
+    QKEEP(Quu[15]); QKEEP(Quu[0]); QKEEP(col[3]);
+    QSTAMP(4);  // gather + broadcast of Q_uu
     // LDL^T of the lower triangle of Q_uu (ilqr.hh:126), as in k_backward
     const double i0 = rcp_nr(Quu[0]);
     const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
@@ -882,6 +893,8 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
                    x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
       kcol[0] = -x0; kcol[1] = -x1; kcol[2] = -x2; kcol[3] = -x3;  // K[:, j] (ilqr.hh:127)
     }
+    QKEEP(kcol[0]); QKEEP(kcol[3]);
+    QSTAMP(5);  // factorisation + solve
     {
       const sv2 w0 = {(S)kcol[0], (S)kcol[1]}, w1 = {(S)kcol[2], (S)kcol[3]};
       *gdst0 = w0;
@@ -902,8 +915,15 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
     for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
     m[0] = m_n0; m[1] = m_n1; m[2] = m_n2;
     cx[0] = cx_n0; cx[1] = cx_n1; cx[2] = cx_n2;
+    QKEEP(va[0]); QKEEP(m[2]);
+    QSTAMP(6);  // stores, hand-off to G, V_xx MFMA
     __syncthreads();
+    QSTAMP(7);  // barrier
   }
+#ifdef QILQR_STAMPS
+  if (lane == 0 && st.stamps)
+    for (int k = 0; k < 8; ++k) st.stamps[(long)b * 8 + k] = stamp_sum[k];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

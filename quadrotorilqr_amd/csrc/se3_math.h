@@ -132,6 +132,18 @@ QILQR_HD void quat_mul(const T a[4], const T b[4], T o[4]) {
   o[2] = aw * bz + az * bw + ax * by - ay * bx;
 }
 
+// the same product where exactness of conj(q) * q does not matter (pose composition): the compiler
+// may fuse the multiply-adds (16 instructions instead of 28 on the rollout's serial chain)
+template <typename T>
+QILQR_HD void quat_mul_fused(const T a[4], const T b[4], T o[4]) {
+  const T ax = a[0], ay = a[1], az = a[2], aw = a[3];
+  const T bx = b[0], by = b[1], bz = b[2], bw = b[3];
+  o[3] = aw * bw - ax * bx - ay * by - az * bz;
+  o[0] = aw * bx + ax * bw + ay * bz - az * by;
+  o[1] = aw * by + ay * bw + az * bx - ax * bz;
+  o[2] = aw * bz + az * bw + ax * by - ay * bx;
+}
+
 // ----------------------------------------------------------------- SO(3)
 // Exp: [sin(|th|/2) th/|th| ; cos(|th|/2)], small angle [th/2 ; 1]
 template <typename T>
@@ -919,7 +931,7 @@ QILQR_HD void se3_rplus_fast(T t[3], T q[4], const T tau[6]) {
   p[1] = rho[1] + a * w1[1] + b * w2[1];
   p[2] = rho[2] + a * w1[2] + b * w2[2];
   quat_rotate(q, p, Rp);
-  quat_mul(q, qe, qo);
+  quat_mul_fused(q, qe, qo);
   const T n = qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3];
   if (fabs(n - T(1)) > Eps<T>::manif) {
     const T sc = T(2) / (T(1) + n);
