@@ -138,13 +138,18 @@ def main():
                 traffic_src = os.path.basename(summaries[-1])
             except Exception:
                 traffic = None
+        # k_backward is matrix-core work (fp64 MFMA); k_rollout has none: its bound is the bytes it moves
+        if dom == "k_backward":
+            bound = dict(bound="mfma", achieved=tflops, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=tflops / FP64_PEAK_TFLOPS)
+        else:
+            bound = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
         roofline = {
-            "kernel": dom, "bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tflops / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": dom, **bound, "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": kd["ms"] * 1e3 / max(kd["launches"], 1), "launches": kd["launches"],
             "alg_flops_per_launch": kd["flops"] / max(kd["launches"], 1),
             "alg_bytes_per_launch": kd["bytes"] / max(kd["launches"], 1),
             "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+            "flops": {"achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS},
             "kernels_ms": {k: round(v["ms"], 3) for k, v in kern.items()}
                           | {"k_linearize": round(prof["linearize_ms"], 3), "other": round(prof["other_ms"], 3)},
             "warmup_avg_launch_us": {k: round(calib[k + "_ms"] * 1e3 / max(calib[k + "_launches"], 1), 2)
