@@ -68,16 +68,21 @@ def main():
                               force_general=args.backward, **({} if args.rollout < 0 else dict(single_wave_rollout=args.rollout)))
 
     init = torch.from_numpy(cfg["init"]).to(dev)
-    out_traj = torch.empty_like(init)
-    out_cost = torch.empty(B, dtype=torch.float64, device=dev)
+    # two sets of output buffers, used alternately: with N > 1 the gather of step s (RCCL, torch's stream) runs
+    # while the solver's own stream is already solving step s + 1
+    out_traj = [torch.empty_like(init) for _ in range(2)]
+    out_cost = [torch.empty(B, dtype=torch.float64, device=dev) for _ in range(2)]
     out_i = [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(4)]  # status, iters, n_bwd, n_fwd
     sizes = [B] * world
+    step_no = [0]
 
     def step():
-        solver.solve_batch_device(init, out_traj, out_cost, out_i[0], out_i[1], out_i[2], out_i[3])
+        k = step_no[0] & 1
+        step_no[0] += 1
+        solver.solve_batch_device(init, out_traj[k], out_cost[k], out_i[0], out_i[1], out_i[2], out_i[3])
         if world > 1:  # the one exchange of the path: converged trajectories to rank 0
-            sharding.gather_to_root(out_traj, sizes)
-            sharding.gather_to_root(out_cost, sizes)
+            sharding.gather_to_root(out_traj[k], sizes)
+            sharding.gather_to_root(out_cost[k], sizes)
 
     def fence():
         if world > 1:
@@ -173,7 +178,7 @@ def main():
             t1 = time.perf_counter()
             ref.solve_batch(cfg["init"][:16], n_threads=1)
             t1c = time.perf_counter() - t1
-            got = out_cost.cpu().numpy()[:sample]
+            got = out_cost[(step_no[0] - 1) & 1].cpu().numpy()[:sample]
             cpu = {"value": sample * reps / tc, "unit": "solves/s", "cores": cores, "kind": "port",
                    "sample": f"first {sample} of the {B} problems of rank 0 x {reps} repeats, {cores} threads, {tc:.2f} s; "
                              f"single thread: {16 / t1c:.1f} solves/s on 16 problems",
