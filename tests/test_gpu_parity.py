@@ -527,10 +527,11 @@ def test_config3_mixed_precision_reduced():
 
 
 # ------------------------------------------------------------------ randomised parity sweep
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(12))
 def test_randomised_models_and_horizons_match_oracle(seed):
     """Random physical parameters (mass, SPD inertia, arm, rotor torque ratio, gravity), time step,
-    horizon, diagonal weights and option values; random SE(3) starts towards a random hover pose."""
+    horizon, weights (diagonal / block-diagonal dense / fully dense symmetric, by seed) and option values;
+    random SE(3) starts towards a random hover pose."""
     r = np.random.default_rng(1000 + seed)
     A = r.uniform(-0.3, 0.3, (3, 3))
     model = dict(mass_kg=r.uniform(0.5, 3.0), inertia=A @ A.T + np.diag(r.uniform(0.5, 2.0, 3)),
@@ -541,6 +542,17 @@ def test_randomised_models_and_horizons_match_oracle(seed):
     B = int(r.integers(1, 40))
     Q = np.diag(np.concatenate([r.uniform(10, 200, 6), r.uniform(0.5, 5, 6)]))
     R = np.diag(r.uniform(0.5, 3.0, 4))
+    if seed % 3 == 1:    # dense symmetric blocks, no pose x velocity coupling (block-diagonal record layout)
+        for lo in (0, 6):
+            G = r.uniform(-1, 1, (6, 6))
+            Q[lo:lo + 6, lo:lo + 6] += (G @ G.T) * (3.0 if lo == 0 else 0.1)
+        G = r.uniform(-0.3, 0.3, (4, 4))
+        R = R + G @ G.T
+    elif seed % 3 == 2:  # fully dense symmetric weights (pose x velocity block stored per knot)
+        G = r.uniform(-1, 1, (12, 12))
+        Q = Q + 0.3 * (G @ G.T)
+        G = r.uniform(-0.3, 0.3, (4, 4))
+        R = R + G @ G.T
     desired = pb.hover_desired(n, dt, model["mass_kg"] * model["g_mpss"] / 4.0)
     desired[:, 1:8] = orc.se3_exp(np.concatenate([r.uniform(-1, 1, 3), r.uniform(-0.3, 0.3, 3)]))
     init = pb.random_start_batch(np.arange(B), desired, 77 + seed, pos_m=0.8, ang_rad=0.6, vel_sigma=0.4)
