@@ -224,8 +224,7 @@ int begin_batch(qilqr_solver *s, long B, long n, const double *d_desired_batch) 
     s->st.desired = s->d_desired;
     s->st.desired_tiled = 0;
   }
-  HIP_TRY(hipMemsetAsync(s->st.cur, 0, sizeof(int) * B, s->stream));
-  HIP_TRY(hipMemsetAsync(s->st.flags, 0, sizeof(int) * B, s->stream));
+  launch(s, K_OTHER, k_begin, dim3(cdiv(B, 256)), dim3(256), s->st, (int)B);
   return QILQR_OK;
 }
 // host plain array -> device tiled buffer through the io scratch
@@ -323,8 +322,10 @@ int read_active(qilqr_solver *s, int *n_active) {
 
 // The outer loop of ILQR::solve (ilqr.hh:53-87) for trajectories already in st.traj[0].
 // on_round (optional) is called after every synchronised round (debug capture).
+// drain = false: return as soon as the host knows that no trajectory is active; the caller enqueues
+// its own work behind the rounds still in flight and waits for the stream itself.
 template <typename F>
-int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round) {
+int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool drain = true) {
   int rc;
   if ((rc = launch_linearize(s, B, n, 0, 0))) return rc;
   {
@@ -384,8 +385,10 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round) {
       }
     }
   }
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  HIP_TRY(hipGetLastError());
+  if (drain) {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipGetLastError());
+  }
   return QILQR_OK;
 }
 
@@ -592,7 +595,7 @@ int qilqr_solve_batch_device(qilqr_solver *s, const double *d_init, const double
   int rc = begin_batch(s, B, n, d_desired_batch);
   if (rc) return rc;
   if ((rc = to_tiled(s, d_init, s->st.traj[0], B, n, 18))) return rc;
-  if ((rc = run_solve(s, B, n, s->dev.sync_every, [] { return QILQR_OK; }))) return rc;
+  if ((rc = run_solve(s, B, n, s->dev.sync_every, [] { return QILQR_OK; }, false))) return rc;
   if ((rc = gather(s, B, n, d_out_traj, d_out_cost, d_out_status, d_out_iters, d_out_n_bwd, d_out_n_fwd)))
     return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));

@@ -171,6 +171,15 @@ k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState 
 #endif
 }
 
+// k_begin: thread b.  A new batch starts with every selector at buffer 0 and no flags (one launch in
+// place of two hipMemsetAsync, each of which is a fill kernel plus a barrier packet).
+__global__ void k_begin(BatchState st, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  st.cur[b] = 0;
+  st.flags[b] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_init: thread b.  cost = sum of knot costs (left to right, ilqr.hh:89-95); arm the state machine.
 // ---------------------------------------------------------------------------------------------
@@ -179,7 +188,16 @@ __global__ void k_init(SolveParams p, BatchState st, int B, int n) {
   if (b >= B) return;
   const double *kc = st.knot_cost[st.cur[b]];
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += kc[cost_index(b, i, n)];
+  // the additions stay in knot order; the loads are requested eight at a time
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    double v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = kc[cost_index(b, i + e, n)];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e];
+  }
+  for (; i < n; ++i) s += kc[cost_index(b, i, n)];
   st.cost[b] = s;
   st.prev_cost[b] = s;
   st.iters[b] = 0;
