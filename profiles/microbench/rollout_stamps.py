@@ -13,7 +13,7 @@ from quadrotorilqr_amd import capi, problems as pb  # noqa: E402
 capi.LIB_PATH = os.path.join(ROOT, "quadrotorilqr_amd", "lib", "libquadrotor_ilqr_stamps.so")
 B, N = 1024, 100
 cfg = pb.config2(B=B, N=N)
-s = capi.from_config(cfg)
+s = capi.from_config(cfg, single_wave_rollout=2)  # the stamps live in k_rollout3
 mode = sys.argv[1] if len(sys.argv) > 1 else "converged"
 if mode == "first":   # first iteration: the rollout is far from the nominal trajectory (general branches)
     trajs = s.forward_sim(cfg["init"], np.zeros((B, N, 52)), 1.0)

@@ -290,6 +290,11 @@ int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
     else
       launch(s, K_ROLLOUT, k_rollout<double>, dim3(cdiv(B, 64)), dim3(64), s->consts, s->st, (int)B, (int)n,
                          need_flag);
+  } else if (s->dev.single_wave_rollout == 4) {
+    if (s->f32)
+      launch(s, K_ROLLOUT, k_rollout4<float>, dim3(cdiv(B, 64)), dim3(256), s->constsf, s->st, (int)B, (int)n, need_flag);
+    else
+      launch(s, K_ROLLOUT, k_rollout4<double>, dim3(cdiv(B, 64)), dim3(256), s->consts, s->st, (int)B, (int)n, need_flag);
   } else if (s->dev.single_wave_rollout != 3) {
     if (s->f32)
       launch(s, K_ROLLOUT, k_rollout3<float>, dim3(cdiv(B, 64)), dim3(192), s->constsf, s->st, (int)B,

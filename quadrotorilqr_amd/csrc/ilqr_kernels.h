@@ -1388,6 +1388,232 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_rollout4: k_rollout3 with the pose wave cut in two (block = 256).  The serial dependency of a
+// rollout is  v_k -> T_{k+1} = T_k Exp(dt v_k) -> Log(Tnom_{k+1}^-1 T_{k+1}) -> u_{k+1} -> v_{k+2}:
+// in k_rollout3 the pose wave does Exp-compose AND Log inside one knot interval, the control wave waits.
+//   wave Y (compose):  T_{k+1} = T_k Exp(dt v_k)                          in interval k
+//   wave Z (log):      td, theta, c of Tnom_k^-1 T_k                       at the start of interval k
+//   wave X (control):  interval k: what needs no Log first (operands, velocity error), then waits for Z's
+//                      flag in LDS (no barrier: the others must not stop there), rho, u_k, v_{k+1}
+//   wave L (loader):   as in k_rollout3 (the nominal pose one knot later, for Z)
+// The chain per interval is max(Y, Z + X's dependent part) instead of max(Y + Z, X) -- on paper.  Measured
+// (B = 1024, N = 100): 97 us against 87.5 us for k_rollout3; the two extra hand-offs through LDS on the chain
+// (pose to Z, Log to X with a polled flag) cost more than the overlap returns.  At B = 8192 it is 7% faster,
+// at 2048, 4096 and 16384 it is not.  Not the default; kept selectable (single_wave_rollout = 4) with its
+// parity test.  Same arithmetic as k_rollout / k_rollout2 / k_rollout3.
+// ---------------------------------------------------------------------------------------------
+template <typename S>
+__global__ __launch_bounds__(256) void k_rollout4(ModelConsts<S> c, BatchState st, int B, int n, int need_flag) {
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: X, 1: Y, 2: Z, 3: L
+  const int b = blockIdx.x * 64 + lane;
+  const bool live = (b < B) && (!need_flag || (st.flags[b < B ? b : 0] & need_flag));
+  if (__ballot(live) == 0ull) return;  // identical in the four waves: block-uniform
+  const int bs = (b < B) ? b : (B - 1);
+  const int cur = st.cur[bs];
+  const S *traj = (const S *)st.traj[cur] + knot_base<true>(bs, n, 18);
+  const S *gains = (const S *)st.gains + knot_base<true>(bs, n, 52);
+  S *out = (S *)st.traj[cur ^ 1] + knot_base<true>(bs, n, 18);
+
+  typedef S sv2 __attribute__((ext_vector_type(2)));
+  __shared__ sv2 bx[2][35][64];  // [parity][pair: 0..8 nominal knot, 9..34 gains][lane]
+  __shared__ sv2 by[2][4][64];   // [parity][pair 0..3 of the nominal knot = time, t, q][lane]
+  __shared__ S shT[2][7][64];    // Y -> Z, X: pose of knot k in shT[k & 1]: t(3), q(x,y,z,w)
+  __shared__ S shZ[2][7][64];    // Z -> X: td(3), theta(3), c of knot k in shZ[k & 1]
+  __shared__ S shV[2][6][64];    // X -> Y: v of knot k in shV[k & 1]
+  __shared__ int zflag;          // Z: "the Log of knot zflag is in shZ"
+
+  if (role == 3) {
+    // ------------------------------------------------------------------ L: loader
+    const sv2 *tp = reinterpret_cast<const sv2 *>(traj);   // pair k of knot i: tp[(i * 9 + k) * 64]
+    const sv2 *gp = reinterpret_cast<const sv2 *>(gains);  //                   gp[(i * 26 + k) * 64]
+    sv2 ra[35], rb[35], pa[4], pb[4];
+    auto load_ops = [&](int k, sv2 (&r)[35]) {
+      if (k < n) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) r[e] = tp[((long)k * 9 + e) * 64];
+#pragma unroll
+        for (int e = 0; e < 26; ++e) r[9 + e] = gp[((long)k * 26 + e) * 64];
+      }
+    };
+    auto load_pose = [&](int k, sv2 (&r)[4]) {
+      if (k < n) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = tp[((long)k * 9 + e) * 64];
+      }
+    };
+    load_ops(0, ra);
+#pragma unroll
+    for (int e = 0; e < 35; ++e) bx[0][e][lane] = ra[e];
+    load_ops(1, ra);   // written during interval 0
+    load_pose(1, pa);  // written during interval 0, read by Z in interval 1
+    __syncthreads();
+    auto knot = [&](int i, sv2 (&rc)[35], sv2 (&rn)[35], sv2 (&pc)[4], sv2 (&pn)[4]) {
+      load_ops(i + 2, rn);   // consumed by X in interval i + 2
+      load_pose(i + 2, pn);  // consumed by Z in interval i + 2
+      if (i + 1 < n) {
+#pragma unroll
+        for (int e = 0; e < 35; ++e) bx[(i + 1) & 1][e][lane] = rc[e];  // knot i + 1
+#pragma unroll
+        for (int e = 0; e < 4; ++e) by[(i + 1) & 1][e][lane] = pc[e];   // nominal pose of knot i + 1
+      }
+      __syncthreads();
+    };
+    for (int i = 0; i < n; i += 2) {
+      knot(i, ra, rb, pa, pb);
+      if (i + 1 < n) knot(i + 1, rb, ra, pb, pa);
+    }
+    return;
+  }
+
+  S t[3], q[4], v[6];
+  {
+    S p0[18];
+    load_knot<true>(traj, 0, 18, p0);
+    t[0] = p0[1]; t[1] = p0[2]; t[2] = p0[3];
+    q[0] = p0[5]; q[1] = p0[6]; q[2] = p0[7]; q[3] = p0[4];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) v[a] = p0[8 + a];
+    if (role == 2) {
+      // Log of knot 0 (the rollout starts on the nominal trajectory's first state: exactly zero)
+      S td[3], th[3], cj;
+      const S qn[4] = {p0[5], p0[6], p0[7], p0[4]};
+      se3_rminus_part1(t, q, p0 + 1, qn, td, th, cj);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        shZ[0][a][lane] = td[a];
+        shZ[0][3 + a][lane] = th[a];
+      }
+      shZ[0][6][lane] = cj;
+      if (lane == 0) zflag = 0;
+    }
+    if (role == 1 && live) {
+      const S po[8] = {0, t[0], t[1], t[2], q[3], q[0], q[1], q[2]};
+#pragma unroll
+      for (int e = 1; e < 8; ++e) out[knot_elem<true>(0, e, 18)] = po[e];
+    }
+  }
+  __syncthreads();
+
+  if (role == 0) {
+    // ------------------------------------------------------------------ X: control + velocity
+    const S alpha = (S)st.alpha[bs];
+    for (int i = 0; i < n; ++i) {
+      const bool more = (i + 1 < n);
+      S pt[18], g[52];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        const sv2 w = bx[i & 1][e][lane];
+        pt[2 * e] = w[0];
+        pt[2 * e + 1] = w[1];
+      }
+#pragma unroll
+      for (int e = 0; e < 26; ++e) {
+        const sv2 w = bx[i & 1][9 + e][lane];
+        g[2 * e] = w[0];
+        g[2 * e + 1] = w[1];
+      }
+      if (i > 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) q[a] = shT[i & 1][3 + a][lane];
+      }
+      S dx[12];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) dx[6 + a] = v[a] - pt[8 + a];
+      // wait for the Log of knot i (bounded: a lost flag must not hang the wave)
+      if (i > 0) {
+        int spins = 0;
+        while (__hip_atomic_load(&zflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < i && ++spins < (1 << 24)) {
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      S td[3], th[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        td[a] = shZ[i & 1][a][lane];
+        th[a] = shZ[i & 1][3 + a][lane];
+      }
+      const S cj = shZ[i & 1][6][lane];
+      se3_rminus_part2(td, th, cj, dx);
+      dx[3] = th[0]; dx[4] = th[1]; dx[5] = th[2];
+      S u[4];
+      control_law(pt, g, alpha, dx, u);
+      if (live) {
+        out[knot_elem<true>(i, 0, 18)] = pt[0];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) out[knot_elem<true>(i, 8 + a, 18)] = v[a];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) out[knot_elem<true>(i, 14 + a, 18)] = u[a];
+      }
+      if (more) {
+        S acc[6];
+        body_acceleration_fast(c, q, v, u, acc);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          v[a] = v[a] + c.dt * acc[a];
+          shV[(i + 1) & 1][a][lane] = v[a];
+        }
+      }
+      __syncthreads();
+    }
+  } else if (role == 1) {
+    // ------------------------------------------------------------------ Y: compose
+    for (int i = 0; i < n; ++i) {
+      const bool more = (i + 1 < n);
+      if (more) {
+        S tau[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) tau[a] = c.dt * v[a];  // pose integrates with the OLD velocity
+        se3_rplus_fast(t, q, tau);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) shT[(i + 1) & 1][a][lane] = t[a];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) shT[(i + 1) & 1][3 + a][lane] = q[a];
+        if (live) {
+          const S po[8] = {0, t[0], t[1], t[2], q[3], q[0], q[1], q[2]};
+#pragma unroll
+          for (int e = 1; e < 8; ++e) out[knot_elem<true>(i + 1, e, 18)] = po[e];
+        }
+      }
+      __syncthreads();
+      if (more) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v[a] = shV[(i + 1) & 1][a][lane];
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------ Z: Log
+    for (int i = 0; i < n; ++i) {
+      if (i > 0) {
+        S tk[3], qk[4], pnm[8];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) tk[a] = shT[i & 1][a][lane];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) qk[a] = shT[i & 1][3 + a][lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const sv2 w = by[i & 1][e][lane];  // nominal pose of knot i
+          pnm[2 * e] = w[0];
+          pnm[2 * e + 1] = w[1];
+        }
+        S td[3], th[3], cj;
+        const S qn[4] = {pnm[5], pnm[6], pnm[7], pnm[4]};
+        se3_rminus_part1(tk, qk, pnm + 1, qn, td, th, cj);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          shZ[i & 1][a][lane] = td[a];
+          shZ[i & 1][3 + a][lane] = th[a];
+        }
+        shZ[i & 1][6][lane] = cj;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&zflag, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_accept: thread b.  Cost of the candidate, acceptance, convergence (ilqr.hh:70-84, 174-194)
 // ---------------------------------------------------------------------------------------------
 __global__ void k_accept(SolveParams p, BatchState st, int B, int n, int ls_only) {

@@ -239,6 +239,9 @@ def test_two_wave_rollout_matches_single_wave():
         three = capi.from_config(cfg, single_wave_rollout=2)   # pair + loader wave (k_rollout3)
         np.testing.assert_allclose(three.forward_sim(trajs, gains, alpha), one.forward_sim(trajs, gains, alpha),
                                    rtol=1e-12, atol=1e-12)
+        four = capi.from_config(cfg, single_wave_rollout=4)    # compose / log / control / loader (k_rollout4)
+        np.testing.assert_allclose(four.forward_sim(trajs, gains, alpha), one.forward_sim(trajs, gains, alpha),
+                                   rtol=1e-12, atol=1e-12)
     cfg = pb.config2(B=96, N=40)
     a, b = capi.from_config(cfg).solve_batch(cfg["init"]), capi.from_config(cfg, single_wave_rollout=True).solve_batch(cfg["init"])
     np.testing.assert_allclose(a["traj"], b["traj"], atol=1e-8)
