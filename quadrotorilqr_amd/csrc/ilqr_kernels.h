@@ -1331,6 +1331,8 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
     }
   } else {
     // ------------------------------------------------------------------ Y: pose
+    RolloutSeries<S> sr;  // the series coefficients, in vector registers for the whole loop
+    sr.load();
 #ifdef QILQR_STAMPS
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
@@ -1350,11 +1352,11 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
         for (int a = 0; a < 6; ++a) tau[a] = c.dt * v[a];  // pose integrates with the OLD velocity
         QKEEP(pnm[7]);
         QSTAMP(0);  // Y: nominal pose from LDS
-        se3_rplus_fast(t, q, tau);
+        se3_rplus_fast(t, q, tau, sr);
         QKEEP(t[0]); QKEEP(q[3]);
         QSTAMP(1);  // Y: T <- T Exp(dt v)
         const S qn[4] = {pnm[5], pnm[6], pnm[7], pnm[4]};
-        se3_rminus_part1(t, q, pnm + 1, qn, td, th, cj);
+        se3_rminus_part1(t, q, pnm + 1, qn, td, th, cj, sr);
         QKEEP(td[0]); QKEEP(th[2]); QKEEP(cj);
         QSTAMP(2);  // Y: pose part of x (-) xnom
 #pragma unroll
@@ -1558,13 +1560,15 @@ __global__ __launch_bounds__(256) void k_rollout4(ModelConsts<S> c, BatchState s
     }
   } else if (role == 1) {
     // ------------------------------------------------------------------ Y: compose
+    RolloutSeries<S> sr;
+    sr.load();
     for (int i = 0; i < n; ++i) {
       const bool more = (i + 1 < n);
       if (more) {
         S tau[6];
 #pragma unroll
         for (int a = 0; a < 6; ++a) tau[a] = c.dt * v[a];  // pose integrates with the OLD velocity
-        se3_rplus_fast(t, q, tau);
+        se3_rplus_fast(t, q, tau, sr);
 #pragma unroll
         for (int a = 0; a < 3; ++a) shT[(i + 1) & 1][a][lane] = t[a];
 #pragma unroll
@@ -1583,6 +1587,8 @@ __global__ __launch_bounds__(256) void k_rollout4(ModelConsts<S> c, BatchState s
     }
   } else {
     // ------------------------------------------------------------------ Z: Log
+    RolloutSeries<S> sr;
+    sr.load();
     for (int i = 0; i < n; ++i) {
       if (i > 0) {
         S tk[3], qk[4], pnm[8];
@@ -1598,7 +1604,7 @@ __global__ __launch_bounds__(256) void k_rollout4(ModelConsts<S> c, BatchState s
         }
         S td[3], th[3], cj;
         const S qn[4] = {pnm[5], pnm[6], pnm[7], pnm[4]};
-        se3_rminus_part1(tk, qk, pnm + 1, qn, td, th, cj);
+        se3_rminus_part1(tk, qk, pnm + 1, qn, td, th, cj, sr);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           shZ[i & 1][a][lane] = td[a];

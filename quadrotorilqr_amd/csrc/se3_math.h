@@ -840,8 +840,9 @@ QILQR_HD void quat_rotate(const T q[4], const T v[3], T o[3]) {
 // tau = Log(X^-1 Y), same value as se3_rminus, in two parts so that the rollout can run them in
 // two cooperating wavefronts: part 1 (pose -> td, theta, c) needs only poses; part 2 applies
 // Jl^-1(theta) to td.
-template <typename T>
-QILQR_HD void se3_rminus_part1(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T td[3], T th[3], T &c) {
+template <typename T, typename SR>
+QILQR_HD void se3_rminus_part1(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T td[3], T th[3], T &c,
+                               const SR &sr) {
 #if defined(__clang__)
 #pragma clang fp contract(off)  // x (-) x must be exactly zero (cost_test.cc:27-39)
 #endif
@@ -862,7 +863,7 @@ QILQR_HD void se3_rminus_part1(const T ty[3], const T qy[4], const T tx[3], cons
     coeff = T(2);
   } else if (qd[3] > T(0) && s2 <= Series<T>::LOG_MAX) {
     const T y4 = (s2 * s2) * (s2 * s2);
-    coeff = T(2) * (poly8(Series<T>::asin_lo, s2) + poly8(Series<T>::asin_hi, s2) * (y4 * y4));
+    coeff = T(2) * (poly8(sr.asin_lo, s2) + poly8(sr.asin_hi, s2) * (y4 * y4));
   } else {
     const T s = sqrt(s2);
     const T w = qd[3];
@@ -873,7 +874,7 @@ QILQR_HD void se3_rminus_part1(const T ty[3], const T qy[4], const T tx[3], cons
   if (!(th2 > Eps<T>::manif)) {
     c = T(0);
   } else if (th2 <= Series<T>::JINV_MAX) {
-    c = poly8(Series<T>::jinv_c, th2);
+    c = poly8(sr.jinv_c, th2);
   } else {
     // manif's closed form, evaluated as manif does (it is ill-conditioned near theta = pi, where
     // only the same evaluation order reproduces the same digits)
@@ -881,6 +882,10 @@ QILQR_HD void se3_rminus_part1(const T ty[3], const T qy[4], const T tx[3], cons
     c = T(1) / th2 - (T(1) + cos(theta)) / (T(2) * theta * sin(theta));
   }
   th[0] = qd[0] * coeff; th[1] = qd[1] * coeff; th[2] = qd[2] * coeff;
+}
+template <typename T>
+QILQR_HD void se3_rminus_part1(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T td[3], T th[3], T &c) {
+  se3_rminus_part1(ty, qy, tx, qx, td, th, c, Series<T>());
 }
 template <typename T>
 QILQR_HD void se3_rminus_part2(const T td[3], const T th[3], T c, T rho[3]) {
@@ -894,6 +899,12 @@ QILQR_HD void se3_rminus_part2(const T td[3], const T th[3], T c, T rho[3]) {
   rho[1] = td[1] - T(0.5) * w1[1] + c * w2[1];
   rho[2] = td[2] - T(0.5) * w1[2] + c * w2[2];
 }
+template <typename T, typename SR>
+QILQR_HD void se3_rminus_fast(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T tau[6], const SR &sr) {
+  T td[3], c;
+  se3_rminus_part1(ty, qy, tx, qx, td, tau + 3, c, sr);
+  se3_rminus_part2(td, tau + 3, c, tau);
+}
 template <typename T>
 QILQR_HD void se3_rminus_fast(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T tau[6]) {
   T td[3], c;
@@ -902,18 +913,18 @@ QILQR_HD void se3_rminus_fast(const T ty[3], const T qy[4], const T tx[3], const
 }
 
 // (t, q) <- (t, q) * Exp(tau), same value as se3_rplus
-template <typename T>
-QILQR_HD void se3_rplus_fast(T t[3], T q[4], const T tau[6]) {
+template <typename T, typename SR>
+QILQR_HD void se3_rplus_fast(T t[3], T q[4], const T tau[6], const SR &sr) {
   const T *rho = tau, *th = tau + 3;
   const T th2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2];
   T ch, sh, a, b;
   if (!(th2 > Eps<T>::manif)) {
     ch = T(1); sh = T(0.5); a = T(0.5); b = T(0);
   } else if (th2 <= Series<T>::EXP_MAX) {
-    ch = poly8(Series<T>::cos_half, th2);
-    sh = poly8(Series<T>::sin_half_over, th2);
-    a = poly8(Series<T>::jac_a, th2);
-    b = poly8(Series<T>::jac_b, th2);
+    ch = poly8(sr.cos_half, th2);
+    sh = poly8(sr.sin_half_over, th2);
+    a = poly8(sr.jac_a, th2);
+    b = poly8(sr.jac_b, th2);
   } else {
     const T theta = sqrt(th2);
     const T ha = T(0.5) * theta;
@@ -940,6 +951,30 @@ QILQR_HD void se3_rplus_fast(T t[3], T q[4], const T tau[6]) {
   t[0] += Rp[0]; t[1] += Rp[1]; t[2] += Rp[2];
   q[0] = qo[0]; q[1] = qo[1]; q[2] = qo[2]; q[3] = qo[3];
 }
+
+template <typename T>
+QILQR_HD void se3_rplus_fast(T t[3], T q[4], const T tau[6]) {
+  se3_rplus_fast(t, q, tau, Series<T>());
+}
+// The series coefficients the pose chain of the rollout needs, as values held in vector registers for
+// the whole loop.  As compile-time constants they are 112 scalar registers' worth: the compiler parked
+// them in spare VGPR lanes and fetched them back with two v_readlane each, every knot (a sixth of the
+// pose wave's knot).  load() makes them opaque run-time values once.
+template <typename T>
+struct RolloutSeries {
+  T cos_half[8], sin_half_over[8], jac_a[8], jac_b[8], asin_lo[8], asin_hi[8], jinv_c[8];
+  QILQR_HD void load() {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      cos_half[k] = Series<T>::cos_half[k]; sin_half_over[k] = Series<T>::sin_half_over[k];
+      jac_a[k] = Series<T>::jac_a[k]; jac_b[k] = Series<T>::jac_b[k];
+      asin_lo[k] = Series<T>::asin_lo[k]; asin_hi[k] = Series<T>::asin_hi[k];
+      jinv_c[k] = Series<T>::jinv_c[k];
+      QILQR_PIN(cos_half[k]); QILQR_PIN(sin_half_over[k]); QILQR_PIN(jac_a[k]); QILQR_PIN(jac_b[k]);
+      QILQR_PIN(asin_lo[k]); QILQR_PIN(asin_hi[k]); QILQR_PIN(jinv_c[k]);
+    }
+  }
+};
 
 // body acceleration without forming the whole rotation matrix (only R^T e_z is needed)
 template <typename T>
@@ -992,13 +1027,15 @@ QILQR_HD void rollout_problem(const ModelConsts<T> &c, const T *traj, const T *g
   T v[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) v[i] = pt[8 + i];
+  RolloutSeries<T> sr;  // series coefficients in registers for the whole loop
+  sr.load();
   for (int i = 0; i < n; ++i) {
     load_knot<TILED>(traj, i, 18, pt);
     load_knot<TILED>(gains, i, 52, g);
     // dx = state (-) x_i
     T dx[12];
     const T qi[4] = {pt[5], pt[6], pt[7], pt[4]};
-    se3_rminus_fast(t, q, pt + 1, qi, dx);
+    se3_rminus_fast(t, q, pt + 1, qi, dx, sr);
 #pragma unroll
     for (int a = 0; a < 6; ++a) dx[6 + a] = v[a] - pt[8 + a];
     T u[4];
@@ -1012,7 +1049,7 @@ QILQR_HD void rollout_problem(const ModelConsts<T> &c, const T *traj, const T *g
       body_acceleration_fast(c, q, v, u, acc);
 #pragma unroll
       for (int a = 0; a < 6; ++a) tau[a] = c.dt * v[a];  // pose integrates with the OLD velocity
-      se3_rplus_fast(t, q, tau);
+      se3_rplus_fast(t, q, tau, sr);
 #pragma unroll
       for (int a = 0; a < 6; ++a) v[a] = v[a] + c.dt * acc[a];
     }
