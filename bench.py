@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="HIP events around every kernel, not only the two candidates for dominant kernel")
     ap.add_argument("--rollout", type=int, default=-1, help="rollout kernel: 0 pair, 1 single wave, 2 pair + loader (default: library default)")
     ap.add_argument("--backward", type=int, default=0, help="diagnostic: backward kernel (qilqr_device_config.force_general: 0 automatic, 1 general, 2 one wavefront per trajectory)")
+    ap.add_argument("--streams", type=int, default=0, help="sub-batches on their own streams (qilqr_device_config.streams; 0 automatic)")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP events around the kernels (roofline = null)")
     args = ap.parse_args()
 
@@ -65,7 +66,7 @@ def main():
     B, N = args.batch, args.knots
     cfg = pb.config2(B=B, N=N, seed=2, b0=rank * B)  # counter-based generator: shard-independent
     solver = capi.from_config(cfg, device=dev.index, profile=(0 if args.no_profile else (2 if args.profile_all else 1)), sync_every=args.sync_every,
-                              force_general=args.backward, **({} if args.rollout < 0 else dict(single_wave_rollout=args.rollout)))
+                              force_general=args.backward, streams=args.streams, **({} if args.rollout < 0 else dict(single_wave_rollout=args.rollout)))
 
     init = torch.from_numpy(cfg["init"]).to(dev)
     # two sets of output buffers, used alternately: with N > 1 the gather of step s (RCCL, torch's stream) runs

@@ -82,6 +82,9 @@ typedef struct {
   int32_t precision; /* 0: fp64 everywhere (reference parity).  1: mixed: trajectories, gains and knot records
                         stored in fp32, rollout and linearisation computed in fp32, Riccati recursion on the fp64
                         matrix core, cost sums / Armijo / convergence tests in fp64 (BASELINE.json configs[2]) */
+  int32_t streams; /* batch solves with sync_every > 1: number of contiguous sub-batches that run their rounds on
+                      their own HIP streams (their kernels are bound by different resources and overlap);
+                      0 = automatic (2 from 4096 trajectories on, else 1: see auto_parts in ilqr_capi.hip), at most 8 */
 } qilqr_device_config;
 
 /* A handle owns its device workspace and stream: use it from one thread at a time (different handles are

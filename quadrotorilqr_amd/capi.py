@@ -53,7 +53,8 @@ class Options(C.Structure):
 
 class DeviceConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("profile", C.c_int32), ("sync_every", C.c_int32),
-                ("force_general", C.c_int32), ("single_wave_rollout", C.c_int32), ("precision", C.c_int32)]
+                ("force_general", C.c_int32), ("single_wave_rollout", C.c_int32), ("precision", C.c_int32),
+                ("streams", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -113,7 +114,7 @@ class QuadrotorILQRBatch:
 
     def __init__(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired,
                  dt_s, options, device=0, profile=0, sync_every=1, force_general=False,
-                 single_wave_rollout=False, precision="f64"):
+                 single_wave_rollout=False, precision="f64", streams=0):
         lib = load()
         m = Model()
         m.mass_kg = mass_kg
@@ -139,7 +140,7 @@ class QuadrotorILQRBatch:
         self.options = dict(options)
         self.desired = _d(desired).reshape(-1, KNOT)
         dc = DeviceConfig(int(device), int(profile), int(sync_every), int(force_general),
-                          int(single_wave_rollout), {"f64": 0, "f32": 1}[precision])
+                          int(single_wave_rollout), {"f64": 0, "f32": 1}[precision], int(streams))
         self._h = C.c_void_p()
         rc = lib.qilqr_create(C.byref(m), _p(Q), _p(R), _p(self.desired), C.c_int32(len(self.desired)),
                               C.c_double(dt_s), C.byref(o), C.byref(dc), C.byref(self._h))

@@ -63,7 +63,16 @@ struct qilqr_solver {
   BatchState st{};
   std::vector<void *> allocs;
   int *h_counters = nullptr;  // pinned, 16 slots
-  unsigned long long *h_active = nullptr;  // pinned + mapped, 8 words written by k_linearize (BatchState::host_active)
+  // pinned + mapped, 8 words per part written by k_linearize (BatchState::host_active): part 0 is the
+  // whole batch on the main stream, parts 1..MAX_PARTS are sub-batches on their own streams
+  unsigned long long *h_active = nullptr;
+  unsigned long long *d_active = nullptr;  // the same memory as the device sees it
+  static constexpr int MAX_PARTS = 8;
+  hipStream_t part_stream[MAX_PARTS] = {};
+  hipEvent_t part_done[MAX_PARTS] = {};
+  hipEvent_t main_ready = nullptr;
+  int *d_part_counters = nullptr;  // [MAX_PARTS][4]
+  long total_B = 0;                // trajectories in flight on the device in this call (kernel choices go by it)
   double *io_aos = nullptr;         // device scratch in the plain [B][n][W] layout (W <= 52), for host I/O
   void *desired_tiled = nullptr;    // per-problem desired trajectories, tiled (allocated on first use)
   // profiling
@@ -224,6 +233,7 @@ int begin_batch(qilqr_solver *s, long B, long n, const double *d_desired_batch) 
     s->st.desired = s->d_desired;
     s->st.desired_tiled = 0;
   }
+  s->total_B = B;
   launch(s, K_OTHER, k_begin, dim3(cdiv(B, 256)), dim3(256), s->st, (int)B);
   return QILQR_OK;
 }
@@ -260,7 +270,7 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
 #define QILQR_LAUNCH_BWD(SYM, S)                                                                              \
   launch(s, K_BACKWARD, (k_backward<SYM, S>), dim3((unsigned)B), dim3(64), s->consts, s->params, s->st, \
                      (int)B, (int)n, force)
-  if (s->symmetric && s->dev.force_general != 2 && B <= 8192) {
+  if (s->symmetric && s->dev.force_general != 2 && std::max(B, s->total_B) <= 8192) {
     // two cooperating wavefronts per trajectory (matrix recursion / gradient recursion + operand streaming):
     // shortens one trajectory's chain; above ~8 trajectories per SIMD the chip is bound by the matrix pipe and
     // the one-wavefront kernel gives 2% more throughput
@@ -283,7 +293,7 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
 int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
   // the cooperating pair shortens one trajectory's chain; with more tiles than the chip has room for
   // pairs (1 pair per SIMD at 256 VGPRs) the single-wave form gives the higher throughput
-  if (s->dev.single_wave_rollout == 1 || B > 16384) {
+  if (s->dev.single_wave_rollout == 1 || std::max(B, s->total_B) > 16384) {
     if (s->f32)
       launch(s, K_ROLLOUT, k_rollout<float>, dim3(cdiv(B, 64)), dim3(64), s->constsf, s->st, (int)B, (int)n,
                          need_flag);
@@ -397,6 +407,141 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
   return QILQR_OK;
 }
 
+// ---- sub-batches on their own streams
+// The three kernels of a round are bound by three different things (serial latency and the matrix pipe,
+// serial latency at a handful of wavefronts, HBM writes), and one stream runs them one after the other.
+// A batch is therefore cut into `parts` contiguous ranges of 64-trajectory tiles, each with its own
+// stream, counters and host hand-off words, whose rounds run independently: while one part is in its
+// rollout another is in its backward pass and a third writes its knot records.  Trajectories are
+// independent, so the results are those of the single-stream solve.
+struct Part {
+  hipStream_t stream;
+  BatchState st;  // the solver's workspace seen from the part's first trajectory
+  long nb;        // trajectories in the part
+  unsigned long long *h_active;
+  bool done;
+};
+// the workspace of trajectories [b0, b0 + nb), b0 a multiple of 64
+BatchState slice_state(const qilqr_solver *s, long b0, long n, int part) {
+  const BatchState &w = s->st;
+  BatchState v = w;
+  const size_t es = s->f32 ? sizeof(float) : sizeof(double);
+  auto adv = [&](const void *p, long elems) { return (void *)((char *)p + (size_t)elems * es); };
+  for (int k = 0; k < 2; ++k) {
+    v.traj[k] = adv(w.traj[k], knot_base<true>(b0, n, 18));
+    v.lin[k] = adv(w.lin[k], rec_base(b0, n, w.layout.stride));
+    v.knot_cost[k] = w.knot_cost[k] + cost_index(b0, 0, n);
+  }
+  v.gains = adv(w.gains, knot_base<true>(b0, n, 52));
+  if (w.desired_tiled) v.desired = adv(w.desired, knot_base<true>(b0, n, 18));
+  v.cur = w.cur + b0; v.cost = w.cost + b0; v.prev_cost = w.prev_cost + b0; v.terms = w.terms + 2 * b0;
+  v.alpha = w.alpha + b0; v.trial = w.trial + b0; v.flags = w.flags + b0; v.status = w.status + b0;
+  v.iters = w.iters + b0; v.n_bwd = w.n_bwd + b0; v.n_fwd = w.n_fwd + b0;
+  v.counters = s->d_part_counters + 4 * part;
+  v.host_active = s->d_active + 8 * (1 + part);
+  if (w.cost_hist) v.cost_hist = w.cost_hist + b0 * w.hist_cap;
+  v.dump = adv(w.dump, 4 * b0);
+  if (w.stamps) v.stamps = w.stamps + 8 * b0;
+  return v;
+}
+// launch_* work on s->st / s->stream: point them at a part for the duration of a scope
+struct PartScope {
+  qilqr_solver *s;
+  BatchState st0;
+  hipStream_t stream0;
+  PartScope(qilqr_solver *s_, const Part &p) : s(s_), st0(s_->st), stream0(s_->stream) {
+    s->st = p.st;
+    s->stream = p.stream;
+  }
+  ~PartScope() {
+    s->st = st0;
+    s->stream = stream0;
+  }
+};
+int auto_parts(const qilqr_solver *s, long B) {
+  const long tiles = (B + 63) / 64;
+  // Measured (MI355X, N = 100): up to a few thousand trajectories every kernel is latency-bound and sharing
+  // SIMDs with another part's kernels only slows both (B = 1024: 138k solves/s on one stream, 136k on two,
+  // 132k on four); from about 4096 on two parts gain 4-5% (B = 8192: 335k -> 352k, B = 65536: 499k -> 518k).
+  // More than two need more hardware queues than HIP creates by default (GPU_MAX_HW_QUEUES).
+  int want = s->dev.streams > 0 ? s->dev.streams : (B >= 4096 ? 2 : 1);
+  if (want > qilqr_solver::MAX_PARTS) want = qilqr_solver::MAX_PARTS;
+  while (want > 1 && tiles < 2 * want) --want;  // at least two tiles per part
+  return want;
+}
+// The outer loop of ILQR::solve for a batch cut into parts (free-running rounds only).  On return the
+// main stream waits for every part; the caller enqueues its own work there.
+int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
+  int rc;
+  const long tiles = (B + 63) / 64;
+  std::vector<Part> parts;
+  for (int p = 0; p < nparts; ++p) {
+    const long t0 = tiles * p / nparts, t1 = tiles * (p + 1) / nparts;
+    const long b0 = t0 * 64, b1 = std::min(t1 * 64, B);
+    Part part;
+    part.stream = s->part_stream[p];
+    part.st = slice_state(s, b0, n, p);
+    part.nb = b1 - b0;
+    part.h_active = s->h_active + 8 * (1 + p);
+    part.done = false;
+    for (int k = 0; k < 8; ++k) part.h_active[k] = 0;
+    parts.push_back(part);
+  }
+  // the parts start when the main stream has tiled the inputs
+  HIP_TRY(hipEventRecord(s->main_ready, s->stream));
+  for (auto &part : parts) HIP_TRY(hipStreamWaitEvent(part.stream, s->main_ready, 0));
+  for (auto &part : parts) {
+    PartScope scope(s, part);
+    if ((rc = launch_linearize(s, part.nb, n, 0, 0))) return rc;
+    launch(s, K_OTHER, k_init, dim3(cdiv(part.nb, 64)), dim3(64), s->params, s->st, (int)part.nb, (int)n);
+  }
+  int remaining = nparts;
+  if (0.0 < s->params.max_iters) {
+    const double bound =
+        (std::fmin(s->params.max_iters, 1e7) + 1.0) * ((double)std::max(s->params.ls_max_iters, 1) + 1.0);
+    const long max_rounds = (long)std::fmin(bound, 2e9);
+    const int lag = std::max(1, std::min(s->dev.sync_every, 6));
+    for (long round = 0; round < max_rounds && remaining > 0; ++round) {
+      for (auto &part : parts) {
+        if (part.done) continue;
+        PartScope scope(s, part);
+        if ((rc = launch_backward(s, part.nb, n, 0))) return rc;
+        if ((rc = launch_rollout(s, part.nb, n, F_SEARCH))) return rc;
+        if ((rc = launch_linearize(s, part.nb, n, 1, F_SEARCH, (int)(round & 0x3fffffff)))) return rc;
+      }
+      if (round < lag) continue;
+      const long old = round - lag;
+      const unsigned tag = (unsigned)((old & 0x3fffffff) + 1);
+      for (auto &part : parts) {
+        if (part.done) continue;
+        unsigned long long v;
+        for (long spins = 0;; ++spins) {
+          v = __atomic_load_n(&part.h_active[old & 7], __ATOMIC_ACQUIRE);
+          if ((unsigned)(v >> 32) == tag) break;
+          if ((spins & 1023) == 1023) {
+            const hipError_t q = hipStreamQuery(part.stream);
+            if (q != hipErrorNotReady) {
+              v = __atomic_load_n(&part.h_active[old & 7], __ATOMIC_ACQUIRE);
+              if ((unsigned)(v >> 32) == tag) break;
+              return fail(QILQR_ERR_HIP, std::string("a round never reported its active count: ") + hipGetErrorString(q));
+            }
+          }
+          __builtin_ia32_pause();
+        }
+        if ((unsigned)v == 0) {
+          part.done = true;
+          --remaining;
+        }
+      }
+    }
+  }
+  for (int p = 0; p < nparts; ++p) {
+    HIP_TRY(hipEventRecord(s->part_done[p], parts[p].stream));
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->part_done[p], 0));
+  }
+  return QILQR_OK;
+}
+
 int gather(qilqr_solver *s, long B, long n, double *d_traj, double *d_cost, int *d_status, int *d_iters,
            int *d_bwd, int *d_fwd) {
   if (s->f32)
@@ -423,7 +568,7 @@ int check_quaternions(const double *traj, long count, const char *what) {
 
 extern "C" {
 
-int qilqr_abi_version(void) { return 1; }
+int qilqr_abi_version(void) { return 2; }
 
 const char *qilqr_last_error(void) { return g_last_error.c_str(); }
 
@@ -444,7 +589,7 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(QILQR_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
-  qilqr_device_config dc = {0, 0, 1, 0, 0, 0};
+  qilqr_device_config dc = {0, 0, 1, 0, 0, 0, 0};
   if (dev) dc = *dev;
   if (dc.device < 0 || dc.device >= ndev) return fail(QILQR_ERR_INVALID_ARG, "bad device ordinal");
   if (dc.sync_every < 1) dc.sync_every = 1;
@@ -490,10 +635,18 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   }
   if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_counters, sizeof(int) * 16, hipHostMallocDefault);
   if (e == hipSuccess)
-    e = hipHostMalloc((void **)&s->h_active, sizeof(unsigned long long) * 8, hipHostMallocMapped | hipHostMallocCoherent);
+    e = hipHostMalloc((void **)&s->h_active, sizeof(unsigned long long) * 8 * (1 + qilqr_solver::MAX_PARTS),
+                      hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) {
-    for (int k = 0; k < 8; ++k) s->h_active[k] = 0;
-    e = hipHostGetDevicePointer((void **)&s->st.host_active, s->h_active, 0);
+    for (int k = 0; k < 8 * (1 + qilqr_solver::MAX_PARTS); ++k) s->h_active[k] = 0;
+    e = hipHostGetDevicePointer((void **)&s->d_active, s->h_active, 0);
+    s->st.host_active = s->d_active;
+  }
+  if (e == hipSuccess) e = hipMalloc((void **)&s->d_part_counters, sizeof(int) * 4 * qilqr_solver::MAX_PARTS);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->main_ready, hipEventDisableTiming);
+  for (int k = 0; k < qilqr_solver::MAX_PARTS && e == hipSuccess; ++k) {
+    e = hipStreamCreateWithFlags(&s->part_stream[k], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->part_done[k], hipEventDisableTiming);
   }
   if (e == hipSuccess) e = hipMalloc(&s->d_consts, s->f32 ? sizeof(ModelConsts<float>) : sizeof(ModelConsts<double>));
   if (e == hipSuccess)
@@ -530,6 +683,12 @@ void qilqr_destroy(qilqr_solver *s) {
   if (s->d_consts) (void)hipFree(s->d_consts);
   if (s->h_counters) (void)hipHostFree(s->h_counters);
   if (s->h_active) (void)hipHostFree(s->h_active);
+  if (s->d_part_counters) (void)hipFree(s->d_part_counters);
+  if (s->main_ready) (void)hipEventDestroy(s->main_ready);
+  for (int k = 0; k < qilqr_solver::MAX_PARTS; ++k) {
+    if (s->part_done[k]) (void)hipEventDestroy(s->part_done[k]);
+    if (s->part_stream[k]) (void)hipStreamDestroy(s->part_stream[k]);
+  }
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -600,7 +759,12 @@ int qilqr_solve_batch_device(qilqr_solver *s, const double *d_init, const double
   int rc = begin_batch(s, B, n, d_desired_batch);
   if (rc) return rc;
   if ((rc = to_tiled(s, d_init, s->st.traj[0], B, n, 18))) return rc;
-  if ((rc = run_solve(s, B, n, s->dev.sync_every, [] { return QILQR_OK; }, false))) return rc;
+  const int nparts = (s->dev.sync_every > 1) ? auto_parts(s, B) : 1;
+  if (nparts > 1) {
+    if ((rc = run_solve_parts(s, B, n, nparts))) return rc;
+  } else if ((rc = run_solve(s, B, n, s->dev.sync_every, [] { return QILQR_OK; }, false))) {
+    return rc;
+  }
   if ((rc = gather(s, B, n, d_out_traj, d_out_cost, d_out_status, d_out_iters, d_out_n_bwd, d_out_n_fwd)))
     return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
