@@ -270,7 +270,7 @@ __device__ __forceinline__ void gather_rows(double x, double r[4]) {
 // through the scalar registers)
 template <int SRC>
 __device__ __forceinline__ double row_bcast(double x) {
-  return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + SRC, 0xf, 0xf, false);
+  return __builtin_amdgcn_mov_dpp(x, 0x150 + SRC, 0xf, 0xf, false);  // no `old` operand: nothing to zero or copy first
 }
 template <int A>
 __device__ __forceinline__ void bcast_quu_row(const double col[4], double ghat, double Quu[16], double Qu[4]) {
