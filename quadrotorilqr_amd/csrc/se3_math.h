@@ -502,7 +502,8 @@ QILQR_HD constexpr RecLayout make_layout(bool sym, bool ur_zero) {
 // Device layout of the knot records: [b][knot i][stride], one contiguous record per knot.
 // (A layout with the 64 trajectories of a tile interleaved in 128-byte chunks, written out coalesced
 // through LDS, was measured: k_linearize is bound by the bytes it writes, not by how they are
-// addressed, and the padding such a layout needs made both it and k_backward slower.)
+// addressed, and the padding such a layout needs made both it and k_backward slower.  Placing the 64
+// records of a wavefront next to each other ([tile][knot][lane][stride]) changes nothing either.)
 QILQR_HD long rec_base(long b, long n, int stride) { return b * n * stride; }
 QILQR_HD long rec_elem(long i, int k, int stride) { return i * stride + k; }
 QILQR_HD long rec_count(long B, long n, int stride) { return B * n * stride; }
