@@ -1,15 +1,19 @@
 // ilqr_kernels.h -- device kernels of the batched iLQR solver (gfx950 only).
 //
-// One outer "round" of the solver is four launches on one stream:
-//   k_backward   one wavefront per trajectory, fp64 MFMA Riccati recursion   (ilqr.hh:97-147)
-//   k_rollout    one lane per trajectory, closed-loop forward simulation     (ilqr.hh:149-172)
-//   k_linearize  one lane per knot: dynamics Jacobian blocks + cost differentials + knot cost
-//                of the candidate trajectory (quadrotor_model.cc:33-49, cost.hh:36-61)
-//   k_accept     one lane per trajectory: cost sum, Armijo test, convergence tests
-//                (ilqr.hh:61-84, 174-194)
+// One outer "round" of the solver is three launches, back to back on one stream:
+//   k_backward2 / k_backward   settles the previous candidate (cost sum, Armijo test, convergence tests:
+//                ilqr.hh:61-84, 174-194), then the Riccati recursion on the fp64 matrix core
+//                (ilqr.hh:97-147): a matrix wavefront and a gradient wavefront per trajectory
+//                (k_backward2), or one wavefront per trajectory (k_backward)
+//   k_rollout3 / k_rollout     closed-loop forward simulation (ilqr.hh:149-172): pose wave + control
+//                wave + loader wave per 64 trajectories, or one lane per trajectory in one wavefront
+//   k_linearize  two lanes per knot: dynamics Jacobian blocks / cost differentials + knot cost of the
+//                candidate trajectory (quadrotor_model.cc:33-49, cost.hh:36-61); also hands the
+//                count of still-active trajectories to the host (pinned memory)
+// (k_accept is the stand-alone acceptance step of the qilqr_line_search entry point.)
 // Every trajectory carries its own outer-iteration counter, step size and state machine, so
 // trajectories that are back-tracking and trajectories that already accepted a step advance
-// in the same round; the host only polls one counter of still-active trajectories.
+// in the same round; the host only reads one count of still-active trajectories, late.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
