@@ -70,8 +70,9 @@ typedef struct {
   int32_t device;   /* HIP device ordinal */
   int32_t profile;  /* start/stop HIP events attached to kernel dispatches.  0: off; 1: k_backward and k_rollout;
                        2: every kernel; 3: k_backward only; 4: k_rollout only */
-  int32_t sync_every; /* 1: the host waits for every round's count of active trajectories; k > 1: it reads the
-                         count k rounds late, i.e. keeps the stream k rounds ahead of the device (k <= 6) */
+  int32_t sync_every; /* 1: the host waits for every round's count of active trajectories; k > 1 (default 2 when no
+                         configuration is given): it reads the count k rounds late, i.e. keeps the stream k rounds
+                         ahead of the device (k <= 6).  The results do not depend on it. */
   int32_t force_general; /* backward kernel.  0: by the weights and the batch (symmetric Q, R and B <= 8192: k_backward2, two
                             wavefronts per trajectory); 1: the general kernel even when Q, R are symmetric; 2: the one-wavefront
                             kernel for symmetric weights (k_backward<true>) */

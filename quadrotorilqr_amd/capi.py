@@ -113,7 +113,7 @@ class QuadrotorILQRBatch:
     """ILQR<QuadrotorModel> (ilqr.hh:25-41) for batches of independent problems on one MI355X."""
 
     def __init__(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired,
-                 dt_s, options, device=0, profile=0, sync_every=1, force_general=False,
+                 dt_s, options, device=0, profile=0, sync_every=2, force_general=False,
                  single_wave_rollout=False, precision="f64", streams=0):
         lib = load()
         m = Model()

@@ -589,7 +589,7 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(QILQR_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
-  qilqr_device_config dc = {0, 0, 1, 0, 0, 0, 0};
+  qilqr_device_config dc = {0, 0, 2, 0, 0, 0, 0};
   if (dev) dc = *dev;
   if (dc.device < 0 || dc.device >= ndev) return fail(QILQR_ERR_INVALID_ARG, "bad device ordinal");
   if (dc.sync_every < 1) dc.sync_every = 1;
