@@ -29,7 +29,16 @@ def random_cfg(seed, n=25, dense=False, B=6):
     A = r.uniform(-1, 1, (3, 3))
     model = dict(mass_kg=1.3, inertia=A @ A.T + 3 * np.eye(3), arm_length_m=0.7,
                  torque_to_thrust_ratio_m=0.2, g_mpss=9.81)
-    if dense:
+    if dense == "qsym":   # symmetric Q (packed record layout) with a NON-symmetric R (general backward kernel)
+        Q = r.uniform(-1, 1, (12, 12))
+        Q = Q @ Q.T + 12 * np.eye(12)
+        R = r.uniform(-0.3, 0.3, (4, 4)) + 2 * np.eye(4)
+    elif dense == "sym":  # dense symmetric Q and R (two-wavefront backward kernel, 128-entry records)
+        Q = r.uniform(-1, 1, (12, 12))
+        Q = Q @ Q.T + 12 * np.eye(12)
+        R = r.uniform(-0.3, 0.3, (4, 4))
+        R = R + R.T + 2 * np.eye(4)
+    elif dense:
         Q = r.uniform(-1, 1, (12, 12))
         Q = Q @ Q.T + 12 * np.eye(12) + 0.3 * r.uniform(-1, 1, (12, 12))  # NOT symmetric
         R = r.uniform(-0.3, 0.3, (4, 4)) + 2 * np.eye(4)
@@ -133,7 +142,7 @@ def test_solve_finds_optimal_trajectory(fx):  # ilqr_test.cc:179-190
 
 
 # ------------------------------------------------------------------ per-pass parity on random inputs
-@pytest.mark.parametrize("seed,dense", [(11, False), (12, True), (13, True)])
+@pytest.mark.parametrize("seed,dense", [(11, False), (12, True), (13, True), (14, "qsym"), (15, "sym")])
 def test_passes_match_oracle(seed, dense):
     cfg = random_cfg(seed, dense=dense)
     s = capi.from_config(cfg)
