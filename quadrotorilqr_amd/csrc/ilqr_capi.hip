@@ -270,7 +270,22 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
 #define QILQR_LAUNCH_BWD(SYM, S)                                                                              \
   launch(s, K_BACKWARD, (k_backward<SYM, S>), dim3((unsigned)B), dim3(64), s->consts, s->params, s->st, \
                      (int)B, (int)n, force)
-  if (s->symmetric && s->dev.force_general != 2 && std::max(B, s->total_B) <= 8192) {
+  const long load_B = std::max(B, s->total_B);
+  // Which backward kernel (symmetric weights), by how many trajectories share the chip's 1024 SIMDs:
+  //   up to 640: k_backward2 (a matrix and a gradient wavefront per trajectory, each alone on its SIMD)
+  //   up to 4096: k_backward4 (one gradient wavefront per four trajectories: fewer co-resident waves;
+  //               80.5 vs 83.5 us at 1024, 114 vs 132 us at 2048, equal from 4096 on)
+  //   up to 8192: k_backward2; beyond: one wavefront per trajectory (the matrix pipe is the bound)
+  const bool want4 = s->dev.force_general == 4 || (s->dev.force_general == 0 && load_B > 640 && load_B < 4096);
+  if (s->symmetric && want4 && load_B <= 8192) {
+    // four matrix wavefronts + one gradient wavefront per four trajectories
+    if (s->f32)
+      launch(s, K_BACKWARD, k_backward4<float>, dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n,
+             force);
+    else
+      launch(s, K_BACKWARD, k_backward4<double>, dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B,
+             (int)n, force);
+  } else if (s->symmetric && s->dev.force_general != 2 && load_B <= 8192) {
     // two cooperating wavefronts per trajectory (matrix recursion / gradient recursion + operand streaming):
     // shortens one trajectory's chain; above ~8 trajectories per SIMD the chip is bound by the matrix pipe and
     // the one-wavefront kernel gives 2% more throughput

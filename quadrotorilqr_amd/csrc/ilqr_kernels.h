@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "backward_layout.h"
 #include "se3_math.h"
 
@@ -945,6 +947,381 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
 #ifdef QILQR_STAMPS
   if (lane == 0 && st.stamps)
     for (int k = 0; k < 8; ++k) st.stamps[(long)b * 8 + k] = stamp_sum[k];
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_backward4: k_backward2 with ONE gradient wavefront for FOUR trajectories (block = 320: matrix waves
+// M0..M3, gradient wave G).  With a gradient wave per trajectory, 1024 trajectories are 2048 wavefronts
+// on 1024 SIMDs and every matrix wave shares its SIMD (the kernel takes 84 us against 64 us for 512
+// trajectories).  G gives a row of 16 lanes to each trajectory: lane (g, j) holds column j of M = [J_x | J_u]
+// and V_x[j]; the products M^T V_x take the 12 entries of V_x by DPP row broadcasts (no shuffles, no
+// butterflies), Q_u is broadcast the same way, and V_x = Q_x + K^T Q_u lands in the lane that owns it.
+// G also streams the records of the four trajectories into their LDS rings.  Everything else as k_backward2.
+// ---------------------------------------------------------------------------------------------
+// acc += m * (vx of lane R of the caller's row of 16): one v_fmac_f64_dpp (the compiler keeps broadcast and
+// multiply-add apart).  vx must have been written at least two instructions earlier (DPP read hazard): it is
+// the previous knot's result here.
+template <int R>
+__device__ __forceinline__ double bw4_dot_step(double acc, double m, double vx) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(vx), "v"(m), "n"(R));
+  return acc;
+}
+template <typename S>
+__global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n,
+                                                   int force) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0..3: matrix wave of trajectory b0 + w; 4: G
+  const int b0 = blockIdx.x * 4;
+  __shared__ int s_run[4], s_cur[4], s_iters[4];
+  __shared__ double s_cost[4];
+  // four slots per trajectory: in interval i the matrix wave reads slot (i-1) & 3 and writes slot (i-2) & 3
+  // while G reads slot (i+1) & 3
+  __shared__ double ring[4][4][BW2_BUF];
+  __shared__ double kf[4][2][80];
+  const RecLayout L = st.layout;
+
+  // ---- every matrix wave settles its own trajectory's pending candidate (as in k_backward2)
+  if (w < 4) {
+    const int b = b0 + w;
+    bool run = false;
+    int cur = 0, iters_now = 0;
+    double cost_now = 0.0;
+    if (b < B) {
+      int fl = st.flags[b];
+      cur = st.cur[b];
+      const int it0 = st.iters[b];
+      const int trial0 = st.trial[b];
+      const double prev_cost0 = st.prev_cost[b], alpha0 = st.alpha[b];
+      const double term0 = st.terms[2 * b], term1 = st.terms[2 * b + 1];
+      cost_now = st.cost[b];
+      bool settle = false, accept = false, count_active = false, known = true;
+      int status = -1;
+      double new_cost = 0.0;
+      if (!force) {
+        if (fl & F_SEARCH) {
+          settle = true;
+          const double *kc = st.knot_cost[cur ^ 1];
+          for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            const double v = (i < n) ? kc[cost_index(b, i, n)] : 0.0;
+            const int cnt = (n - base < 64) ? n - base : 64;
+            const long long bits = __double_as_longlong(v);
+            for (int t = 0; t < cnt; ++t) {
+              const int lo = __builtin_amdgcn_readlane((int)bits, t);
+              const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), t);
+              new_cost += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+            }
+          }
+          if (it0 == 0) {
+            accept = true;  // ilqr.hh:71-73
+          } else {
+            const double desired = p.reduction_frac * cost_reduction(term0, term1, alpha0);
+            accept = (new_cost - prev_cost0 < desired);  // ilqr.hh:186
+          }
+          if (accept) {
+            cur ^= 1;
+            fl = F_ACTIVE;
+            cost_now = new_cost;
+            if (it0 > 0 && is_converged(p, prev_cost0, new_cost)) {
+              status = 1;  // ilqr.hh:82-84
+              fl = 0;
+            } else if (!((double)(it0 + 1) < p.max_iters)) {
+              status = 2;  // ilqr.hh:86
+              fl = 0;
+            }
+          } else if (trial0 + 1 >= p.ls_max_iters) {
+            status = 3;  // ilqr.hh:191-193
+            fl = 0;
+          }
+          count_active = (fl & F_ACTIVE) != 0;
+        } else if (fl == F_ACTIVE) {
+          count_active = true;
+        } else {
+          known = false;  // nothing to do for this trajectory
+        }
+      }
+      run = known && (force || !settle || (accept && fl != 0));
+      iters_now = (settle && accept) ? it0 + 1 : it0;
+      if (lane == 0 && known) {  // only this wave has read these words
+        if (settle) {
+          st.n_fwd[b] += 1;
+          if (accept) {
+            st.cur[b] = cur;
+            st.cost[b] = new_cost;
+            if (st.cost_hist && it0 < st.hist_cap) st.cost_hist[(long)b * st.hist_cap + it0] = new_cost;
+            st.iters[b] = it0 + 1;
+          } else {
+            st.trial[b] = trial0 + 1;
+            st.alpha[b] = alpha0 * p.step_update;  // ilqr.hh:189
+          }
+          if (status >= 0) st.status[b] = status;
+          st.flags[b] = fl;
+        }
+        if (count_active) atomicAdd(&st.counters[0], 1);
+      }
+    }
+    if (lane == 0) {
+      s_run[w] = run ? 1 : 0;
+      s_cur[w] = cur;
+      s_iters[w] = iters_now;
+      s_cost[w] = cost_now;
+    }
+  }
+  __syncthreads();
+  if ((s_run[0] | s_run[1] | s_run[2] | s_run[3]) == 0) return;  // block-uniform
+
+  // constant operand table behind every ring slot
+  for (int t = threadIdx.x; t < CTAB_SIZE; t += 320) {
+    const double v = (double)((const S *)st.ctab)[t];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      ring[g][0][BW2_REC + t] = v;
+      ring[g][1][BW2_REC + t] = v;
+      ring[g][2][BW2_REC + t] = v;
+      ring[g][3][BW2_REC + t] = v;
+    }
+  }
+  typedef typename GA<S>::cptr gptr;
+  typedef typename GA<S>::v2 sv2;
+  typedef typename GA<S>::ptr2 gptr2;
+
+  if (w == 4) {
+    // ------------------------------------------------------------------ G: records + gradients of four trajectories
+    const int g = lane >> 4, j = lane & 15;
+    const int bg = (b0 + g < B) ? b0 + g : B - 1;  // a valid stand-in for a missing trajectory (never stored)
+    const bool grun = s_run[g] != 0;
+    // operand addresses of lane (g, j) in ring slot 0: column j of M (12 rows) and entry j of [C_x ; C_u]
+    // (the slot is a compile-time constant in gradient_step, so it folds into the ds_read offset field)
+    const double *mp[12];
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {
+      const int src = m_source_tab(r, j);
+      mp[r] = &ring[g][0][(src >= 0) ? src : BW2_REC + (-1 - src)];
+    }
+    const double *gp = &ring[g][0][L.off_g + j];
+    S *gains = (S *)st.gains + knot_base<true>(bg, n, 52);
+    const bool kowner = grun && (j == 0);
+    gptr2 kdst0 = (gptr2)(kowner ? gains + knot_elem<true>(n - 1, 0, 52) : (S *)st.dump + 4 * (long)bg);
+    gptr2 kdst1 = (gptr2)(kowner ? gains + knot_elem<true>(n - 1, 2, 52) : (S *)st.dump + 4 * (long)bg + 2);
+    const long kst = kowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
+    double vx = 0.0;  // V_x[j] (lanes j < 12)
+    double QuTk = 0.0;
+    __syncthreads();
+    auto gradient_slot = [&](int q, auto slot_tag) {
+      constexpr int SLOT = decltype(slot_tag)::value;
+      const double *f = kf[g][q & 1];
+      // every LDS read of the step first, in the order of use (LDS returns in order): one exposed round trip
+      double m[12];
+#pragma unroll
+      for (int r = 0; r < 12; ++r) m[r] = mp[r][SLOT * BW2_BUF];
+      const double gcj = gp[SLOT * BW2_BUF];
+      asm volatile("" ::: "memory");
+      const double c0 = f[4 * j], c1 = f[4 * j + 1], c2 = f[4 * j + 2], c3 = f[4 * j + 3];  // K[:, j]
+      const double l10 = f[64], l20 = f[65], l30 = f[66], l21 = f[67], l31 = f[68], l32 = f[69], i0 = f[70],
+                   i1 = f[71], i2 = f[72], i3 = f[73];
+      asm volatile("" ::: "memory");
+      // [Q_x ; Q_u][j] = [C_x ; C_u][j] + sum_r M[r][j] V_x[r], three partial sums of four rows.  (Not the
+      // summation order of k_backward / k_backward2 -- rows kk, 4 + kk, 8 + kk chained, then a butterfly: that
+      // order was tried here for bit-identical results across batch sizes, costs 3% and still differs in the
+      // last bit elsewhere.  Results agree to ~1e-15 relative; the tests state it.)
+      double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+      p0 = bw4_dot_step<0>(p0, m[0], vx); p1 = bw4_dot_step<4>(p1, m[4], vx); p2 = bw4_dot_step<8>(p2, m[8], vx);
+      p0 = bw4_dot_step<1>(p0, m[1], vx); p1 = bw4_dot_step<5>(p1, m[5], vx); p2 = bw4_dot_step<9>(p2, m[9], vx);
+      p0 = bw4_dot_step<2>(p0, m[2], vx); p1 = bw4_dot_step<6>(p1, m[6], vx); p2 = bw4_dot_step<10>(p2, m[10], vx);
+      p0 = bw4_dot_step<3>(p0, m[3], vx); p1 = bw4_dot_step<7>(p1, m[7], vx); p2 = bw4_dot_step<11>(p2, m[11], vx);
+      const double ghat = gcj + ((p0 + p1) + p2);
+      const double Qu0 = row_bcast<12>(ghat), Qu1 = row_bcast<13>(ghat), Qu2 = row_bcast<14>(ghat),
+                   Qu3 = row_bcast<15>(ghat);
+      vx = ghat + ((c0 * Qu0 + c1 * Qu1) + (c2 * Qu2 + c3 * Qu3));  // V_x = Q_x + K^T Q_u: the recurrence ends here
+      const double y0 = Qu0, y1 = Qu1 - l10 * y0, y2 = Qu2 - l20 * y0 - l21 * y1,
+                   y3 = Qu3 - l30 * y0 - l31 * y1 - l32 * y2;
+      const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
+                   x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
+      const double k0 = -x0, k1 = -x1, k2 = -x2, k3 = -x3;  // feed-forward (ilqr.hh:128)
+      const sv2 w0 = {(S)k0, (S)k1}, w1 = {(S)k2, (S)k3};
+      *kdst0 = w0;
+      *kdst1 = w1;
+      kdst0 -= kst;
+      kdst1 -= kst;
+      QuTk += Qu0 * k0 + Qu1 * k1 + Qu2 * k2 + Qu3 * k3;
+    };
+    auto gradient_step = [&](int q) {
+      switch (q & 3) {
+        case 0: gradient_slot(q, std::integral_constant<int, 0>()); break;
+        case 1: gradient_slot(q, std::integral_constant<int, 1>()); break;
+        case 2: gradient_slot(q, std::integral_constant<int, 2>()); break;
+        default: gradient_slot(q, std::integral_constant<int, 3>()); break;
+      }
+    };
+    // interval i: issue the loads of record i-3 (set B), gradient step of knot i+1, record i-2 (set A, loaded
+    // one interval ago) into the ring; the two sets swap roles every interval
+    for (int i = n - 1; i >= 0; --i) {
+      if (i + 1 <= n - 1) gradient_step(i + 1);
+      __syncthreads();
+    }
+    gradient_step(0);
+    if (j == 0 && grun) {
+      const int b = b0 + g;
+      st.terms[2 * b] = QuTk;
+      st.terms[2 * b + 1] = -QuTk;  // k^T Quu k = -Q_u^T k for the exact solve (see k_backward)
+      st.n_bwd[b] += 1;
+      if (!force) {
+        const double cost_now = s_cost[g];
+        const int iters_now = s_iters[g];
+        st.prev_cost[b] = cost_now;  // ilqr.hh:61
+        if (iters_now > 0 && is_converged(p, cost_now, cost_now + cost_reduction(QuTk, -QuTk, 1.0))) {
+          st.status[b] = 0;  // ilqr.hh:66-68
+          st.flags[b] = 0;
+        } else if (iters_now > 0 && p.ls_max_iters <= 0) {
+          st.status[b] = 3;  // line_search with no trial allowed throws at once
+          st.flags[b] = 0;
+        } else {
+          st.alpha[b] = 1.0;
+          st.trial[b] = 0;
+          st.flags[b] = F_ACTIVE | F_SEARCH;
+        }
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- M_w: matrix recursion of trajectory b0 + w
+  const bool run = s_run[w] != 0;
+  const int b = (b0 + w < B) ? b0 + w : B - 1;
+  const int j = lane & 15, kk = lane >> 4;
+  int off[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int src;
+    if (k < 3) src = m_source_tab(4 * k + kk, j);
+    else src = (j < 12) ? cxx_source_tab(L, 4 * (k - 3) + kk, j) : -1 - CTAB_ZERO;
+    off[k] = (src >= 0) ? src : BW2_REC + (-1 - src);
+  }
+  S *gains = (S *)st.gains + knot_base<true>(b, n, 52);
+  const bool gowner = run && (kk == 0 && j < 12);
+  const int ge0 = 4 + 4 * j;
+  gptr2 gdst0 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0, 52) : (S *)st.dump + 4 * (long)b);
+  gptr2 gdst1 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0 + 2, 52) : (S *)st.dump + 4 * (long)b + 2);
+  const long gstep = gowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
+  const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] : 0.0;  // register 3 <-> row 12 + kk: C_uu = 2 R
+  double va[3] = {0.0, 0.0, 0.0};  // V_xx[j][4 kc + kk]  (A operand)
+  // Every matrix wave streams its own trajectory's records into its ring (two coalesced loads per knot, issued
+  // in the shadow of the first MFMAs): record i-3 is requested in interval i and written in interval i-1.
+  const int tail = (L.stride - 65 < lane) ? L.stride - 65 : lane;  // second load: elements 64 .. stride-1, clamped
+  const S *lin = (const S *)st.lin[s_cur[w]] + rec_base(b, n, L.stride);
+  auto rec_ptr = [&](int i) { return (gptr)(lin + rec_elem(i, 0, L.stride)); };
+  S r0 = 0, r1 = 0;
+  if (run) {
+    gptr q1 = rec_ptr(n - 1);
+    const S a0 = q1[lane], a1 = q1[64 + tail];
+    ring[w][(n - 1) & 3][lane] = (double)a0;
+    ring[w][(n - 1) & 3][64 + lane] = (double)a1;
+    if (n >= 2) {
+      gptr q2 = rec_ptr(n - 2);
+      const S c0_ = q2[lane], c1_ = q2[64 + tail];
+      ring[w][(n - 2) & 3][lane] = (double)c0_;
+      ring[w][(n - 2) & 3][64 + lane] = (double)c1_;
+    }
+    if (n >= 3) {
+      gptr q3 = rec_ptr(n - 3);
+      r0 = q3[lane];
+      r1 = q3[64 + tail];
+    }
+  }
+  __syncthreads();  // rings and constant tables are filled
+  if (!run) {
+    // this trajectory has nothing to do in this round: keep the block's barriers company
+    for (int i = n - 1; i >= 0; --i) __syncthreads();
+    return;
+  }
+  double m[3], cx[3];
+  {
+    const double *buf = ring[w][(n - 1) & 3];
+    m[0] = buf[off[0]]; m[1] = buf[off[1]]; m[2] = buf[off[2]];
+    cx[0] = buf[off[3]]; cx[1] = buf[off[4]]; cx[2] = buf[off[5]];
+  }
+#ifdef QILQR_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+  for (int i = n - 1; i >= 0; --i) {
+    // operands of knot i-1, for the next iteration (the slot was filled during the previous interval)
+    const double *nb = ring[w][(i > 0 ? i - 1 : 0) & 3];
+    const double m_n0 = nb[off[0]], m_n1 = nb[off[1]], m_n2 = nb[off[2]], cx_n0 = nb[off[3]], cx_n1 = nb[off[4]],
+                 cx_n2 = nb[off[5]];
+    d4 T = {0.0, 0.0, 0.0, 0.0};
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0], m[0], T, 0, 0, 0);
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1], m[1], T, 0, 0, 0);
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2], m[2], T, 0, 0, 0);
+    d4 H = {cx[0], cx[1], cx[2], cuu};
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
+    double Quu[16], Qu_unused[4], col[4];
+    gather_rows(H[3], col);
+    bcast_quu_row<0>(col, 0.0, Quu, Qu_unused);
+    bcast_quu_row<1>(col, 0.0, Quu, Qu_unused);
+    bcast_quu_row<2>(col, 0.0, Quu, Qu_unused);
+    bcast_quu_row<3>(col, 0.0, Quu, Qu_unused);
+    // LDL^T of the lower triangle of Q_uu (ilqr.hh:126), as in k_backward
+    const double i0 = rcp_nr(Quu[0]);
+    const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
+    const double d1 = Quu[5] - l10 * Quu[4];
+    const double i1 = rcp_nr(d1);
+    const double c21 = Quu[9] - l20 * Quu[4], c31 = Quu[13] - l30 * Quu[4];
+    const double l21 = c21 * i1, l31 = c31 * i1;
+    const double d2 = Quu[10] - l20 * Quu[8] - l21 * c21;
+    const double i2 = rcp_nr(d2);
+    const double c32 = Quu[14] - l30 * Quu[8] - l31 * c21;
+    const double l32 = c32 * i2;
+    const double d3 = Quu[15] - l30 * Quu[12] - l31 * c31 - l32 * c32;
+    const double i3 = rcp_nr(d3);
+    double kcol[4];
+    {
+      const double y0 = col[0], y1 = col[1] - l10 * y0, y2 = col[2] - l20 * y0 - l21 * y1,
+                   y3 = col[3] - l30 * y0 - l31 * y1 - l32 * y2;
+      const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
+                   x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
+      kcol[0] = -x0; kcol[1] = -x1; kcol[2] = -x2; kcol[3] = -x3;  // K[:, j] (ilqr.hh:127)
+    }
+    {
+      const sv2 w0 = {(S)kcol[0], (S)kcol[1]}, w1 = {(S)kcol[2], (S)kcol[3]};
+      *gdst0 = w0;
+      *gdst1 = w1;
+      gdst0 -= gstep;
+      gdst1 -= gstep;
+    }
+    // hand K and the factors to G (the four lanes of a column hold the same K[:, j]: same address, same data)
+    double *f = kf[w][i & 1];
+    f[4 * j] = kcol[0]; f[4 * j + 1] = kcol[1]; f[4 * j + 2] = kcol[2]; f[4 * j + 3] = kcol[3];
+    if (lane == 0) {
+      f[64] = l10; f[65] = l20; f[66] = l30; f[67] = l21; f[68] = l31; f[69] = l32;
+      f[70] = i0; f[71] = i1; f[72] = i2; f[73] = i3;
+    }
+    // V_xx = Q_xx + Q_xu K: A[j][kk] = Q_xu[j][kk] = H[12 + kk][j] is accumulator register 3
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(H[3], sel4(kcol, kk), H, 0, 0, 0);
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
+    m[0] = m_n0; m[1] = m_n1; m[2] = m_n2;
+    cx[0] = cx_n0; cx[1] = cx_n1; cx[2] = cx_n2;
+    if (i - 2 >= 0) {
+      ring[w][(i - 2) & 3][lane] = (double)r0;
+      ring[w][(i - 2) & 3][64 + lane] = (double)r1;
+    }
+    if (i - 3 >= 0) {
+      gptr q = rec_ptr(i - 3);
+      r0 = q[lane];
+      r1 = q[64 + tail];
+    }
+    QKEEP(va[0]); QKEEP(m[2]);
+    QSTAMP(6);  // the knot
+    __syncthreads();
+    QSTAMP(7);  // barrier
+  }
+#ifdef QILQR_STAMPS
+  if (lane == 0 && st.stamps)
+    for (int k = 0; k < 8; ++k) st.stamps[(long)(b0 + w) * 8 + k] = stamp_sum[k];
 #endif
 }
 
