@@ -575,6 +575,19 @@ def test_config3_mixed_precision_reduced():
 
 
 # ------------------------------------------------------------------ randomised parity sweep
+def test_mixed_precision_at_headline_size():
+    """precision = 1 (fp32 storage and lane-local arithmetic, fp64 recursion and cost sums) on configs[1]'s shape,
+    where the four-trajectory backward kernel is the one selected: final costs within 1e-5 relative of the fp64
+    solve at tolerances fp32 can reach, trajectories within 1e-4."""
+    cfg = pb.config2(B=1024, N=100, seed=2)
+    cfg["options"] = dict(cfg["options"], rtol=1e-5, atol=1e-5)
+    a = capi.from_config(cfg, precision="f32").solve_batch(cfg["init"])
+    b = capi.from_config(cfg, precision="f64").solve_batch(cfg["init"])
+    assert np.isin(a["status"], [0, 1]).all() and np.isin(b["status"], [0, 1]).all()
+    np.testing.assert_allclose(a["cost"], b["cost"], rtol=1e-5)
+    np.testing.assert_allclose(a["traj"], b["traj"], atol=1e-4)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_randomised_models_and_horizons_match_oracle(seed):
     """Random physical parameters (mass, SPD inertia, arm, rotor torque ratio, gravity), time step,
