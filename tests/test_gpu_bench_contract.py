@@ -1,0 +1,39 @@
+"""bench.py's output contract (task statement): one JSON line on rank 0 with the agreed keys, the roofline of
+the dominant kernel measured live, and the CPU baseline at N = 1.  Runs the real script on the GPU, short."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1
+    assert j["unit"] == "solves/s" and j["higher_is_better"] is True and j["scaling"] == "weak"
+    assert j["vs_baseline"] is None and j["dtype"] == "f64" and j["data"] == "synthetic"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    assert j["value"] > 10000  # the north star's floor for configs[1]
+    assert abs(j["value"] - 1024 * 1e3 / j["ms_per_step"]) / j["value"] < 1e-6
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["kernel"] in ("k_backward", "k_rollout")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["launches"] > 0 and r["avg_launch_us"] > 1.0
+    c = j["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["value"] > 0 and c["parity_max_rel_cost_err"] < 1e-9
