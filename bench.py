@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--rollout", type=int, default=-1, help="rollout kernel: 0 pair, 1 single wave, 2 pair + loader (default: library default)")
     ap.add_argument("--backward", type=int, default=0, help="diagnostic: backward kernel (qilqr_device_config.force_general: 0 automatic, 1 general, 2 one wavefront per trajectory)")
     ap.add_argument("--streams", type=int, default=0, help="sub-batches on their own streams (qilqr_device_config.streams; 0 automatic)")
+    ap.add_argument("--event-stride", type=int, default=4, help="time every k-th launch of the dominant kernel in the timed region (a timed dispatch costs the stream about 6 us)")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP events around the kernels (roofline = null)")
     args = ap.parse_args()
 
@@ -98,7 +99,7 @@ def main():
     # perturbation of the rounds being measured).
     calib = solver.profile_get()
     if not args.no_profile and not args.profile_all and args.warmup > 0:
-        solver.profile_mode(3 if calib["backward_ms"] >= calib["rollout_ms"] else 4)
+        solver.profile_mode((3 if calib["backward_ms"] >= calib["rollout_ms"] else 4) | (args.event_stride << 8))
     solver.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -119,15 +120,18 @@ def main():
         # ---- roofline of the dominant kernel (this rank's launches, timed region only)
         knots_bwd = float(n_bwd.sum()) * N * args.steps
         knots_fwd = float(n_fwd.sum()) * N * args.steps
+        # ms / launches: the launches that carried events (every event_stride-th launch of the dominant kernel);
+        # seen: all its launches in the timed region.  Work is per launch: total work / all launches.
         kern = {
-            "k_backward": dict(ms=prof["backward_ms"], launches=prof["backward_launches"],
+            "k_backward": dict(ms=prof["backward_ms"], launches=prof["backward_launches"], seen=prof["backward_seen"],
                                flops=FLOP_BWD_KNOT * knots_bwd, bytes=BYTES_BWD_KNOT * knots_bwd),
-            "k_rollout": dict(ms=prof["rollout_ms"], launches=prof["rollout_launches"],
+            "k_rollout": dict(ms=prof["rollout_ms"], launches=prof["rollout_launches"], seen=prof["rollout_seen"],
                               flops=FLOP_FWD_KNOT * knots_fwd, bytes=BYTES_FWD_KNOT * knots_fwd),
         }
         dom = max(kern, key=lambda k: kern[k]["ms"])
         kd = kern[dom]
-        sec = max(kd["ms"], 1e-9) * 1e-3
+        # time all launches would take at the measured average launch duration
+        sec = max(kd["ms"], 1e-9) * 1e-3 * max(kd["seen"], 1) / max(kd["launches"], 1)
         tflops = kd["flops"] / sec / 1e12
         gbs = kd["bytes"] / sec / 1e9
         # HBM bytes per launch of that kernel from the latest committed PMC summary (profiles/, produced by
@@ -151,9 +155,10 @@ def main():
             bound = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
         roofline = {
             "kernel": dom, **bound, "traffic": traffic, "traffic_source": traffic_src,
-            "avg_launch_us": kd["ms"] * 1e3 / max(kd["launches"], 1), "launches": kd["launches"],
-            "alg_flops_per_launch": kd["flops"] / max(kd["launches"], 1),
-            "alg_bytes_per_launch": kd["bytes"] / max(kd["launches"], 1),
+            "avg_launch_us": kd["ms"] * 1e3 / max(kd["launches"], 1), "launches": kd["seen"],
+            "timed_launches": kd["launches"],
+            "alg_flops_per_launch": kd["flops"] / max(kd["seen"], 1),
+            "alg_bytes_per_launch": kd["bytes"] / max(kd["seen"], 1),
             "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
             "flops": {"achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS},
             "kernels_ms": {k: round(v["ms"], 3) for k, v in kern.items()}

@@ -68,8 +68,10 @@ typedef struct {
 /* device-side configuration (no counterpart in the reference, which is CPU only) */
 typedef struct {
   int32_t device;   /* HIP device ordinal */
-  int32_t profile;  /* start/stop HIP events attached to kernel dispatches.  0: off; 1: k_backward and k_rollout;
-                       2: every kernel; 3: k_backward only; 4: k_rollout only */
+  int32_t profile;  /* start/stop HIP events attached to kernel dispatches.  Low byte: 0 off; 1 k_backward and
+                       k_rollout; 2 every kernel; 3 k_backward only; 4 k_rollout only.  Second byte: sampling
+                       stride s (0 or 1: every selected launch; s > 1: every s-th launch of a kind is timed, the
+                       averages of qilqr_profile_get are over the timed launches) */
   int32_t sync_every; /* 1: the host waits for every round's count of active trajectories; k > 1 (default 2 when no
                          configuration is given): it reads the count k rounds late, i.e. keeps the stream k rounds
                          ahead of the device (k <= 6).  The results do not depend on it. */
@@ -95,12 +97,15 @@ typedef struct {
  * independent; the reference's ILQR object is const and re-entrant). */
 typedef struct qilqr_solver qilqr_solver;
 
-/* per-kernel device time accumulated since the last reset (kernels not selected by `profile` stay at 0) */
+/* per-kernel device time accumulated since the last reset: *_ms and *_launches cover the launches that carried
+ * events (kernels not selected by `profile`, and launches skipped by the sampling stride, do not), *_seen counts
+ * every launch of the kind while profiling was on */
 typedef struct {
   double backward_ms;  int32_t backward_launches;
   double rollout_ms;   int32_t rollout_launches;
   double linearize_ms; int32_t linearize_launches;
   double other_ms;     int32_t other_launches;
+  int32_t backward_seen, rollout_seen, linearize_seen, other_seen;
 } qilqr_profile;
 
 /* Replaces src::init, quadrotor_ilqr_binding.cc:20-32 (QuadrotorModel ctor + CostFunction +

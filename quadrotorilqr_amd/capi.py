@@ -61,7 +61,9 @@ class Profile(C.Structure):
     _fields_ = [("backward_ms", C.c_double), ("backward_launches", C.c_int32),
                 ("rollout_ms", C.c_double), ("rollout_launches", C.c_int32),
                 ("linearize_ms", C.c_double), ("linearize_launches", C.c_int32),
-                ("other_ms", C.c_double), ("other_launches", C.c_int32)]
+                ("other_ms", C.c_double), ("other_launches", C.c_int32),
+                ("backward_seen", C.c_int32), ("rollout_seen", C.c_int32), ("linearize_seen", C.c_int32),
+                ("other_seen", C.c_int32)]
 
 
 _lib = None

@@ -79,6 +79,7 @@ struct qilqr_solver {
   std::vector<EventPair> events;
   size_t events_used = 0;
   double prof_ms[K_KINDS] = {0, 0, 0, 0};
+  unsigned prof_seen[K_KINDS] = {0, 0, 0, 0};  // launches of each kind seen by the sampler
   int prof_n[K_KINDS] = {0, 0, 0, 0};
 };
 
@@ -86,10 +87,14 @@ namespace {
 
 // Slot for the start/stop events of one launch, or null when this kind of kernel is not being timed.
 EventPair *timing_slot(qilqr_solver *s, int kind) {
-  if (!s->dev.profile) return nullptr;
-  if (s->dev.profile == 1 && kind != K_BACKWARD && kind != K_ROLLOUT) return nullptr;
-  if (s->dev.profile == 3 && kind != K_BACKWARD) return nullptr;
-  if (s->dev.profile == 4 && kind != K_ROLLOUT) return nullptr;
+  const int mode = s->dev.profile & 0xff, stride = (s->dev.profile >> 8) & 0xff;
+  if (!mode) return nullptr;
+  const unsigned seen = s->prof_seen[kind]++;  // every launch of the kind since the last reset
+  if (mode == 1 && kind != K_BACKWARD && kind != K_ROLLOUT) return nullptr;
+  if (mode == 3 && kind != K_BACKWARD) return nullptr;
+  if (mode == 4 && kind != K_ROLLOUT) return nullptr;
+  // sampling: every stride-th launch of a kind carries events (a timed dispatch costs the stream ~6 us)
+  if (stride > 1 && (seen % stride) != 0) return nullptr;
   if (s->events_used == s->events.size()) {
     EventPair e;
     if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return nullptr;
@@ -738,13 +743,14 @@ int qilqr_profile_reset(qilqr_solver *s) {
   for (int k = 0; k < K_KINDS; ++k) {
     s->prof_ms[k] = 0;
     s->prof_n[k] = 0;
+    s->prof_seen[k] = 0;
   }
   return QILQR_OK;
 }
 
 int qilqr_profile_mode(qilqr_solver *s, int32_t mode) {
   if (!s) return fail(QILQR_ERR_INVALID_ARG, "null solver");
-  if (mode < 0 || mode > 4) return fail(QILQR_ERR_INVALID_ARG, "profile mode must be 0..4");
+  if (mode < 0 || (mode & 0xff) > 4 || (mode >> 16)) return fail(QILQR_ERR_INVALID_ARG, "profile mode must be 0..4 (+ stride << 8)");
   int rc = qilqr_profile_reset(s);
   if (rc) return rc;
   s->dev.profile = mode;
@@ -764,6 +770,10 @@ int qilqr_profile_get(qilqr_solver *s, qilqr_profile *out) {
   out->linearize_launches = s->prof_n[K_LINEARIZE];
   out->other_ms = s->prof_ms[K_OTHER];
   out->other_launches = s->prof_n[K_OTHER];
+  out->backward_seen = (int32_t)s->prof_seen[K_BACKWARD];
+  out->rollout_seen = (int32_t)s->prof_seen[K_ROLLOUT];
+  out->linearize_seen = (int32_t)s->prof_seen[K_LINEARIZE];
+  out->other_seen = (int32_t)s->prof_seen[K_OTHER];
   return QILQR_OK;
 }
 
