@@ -1,7 +1,7 @@
 // backward_layout.h -- where each lane of the backward-pass wavefront finds its operands.
 //
-// k_backward gives one 64-lane wavefront to one trajectory and contracts the per-knot
-// matrices on the fp64 matrix core: v_mfma_f64_16x16x4_f64, D(16x16) = A(16x4) B(4x16) + C.
+// The backward kernels (k_backward, and the matrix wavefronts of k_backward2 / k_backward4) give one 64-lane
+// wavefront to one trajectory's matrix recursion and contract the per-knot matrices on the fp64 matrix core: v_mfma_f64_16x16x4_f64, D(16x16) = A(16x4) B(4x16) + C.
 // Lane l = (j = l & 15, kk = l >> 4) supplies A[j][kk] and B[kk][j]; it receives
 // D[4 r + kk][j] in result register r (r = 0..3).  With the stacked Jacobian
 //        M = [ J_x | J_u ]          (12 x 16: the control Jacobian fills the tile exactly)
