@@ -1,11 +1,31 @@
-import sys, numpy as np
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
-import test_gpu_parity as T
+#!/usr/bin/env python3
+"""Randomised parity soak: the randomised GPU test of tests/test_gpu_parity.py over many more seeds, with every
+backward kernel (automatic, k_backward2, k_backward4, one wavefront, general) and rollout kernel forced in turn.
+usage: python profiles/microbench/soak.py [first_seed [n_seeds]]"""
+import sys
+
+sys.path.insert(0, "tests")
+sys.path.insert(0, ".")
+import test_gpu_parity as T  # noqa: E402
+from quadrotorilqr_amd import capi  # noqa: E402
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+orig = capi.from_config
 bad = 0
-for seed in range(12, 132):
-    try:
-        T.test_randomised_models_and_horizons_match_oracle(seed)
-    except AssertionError as e:
-        bad += 1
-        print("seed", seed, "FAILED:", str(e).splitlines()[:6])
+for label, kw in [("automatic", {}), ("k_backward2", dict(force_general=3)), ("k_backward4", dict(force_general=4)),
+                  ("one wavefront", dict(force_general=2)), ("general", dict(force_general=1)),
+                  ("k_rollout", dict(single_wave_rollout=1)), ("k_rollout4", dict(single_wave_rollout=4)),
+                  ("three streams", dict(streams=3))]:
+    capi.from_config = lambda cfg, _kw=kw, **k: orig(cfg, **{**_kw, **k})
+    fails = 0
+    for seed in range(first, first + count):
+        try:
+            T.test_randomised_models_and_horizons_match_oracle(seed)
+        except AssertionError as e:
+            fails += 1
+            print(label, "seed", seed, "FAILED:", str(e).splitlines()[:4])
+    print(f"{label:14s}: {count - fails}/{count} seeds agree with the oracle")
+    bad += fails
+capi.from_config = orig
 print("soak done, failures:", bad)
