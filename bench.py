@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--backward", type=int, default=0, help="diagnostic: backward kernel (qilqr_device_config.force_general: 0 automatic, 1 general, 2 one wavefront per trajectory)")
     ap.add_argument("--streams", type=int, default=0, help="sub-batches on their own streams (qilqr_device_config.streams; 0 automatic)")
     ap.add_argument("--event-stride", type=int, default=4, help="time every k-th launch of the dominant kernel in the timed region (a timed dispatch costs the stream about 6 us)")
+    ap.add_argument("--no-serving", action="store_true", help="skip the extra several-batches-in-flight measurement (never part of value)")
+    ap.add_argument("--serving-batches", type=int, default=18)
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP events around the kernels (roofline = null)")
     args = ap.parse_args()
 
@@ -189,6 +191,39 @@ def main():
                    "sample": f"first {sample} of the {B} problems of rank 0 x {reps} repeats, {cores} threads, {tc:.2f} s; "
                              f"single thread: {16 / t1c:.1f} solves/s on 16 problems",
                    "parity_max_rel_cost_err": float(np.max(np.abs(got - r["cost"]) / np.abs(r["cost"])))}
+        # ---- extra, outside the timed region and never `value`: a stream of such batches with several in flight
+        # (one solver handle and one host thread per batch in flight): the tail of one batch -- a few trajectories
+        # still iterating on an almost idle chip -- overlaps the head of the next
+        serving = None
+        if not args.no_serving and world == 1:
+            import threading
+            serving = {"what": f"solves/s over {args.serving_batches} batches of {B} with k batches in flight "
+                               "(independent handles, streams and host threads); k = 1 is `value`'s configuration"}
+            for k in (2, 3):
+                ws = []
+                for _ in range(k):
+                    sv = capi.from_config(cfg, device=dev.index, sync_every=args.sync_every)
+                    bufs = (torch.empty_like(init), torch.empty(B, dtype=torch.float64, device=dev),
+                            [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(4)])
+                    sv.solve_batch_device(init, bufs[0], bufs[1], *bufs[2])
+                    ws.append((sv, bufs))
+                per = max(1, args.serving_batches // k)
+
+                def drive(w):
+                    for _ in range(per):
+                        w[0].solve_batch_device(init, w[1][0], w[1][1], *w[1][2])
+
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                th = [threading.Thread(target=drive, args=(w,)) for w in ws]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                torch.cuda.synchronize()
+                serving[f"in_flight_{k}"] = per * k * B / (time.perf_counter() - t1)
+                for w in ws:
+                    w[0].close()
         line = {
             "metric": "iLQR solves/sec (batch, 100-knot SE(3) quadrotor)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -200,7 +235,7 @@ def main():
             "iters_mean": float(iters.mean()), "iters_max": int(iters.max()),
             "status_counts": np.bincount(status, minlength=4).tolist(),
             "knot_steps_per_s": float((n_bwd.sum() + n_fwd.sum()) * N * world * args.steps / dt),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "serving": serving,
         }
         print(json.dumps(line))
     if world > 1:
