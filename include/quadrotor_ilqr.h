@@ -171,6 +171,16 @@ int qilqr_profile_get(qilqr_solver *s, qilqr_profile *out);
 /* change qilqr_device_config.profile of a live solver (drains the stream, resets the accumulated times) */
 int qilqr_profile_mode(qilqr_solver *s, int32_t mode);
 
+/* Levenberg-Marquardt restarts -- an EXTENSION the reference does not have (SURVEY.md section 8f row 4;
+ * BASELINE.json configs[4] "line-search/regularisation restarts"); off by default and when mu_init == 0,
+ * and then every result is the reference's.  Where ILQR::line_search would throw after ls_max_iters trials
+ * (ilqr.hh:191-193) the problem instead keeps its iterate, sets mu = mu_init (then mu *= mu_factor on each
+ * further exhaustion), repeats ILQR::backwards_pass with Q_uu + mu 1 in place of Q_uu in every formula of
+ * ilqr.hh:126-140, and searches again from a full step.  An accepted step divides mu by mu_factor (below
+ * mu_init it returns to 0).  Past mu_max the problem ends with QILQR_STATUS_LINE_SEARCH_FAILED as before.
+ * Restarts are not iterations; they show in out_n_bwd.  Requires mu_factor > 1, mu_max >= mu_init. */
+int qilqr_set_regularisation(qilqr_solver *s, double mu_init, double mu_factor, double mu_max);
+
 /* device the solver is bound to, and the HIP stream it launches on (hipStream_t as void*) */
 int qilqr_device(const qilqr_solver *s);
 void *qilqr_stream(const qilqr_solver *s);

@@ -772,6 +772,8 @@ struct orc_solver {
   int n_desired;
   double dt;
   orc_options opt;
+  /* Levenberg-Marquardt restarts: NOT in the reference (extension); all zero = off */
+  double mu_init, mu_factor, mu_max;
 };
 
 int orc_solver_create(const orc_model_params *mp, const double Q[144], const double R[16],
@@ -830,9 +832,25 @@ int orc_cost_trajectory(const orc_solver *s, const double *traj, int n, double *
   return ORC_OK;
 }
 
-/* ilqr.hh:97-147 */
+/* Extension (not in the reference): switch Levenberg-Marquardt restarts on (mu_init > 0) or off. */
+int orc_set_regularisation(orc_solver *s, double mu_init, double mu_factor, double mu_max) {
+  if (!s || !(mu_init >= 0.0)) return ORC_ERR_INVALID;
+  if (mu_init > 0.0 && (!(mu_factor > 1.0) || !(mu_max >= mu_init))) return ORC_ERR_INVALID;
+  s->mu_init = mu_init;
+  s->mu_factor = mu_init > 0.0 ? mu_factor : 1.0;
+  s->mu_max = mu_init > 0.0 ? mu_max : 0.0;
+  return ORC_OK;
+}
+
 int orc_backwards_pass(const orc_solver *s, const double *traj, int n, double *gains,
                        double terms[2]) {
+  return orc_backwards_pass_reg(s, traj, n, 0.0, gains, terms);
+}
+
+/* ilqr.hh:97-147; mu (extension, 0 in the reference) is added to the diagonal of Q_uu before it is
+ * used anywhere */
+int orc_backwards_pass_reg(const orc_solver *s, const double *traj, int n, double mu, double *gains,
+                           double terms[2]) {
   if (n > s->n_desired) return ORC_ERR_LENGTH_MISMATCH;
   double v_x[12] = {0}, v_xx[144] = {0};
   terms[0] = 0.0;
@@ -859,6 +877,8 @@ int orc_backwards_pass(const orc_solver *s, const double *traj, int n, double *g
     mat_tmul(Ju, v_xx, JuTV, 12, 4, 12);
     mat_mul(JuTV, Ju, T16, 4, 12, 4);
     for (int a = 0; a < 16; ++a) Quu[a] = Cuu[a] + T16[a];
+    if (mu != 0.0)
+      for (int a = 0; a < 4; ++a) Quu[a * 5] += mu;
     mat_mul(JxTV, Ju, T48, 12, 12, 4);
     for (int a = 0; a < 48; ++a) Qxu[a] = Cxu[a] + T48[a];
 
@@ -964,9 +984,10 @@ int orc_solve(const orc_solver *s, const double *init, int n, double *out_traj, 
   double new_cost;
   orc_cost_trajectory(s, traj, n, &new_cost);
   int status = ORC_STATUS_MAX_ITERS, iters = 0, n_bwd = 0, n_fwd = 0, n_hist = 0;
-  for (int i = 0; i < s->opt.max_iters; ++i) {
+  double mu = 0.0; /* extension; stays 0 (the reference) unless restarts are switched on */
+  for (int i = 0; i < s->opt.max_iters;) {
     double terms[2];
-    orc_backwards_pass(s, traj, n, gains, terms);
+    orc_backwards_pass_reg(s, traj, n, mu, gains, terms);
     ++n_bwd;
     const double cost = new_cost;
     const double expected_new_cost = cost + cost_reduction(terms, 1.0);
@@ -987,10 +1008,22 @@ int orc_solve(const orc_solver *s, const double *init, int n, double *out_traj, 
       n_fwd += trials;
       if (ls == ORC_STATUS_LINE_SEARCH_FAILED) {
         new_cost = cost;
+        if (s->mu_init > 0.0) {
+          /* extension: same iterate, larger mu, backward pass again (not an iteration) */
+          const double next = (mu > 0.0) ? mu * s->mu_factor : s->mu_init;
+          if (next <= s->mu_max) {
+            mu = next;
+            continue;
+          }
+        }
         status = ORC_STATUS_LINE_SEARCH_FAILED;
         break;
       }
       double *t = traj; traj = cand; cand = t;
+    }
+    if (mu > 0.0) {
+      mu = mu / s->mu_factor;
+      if (mu < s->mu_init) mu = 0.0;
     }
     ++iters;
     if (cost_hist && n_hist < cap) {
@@ -1002,6 +1035,7 @@ int orc_solve(const orc_solver *s, const double *init, int n, double *out_traj, 
       status = ORC_STATUS_CONVERGED;
       break;
     }
+    ++i;
   }
   memcpy(out_traj, traj, tsz);
   if (out_cost) *out_cost = new_cost;

@@ -126,6 +126,13 @@ int orc_cost_trajectory(const orc_solver *s, const double *traj, int n, double *
 int orc_backwards_pass(const orc_solver *s, const double *traj, int n, double *gains,
                        double terms[2]);
 /* ilqr.hh:149-172 */
+/* Extensions the reference does not have (Levenberg-Marquardt restarts, the counterpart of
+ * qilqr_set_regularisation in include/quadrotor_ilqr.h): the backward pass with mu added to the diagonal
+ * of Q_uu, and the switch that makes orc_solve / orc_solve_batch restart an exhausted line search. */
+int orc_backwards_pass_reg(const orc_solver *s, const double *traj, int n, double mu, double *gains,
+                           double terms[2]);
+int orc_set_regularisation(orc_solver *s, double mu_init, double mu_factor, double mu_max);
+
 int orc_forward_sim(const orc_solver *s, const double *traj, int n, const double *gains,
                     double alpha, double *out_traj);
 /* ilqr.hh:174-194; returns ORC_STATUS_LINE_SEARCH_FAILED where the reference throws */

@@ -284,6 +284,20 @@ class OracleSolver:
                                              _p(terms)))
         return gains, terms
 
+    def backwards_pass_reg(self, traj, mu):
+        """Extension (not in the reference): backward pass with mu on the diagonal of Q_uu."""
+        traj = _d(traj).reshape(-1, 18)
+        gains = np.zeros((len(traj), 52))
+        terms = np.zeros(2)
+        self._check(lib().orc_backwards_pass_reg(self._h, _p(traj), C.c_int(len(traj)), C.c_double(mu),
+                                                 _p(gains), _p(terms)))
+        return gains, terms
+
+    def set_regularisation(self, mu_init, mu_factor=10.0, mu_max=1e6):
+        """Extension (not in the reference): Levenberg-Marquardt restarts in solve / solve_batch."""
+        self._check(lib().orc_set_regularisation(self._h, C.c_double(mu_init), C.c_double(mu_factor),
+                                                 C.c_double(mu_max)))
+
     def forward_sim(self, traj, gains, alpha=1.0):
         traj = _d(traj).reshape(-1, 18)
         gains = _d(gains).reshape(-1, 52)

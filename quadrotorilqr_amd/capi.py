@@ -34,7 +34,7 @@ STATUS_LINE_SEARCH_FAILED = 3
 EXPORTS = (
     "qilqr_create", "qilqr_destroy", "qilqr_last_error", "qilqr_solve", "qilqr_solve_batch",
     "qilqr_solve_batch_device", "qilqr_cost_trajectory", "qilqr_backwards_pass", "qilqr_forward_sim",
-    "qilqr_line_search", "qilqr_cost_history", "qilqr_profile_reset", "qilqr_profile_get", "qilqr_profile_mode",
+    "qilqr_line_search", "qilqr_cost_history", "qilqr_profile_reset", "qilqr_profile_get", "qilqr_profile_mode", "qilqr_set_regularisation",
     "qilqr_device", "qilqr_stream",
     "qilqr_abi_version",
 )
@@ -265,6 +265,16 @@ class QuadrotorILQRBatch:
     def profile_mode(self, mode):
         """0 off, 1 k_backward + k_rollout, 2 every kernel, 3 k_backward only, 4 k_rollout only"""
         rc = load().qilqr_profile_mode(self._h, C.c_int32(int(mode)))
+        if rc:
+            _raise(rc)
+
+    def set_regularisation(self, mu_init, mu_factor=10.0, mu_max=1e6):
+        """Levenberg-Marquardt restarts (an extension the reference lacks; mu_init = 0 switches it off):
+        see qilqr_set_regularisation in include/quadrotor_ilqr.h"""
+        rc = load().qilqr_set_regularisation(self._h, C.c_double(mu_init), C.c_double(mu_factor),
+                                              C.c_double(mu_max))
+        if rc == ERR_INVALID_ARG:
+            raise ValueError(load().qilqr_last_error().decode())
         if rc:
             _raise(rc)
 

@@ -172,6 +172,7 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
   if ((rc = dalloc(s, &st.prev_cost, cB))) return rc;
   if ((rc = dalloc(s, &st.terms, 2 * cB))) return rc;
   if ((rc = dalloc(s, &st.alpha, cB))) return rc;
+  if ((rc = dalloc(s, &st.mu, cB))) return rc;
   if ((rc = dalloc(s, &st.trial, cB))) return rc;
   if ((rc = dalloc(s, &st.flags, cB))) return rc;
   if ((rc = dalloc(s, &st.status, cB))) return rc;
@@ -198,6 +199,11 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
 }
 
 inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+// largest number of consecutive restarts lm_restart (ilqr_kernels.h) can grant one iteration
+inline double max_restarts(const SolveParams &p) {
+  if (!(p.mu_init > 0.0) || !(p.mu_init <= p.mu_max)) return 0.0;
+  return 1.0 + std::floor(std::log(p.mu_max / p.mu_init) / std::log(p.mu_factor));
+}
 
 // plain [B][n][W] fp64 (device) -> tiled, storage precision
 int to_tiled(qilqr_solver *s, const double *d_plain, void *tiled, long B, long n, int W) {
@@ -371,7 +377,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
     return QILQR_OK;
   }
   // a trajectory needs at most max_iters backward passes and max_iters * ls_max_iters trials
-  const double bound = (std::fmin(s->params.max_iters, 1e7) + 1.0) * ((double)std::max(s->params.ls_max_iters, 1) + 1.0);
+  const double bound = (std::fmin(s->params.max_iters, 1e7) + 1.0) * ((double)std::max(s->params.ls_max_iters, 1) + 1.0) * (1.0 + max_restarts(s->params));
   const long max_rounds = (long)std::fmin(bound, 2e9);
   const int lag = (sync_every > 1) ? std::min(sync_every, 6) : 0;
   if (lag == 0) {
@@ -455,7 +461,7 @@ BatchState slice_state(const qilqr_solver *s, long b0, long n, int part) {
   v.gains = adv(w.gains, knot_base<true>(b0, n, 52));
   if (w.desired_tiled) v.desired = adv(w.desired, knot_base<true>(b0, n, 18));
   v.cur = w.cur + b0; v.cost = w.cost + b0; v.prev_cost = w.prev_cost + b0; v.terms = w.terms + 2 * b0;
-  v.alpha = w.alpha + b0; v.trial = w.trial + b0; v.flags = w.flags + b0; v.status = w.status + b0;
+  v.alpha = w.alpha + b0; v.mu = w.mu + b0; v.trial = w.trial + b0; v.flags = w.flags + b0; v.status = w.status + b0;
   v.iters = w.iters + b0; v.n_bwd = w.n_bwd + b0; v.n_fwd = w.n_fwd + b0;
   v.counters = s->d_part_counters + 4 * part;
   v.host_active = s->d_active + 8 * (1 + part);
@@ -518,7 +524,7 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
   int remaining = nparts;
   if (0.0 < s->params.max_iters) {
     const double bound =
-        (std::fmin(s->params.max_iters, 1e7) + 1.0) * ((double)std::max(s->params.ls_max_iters, 1) + 1.0);
+        (std::fmin(s->params.max_iters, 1e7) + 1.0) * ((double)std::max(s->params.ls_max_iters, 1) + 1.0) * (1.0 + max_restarts(s->params));
     const long max_rounds = (long)std::fmin(bound, 2e9);
     const int lag = std::max(1, std::min(s->dev.sync_every, 6));
     for (long round = 0; round < max_rounds && remaining > 0; ++round) {
@@ -619,7 +625,7 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   s->dev = dc;
   s->options = *options;
   s->params = SolveParams{options->step_update, options->desired_reduction_frac, options->rtol, options->atol,
-                          options->max_iters, options->ls_max_iters};
+                          options->max_iters, options->ls_max_iters, 0.0, 1.0, 0.0};
   s->consts = mc;
   s->f32 = (dc.precision == 1);
   convert_consts(mc, s->constsf);
@@ -754,6 +760,25 @@ int qilqr_profile_mode(qilqr_solver *s, int32_t mode) {
   int rc = qilqr_profile_reset(s);
   if (rc) return rc;
   s->dev.profile = mode;
+  return QILQR_OK;
+}
+
+int qilqr_set_regularisation(qilqr_solver *s, double mu_init, double mu_factor, double mu_max) {
+  if (!s) return fail(QILQR_ERR_INVALID_ARG, "null solver");
+  if (!(mu_init >= 0.0) || !std::isfinite(mu_init)) return fail(QILQR_ERR_INVALID_ARG, "mu_init must be finite and >= 0");
+  if (mu_init > 0.0) {
+    if (!(mu_factor > 1.0) || !std::isfinite(mu_factor)) return fail(QILQR_ERR_INVALID_ARG, "mu_factor must be finite and > 1");
+    if (!(mu_max >= mu_init) || !std::isfinite(mu_max)) return fail(QILQR_ERR_INVALID_ARG, "mu_max must be finite and >= mu_init");
+    // the restarts of one iteration must fit the round bound of run_solve
+    if (std::log(mu_max / mu_init) / std::log(mu_factor) > 1000.0)
+      return fail(QILQR_ERR_INVALID_ARG, "more than 1000 restarts between mu_init and mu_max");
+  } else {
+    mu_factor = 1.0;
+    mu_max = 0.0;
+  }
+  s->params.mu_init = mu_init;
+  s->params.mu_factor = mu_factor;
+  s->params.mu_max = mu_max;
   return QILQR_OK;
 }
 

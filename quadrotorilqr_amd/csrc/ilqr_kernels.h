@@ -31,6 +31,9 @@ constexpr int F_SEARCH = 2;  // has gains, needs a (further) rollout trial
 struct SolveParams {
   double step_update, reduction_frac, rtol, atol, max_iters;
   int ls_max_iters;
+  // Levenberg-Marquardt restarts (an extension; the reference has none and mu_init = 0 switches them
+  // off): see lm_restart below
+  double mu_init, mu_factor, mu_max;
 };
 
 // all device pointers; [B] unless noted
@@ -49,6 +52,7 @@ struct BatchState {
   double *prev_cost;     // "cost" inside the iteration (ilqr.hh:61)
   double *terms;         // [B][2] QuTk, kTQuuk
   double *alpha;
+  double *mu;            // regularisation currently added to the diagonal of Q_uu (0 unless restarts are on)
   int *trial;
   int *flags;
   int *status, *iters, *n_bwd, *n_fwd;
@@ -186,6 +190,26 @@ __global__ void k_begin(BatchState st, int B) {
   st.flags[b] = 0;
 }
 
+// Levenberg-Marquardt restarts (extension; off when mu_init == 0, which is
+// the reference's behaviour).  When the line search of ilqr.hh:174-194 runs out of trials the reference
+// throws; with restarts on, the trajectory instead keeps its current iterate, raises mu (mu_init first,
+// then x mu_factor) and repeats the backward pass with Q_uu + mu 1 in place of Q_uu everywhere -- i.e. the
+// exact LQR step of the model whose control cost carries an extra (mu / 2) |du|^2 -- and searches again
+// from alpha = 1.  An accepted step divides mu by mu_factor (below mu_init it returns to 0).  Past mu_max
+// the status is the reference's line-search failure.  A restart is not an iteration (ilqr.hh:58 counter).
+__device__ __forceinline__ bool lm_restart(const SolveParams &p, double &mu) {
+  if (!(p.mu_init > 0.0)) return false;
+  const double next = (mu > 0.0) ? mu * p.mu_factor : p.mu_init;
+  if (!(next <= p.mu_max)) return false;
+  mu = next;
+  return true;
+}
+__device__ __forceinline__ double lm_relax(const SolveParams &p, double mu) {
+  if (!(mu > 0.0)) return mu;
+  const double next = mu / p.mu_factor;
+  return (next < p.mu_init) ? 0.0 : next;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_init: thread b.  cost = sum of knot costs (left to right, ilqr.hh:89-95); arm the state machine.
 // ---------------------------------------------------------------------------------------------
@@ -211,6 +235,7 @@ __global__ void k_init(SolveParams p, BatchState st, int B, int n) {
   st.n_fwd[b] = 0;
   st.trial[b] = 0;
   st.alpha[b] = 1.0;
+  st.mu[b] = 0.0;
   st.terms[2 * b] = 0.0;
   st.terms[2 * b + 1] = 0.0;
   st.status[b] = 2;  // QILQR_STATUS_MAX_ITERS unless an exit path fires
@@ -307,6 +332,8 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   const int trial0 = st.trial[b];
   const double prev_cost0 = st.prev_cost[b], alpha0 = st.alpha[b];
   const double term0 = st.terms[2 * b], term1 = st.terms[2 * b + 1];
+  double mu = (p.mu_init > 0.0) ? st.mu[b] : 0.0;
+  bool restart = false;
   if (!force) {
     if (fl & F_SEARCH) {
       // ---- acceptance of the pending candidate (ilqr.hh:70-84, 174-194), fused here so that a round
@@ -339,6 +366,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
       if (accept) {
         cur ^= 1;
         fl = F_ACTIVE;
+        mu = lm_relax(p, mu);
         if (it > 0 && is_converged(p, cost, new_cost)) {
           status = 1;  // ilqr.hh:82-84
           fl = 0;
@@ -348,11 +376,17 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
         }
       } else {
         if (trial0 + 1 >= p.ls_max_iters) {
-          status = 3;  // ilqr.hh:191-193
-          fl = 0;
+          if (lm_restart(p, mu)) {
+            restart = true;  // same iterate, larger mu: the recursion below runs again
+            fl = F_ACTIVE;
+          } else {
+            status = 3;  // ilqr.hh:191-193
+            fl = 0;
+          }
         }
       }
       if (lane == 0) {
+        if (p.mu_init > 0.0) st.mu[b] = mu;
         st.n_fwd[b] += 1;
         if (accept) {
           st.cur[b] = cur;
@@ -367,7 +401,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
         st.flags[b] = fl;
         if (fl & F_ACTIVE) atomicAdd(&st.counters[0], 1);
       }
-      if (!accept || fl == 0) return;  // back-tracking continues with the old gains, or the trajectory is done
+      if ((!accept && !restart) || fl == 0) return;  // back-tracking continues with the old gains, or the trajectory is done
     } else if (fl == F_ACTIVE) {
       if (lane == 0) atomicAdd(&st.counters[0], 1);
     } else {
@@ -415,7 +449,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   gptr2 gdst1 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0 + 2, 52) : (S *)st.dump + 4 * (long)b + 2);
   const long gstep = gowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
   // register 3 <-> row 12 + kk: C_uu = 2 R (cost.hh:55) in columns 12..15
-  const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] : 0.0;
+  const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] + ((j - 12 == kk) ? mu : 0.0) : 0.0;
 
   double va[3] = {0.0, 0.0, 0.0};   // V_xx[j][4 kc + kk]  (A operand)
   double vxl[3] = {0.0, 0.0, 0.0};  // V_x[4 kc + kk]
@@ -661,6 +695,8 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
   const double prev_cost0 = st.prev_cost[b], alpha0 = st.alpha[b];
   const double term0 = st.terms[2 * b], term1 = st.terms[2 * b + 1];
   double cost_now = st.cost[b];
+  double mu = (p.mu_init > 0.0) ? st.mu[b] : 0.0;
+  bool restart = false;
   bool settle = false, accept = false, count_active = false;
   int status = -1;
   double new_cost = 0.0;
@@ -689,6 +725,7 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
         cur ^= 1;
         fl = F_ACTIVE;
         cost_now = new_cost;
+        mu = lm_relax(p, mu);
         if (it0 > 0 && is_converged(p, prev_cost0, new_cost)) {
           status = 1;  // ilqr.hh:82-84
           fl = 0;
@@ -697,8 +734,13 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
           fl = 0;
         }
       } else if (trial0 + 1 >= p.ls_max_iters) {
-        status = 3;  // ilqr.hh:191-193
-        fl = 0;
+        if (lm_restart(p, mu)) {
+          restart = true;  // same iterate, larger mu: the recursion runs again
+          fl = F_ACTIVE;
+        } else {
+          status = 3;  // ilqr.hh:191-193
+          fl = 0;
+        }
       }
       count_active = (fl & F_ACTIVE) != 0;
     } else if (fl == F_ACTIVE) {
@@ -707,11 +749,12 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
       return;  // both waves
     }
   }
-  const bool run = force || !settle || (accept && fl != 0);
+  const bool run = force || !settle || ((accept || restart) && fl != 0);
   const int iters_now = (settle && accept) ? it0 + 1 : it0;
   __syncthreads();
   if (role == 1 && lane == 0) {
     if (settle) {
+      if (p.mu_init > 0.0) st.mu[b] = mu;
       st.n_fwd[b] += 1;
       if (accept) {
         st.cur[b] = cur;
@@ -857,7 +900,8 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
   gptr2 gdst0 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0, 52) : (S *)st.dump + 4 * (long)b);
   gptr2 gdst1 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0 + 2, 52) : (S *)st.dump + 4 * (long)b + 2);
   const long gstep = gowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
-  const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] : 0.0;  // register 3 <-> row 12 + kk: C_uu = 2 R
+  // register 3 <-> row 12 + kk: C_uu = 2 R (+ mu on the diagonal, lm_restart)
+  const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] + ((j - 12 == kk) ? mu : 0.0) : 0.0;
   double va[3] = {0.0, 0.0, 0.0};  // V_xx[j][4 kc + kk]  (A operand)
   __syncthreads();  // ring[(n-1) % 3], ring[(n-2) % 3] and the constant tables are filled
   double m[3], cx[3];
@@ -982,6 +1026,7 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
   const RecLayout L = st.layout;
 
   // ---- every matrix wave settles its own trajectory's pending candidate (as in k_backward2)
+  double mu = 0.0;  // of matrix wave w's trajectory (lm_restart)
   if (w < 4) {
     const int b = b0 + w;
     bool run = false;
@@ -995,6 +1040,8 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
       const double prev_cost0 = st.prev_cost[b], alpha0 = st.alpha[b];
       const double term0 = st.terms[2 * b], term1 = st.terms[2 * b + 1];
       cost_now = st.cost[b];
+      mu = (p.mu_init > 0.0) ? st.mu[b] : 0.0;
+      bool restart = false;
       bool settle = false, accept = false, count_active = false, known = true;
       int status = -1;
       double new_cost = 0.0;
@@ -1023,6 +1070,7 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
             cur ^= 1;
             fl = F_ACTIVE;
             cost_now = new_cost;
+            mu = lm_relax(p, mu);
             if (it0 > 0 && is_converged(p, prev_cost0, new_cost)) {
               status = 1;  // ilqr.hh:82-84
               fl = 0;
@@ -1031,8 +1079,13 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
               fl = 0;
             }
           } else if (trial0 + 1 >= p.ls_max_iters) {
-            status = 3;  // ilqr.hh:191-193
-            fl = 0;
+            if (lm_restart(p, mu)) {
+              restart = true;  // same iterate, larger mu: the recursion runs again
+              fl = F_ACTIVE;
+            } else {
+              status = 3;  // ilqr.hh:191-193
+              fl = 0;
+            }
           }
           count_active = (fl & F_ACTIVE) != 0;
         } else if (fl == F_ACTIVE) {
@@ -1041,10 +1094,11 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
           known = false;  // nothing to do for this trajectory
         }
       }
-      run = known && (force || !settle || (accept && fl != 0));
+      run = known && (force || !settle || ((accept || restart) && fl != 0));
       iters_now = (settle && accept) ? it0 + 1 : it0;
       if (lane == 0 && known) {  // only this wave has read these words
         if (settle) {
+          if (p.mu_init > 0.0) st.mu[b] = mu;
           st.n_fwd[b] += 1;
           if (accept) {
             st.cur[b] = cur;
@@ -1204,7 +1258,8 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
   gptr2 gdst0 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0, 52) : (S *)st.dump + 4 * (long)b);
   gptr2 gdst1 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0 + 2, 52) : (S *)st.dump + 4 * (long)b + 2);
   const long gstep = gowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
-  const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] : 0.0;  // register 3 <-> row 12 + kk: C_uu = 2 R
+  // register 3 <-> row 12 + kk: C_uu = 2 R (+ mu on the diagonal, lm_restart)
+  const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] + ((j - 12 == kk) ? mu : 0.0) : 0.0;
   double va[3] = {0.0, 0.0, 0.0};  // V_xx[j][4 kc + kk]  (A operand)
   // Every matrix wave streams its own trajectory's records into its ring (two coalesced loads per knot, issued
   // in the shadow of the first MFMAs): record i-3 is requested in interval i and written in interval i-1.
@@ -2034,6 +2089,7 @@ __global__ void k_accept(SolveParams p, BatchState st, int B, int n, int ls_only
       st.cost[b] = new_cost;
       if (st.cost_hist && it < st.hist_cap) st.cost_hist[(long)b * st.hist_cap + it] = new_cost;
       st.iters[b] = it + 1;
+      st.mu[b] = lm_relax(p, st.mu[b]);
       fl = F_ACTIVE;
       if (it > 0 && is_converged(p, cost, new_cost)) {
         st.status[b] = 1;  // ilqr.hh:82-84
@@ -2047,8 +2103,14 @@ __global__ void k_accept(SolveParams p, BatchState st, int B, int n, int ls_only
       st.trial[b] = trial;
       st.alpha[b] = alpha * p.step_update;  // ilqr.hh:189
       if (trial >= p.ls_max_iters) {
-        st.status[b] = 3;  // ilqr.hh:191-193
-        fl = 0;
+        double mu = (p.mu_init > 0.0) ? st.mu[b] : 0.0;
+        if (!ls_only && lm_restart(p, mu)) {
+          st.mu[b] = mu;
+          fl = F_ACTIVE;  // the next backward pass runs on the same iterate with the larger mu
+        } else {
+          st.status[b] = 3;  // ilqr.hh:191-193
+          fl = 0;
+        }
       }
     }
     st.flags[b] = fl;

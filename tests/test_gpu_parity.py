@@ -421,6 +421,80 @@ def test_line_search_exhaustion():
     assert (ls["status"] == capi.STATUS_LINE_SEARCH_FAILED).all()
 
 
+def _restart_cfg(B=24, n=30, ls_max_iters=1, seed=7):
+    cfg = pb.config2(B=B, N=n, seed=seed)
+    cfg["init"][:, 0, 8:14] *= 4.0  # faster starts: more rejected full steps
+    cfg["options"] = dict(cfg["options"], ls_max_iters=ls_max_iters)
+    return cfg
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4])
+def test_levenberg_marquardt_restarts_match_oracle(kernel):
+    """qilqr_set_regularisation (an extension; the oracle states it, no reference
+    behaviour to match): with one trial per line search most problems exhaust it and restart with mu on the
+    diagonal of Q_uu.  Every backward kernel carries mu; all must follow the oracle's sequence of restarts,
+    trials and accepted steps."""
+    cfg = _restart_cfg()
+    o = oracle_for(cfg)
+    plain = o.solve_batch(cfg["init"], n_threads=8)
+    assert (plain["status"] == 3).sum() >= 8
+    o.set_regularisation(1.0, 4.0, 1e6)
+    ref = o.solve_batch(cfg["init"], n_threads=8)
+    assert (ref["status"] != 3).all() and (ref["n_bwd"] > ref["iters"] + 1).sum() >= 8
+    s = capi.from_config(cfg, force_general=kernel)
+    off = s.solve_batch(cfg["init"])  # default: off, the reference's behaviour
+    np.testing.assert_array_equal(off["status"], plain["status"])
+    np.testing.assert_array_equal(off["n_bwd"], plain["n_bwd"])
+    s.set_regularisation(1.0, 4.0, 1e6)
+    out = s.solve_batch(cfg["init"])
+    for k in ("status", "iters", "n_bwd", "n_fwd"):
+        np.testing.assert_array_equal(out[k], ref[k], err_msg=k)
+    np.testing.assert_allclose(out["cost"], ref["cost"], rtol=1e-9)
+    np.testing.assert_allclose(out["traj"], ref["traj"], atol=1e-6)
+    s.set_regularisation(0.0)
+    again = s.solve_batch(cfg["init"])
+    np.testing.assert_array_equal(again["status"], plain["status"])
+    np.testing.assert_array_equal(again["traj"], off["traj"])
+
+
+def test_restarts_past_mu_max_and_argument_checks():
+    cfg = _restart_cfg(B=4, n=10, ls_max_iters=3)
+    cfg["options"] = dict(cfg["options"], desired_reduction_frac=10.0)
+    s = capi.from_config(cfg)
+    s.set_regularisation(0.5, 2.0, 4.0)  # 0.5, 1, 2, 4: four restarts, then ilqr.hh:191-193
+    out = s.solve_batch(cfg["init"])
+    assert (out["status"] == capi.STATUS_LINE_SEARCH_FAILED).all()
+    np.testing.assert_array_equal(out["iters"], 1)
+    np.testing.assert_array_equal(out["n_bwd"], 2 + 4)
+    np.testing.assert_array_equal(out["n_fwd"], 1 + 3 * 5)
+    with pytest.raises(RuntimeError, match=r"Reached maximum number of line search iterations, 3\n"):
+        s.solve(cfg["init"][0])
+    for bad in [(1.0, 1.0, 10.0), (1.0, 2.0, 0.5), (-1.0, 2.0, 4.0), (float("nan"), 2.0, 4.0), (1e-300, 1.0000001, 1e300)]:
+        with pytest.raises(ValueError):
+            s.set_regularisation(*bad)
+
+
+def test_restarts_with_sub_batches_on_their_own_streams():
+    """The per-problem mu travels with the slice of the batch a stream owns: two and three parts give the
+    one-stream results bit for bit, and the oracle's counts, with restarts on (ragged last tile)."""
+    cfg = _restart_cfg(B=200, n=24, seed=9)
+    o = oracle_for(cfg)
+    o.set_regularisation(2.0, 8.0, 1e5)
+    ref = o.solve_batch(cfg["init"], n_threads=8)
+    assert (ref["n_bwd"] > ref["iters"] + 1).sum() >= 50
+    outs = []
+    for streams in (1, 2, 3):
+        s = capi.from_config(cfg, streams=streams)
+        s.set_regularisation(2.0, 8.0, 1e5)
+        outs.append(s.solve_batch(cfg["init"]))
+    for k in ("status", "iters", "n_bwd", "n_fwd"):
+        np.testing.assert_array_equal(outs[0][k], ref[k], err_msg=k)
+    np.testing.assert_allclose(outs[0]["cost"], ref["cost"], rtol=1e-9)
+    for other in outs[1:]:
+        for k in ("traj", "cost", "status", "iters", "n_bwd", "n_fwd"):
+            np.testing.assert_array_equal(other[k], outs[0][k], err_msg=k)
+
+
 def test_longer_than_desired_is_index_error():
     cfg = pb.config2(B=2, N=10)
     s = capi.from_config(cfg)

@@ -140,3 +140,79 @@ def test_ldlt4_solve_matches_numpy():
     A[0, 1] = A[1, 0] = 0.3
     b = np.array([1.0, 2.0, 3.0, 4.0])
     np.testing.assert_allclose(orc.ldlt4_solve(A, b), np.linalg.solve(A, b), rtol=1e-12)
+
+
+# ---- Levenberg-Marquardt restarts: an EXTENSION, not reference behaviour.
+# These tests pin the oracle's statement of it, which the GPU path is compared with.
+def _hover_cfg(B=24, n=30, ls_max_iters=1, seed=7):
+    cfg = pb.config2(B=B, N=n, seed=seed)
+    cfg["init"][:, 0, 8:14] *= 4.0  # faster starts: more rejected full steps
+    cfg["options"] = dict(cfg["options"], ls_max_iters=ls_max_iters)
+    return cfg
+
+
+def _oracle(cfg):
+    return orc.OracleSolver(orc.model_params(**cfg["model"]), cfg["Q"], cfg["R"], cfg["desired"], cfg["dt"],
+                            orc.options(**cfg["options"]))
+
+
+def test_regularised_backward_pass_is_the_lqr_step_of_a_heavier_control_cost():
+    """Q_uu + mu 1 everywhere = the backward pass of the problem whose R is R + (mu / 2) 1, as long as
+    C_u = 2 R (u - u_d) is the same, i.e. on a trajectory flown with the desired controls."""
+    cfg = _hover_cfg(B=3, n=12)
+    s = _oracle(cfg)
+    mu = 0.75
+    heavier = dict(cfg, R=cfg["R"] + 0.5 * mu * np.eye(4))
+    h = _oracle(heavier)
+    for b in range(3):
+        traj = s.forward_sim(cfg["init"][b], np.zeros((12, 52)), 1.0)  # controls stay u_d, states move
+        g_mu, t_mu = s.backwards_pass_reg(traj, mu)
+        g_h, t_h = h.backwards_pass(traj)
+        np.testing.assert_allclose(g_mu, g_h, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(t_mu, t_h, rtol=1e-11)
+        g0, t0 = s.backwards_pass_reg(traj, 0.0)
+        g, t = s.backwards_pass(traj)
+        assert np.array_equal(g0, g) and np.array_equal(t0, t)
+
+
+def test_restarts_take_over_where_the_line_search_gives_up():
+    """With one trial per line search (full steps only) most problems end in ilqr.hh:191-193; with restarts
+    the same problems reach the optimum the back-tracking solver finds."""
+    cfg = _hover_cfg()
+    plain = _oracle(cfg).solve_batch(cfg["init"], n_threads=4)
+    failed = plain["status"] == orc.STATUS_LINE_SEARCH_FAILED
+    assert failed.sum() >= 8
+    s = _oracle(cfg)
+    s.set_regularisation(1.0, 4.0, 1e6)
+    reg = s.solve_batch(cfg["init"], n_threads=4)
+    assert (reg["status"] != orc.STATUS_LINE_SEARCH_FAILED).all()
+    # problems that never exhausted a line search are untouched, bit for bit
+    for k in ("traj", "cost", "iters", "n_bwd", "n_fwd", "status"):
+        assert np.array_equal(reg[k][~failed], plain[k][~failed]), k
+    # the others went on from the iterate they were stuck at: never worse, and restarts show in n_bwd
+    assert (reg["cost"][failed] <= plain["cost"][failed]).all()
+    assert (reg["n_bwd"][failed] > reg["iters"][failed] + 1).all()
+    backtracking = _oracle(dict(cfg, options=dict(cfg["options"], ls_max_iters=100))).solve_batch(cfg["init"], n_threads=4)
+    done = reg["status"] != orc.STATUS_MAX_ITERS
+    np.testing.assert_allclose(reg["cost"][done], backtracking["cost"][done], rtol=1e-8)
+
+
+def test_restarts_end_in_line_search_failure_past_mu_max():
+    """No step satisfies a 10x Armijo demand whatever mu: mu_init, x factor ... until mu_max, then status 3;
+    every restart costs one backward pass and ls_max_iters trials."""
+    cfg = _hover_cfg(B=4, n=10, ls_max_iters=3)
+    cfg["options"] = dict(cfg["options"], desired_reduction_frac=10.0)
+    s = _oracle(cfg)
+    s.set_regularisation(0.5, 2.0, 4.0)  # 0.5, 1, 2, 4: four restarts
+    out = s.solve_batch(cfg["init"])
+    assert (out["status"] == orc.STATUS_LINE_SEARCH_FAILED).all()
+    np.testing.assert_array_equal(out["iters"], 1)
+    np.testing.assert_array_equal(out["n_bwd"], 2 + 4)
+    np.testing.assert_array_equal(out["n_fwd"], 1 + 3 * 5)
+    with pytest.raises(ValueError):
+        s.set_regularisation(1.0, 1.0, 10.0)  # factor must exceed 1
+    with pytest.raises(ValueError):
+        s.set_regularisation(1.0, 2.0, 0.5)   # mu_max below mu_init
+    s.set_regularisation(0.0)                  # off again: the reference's behaviour
+    off = s.solve_batch(cfg["init"])
+    np.testing.assert_array_equal(off["n_bwd"], 2)
