@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Runs the non-headline BASELINE.json configurations at full size on the GPU box and prints one
 JSON line per configuration (wall time of qilqr_solve_batch_device with inputs resident in HBM,
-status histogram, pass counts).  Usage: python profiles/run_configs.py [config4shard] [config5] [big]"""
+status histogram, pass counts).  Usage: python profiles/run_configs.py [config4shard] [config5] [config5reg] [big]"""
 import json
 import os
 import sys
@@ -14,10 +14,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quadrotorilqr_amd import capi, problems as pb  # noqa: E402
 
 
-def run(name, cfg, reps=2):
+def run(name, cfg, reps=2, reg=None):
     dev = torch.device("cuda", 0)
     B, N = cfg["init"].shape[:2]
     s = capi.from_config(cfg, sync_every=2)
+    if reg:
+        s.set_regularisation(*reg)  # Levenberg-Marquardt restarts (extension)
     init = torch.from_numpy(cfg["init"]).to(dev)
     out = torch.empty_like(init)
     cost = torch.empty(B, dtype=torch.float64, device=dev)
@@ -44,5 +46,12 @@ if __name__ == "__main__":
         a, b = pb.config5()
         run("configs[4] half A: model A hover (B=2048, N=500)", a, reps=1)
         run("configs[4] half B: demo box-climb, random starts (B=2048, N=500)", b, reps=1)
+    if "config5reg" in which:  # the same with restarts on, and with one trial per line search (restarts do the damping)
+        a, b = pb.config5()
+        run("configs[4] half A, restarts (1, x10, <= 1e8) on", a, reps=1, reg=(1.0, 10.0, 1e8))
+        a["options"] = dict(a["options"], ls_max_iters=1)
+        run("configs[4] half A, ls_max_iters = 1, restarts off", a, reps=1)
+        run("configs[4] half A, ls_max_iters = 1, restarts (1, x10, <= 1e8) on", a, reps=1, reg=(1.0, 10.0, 1e8))
+        run("configs[4] half B, restarts (1, x10, <= 1e8) on", b, reps=1, reg=(1.0, 10.0, 1e8))
     if "big" in which:
         run("B=65536, N=100, model A (whole configs[3] on one GPU)", pb.config2(B=65536, N=100, seed=4), reps=1)
