@@ -495,6 +495,36 @@ def test_restarts_with_sub_batches_on_their_own_streams():
             np.testing.assert_array_equal(other[k], outs[0][k], err_msg=k)
 
 
+def test_handles_in_flight_from_several_host_threads():
+    """Per-handle re-entrancy (SURVEY.md section 8b "Threading"): three solver handles driven from three
+    host threads at once -- the configuration bench.py's `serving` object measures -- give, bit for bit,
+    what one handle gives solving the same batches one after the other."""
+    import threading
+    cfgs = [pb.config2(B=96, N=40, seed=21 + k) for k in range(3)]
+    seq = capi.from_config(cfgs[0])
+    want = [seq.solve_batch(c["init"]) for c in cfgs]  # same model / weights / desired trajectory in all three
+    got = [None] * 3
+    errs = []
+
+    def drive(k):
+        try:
+            s = capi.from_config(cfgs[k])
+            for _ in range(3):
+                got[k] = s.solve_batch(cfgs[k]["init"])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=drive, args=(k,)) for k in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for k in range(3):
+        for key in ("traj", "cost", "status", "iters", "n_bwd", "n_fwd"):
+            np.testing.assert_array_equal(got[k][key], want[k][key], err_msg=f"{k} {key}")
+
+
 def test_longer_than_desired_is_index_error():
     cfg = pb.config2(B=2, N=10)
     s = capi.from_config(cfg)
