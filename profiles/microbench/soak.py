@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity soak: the randomised GPU test of tests/test_gpu_parity.py over many more seeds, with every
-backward kernel (automatic, k_backward2, k_backward4, one wavefront, general) and rollout kernel forced in turn.
+backward kernel (automatic, k_backward2, k_backward4, one wavefront, general) and rollout kernel forced in turn, and with Levenberg-Marquardt restarts on (few trials per line search).
 usage: python profiles/microbench/soak.py [first_seed [n_seeds]]"""
 import sys
 
@@ -16,12 +16,13 @@ bad = 0
 for label, kw in [("automatic", {}), ("k_backward2", dict(force_general=3)), ("k_backward4", dict(force_general=4)),
                   ("one wavefront", dict(force_general=2)), ("general", dict(force_general=1)),
                   ("k_rollout", dict(single_wave_rollout=1)), ("k_rollout4", dict(single_wave_rollout=4)),
-                  ("three streams", dict(streams=3))]:
+                  ("three streams", dict(streams=3)), ("restarts", dict()), ("restarts, k_backward2", dict(force_general=3)),
+                  ("restarts, one wavefront", dict(force_general=2)), ("restarts, general", dict(force_general=1))]:
     capi.from_config = lambda cfg, _kw=kw, **k: orig(cfg, **{**_kw, **k})
     fails = 0
     for seed in range(first, first + count):
         try:
-            T.test_randomised_models_and_horizons_match_oracle(seed)
+            T.test_randomised_models_and_horizons_match_oracle(seed, restarts=label.startswith("restarts"))
         except AssertionError as e:
             fails += 1
             print(label, "seed", seed, "FAILED:", str(e).splitlines()[:4])

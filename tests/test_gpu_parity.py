@@ -693,7 +693,7 @@ def test_mixed_precision_at_headline_size():
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_randomised_models_and_horizons_match_oracle(seed):
+def test_randomised_models_and_horizons_match_oracle(seed, restarts=False):
     """Random physical parameters (mass, SPD inertia, arm, rotor torque ratio, gravity), time step,
     horizon, weights (diagonal / block-diagonal dense / fully dense symmetric, by seed) and option values;
     random SE(3) starts towards a random hover pose."""
@@ -724,11 +724,27 @@ def test_randomised_models_and_horizons_match_oracle(seed):
     opts = dict(step_update=float(r.choice([0.5, 0.3, 0.7])), desired_reduction_frac=float(r.choice([0.5, 0.1, 0.01])),
                 ls_max_iters=int(r.integers(5, 40)), rtol=1e-10, atol=1e-10, max_iters=int(r.integers(3, 60)),
                 populate_debug=False)
+    reg = None
+    if restarts:  # few trials per line search, so that searches are exhausted, and Levenberg-Marquardt restarts on
+        opts["ls_max_iters"] = int(r.integers(1, 4))
+        reg = (float(r.choice([0.1, 1.0, 10.0])), float(r.choice([2.0, 4.0, 10.0])), float(r.choice([1e3, 1e6])))
     cfg = dict(model=model, Q=Q, R=R, dt=dt, options=opts, desired=desired, init=init)
-    out = capi.from_config(cfg).solve_batch(init)
-    ref = oracle_for(cfg).solve_batch(init, n_threads=8)
+    s, o = capi.from_config(cfg), oracle_for(cfg)
+    if reg:
+        s.set_regularisation(*reg)
+        o.set_regularisation(*reg)
+    out = s.solve_batch(init)
+    ref = o.solve_batch(init, n_threads=8)
     np.testing.assert_array_equal(out["status"], ref["status"])
     np.testing.assert_array_equal(out["iters"], ref["iters"])
+    np.testing.assert_array_equal(out["n_bwd"], ref["n_bwd"])
     np.testing.assert_array_equal(out["n_fwd"], ref["n_fwd"])
     np.testing.assert_allclose(out["cost"], ref["cost"], rtol=1e-8)
     np.testing.assert_allclose(out["traj"], ref["traj"], atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", range(100, 108))
+def test_randomised_restarts_match_oracle(seed):
+    """The randomised case above with one to three trials per line search and Levenberg-Marquardt restarts
+    (random mu_init, factor, mu_max) on both sides: same sequence of restarts, trials and accepted steps."""
+    test_randomised_models_and_horizons_match_oracle(seed, restarts=True)
