@@ -57,14 +57,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # test hook (tests/test_gpu_bench_contract.py): run the N > 1 code path with every rank on GPU 0 and gloo,
+    # because a one-GPU box cannot host two RCCL ranks; never set by the driver
+    one_device_test = os.environ.get("QILQR_BENCH_ONE_DEVICE_TEST") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        torch.cuda.set_device(0 if one_device_test else local_rank)
+        dist.init_process_group("gloo" if one_device_test else "nccl", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if (world > 1 and not one_device_test) else 0)
+    to_wire = (lambda t: t.cpu()) if one_device_test else (lambda t: t)  # gloo gathers host tensors
 
     B, N = args.batch, args.knots
     cfg = pb.config2(B=B, N=N, seed=2, b0=rank * B)  # counter-based generator: shard-independent
@@ -72,6 +76,15 @@ def main():
                               force_general=args.backward, streams=args.streams, **({} if args.rollout < 0 else dict(single_wave_rollout=args.rollout)))
 
     init = torch.from_numpy(cfg["init"]).to(dev)
+    # N > 1: the global batch of a step is the N shards of 1024 distinct problems (shard k = problems
+    # k*B .. (k+1)*B of the counter-based generator); rank r solves shard (r + step) mod N.  How long a shard
+    # takes is set by its slowest problem (31 to 45 rollouts over the first eight shards), so a fixed
+    # assignment would make every step wait for the same unlucky rank; rotating it evens the ranks' totals
+    # over the steps without any exchange (sharding.shard_of_step).
+    inits = {rank: init}
+    for sh in range(world):
+        if sh not in inits:
+            inits[sh] = torch.from_numpy(pb.config2(B=B, N=N, seed=2, b0=sh * B)["init"]).to(dev)
     # two sets of output buffers, used alternately: with N > 1 the gather of step s (RCCL, torch's stream) runs
     # while the solver's own stream is already solving step s + 1
     out_traj = [torch.empty_like(init) for _ in range(2)]
@@ -80,13 +93,20 @@ def main():
     sizes = [B] * world
     step_no = [0]
 
+    gathered = [None, None]  # per output buffer set: event after its last gather (N > 1)
+
     def step():
         k = step_no[0] & 1
+        sh = sharding.shard_of_step(rank, step_no[0], world)
         step_no[0] += 1
-        solver.solve_batch_device(init, out_traj[k], out_cost[k], out_i[0], out_i[1], out_i[2], out_i[3])
+        if gathered[k] is not None:
+            gathered[k].synchronize()  # the gather that read this buffer set two steps ago has finished
+        solver.solve_batch_device(inits[sh], out_traj[k], out_cost[k], out_i[0], out_i[1], out_i[2], out_i[3])
         if world > 1:  # the one exchange of the path: converged trajectories to rank 0
-            sharding.gather_to_root(out_traj[k], sizes)
-            sharding.gather_to_root(out_cost[k], sizes)
+            sharding.gather_to_root(to_wire(out_traj[k]), sizes)
+            sharding.gather_to_root(to_wire(out_cost[k]), sizes)
+            gathered[k] = torch.cuda.Event()
+            gathered[k].record()
 
     def fence():
         if world > 1:
@@ -109,7 +129,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = to_wire(torch.tensor([dt], dtype=torch.float64, device=dev))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     prof = solver.profile_get()
@@ -231,7 +251,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1]: batch={B}/GPU random SE(3) starts -> hover, "
                                    f"{N} knots, fp64, model A, seed 2", "batch_per_gpu": B, "knots": N,
-                       "parallelism": f"batch-shard x{world}" + (" + RCCL gather to rank 0" if world > 1 else "")},
+                       "parallelism": f"batch-shard x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
+                       "shard_assignment": ("one shard" if world == 1 else
+                                            f"{world} shards of {B} distinct problems per step; rank r solves shard (r + step) mod {world}")},
             "iters_mean": float(iters.mean()), "iters_max": int(iters.max()),
             "status_counts": np.bincount(status, minlength=4).tolist(),
             "knot_steps_per_s": float((n_bwd.sum() + n_fwd.sum()) * N * world * args.steps / dt),

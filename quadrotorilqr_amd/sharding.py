@@ -13,6 +13,14 @@ def shard_range(B, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_of_step(rank, step, world):
+    """Which shard of the global batch `rank` solves at `step` when a sequence of batches is solved: the
+    assignment rotates, so that over any `world` consecutive steps every rank has solved every shard once.
+    A shard's solve time is set by its slowest problem (data-dependent iteration counts); with a fixed
+    assignment the same rank would be the straggler of every step."""
+    return (rank + step) % world
+
+
 def gather_to_root(t, shard_sizes, dst=0, group=None):
     """Gather per-rank tensors (first dim = that rank's shard size) on rank `dst`; returns the
     concatenation there and None elsewhere.  Ragged shards are padded to the largest one."""

@@ -28,6 +28,14 @@ def test_shard_ranges_partition_the_batch():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_rotating_assignment_covers_every_shard_once_per_cycle():
+    for world in (1, 2, 3, 8):
+        for step in range(2 * world):
+            assert sorted(sharding.shard_of_step(r, step, world) for r in range(world)) == list(range(world))
+        for r in range(world):
+            assert sorted(sharding.shard_of_step(r, s, world) for s in range(5, 5 + world)) == list(range(world))
+
+
 def test_generator_is_shard_independent():
     whole = pb.config2(B=37, N=5, seed=4)["init"]
     lo, hi = sharding.shard_range(37, 1, 3)
