@@ -71,7 +71,7 @@ struct qilqr_solver {
   hipStream_t part_stream[MAX_PARTS] = {};
   hipEvent_t part_done[MAX_PARTS] = {};
   hipEvent_t main_ready = nullptr;
-  int *d_part_counters = nullptr;  // [MAX_PARTS][4]
+  int *d_part_counters = nullptr;  // [MAX_PARTS][COUNT_WORDS]
   long total_B = 0;                // trajectories in flight on the device in this call (kernel choices go by it)
   double *io_aos = nullptr;         // device scratch in the plain [B][n][W] layout (W <= 52), for host I/O
   void *desired_tiled = nullptr;    // per-problem desired trajectories, tiled (allocated on first use)
@@ -179,7 +179,7 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
   if ((rc = dalloc(s, &st.iters, cB))) return rc;
   if ((rc = dalloc(s, &st.n_bwd, cB))) return rc;
   if ((rc = dalloc(s, &st.n_fwd, cB))) return rc;
-  if ((rc = dalloc(s, &st.counters, 4))) return rc;
+  if ((rc = dalloc(s, &st.counters, COUNT_WORDS))) return rc;
   if ((rc = dalloc_s(s, &st.dump, 4 * cB))) return rc;
 #ifdef QILQR_STAMPS
   if ((rc = dalloc(s, &st.stamps, 8 * cB))) return rc;
@@ -355,9 +355,12 @@ int launch_accept(qilqr_solver *s, long B, long n, int ls_only) {
 }
 
 int read_active(qilqr_solver *s, int *n_active) {
-  HIP_TRY(hipMemcpyAsync(s->h_counters, s->st.counters, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->h_counters, s->st.counters + COUNT_BASE, sizeof(int) * COUNT_STRIPES, hipMemcpyDeviceToHost,
+                         s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  *n_active = s->h_counters[0];
+  int total = 0;
+  for (int k = 0; k < COUNT_STRIPES; ++k) total += s->h_counters[k];
+  *n_active = total;
   return QILQR_OK;
 }
 
@@ -463,7 +466,7 @@ BatchState slice_state(const qilqr_solver *s, long b0, long n, int part) {
   v.cur = w.cur + b0; v.cost = w.cost + b0; v.prev_cost = w.prev_cost + b0; v.terms = w.terms + 2 * b0;
   v.alpha = w.alpha + b0; v.mu = w.mu + b0; v.trial = w.trial + b0; v.flags = w.flags + b0; v.status = w.status + b0;
   v.iters = w.iters + b0; v.n_bwd = w.n_bwd + b0; v.n_fwd = w.n_fwd + b0;
-  v.counters = s->d_part_counters + 4 * part;
+  v.counters = s->d_part_counters + COUNT_WORDS * part;
   v.host_active = s->d_active + 8 * (1 + part);
   if (w.cost_hist) v.cost_hist = w.cost_hist + b0 * w.hist_cap;
   v.dump = adv(w.dump, 4 * b0);
@@ -659,7 +662,7 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
       e = hipMemcpy(s->d_desired, desired, es * 18 * n_desired, hipMemcpyHostToDevice);
     }
   }
-  if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_counters, sizeof(int) * 16, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_counters, sizeof(int) * COUNT_WORDS, hipHostMallocDefault);
   if (e == hipSuccess)
     e = hipHostMalloc((void **)&s->h_active, sizeof(unsigned long long) * 8 * (1 + qilqr_solver::MAX_PARTS),
                       hipHostMallocMapped | hipHostMallocCoherent);
@@ -668,7 +671,7 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
     e = hipHostGetDevicePointer((void **)&s->d_active, s->h_active, 0);
     s->st.host_active = s->d_active;
   }
-  if (e == hipSuccess) e = hipMalloc((void **)&s->d_part_counters, sizeof(int) * 4 * qilqr_solver::MAX_PARTS);
+  if (e == hipSuccess) e = hipMalloc((void **)&s->d_part_counters, sizeof(int) * COUNT_WORDS * qilqr_solver::MAX_PARTS);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->main_ready, hipEventDisableTiming);
   for (int k = 0; k < qilqr_solver::MAX_PARTS && e == hipSuccess; ++k) {
     e = hipStreamCreateWithFlags(&s->part_stream[k], hipStreamNonBlocking);
@@ -982,7 +985,7 @@ int qilqr_line_search(qilqr_solver *s, const double *traj, const double *cost, c
     return QILQR_OK;
   }
   for (int t = 0; t < s->params.ls_max_iters; ++t) {
-    HIP_TRY(hipMemsetAsync(s->st.counters, 0, sizeof(int), s->stream));
+    HIP_TRY(hipMemsetAsync(s->st.counters, 0, sizeof(int) * COUNT_WORDS, s->stream));
     if ((rc = launch_rollout(s, B, n, F_SEARCH))) return rc;
     if ((rc = launch_linearize(s, B, n, 1, F_SEARCH))) return rc;
     if ((rc = launch_accept(s, B, n, 1))) return rc;

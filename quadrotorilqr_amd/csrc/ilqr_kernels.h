@@ -25,6 +25,10 @@
 
 namespace qilqr {
 
+// The count of still-active trajectories is kept in COUNT_STRIPES words, one per residue of the block index:
+// thousands of atomic adds on ONE word are served one after the other (measured: 1024 of them, one per
+// wavefront at the start of k_backward4, held every block at its first barrier for 7 us).
+constexpr int COUNT_BASE = 8, COUNT_STRIPES = 64, COUNT_WORDS = COUNT_BASE + COUNT_STRIPES;
 constexpr int F_ACTIVE = 1;  // still iterating
 constexpr int F_SEARCH = 2;  // has gains, needs a (further) rollout trial
 
@@ -56,7 +60,7 @@ struct BatchState {
   int *trial;
   int *flags;
   int *status, *iters, *n_bwd, *n_fwd;
-  int *counters;         // [0] trajectories still active, counted by k_backward
+  int *counters;         // [COUNT_BASE + stripe]: trajectories still active, counted by k_backward (active_counter)
   unsigned long long *host_active;  // pinned host memory, 8 words: (round + 1) << 32 | active count (k_linearize)
   double *cost_hist;     // [B][hist_cap] or null
   int hist_cap;
@@ -64,6 +68,10 @@ struct BatchState {
   void *dump;            // [B][4] write-only sink for the lanes of k_backward that own no gain entry
   unsigned long long *stamps;  // diagnostic build only (-DQILQR_STAMPS): [B][8] cycle sums per section of k_backward
 };
+
+__device__ __forceinline__ int *active_counter(const BatchState &st) {
+  return st.counters + COUNT_BASE + (blockIdx.x & (COUNT_STRIPES - 1));
+}
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 // explicit global address space: a pointer selected between two buffers is otherwise 'generic' and
@@ -132,7 +140,7 @@ k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState 
   auto lin_stamp = [&](int half, double keep) {
     unsigned long long t1, r1;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) : "v"(keep) : "memory");
-    if ((id & 63) == 0 && st.stamps && lin_wave < 2048) {
+    if ((id & 63) == 0 && st.stamps && lin_wave < 2048 && round < 0) {  // not inside a solve: k_backward's stamps stay
       st.stamps[lin_wave * 4 + 0] = lin_r0;
       st.stamps[lin_wave * 4 + 1] = r1;
       st.stamps[lin_wave * 4 + 2] = t1 - lin_t0;
@@ -140,14 +148,17 @@ k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState 
     }
   };
 #endif
-  if (id == 0) {
+  if (id < COUNT_STRIPES) {  // first wavefront of block 0 (COUNT_STRIPES == 64)
     // hand the count of trajectories still active after this round's k_backward to the host: one
     // system-scope store into pinned memory, tagged with the round (no copy kernel, no event on the stream)
-    if (round >= 0)
+    int act = st.counters[COUNT_BASE + id];
+    st.counters[COUNT_BASE + id] = 0;  // the next k_backward counts again
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) act += __shfl_xor(act, off);
+    if (id == 0 && round >= 0)
       __hip_atomic_store(&st.host_active[round & 7],
-                         ((unsigned long long)(unsigned)(round + 1) << 32) | (unsigned)st.counters[0], __ATOMIC_RELEASE,
+                         ((unsigned long long)(unsigned)(round + 1) << 32) | (unsigned)act, __ATOMIC_RELEASE,
                          __HIP_MEMORY_SCOPE_SYSTEM);
-    st.counters[0] = 0;  // the next k_backward counts again
   }
   __syncthreads();  // qr is filled
   const long per_half = (long)((B + 63) / 64) * n * 64;
@@ -324,6 +335,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   const int b = blockIdx.x;
   if (b >= B) return;
   const int lane = threadIdx.x;
+  __shared__ double cost_scr[64];  // the settle step's knot costs
   // all per-trajectory scalars are requested at once (independent loads), not one after the other
   // behind the branches that use them
   int fl = st.flags[b];
@@ -343,14 +355,18 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
       double new_cost = 0.0;
       for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
-        const double v = (i < n) ? kc[cost_index(b, i, n)] : 0.0;
         const int cnt = (n - base < 64) ? n - base : 64;
-        const long long bits = __double_as_longlong(v);
-        for (int t = 0; t < cnt; ++t) {
-          const int lo = __builtin_amdgcn_readlane((int)bits, t);
-          const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), t);
-          new_cost += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        // through LDS, every lane adding in order from broadcast reads (see k_backward4)
+        cost_scr[lane] = (i < n) ? kc[cost_index(b, i, n)] : 0.0;
+        int t = 0;
+        for (; t + 8 <= cnt; t += 8) {
+          double x[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = cost_scr[t + e];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) new_cost += x[e];
         }
+        for (; t < cnt; ++t) new_cost += cost_scr[t];
       }
       const int it = it0;
       const double cost = prev_cost0;
@@ -399,11 +415,11 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
         }
         if (status >= 0) st.status[b] = status;
         st.flags[b] = fl;
-        if (fl & F_ACTIVE) atomicAdd(&st.counters[0], 1);
+        if (fl & F_ACTIVE) atomicAdd(active_counter(st), 1);
       }
       if ((!accept && !restart) || fl == 0) return;  // back-tracking continues with the old gains, or the trajectory is done
     } else if (fl == F_ACTIVE) {
-      if (lane == 0) atomicAdd(&st.counters[0], 1);
+      if (lane == 0) atomicAdd(active_counter(st), 1);
     } else {
       return;
     }
@@ -686,6 +702,7 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
   if (b >= B) return;
   const int lane = threadIdx.x & 63;
   const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: M, 1: G
+  __shared__ double cost_scr[2][64];  // the settle step's knot costs, one row per wave
   // ---- settle the pending candidate (ilqr.hh:70-84, 174-194).  Both waves take the decision from the
   // same global data; wave G's lane 0 applies it after a barrier (nobody reads those words afterwards).
   int fl = st.flags[b];
@@ -704,16 +721,20 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
     if (fl & F_SEARCH) {
       settle = true;
       const double *kc = st.knot_cost[cur ^ 1];
+      double *scr = cost_scr[role];  // through LDS, every lane adding in order from broadcast reads (see k_backward4)
       for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
-        const double v = (i < n) ? kc[cost_index(b, i, n)] : 0.0;
         const int cnt = (n - base < 64) ? n - base : 64;
-        const long long bits = __double_as_longlong(v);
-        for (int t = 0; t < cnt; ++t) {
-          const int lo = __builtin_amdgcn_readlane((int)bits, t);
-          const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), t);
-          new_cost += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        scr[lane] = (i < n) ? kc[cost_index(b, i, n)] : 0.0;
+        int t = 0;
+        for (; t + 8 <= cnt; t += 8) {
+          double x[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = scr[t + e];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) new_cost += x[e];
         }
+        for (; t < cnt; ++t) new_cost += scr[t];
       }
       if (it0 == 0) {
         accept = true;  // ilqr.hh:71-73
@@ -768,7 +789,7 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
       if (status >= 0) st.status[b] = status;
       st.flags[b] = fl;
     }
-    if (count_active) atomicAdd(&st.counters[0], 1);
+    if (count_active) atomicAdd(active_counter(st), 1);
   }
   if (!run) return;  // back-tracking continues with the old gains, or the trajectory is done
 
@@ -1017,7 +1038,11 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0..3: matrix wave of trajectory b0 + w; 4: G
   const int b0 = blockIdx.x * 4;
-  __shared__ int s_run[4], s_cur[4], s_iters[4];
+#ifdef QILQR_STAMPS
+  unsigned long long real_entry, real_loaded = 0, real_settled = 0, real_bar1 = 0;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real_entry)::"memory");
+#endif
+  __shared__ int s_run[4], s_cur[4], s_iters[4], s_act[4];
   __shared__ double s_cost[4];
   // four slots per trajectory: in interval i the matrix wave reads slot (i-1) & 3 and writes slot (i-2) & 3
   // while G reads slot (i+1) & 3
@@ -1030,7 +1055,7 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
   if (w < 4) {
     const int b = b0 + w;
     bool run = false;
-    int cur = 0, iters_now = 0;
+    int cur = 0, iters_now = 0, act = 0;
     double cost_now = 0.0;
     if (b < B) {
       int fl = st.flags[b];
@@ -1040,7 +1065,21 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
       const double prev_cost0 = st.prev_cost[b], alpha0 = st.alpha[b];
       const double term0 = st.terms[2 * b], term1 = st.terms[2 * b + 1];
       cost_now = st.cost[b];
+      const int n_fwd0 = st.n_fwd[b];
       mu = (p.mu_init > 0.0) ? st.mu[b] : 0.0;
+      // the knot costs of the first 128 knots of BOTH buffers are requested here, with the scalars above, not
+      // after `cur` has arrived (one memory latency less in front of the recursion)
+      double kc_early[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int i = 64 * h + lane;
+          kc_early[k][h] = (i < n) ? st.knot_cost[k][cost_index(b, i, n)] : 0.0;
+        }
+#ifdef QILQR_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real_loaded)::"memory");
+#endif
       bool restart = false;
       bool settle = false, accept = false, count_active = false, known = true;
       int status = -1;
@@ -1049,16 +1088,28 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
         if (fl & F_SEARCH) {
           settle = true;
           const double *kc = st.knot_cost[cur ^ 1];
-          for (int base = 0; base < n; base += 64) {
-            const int i = base + lane;
-            const double v = (i < n) ? kc[cost_index(b, i, n)] : 0.0;
-            const int cnt = (n - base < 64) ? n - base : 64;
-            const long long bits = __double_as_longlong(v);
-            for (int t = 0; t < cnt; ++t) {
-              const int lo = __builtin_amdgcn_readlane((int)bits, t);
-              const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), t);
-              new_cost += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+          // left to right (ilqr.hh:89-95).  64 lanes hold 64 knot costs; they go through this wave's own ring
+          // slot (nobody touches it before the first barrier) and every lane adds them up in order from
+          // broadcast reads, eight requested at a time: 0.5 us for 100 knots, against 3.5 us when each value
+          // is fetched with a pair of v_readlane inside a rolled loop
+          double *scr = &ring[w][0][0];
+          auto add_chunk = [&](double v, int cnt) {
+            scr[lane] = v;
+            int t = 0;
+            for (; t + 8 <= cnt; t += 8) {
+              double x[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x[e] = scr[t + e];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) new_cost += x[e];
             }
+            for (; t < cnt; ++t) new_cost += scr[t];
+          };
+          add_chunk((cur ^ 1) ? kc_early[1][0] : kc_early[0][0], n < 64 ? n : 64);
+          if (n > 64) add_chunk((cur ^ 1) ? kc_early[1][1] : kc_early[0][1], n < 128 ? n - 64 : 64);
+          for (int base = 128; base < n; base += 64) {
+            const int i = base + lane;
+            add_chunk((i < n) ? kc[cost_index(b, i, n)] : 0.0, (n - base < 64) ? n - base : 64);
           }
           if (it0 == 0) {
             accept = true;  // ilqr.hh:71-73
@@ -1099,7 +1150,7 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
       if (lane == 0 && known) {  // only this wave has read these words
         if (settle) {
           if (p.mu_init > 0.0) st.mu[b] = mu;
-          st.n_fwd[b] += 1;
+          st.n_fwd[b] = n_fwd0 + 1;
           if (accept) {
             st.cur[b] = cur;
             st.cost[b] = new_cost;
@@ -1112,18 +1163,31 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
           if (status >= 0) st.status[b] = status;
           st.flags[b] = fl;
         }
-        if (count_active) atomicAdd(&st.counters[0], 1);
+        act = count_active ? 1 : 0;
       }
     }
     if (lane == 0) {
+      s_act[w] = act;
       s_run[w] = run ? 1 : 0;
       s_cur[w] = cur;
       s_iters[w] = iters_now;
       s_cost[w] = cost_now;
     }
   }
+#ifdef QILQR_STAMPS
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real_settled)::"memory");
+#endif
   __syncthreads();
-  if ((s_run[0] | s_run[1] | s_run[2] | s_run[3]) == 0) return;  // block-uniform
+#ifdef QILQR_STAMPS
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real_bar1)::"memory");
+#endif
+  // one add per block, and where nobody waits for it: here for a block that has no recursion to run, at the
+  // end of the gradient wave otherwise
+  const int block_act = s_act[0] + s_act[1] + s_act[2] + s_act[3];
+  if ((s_run[0] | s_run[1] | s_run[2] | s_run[3]) == 0) {  // block-uniform
+    if (threadIdx.x == 0 && block_act) atomicAdd(active_counter(st), block_act);
+    return;
+  }
 
   // constant operand table behind every ring slot
   for (int t = threadIdx.x; t < CTAB_SIZE; t += 320) {
@@ -1237,6 +1301,7 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
         }
       }
     }
+    if (lane == 0 && block_act) atomicAdd(active_counter(st), block_act);
     return;
   }
 
@@ -1297,7 +1362,8 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
     cx[0] = buf[off[3]]; cx[1] = buf[off[4]]; cx[2] = buf[off[5]];
   }
 #ifdef QILQR_STAMPS
-  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev, real0;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real0)::"memory");
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
   for (int i = n - 1; i >= 0; --i) {
@@ -1375,6 +1441,16 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
     QSTAMP(7);  // barrier
   }
 #ifdef QILQR_STAMPS
+  {
+    // slot 3 (no section of wave M uses it): the loop's duration on the constant 100 MHz clock, so that
+    // cycles / time gives the shader clock the loop ran at
+    unsigned long long real1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real1)::"memory");
+    // loop (16 bits, 10 ns units... 32 bits) | entry -> loads arrived | -> settled | -> first barrier | -> loop
+    stamp_sum[3] = ((real1 - real0) & 0xfffffull) | (((real_loaded - real_entry) & 0x7ffull) << 20) |
+                   (((real_settled - real_loaded) & 0x7ffull) << 31) | (((real_bar1 - real_settled) & 0x7ffull) << 42) |
+                   (((real0 - real_bar1) & 0x7ffull) << 53);
+  }
   if (lane == 0 && st.stamps)
     for (int k = 0; k < 8; ++k) st.stamps[(long)(b0 + w) * 8 + k] = stamp_sum[k];
 #endif
@@ -2115,7 +2191,7 @@ __global__ void k_accept(SolveParams p, BatchState st, int B, int n, int ls_only
     }
     st.flags[b] = fl;
   }
-  if (fl & F_ACTIVE) atomicAdd(&st.counters[0], 1);
+  if (fl & F_ACTIVE) atomicAdd(active_counter(st), 1);
 }
 
 // ---------------------------------------------------------------------------------------------
