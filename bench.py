@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--backward", type=int, default=0, help="diagnostic: backward kernel (qilqr_device_config.force_general: 0 automatic, 1 general, 2 one wavefront per trajectory)")
     ap.add_argument("--streams", type=int, default=0, help="sub-batches on their own streams (qilqr_device_config.streams; 0 automatic)")
     ap.add_argument("--event-stride", type=int, default=4, help="time every k-th launch of the dominant kernel in the timed region (a timed dispatch costs the stream about 6 us)")
+    ap.add_argument("--settle-ms", type=float, default=300.0, help="untimed solves before the warm-up steps (clocks out of idle)")
     ap.add_argument("--no-serving", action="store_true", help="skip the extra several-batches-in-flight measurement (never part of value)")
     ap.add_argument("--serving-batches", type=int, default=18)
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP events around the kernels (roofline = null)")
@@ -113,6 +114,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Not a warm-up step and not timed: bring the host core and the GPU out of their idle clocks.  The host
+    # keeps the stream two rounds ahead of the device; on a freshly started process its first 100 ms can be slow
+    # enough (one run in a dozen, fresh box) for the device to wait on launches during the 70 ms timed region.
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        solver.solve_batch_device(init, out_traj[0], out_cost[0], out_i[0], out_i[1], out_i[2], out_i[3])
     for _ in range(args.warmup):
         step()
     fence()

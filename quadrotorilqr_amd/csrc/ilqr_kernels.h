@@ -1666,7 +1666,8 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
   const bool live = (b < B) && (!need_flag || (st.flags[b < B ? b : 0] & need_flag));
   if (__ballot(live) == 0ull) return;  // identical in the three waves: block-uniform
 #ifdef QILQR_STAMPS
-  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev, real_entry, real0 = 0;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real_entry)::"memory");
   auto stamp_flush = [&]() {
     if (lane == 0 && st.stamps)
       for (int k = 0; k < 8; ++k) st.stamps[((long)blockIdx.x * 3 + role) * 8 + k] = stamp_sum[k];
@@ -1778,6 +1779,7 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
     }
     cj = sh[0][10][lane];
 #ifdef QILQR_STAMPS
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real0)::"memory");
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
     for (int i = 0; i < n; ++i) {
@@ -1841,6 +1843,14 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
       QKEEP(cj); QKEEP(q[0]);
       QSTAMP(6);  // X: LDS read of Y's results
     }
+#ifdef QILQR_STAMPS
+    {
+      // slot 3 (unused by X): the loop on the constant 100 MHz clock (low 20 bits) | entry -> loop (next 20)
+      unsigned long long real1;
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real1)::"memory");
+      stamp_sum[3] = ((real1 - real0) & 0xfffffull) | (((real0 - real_entry) & 0xfffffull) << 20);
+    }
+#endif
   } else {
     // ------------------------------------------------------------------ Y: pose
     RolloutSeries<S> sr;  // the series coefficients, in vector registers for the whole loop
