@@ -20,6 +20,8 @@ for _ in range(3):
     s.backwards_pass(trajs)
 out = np.zeros((B, 8), dtype=np.uint64)
 capi.load().qilqr_debug_stamps(s._h, out.ctypes.data_as(C.c_void_p), C.c_int32(B))
+if os.environ.get("BW", "4") == "4":
+    out[:, 3] = 0  # k_backward4 keeps wall-clock stamps there (backward_clock.py)
 med = np.median(out.astype(np.float64), axis=0) / N
 if os.environ.get("BW", "4") == "1":   # one-wavefront kernel (force_general = 2)
     names = ["prefetch issue (7 loads)", "T = V M (3 MFMA)", "H = C + M^T T (3 MFMA)", "gradient (3 FMA + 2 shuffles)",
