@@ -129,8 +129,10 @@ k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState 
   // The weights Q (144) and R (16) are more constants than a wave has scalar registers: the block keeps
   // them in LDS (filled from the device copy *cp) and the cost half reads them row by row where it uses
   // them; everything else comes from the by-value copy c.
-  __shared__ S qr[160];
-  for (int k = threadIdx.x; k < 160; k += blockDim.x) qr[k] = (k < 144) ? cp->Q[k] : cp->R[k - 144];
+  // (one copy per wavefront, filled by the wavefronts of the cost half only and without a block barrier: the
+  // dynamics half does not wait for weights it never reads)
+  __shared__ S qr_all[2][160];
+  S *qr = qr_all[threadIdx.x >> 6];
   // thread -> (half, tile, knot, lane): the 64 lanes of a wavefront hold one knot of 64 consecutive trajectories
   long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
 #ifdef QILQR_STAMPS
@@ -160,7 +162,6 @@ k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState 
                          ((unsigned long long)(unsigned)(round + 1) << 32) | (unsigned)act, __ATOMIC_RELEASE,
                          __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  __syncthreads();  // qr is filled
   const long per_half = (long)((B + 63) / 64) * n * 64;
   const bool cost_half = id >= per_half;
   if (cost_half) id -= per_half;
@@ -169,9 +170,16 @@ k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState 
   const long rest = id >> 6;
   const int i = (int)(rest % n);
   const long b = (rest / n) * 64 + lane;
+  if (cost_half) {  // wave-uniform (per_half is a multiple of 64)
+    const int wl = threadIdx.x & 63;
+    for (int k = wl; k < 160; k += 64) qr[k] = (k < 144) ? cp->Q[k] : cp->R[k - 144];
+    __builtin_amdgcn_wave_barrier();  // written and read by this wavefront only (LDS operations of a wave stay in order)
+  }
   if (b >= B) return;
-  if (need_flag && !(st.flags[b] & need_flag)) return;
+  // the flag and the buffer selector are requested together (one memory latency, not two, before the knot's)
+  const int fl = st.flags[b];
   const int buf = st.cur[b] ^ which;
+  if (need_flag && !(fl & need_flag)) return;
   S pt[18];
   load_knot<true>((const S *)st.traj[buf] + knot_base<true>(b, n, 18), i, 18, pt);
   const PlainRecWriter<S> w{(S *)st.lin[buf] + rec_base(b, n, st.layout.stride) + rec_elem(i, 0, st.layout.stride)};
