@@ -1699,35 +1699,43 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
     const sv2 *tp = reinterpret_cast<const sv2 *>(traj);   // pair k of knot i: tp[(i * 9 + k) * 64]
     const sv2 *gp = reinterpret_cast<const sv2 *>(gains);  //                   gp[(i * 26 + k) * 64]
     sv2 ra[35], rb[35], pa[4], pb[4];
-    auto load_ops = [&](int k, sv2 (&r)[35]) {
-      if (k < n) {
+    // Lanes whose trajectory is not being rolled out this round request nothing after the first knots (in the
+    // late rounds a tile holds a handful of live trajectories and 16-byte sectors of the others would be most
+    // of the kernel's HBM traffic); their registers keep the first knots' operands, so the other two waves go
+    // on computing finite values for them that nobody stores.
+    auto load_ops = [&](int k, sv2 (&r)[35], bool every_lane) {
+      if (k < n && (every_lane || live)) {
 #pragma unroll
         for (int e = 0; e < 9; ++e) r[e] = tp[((long)k * 9 + e) * 64];
 #pragma unroll
         for (int e = 0; e < 26; ++e) r[9 + e] = gp[((long)k * 26 + e) * 64];
       }
     };
-    auto load_pose = [&](int k, sv2 (&r)[4]) {
-      if (k < n) {
+    auto load_pose = [&](int k, sv2 (&r)[4], bool every_lane) {
+      if (k < n && (every_lane || live)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = tp[((long)k * 9 + e) * 64];
       }
     };
-    load_ops(0, ra);
-    load_pose(1, pa);
+    load_ops(0, ra, true);
+    load_pose(n > 1 ? 1 : 0, pa, true);
 #pragma unroll
     for (int e = 0; e < 35; ++e) bx[0][e][lane] = ra[e];
 #pragma unroll
     for (int e = 0; e < 4; ++e) by[1][e][lane] = pa[e];
-    load_ops(1, ra);   // written during iteration 0
-    load_pose(2, pa);  // written during iteration 0
+#pragma unroll
+    for (int e = 0; e < 35; ++e) rb[e] = ra[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pb[e] = pa[e];
+    load_ops(1, ra, false);   // written during iteration 0
+    load_pose(2, pa, false);  // written during iteration 0
     __syncthreads();
 #ifdef QILQR_STAMPS
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
     auto knot = [&](int i, sv2 (&rc)[35], sv2 (&rn)[35], sv2 (&pc)[4], sv2 (&pn)[4]) {
-      load_ops(i + 2, rn);   // consumed by X at iteration i + 2
-      load_pose(i + 3, pn);  // consumed by Y at iteration i + 2
+      load_ops(i + 2, rn, false);   // consumed by X at iteration i + 2
+      load_pose(i + 3, pn, false);  // consumed by Y at iteration i + 2
       QSTAMP(0);  // L: load issue
       if (i + 1 < n) {
 #pragma unroll
@@ -1751,6 +1759,9 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
     return;
   }
 
+  // the time step of a lane that is not being rolled out is zero: its state stays where it starts, next to the
+  // first knots' nominal values the loader keeps giving it, on the cheap branches of Exp and Log
+  const S dtl = live ? c.dt : S(0);
   S t[3], q[4], v[6], td[3] = {0, 0, 0}, th[3] = {0, 0, 0}, cj = 0;
   {
     S p0[18];
@@ -1831,7 +1842,7 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
         body_acceleration_fast(c, q, v, u, acc);
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-          v[a] = v[a] + c.dt * acc[a];
+          v[a] = v[a] + dtl * acc[a];
           sh[par][11 + a][lane] = v[a];
         }
       }
@@ -1879,7 +1890,7 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
         }
         S tau[6];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) tau[a] = c.dt * v[a];  // pose integrates with the OLD velocity
+        for (int a = 0; a < 6; ++a) tau[a] = dtl * v[a];  // pose integrates with the OLD velocity
         QKEEP(pnm[7]);
         QSTAMP(0);  // Y: nominal pose from LDS
         se3_rplus_fast(t, q, tau, sr);
