@@ -77,10 +77,10 @@ typedef struct {
                          ahead of the device (k <= 6).  The results do not depend on it. */
   int32_t force_general; /* backward kernel.  0: by the weights and the batch (symmetric Q, R: k_backward2 -- a matrix
                             and a gradient wavefront per trajectory -- up to 640 trajectories and from 4096 to 8192,
-                            k_backward4 -- one gradient wavefront per four trajectories -- in between, one wavefront
+                            k_backward4 -- one gradient and one loader wavefront per four trajectories -- in between, one wavefront
                             per trajectory beyond); 1: the general kernel even when Q, R are symmetric; 2: the
                             one-wavefront kernel for symmetric weights (k_backward<true>); 3: k_backward2;
-                            4: k_backward4 */
+                            4: k_backward4; 5: k_backward4 without its loader wavefront (ablation) */
   int32_t single_wave_rollout; /* rollout kernel: 0 (default) or 2 = pose wave + control wave + loader wave per 64
                                   trajectories (k_rollout3); 1 = one wavefront (k_rollout, always used above 16384
                                   trajectories); 3 = pose wave + control wave (k_rollout2); 4 = compose wave + log

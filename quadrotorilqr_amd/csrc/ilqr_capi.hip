@@ -287,14 +287,20 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
   //   up to 4096: k_backward4 (one gradient wavefront per four trajectories: fewer co-resident waves;
   //               80.5 vs 83.5 us at 1024, 114 vs 132 us at 2048, equal from 4096 on)
   //   up to 8192: k_backward2; beyond: one wavefront per trajectory (the matrix pipe is the bound)
-  const bool want4 = s->dev.force_general == 4 || (s->dev.force_general == 0 && load_B > 640 && load_B < 4096);
+  const bool want4 = s->dev.force_general == 4 || s->dev.force_general == 5 ||
+                     (s->dev.force_general == 0 && load_B > 640 && load_B < 4096);
   if (s->symmetric && want4 && load_B <= 8192) {
     // four matrix wavefronts + one gradient wavefront per four trajectories
+    // (force_general = 5: without the loader wavefront, the matrix waves stream their own records -- kept for the
+    // ablation: 78.7 against 73.7 us with four trajectories, 73.4 against 64.1 us with one)
     if (s->f32)
-      launch(s, K_BACKWARD, k_backward4<float>, dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n,
+      launch(s, K_BACKWARD, k_backward4<float, true>, dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n,
              force);
+    else if (s->dev.force_general == 5)
+      launch(s, K_BACKWARD, k_backward4<double, false>, dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B,
+             (int)n, force);
     else
-      launch(s, K_BACKWARD, k_backward4<double>, dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B,
+      launch(s, K_BACKWARD, k_backward4<double, true>, dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B,
              (int)n, force);
   } else if (s->symmetric && s->dev.force_general != 2 && load_B <= 8192) {
     // two cooperating wavefronts per trajectory (matrix recursion / gradient recursion + operand streaming):

@@ -1040,11 +1040,14 @@ __device__ __forceinline__ double bw4_dot_step(double acc, double m, double vx) 
   asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(vx), "v"(m), "n"(R));
   return acc;
 }
-template <typename S>
-__global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n,
-                                                   int force) {
+// LW = true (block = 384): a sixth wavefront L streams the knot records of the block's four trajectories into the
+// rings, on the schedule the matrix waves otherwise keep themselves (record i-3 requested in interval i, written
+// in interval i-1): the matrix waves are left with the recursion and their gain stores.
+template <typename S, bool LW>
+__global__ __launch_bounds__(LW ? 384 : 320) void k_backward4(ModelConsts<double> c, SolveParams p, BatchState st, int B,
+                                                              int n, int force) {
   const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0..3: matrix wave of trajectory b0 + w; 4: G
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0..3: matrix wave of trajectory b0 + w; 4: G; 5: L
   const int b0 = blockIdx.x * 4;
 #ifdef QILQR_STAMPS
   unsigned long long real_entry, real_loaded = 0, real_settled = 0, real_bar1 = 0;
@@ -1198,7 +1201,7 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
   }
 
   // constant operand table behind every ring slot
-  for (int t = threadIdx.x; t < CTAB_SIZE; t += 320) {
+  for (int t = threadIdx.x; t < CTAB_SIZE; t += (LW ? 384 : 320)) {
     const double v = (double)((const S *)st.ctab)[t];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -1313,6 +1316,64 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
     return;
   }
 
+  if constexpr (LW) {
+    if (w == 5) {
+      // ---------------------------------------------------------------- L: knot records of four trajectories
+      const int tl = (L.stride - 65 < lane) ? L.stride - 65 : lane;  // second load: elements 64 .. stride-1, clamped
+      typename GA<S>::cptr lp[4];
+      S q0[4], q1[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int bg = (b0 + g < B) ? b0 + g : B - 1;
+        lp[g] = (typename GA<S>::cptr)((const S *)st.lin[s_cur[g]] + rec_base(bg, n, L.stride));
+        q0[g] = 0; q1[g] = 0;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // (trajectories with nothing to do are streamed too: no branches in this wave)
+        typename GA<S>::cptr a = lp[g] + rec_elem(n - 1, 0, L.stride);
+        const S a0 = a[lane], a1 = a[64 + tl];
+        S b0_ = 0, b1_ = 0;
+        if (n >= 2) {
+          typename GA<S>::cptr b2 = lp[g] + rec_elem(n - 2, 0, L.stride);
+          b0_ = b2[lane];
+          b1_ = b2[64 + tl];
+        }
+        if (n >= 3) {
+          typename GA<S>::cptr c3 = lp[g] + rec_elem(n - 3, 0, L.stride);
+          q0[g] = c3[lane];
+          q1[g] = c3[64 + tl];
+        }
+        ring[g][(n - 1) & 3][lane] = (double)a0;
+        ring[g][(n - 1) & 3][64 + lane] = (double)a1;
+        if (n >= 2) {
+          ring[g][(n - 2) & 3][lane] = (double)b0_;
+          ring[g][(n - 2) & 3][64 + lane] = (double)b1_;
+        }
+      }
+      __syncthreads();  // rings and constant tables are filled
+      for (int i = n - 1; i >= 0; --i) {
+        // first the four records requested one interval ago, then the next four requests: the wait in front of
+        // the LDS writes is for loads that are all older than anything in flight
+        if (i - 2 >= 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            ring[g][(i - 2) & 3][lane] = (double)q0[g];
+            ring[g][(i - 2) & 3][64 + lane] = (double)q1[g];
+          }
+        }
+        if (i - 3 >= 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            typename GA<S>::cptr a = lp[g] + rec_elem(i - 3, 0, L.stride);
+            q0[g] = a[lane];
+            q1[g] = a[64 + tl];
+          }
+        }
+        __syncthreads();
+      }
+      return;
+    }
+  }
   // -------------------------------------------------------------------- M_w: matrix recursion of trajectory b0 + w
   const bool run = s_run[w] != 0;
   const int b = (b0 + w < B) ? b0 + w : B - 1;
@@ -1340,7 +1401,7 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
   const S *lin = (const S *)st.lin[s_cur[w]] + rec_base(b, n, L.stride);
   auto rec_ptr = [&](int i) { return (gptr)(lin + rec_elem(i, 0, L.stride)); };
   S r0 = 0, r1 = 0;
-  if (run) {
+  if (run && !LW) {
     gptr q1 = rec_ptr(n - 1);
     const S a0 = q1[lane], a1 = q1[64 + tail];
     ring[w][(n - 1) & 3][lane] = (double)a0;
@@ -1434,14 +1495,16 @@ __global__ __launch_bounds__(320) void k_backward4(ModelConsts<double> c, SolveP
     for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
     m[0] = m_n0; m[1] = m_n1; m[2] = m_n2;
     cx[0] = cx_n0; cx[1] = cx_n1; cx[2] = cx_n2;
-    if (i - 2 >= 0) {
-      ring[w][(i - 2) & 3][lane] = (double)r0;
-      ring[w][(i - 2) & 3][64 + lane] = (double)r1;
-    }
-    if (i - 3 >= 0) {
-      gptr q = rec_ptr(i - 3);
-      r0 = q[lane];
-      r1 = q[64 + tail];
+    if constexpr (!LW) {
+      if (i - 2 >= 0) {
+        ring[w][(i - 2) & 3][lane] = (double)r0;
+        ring[w][(i - 2) & 3][64 + lane] = (double)r1;
+      }
+      if (i - 3 >= 0) {
+        gptr q = rec_ptr(i - 3);
+        r0 = q[lane];
+        r1 = q[64 + tail];
+      }
     }
     QKEEP(va[0]); QKEEP(m[2]);
     QSTAMP(6);  // the knot

@@ -230,6 +230,8 @@ def test_two_wave_backward_matches_single_wave():
         np.testing.assert_array_equal(o2["n_fwd"], o1["n_fwd"])
         np.testing.assert_allclose(o2["cost"], o1["cost"], rtol=1e-9 if prec == "f64" else 1e-4)
         # k_backward4: one gradient wavefront for four trajectories (blocks of four: B is not always a multiple)
+        # (5: the same kernel with the matrix waves streaming their own records instead of the loader wavefront --
+        # the same arithmetic, bit for bit)
         four = capi.from_config(cfg, precision=prec, force_general=4)
         g4, t4 = four.backwards_pass(trajs)
         np.testing.assert_allclose(t4, t1, rtol=1e-11, atol=1e-300)
@@ -239,6 +241,10 @@ def test_two_wave_backward_matches_single_wave():
         np.testing.assert_array_equal(o4["iters"], o1["iters"])
         np.testing.assert_array_equal(o4["n_fwd"], o1["n_fwd"])
         np.testing.assert_allclose(o4["cost"], o1["cost"], rtol=1e-9 if prec == "f64" else 1e-4)
+        if prec == "f64":
+            g5, t5 = capi.from_config(cfg, force_general=5).backwards_pass(trajs)
+            np.testing.assert_array_equal(g5, g4)
+            np.testing.assert_array_equal(t5, t4)
 
 
 def test_sub_batches_on_their_own_streams_give_identical_results():
@@ -428,7 +434,7 @@ def _restart_cfg(B=24, n=30, ls_max_iters=1, seed=7):
     return cfg
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 5])
 def test_levenberg_marquardt_restarts_match_oracle(kernel):
     """qilqr_set_regularisation (an extension; the oracle states it, no reference
     behaviour to match): with one trial per line search most problems exhaust it and restart with mu on the
