@@ -284,11 +284,12 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
   const long load_B = std::max(B, s->total_B);
   // Which backward kernel (symmetric weights), by how many trajectories share the chip's 1024 SIMDs:
   //   up to 640: k_backward2 (a matrix and a gradient wavefront per trajectory, each alone on its SIMD)
-  //   up to 4096: k_backward4 (one gradient wavefront per four trajectories: fewer co-resident waves;
-  //               80.5 vs 83.5 us at 1024, 114 vs 132 us at 2048, equal from 4096 on)
-  //   up to 8192: k_backward2; beyond: one wavefront per trajectory (the matrix pipe is the bound)
+  //   up to 8192: k_backward4 (one gradient and one loader wavefront per four trajectories: fewer co-resident
+  //               waves; whole solves: 205k against 190k solves/s at 2048, 275k against 265k at 4096, 372k
+  //               against 357k at 8192; equal at 512)
+  //   beyond: one wavefront per trajectory (the matrix pipe is the bound)
   const bool want4 = s->dev.force_general == 4 || s->dev.force_general == 5 ||
-                     (s->dev.force_general == 0 && load_B > 640 && load_B < 4096);
+                     (s->dev.force_general == 0 && load_B > 640 && load_B <= 8192);
   if (s->symmetric && want4 && load_B <= 8192) {
     // four matrix wavefronts + one gradient wavefront per four trajectories
     // (force_general = 5: without the loader wavefront, the matrix waves stream their own records -- kept for the
