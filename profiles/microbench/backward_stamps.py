@@ -26,6 +26,9 @@ med = np.median(out.astype(np.float64), axis=0) / N
 if os.environ.get("BW", "4") == "1":   # one-wavefront kernel (force_general = 2)
     names = ["prefetch issue (7 loads)", "T = V M (3 MFMA)", "H = C + M^T T (3 MFMA)", "gradient (3 FMA + 2 shuffles)",
              "Quu/Qu/rhs broadcast", "LDLT + two solves", "V_x, terms", "V_xx MFMA, stores, hand-off"]
+elif os.environ.get("BW", "4") == "4":  # wave M of k_backward4
+    names = ["ring reads issued, T = V M (3 MFMA)", "H = C + M^T T (3 MFMA)", "gather + Quu broadcast", "-", "LDLT + solve",
+             "gain stores, hand-off to G", "V_xx MFMA, next operands", "barrier"]
 else:                                   # wave M of k_backward2
     names = ["operand reads (LDS) issued", "T = V M (3 MFMA)", "H = C + M^T T (3 MFMA)", "-", "gather + Quu broadcast",
              "LDLT + solve", "stores, hand-off to G, V_xx MFMA", "barrier"]

@@ -1444,16 +1444,22 @@ __global__ __launch_bounds__(LW ? 384 : 320) void k_backward4(ModelConsts<double
     T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0], m[0], T, 0, 0, 0);
     T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1], m[1], T, 0, 0, 0);
     T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2], m[2], T, 0, 0, 0);
+    QKEEP(T[0]); QKEEP(T[3]);
+    QSTAMP(0);  // ring reads issued, T = V M
     d4 H = {cx[0], cx[1], cx[2], cuu};
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
+    QKEEP(H[0]); QKEEP(H[3]);
+    QSTAMP(1);  // H = C + M^T T
     double Quu[16], Qu_unused[4], col[4];
     gather_rows(H[3], col);
     bcast_quu_row<0>(col, 0.0, Quu, Qu_unused);
     bcast_quu_row<1>(col, 0.0, Quu, Qu_unused);
     bcast_quu_row<2>(col, 0.0, Quu, Qu_unused);
     bcast_quu_row<3>(col, 0.0, Quu, Qu_unused);
+    QKEEP(Quu[0]); QKEEP(Quu[15]); QKEEP(col[3]);
+    QSTAMP(2);  // gather + Q_uu broadcast
     // LDL^T of the lower triangle of Q_uu (ilqr.hh:126), as in k_backward
     const double i0 = rcp_nr(Quu[0]);
     const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
@@ -1475,6 +1481,8 @@ __global__ __launch_bounds__(LW ? 384 : 320) void k_backward4(ModelConsts<double
                    x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
       kcol[0] = -x0; kcol[1] = -x1; kcol[2] = -x2; kcol[3] = -x3;  // K[:, j] (ilqr.hh:127)
     }
+    QKEEP(kcol[0]); QKEEP(kcol[3]);
+    QSTAMP(4);  // LDL^T + solve
     {
       const sv2 w0 = {(S)kcol[0], (S)kcol[1]}, w1 = {(S)kcol[2], (S)kcol[3]};
       *gdst0 = w0;
@@ -1489,6 +1497,7 @@ __global__ __launch_bounds__(LW ? 384 : 320) void k_backward4(ModelConsts<double
       f[64] = l10; f[65] = l20; f[66] = l30; f[67] = l21; f[68] = l31; f[69] = l32;
       f[70] = i0; f[71] = i1; f[72] = i2; f[73] = i3;
     }
+    QSTAMP(5);  // gain stores, hand-off to G
     // V_xx = Q_xx + Q_xu K: A[j][kk] = Q_xu[j][kk] = H[12 + kk][j] is accumulator register 3
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(H[3], sel4(kcol, kk), H, 0, 0, 0);
 #pragma unroll
@@ -1507,7 +1516,7 @@ __global__ __launch_bounds__(LW ? 384 : 320) void k_backward4(ModelConsts<double
       }
     }
     QKEEP(va[0]); QKEEP(m[2]);
-    QSTAMP(6);  // the knot
+    QSTAMP(6);  // V_xx MFMA, next operands
     __syncthreads();
     QSTAMP(7);  // barrier
   }
