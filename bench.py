@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--sync-every", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="HIP events around every kernel, not only the two candidates for dominant kernel")
-    ap.add_argument("--rollout", type=int, default=-1, help="rollout kernel: 0 pair, 1 single wave, 2 pair + loader (default: library default)")
+    ap.add_argument("--rollout", type=int, default=-1, help="rollout kernel: 0 pose + control + loader waves, 1 single wave (default: library default)")
     ap.add_argument("--backward", type=int, default=0, help="diagnostic: backward kernel (qilqr_device_config.force_general: 0 automatic, 1 general, 2 one wavefront per trajectory)")
     ap.add_argument("--streams", type=int, default=0, help="sub-batches on their own streams (qilqr_device_config.streams; 0 automatic)")
     ap.add_argument("--event-stride", type=int, default=4, help="time every k-th launch of the dominant kernel in the timed region (a timed dispatch costs the stream about 6 us)")

@@ -80,11 +80,10 @@ typedef struct {
                             gradient and one loader wavefront per four trajectories -- up to 8192, one wavefront
                             per trajectory beyond); 1: the general kernel even when Q, R are symmetric; 2: the
                             one-wavefront kernel for symmetric weights (k_backward<true>); 3: k_backward2;
-                            4: k_backward4; 5: k_backward4 without its loader wavefront (ablation) */
-  int32_t single_wave_rollout; /* rollout kernel: 0 (default) or 2 = pose wave + control wave + loader wave per 64
+                            4: k_backward4 */
+  int32_t single_wave_rollout; /* rollout kernel: 0 (default) = pose wave + control wave + loader wave per 64
                                   trajectories (k_rollout3); 1 = one wavefront (k_rollout, always used above 16384
-                                  trajectories); 3 = pose wave + control wave (k_rollout2); 4 = compose wave + log
-                                  wave + control wave + loader (k_rollout4: measured, not faster, kept selectable) */
+                                  trajectories) */
   int32_t precision; /* 0: fp64 everywhere (reference parity).  1: mixed: trajectories, gains and knot records
                         stored in fp32, rollout and linearisation computed in fp32, Riccati recursion on the fp64
                         matrix core, cost sums / Armijo / convergence tests in fp64 (BASELINE.json configs[2]) */

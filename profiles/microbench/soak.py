@@ -13,9 +13,9 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 orig = capi.from_config
 bad = 0
-for label, kw in [("automatic", {}), ("k_backward2", dict(force_general=3)), ("k_backward4", dict(force_general=4)), ("k_backward4, no loader", dict(force_general=5)),
+for label, kw in [("automatic", {}), ("k_backward2", dict(force_general=3)), ("k_backward4", dict(force_general=4)), 
                   ("one wavefront", dict(force_general=2)), ("general", dict(force_general=1)),
-                  ("k_rollout", dict(single_wave_rollout=1)), ("k_rollout4", dict(single_wave_rollout=4)),
+                  ("k_rollout", dict(single_wave_rollout=1)), 
                   ("three streams", dict(streams=3)), ("restarts", dict()), ("restarts, k_backward2", dict(force_general=3)),
                   ("restarts, one wavefront", dict(force_general=2)), ("restarts, general", dict(force_general=1))]:
     capi.from_config = lambda cfg, _kw=kw, **k: orig(cfg, **{**_kw, **k})

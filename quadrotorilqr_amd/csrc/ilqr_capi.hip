@@ -288,21 +288,13 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
   //               waves; whole solves: 205k against 190k solves/s at 2048, 275k against 265k at 4096, 372k
   //               against 357k at 8192; equal at 512)
   //   beyond: one wavefront per trajectory (the matrix pipe is the bound)
-  const bool want4 = s->dev.force_general == 4 || s->dev.force_general == 5 ||
-                     (s->dev.force_general == 0 && load_B > 640 && load_B <= 8192);
+  const bool want4 = s->dev.force_general == 4 || (s->dev.force_general == 0 && load_B > 640 && load_B <= 8192);
   if (s->symmetric && want4 && load_B <= 8192) {
-    // four matrix wavefronts + one gradient wavefront per four trajectories
-    // (force_general = 5: without the loader wavefront, the matrix waves stream their own records -- kept for the
-    // ablation: 78.7 against 73.7 us with four trajectories, 73.4 against 64.1 us with one)
+    // four matrix wavefronts + one gradient wavefront + one loader wavefront per four trajectories
     if (s->f32)
-      launch(s, K_BACKWARD, k_backward4<float, true>, dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n,
-             force);
-    else if (s->dev.force_general == 5)
-      launch(s, K_BACKWARD, k_backward4<double, false>, dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B,
-             (int)n, force);
+      launch(s, K_BACKWARD, k_backward4<float>, dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
     else
-      launch(s, K_BACKWARD, k_backward4<double, true>, dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B,
-             (int)n, force);
+      launch(s, K_BACKWARD, k_backward4<double>, dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
   } else if (s->symmetric && s->dev.force_general != 2 && load_B <= 8192) {
     // two cooperating wavefronts per trajectory (matrix recursion / gradient recursion + operand streaming):
     // shortens one trajectory's chain; above ~8 trajectories per SIMD the chip is bound by the matrix pipe and
@@ -333,25 +325,11 @@ int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
     else
       launch(s, K_ROLLOUT, k_rollout<double>, dim3(cdiv(B, 64)), dim3(64), s->consts, s->st, (int)B, (int)n,
                          need_flag);
-  } else if (s->dev.single_wave_rollout == 4) {
-    if (s->f32)
-      launch(s, K_ROLLOUT, k_rollout4<float>, dim3(cdiv(B, 64)), dim3(256), s->constsf, s->st, (int)B, (int)n, need_flag);
-    else
-      launch(s, K_ROLLOUT, k_rollout4<double>, dim3(cdiv(B, 64)), dim3(256), s->consts, s->st, (int)B, (int)n, need_flag);
-  } else if (s->dev.single_wave_rollout != 3) {
-    if (s->f32)
-      launch(s, K_ROLLOUT, k_rollout3<float>, dim3(cdiv(B, 64)), dim3(192), s->constsf, s->st, (int)B,
-                         (int)n, need_flag);
-    else
-      launch(s, K_ROLLOUT, k_rollout3<double>, dim3(cdiv(B, 64)), dim3(192), s->consts, s->st, (int)B,
-                         (int)n, need_flag);
   } else {
     if (s->f32)
-      launch(s, K_ROLLOUT, k_rollout2<float>, dim3(cdiv(B, 64)), dim3(128), s->constsf, s->st, (int)B,
-                         (int)n, need_flag);
+      launch(s, K_ROLLOUT, k_rollout3<float>, dim3(cdiv(B, 64)), dim3(192), s->constsf, s->st, (int)B, (int)n, need_flag);
     else
-      launch(s, K_ROLLOUT, k_rollout2<double>, dim3(cdiv(B, 64)), dim3(128), s->consts, s->st, (int)B,
-                         (int)n, need_flag);
+      launch(s, K_ROLLOUT, k_rollout3<double>, dim3(cdiv(B, 64)), dim3(192), s->consts, s->st, (int)B, (int)n, need_flag);
   }
   return QILQR_OK;
 }

@@ -1024,13 +1024,16 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_backward4: k_backward2 with ONE gradient wavefront for FOUR trajectories (block = 320: matrix waves
-// M0..M3, gradient wave G).  With a gradient wave per trajectory, 1024 trajectories are 2048 wavefronts
-// on 1024 SIMDs and every matrix wave shares its SIMD (the kernel takes 84 us against 64 us for 512
-// trajectories).  G gives a row of 16 lanes to each trajectory: lane (g, j) holds column j of M = [J_x | J_u]
-// and V_x[j]; the products M^T V_x take the 12 entries of V_x by DPP row broadcasts (no shuffles, no
-// butterflies), Q_u is broadcast the same way, and V_x = Q_x + K^T Q_u lands in the lane that owns it.
-// G also streams the records of the four trajectories into their LDS rings.  Everything else as k_backward2.
+// k_backward4: k_backward2 with ONE gradient wavefront and ONE loader wavefront for FOUR trajectories
+// (block = 384: matrix waves M0..M3, gradient wave G, loader wave L).  With a gradient wave per trajectory, 1024
+// trajectories are 2048 wavefronts on 1024 SIMDs and every matrix wave shares its SIMD (the kernel takes 84 us
+// against 64 us for 512 trajectories).  G gives a row of 16 lanes to each trajectory: lane (g, j) holds column j
+// of M = [J_x | J_u] and V_x[j]; the products M^T V_x take the 12 entries of V_x by DPP row broadcasts (no
+// shuffles, no butterflies), Q_u is broadcast the same way, and V_x = Q_x + K^T Q_u lands in the lane that owns
+// it.  L streams the knot records of the block's four trajectories into their LDS rings (record i-3 requested in
+// interval i, written in interval i-1): the matrix waves are left with the recursion and their gain stores (their
+// own record loads shared the in-order memory counter with those stores: 78.7 -> 73.7 us).  Everything else as
+// k_backward2.
 // ---------------------------------------------------------------------------------------------
 // acc += m * (vx of lane R of the caller's row of 16): one v_fmac_f64_dpp (the compiler keeps broadcast and
 // multiply-add apart).  vx must have been written at least two instructions earlier (DPP read hazard): it is
@@ -1040,12 +1043,9 @@ __device__ __forceinline__ double bw4_dot_step(double acc, double m, double vx) 
   asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(vx), "v"(m), "n"(R));
   return acc;
 }
-// LW = true (block = 384): a sixth wavefront L streams the knot records of the block's four trajectories into the
-// rings, on the schedule the matrix waves otherwise keep themselves (record i-3 requested in interval i, written
-// in interval i-1): the matrix waves are left with the recursion and their gain stores.
-template <typename S, bool LW>
-__global__ __launch_bounds__(LW ? 384 : 320) void k_backward4(ModelConsts<double> c, SolveParams p, BatchState st, int B,
-                                                              int n, int force) {
+template <typename S>
+__global__ __launch_bounds__(384) void k_backward4(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n,
+                                                   int force) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0..3: matrix wave of trajectory b0 + w; 4: G; 5: L
   const int b0 = blockIdx.x * 4;
@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__(LW ? 384 : 320) void k_backward4(ModelConsts<double
   }
 
   // constant operand table behind every ring slot
-  for (int t = threadIdx.x; t < CTAB_SIZE; t += (LW ? 384 : 320)) {
+  for (int t = threadIdx.x; t < CTAB_SIZE; t += 384) {
     const double v = (double)((const S *)st.ctab)[t];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -1211,7 +1211,6 @@ __global__ __launch_bounds__(LW ? 384 : 320) void k_backward4(ModelConsts<double
       ring[g][3][BW2_REC + t] = v;
     }
   }
-  typedef typename GA<S>::cptr gptr;
   typedef typename GA<S>::v2 sv2;
   typedef typename GA<S>::ptr2 gptr2;
 
@@ -1316,63 +1315,61 @@ __global__ __launch_bounds__(LW ? 384 : 320) void k_backward4(ModelConsts<double
     return;
   }
 
-  if constexpr (LW) {
-    if (w == 5) {
-      // ---------------------------------------------------------------- L: knot records of four trajectories
-      const int tl = (L.stride - 65 < lane) ? L.stride - 65 : lane;  // second load: elements 64 .. stride-1, clamped
-      typename GA<S>::cptr lp[4];
-      S q0[4], q1[4];
+  if (w == 5) {
+    // ---------------------------------------------------------------- L: knot records of four trajectories
+    const int tl = (L.stride - 65 < lane) ? L.stride - 65 : lane;  // second load: elements 64 .. stride-1, clamped
+    typename GA<S>::cptr lp[4];
+    S q0[4], q1[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int bg = (b0 + g < B) ? b0 + g : B - 1;
-        lp[g] = (typename GA<S>::cptr)((const S *)st.lin[s_cur[g]] + rec_base(bg, n, L.stride));
-        q0[g] = 0; q1[g] = 0;
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {  // (trajectories with nothing to do are streamed too: no branches in this wave)
-        typename GA<S>::cptr a = lp[g] + rec_elem(n - 1, 0, L.stride);
-        const S a0 = a[lane], a1 = a[64 + tl];
-        S b0_ = 0, b1_ = 0;
-        if (n >= 2) {
-          typename GA<S>::cptr b2 = lp[g] + rec_elem(n - 2, 0, L.stride);
-          b0_ = b2[lane];
-          b1_ = b2[64 + tl];
-        }
-        if (n >= 3) {
-          typename GA<S>::cptr c3 = lp[g] + rec_elem(n - 3, 0, L.stride);
-          q0[g] = c3[lane];
-          q1[g] = c3[64 + tl];
-        }
-        ring[g][(n - 1) & 3][lane] = (double)a0;
-        ring[g][(n - 1) & 3][64 + lane] = (double)a1;
-        if (n >= 2) {
-          ring[g][(n - 2) & 3][lane] = (double)b0_;
-          ring[g][(n - 2) & 3][64 + lane] = (double)b1_;
-        }
-      }
-      __syncthreads();  // rings and constant tables are filled
-      for (int i = n - 1; i >= 0; --i) {
-        // first the four records requested one interval ago, then the next four requests: the wait in front of
-        // the LDS writes is for loads that are all older than anything in flight
-        if (i - 2 >= 0) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            ring[g][(i - 2) & 3][lane] = (double)q0[g];
-            ring[g][(i - 2) & 3][64 + lane] = (double)q1[g];
-          }
-        }
-        if (i - 3 >= 0) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            typename GA<S>::cptr a = lp[g] + rec_elem(i - 3, 0, L.stride);
-            q0[g] = a[lane];
-            q1[g] = a[64 + tl];
-          }
-        }
-        __syncthreads();
-      }
-      return;
+    for (int g = 0; g < 4; ++g) {
+      const int bg = (b0 + g < B) ? b0 + g : B - 1;
+      lp[g] = (typename GA<S>::cptr)((const S *)st.lin[s_cur[g]] + rec_base(bg, n, L.stride));
+      q0[g] = 0; q1[g] = 0;
     }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {  // (trajectories with nothing to do are streamed too: no branches in this wave)
+      typename GA<S>::cptr a = lp[g] + rec_elem(n - 1, 0, L.stride);
+      const S a0 = a[lane], a1 = a[64 + tl];
+      S b0_ = 0, b1_ = 0;
+      if (n >= 2) {
+        typename GA<S>::cptr b2 = lp[g] + rec_elem(n - 2, 0, L.stride);
+        b0_ = b2[lane];
+        b1_ = b2[64 + tl];
+      }
+      if (n >= 3) {
+        typename GA<S>::cptr c3 = lp[g] + rec_elem(n - 3, 0, L.stride);
+        q0[g] = c3[lane];
+        q1[g] = c3[64 + tl];
+      }
+      ring[g][(n - 1) & 3][lane] = (double)a0;
+      ring[g][(n - 1) & 3][64 + lane] = (double)a1;
+      if (n >= 2) {
+        ring[g][(n - 2) & 3][lane] = (double)b0_;
+        ring[g][(n - 2) & 3][64 + lane] = (double)b1_;
+      }
+    }
+    __syncthreads();  // rings and constant tables are filled
+    for (int i = n - 1; i >= 0; --i) {
+      // first the four records requested one interval ago, then the next four requests: the wait in front of
+      // the LDS writes is for loads that are all older than anything in flight
+      if (i - 2 >= 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          ring[g][(i - 2) & 3][lane] = (double)q0[g];
+          ring[g][(i - 2) & 3][64 + lane] = (double)q1[g];
+        }
+      }
+      if (i - 3 >= 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          typename GA<S>::cptr a = lp[g] + rec_elem(i - 3, 0, L.stride);
+          q0[g] = a[lane];
+          q1[g] = a[64 + tl];
+        }
+      }
+      __syncthreads();
+    }
+    return;
   }
   // -------------------------------------------------------------------- M_w: matrix recursion of trajectory b0 + w
   const bool run = s_run[w] != 0;
@@ -1395,29 +1392,6 @@ __global__ __launch_bounds__(LW ? 384 : 320) void k_backward4(ModelConsts<double
   // register 3 <-> row 12 + kk: C_uu = 2 R (+ mu on the diagonal, lm_restart)
   const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] + ((j - 12 == kk) ? mu : 0.0) : 0.0;
   double va[3] = {0.0, 0.0, 0.0};  // V_xx[j][4 kc + kk]  (A operand)
-  // Every matrix wave streams its own trajectory's records into its ring (two coalesced loads per knot, issued
-  // in the shadow of the first MFMAs): record i-3 is requested in interval i and written in interval i-1.
-  const int tail = (L.stride - 65 < lane) ? L.stride - 65 : lane;  // second load: elements 64 .. stride-1, clamped
-  const S *lin = (const S *)st.lin[s_cur[w]] + rec_base(b, n, L.stride);
-  auto rec_ptr = [&](int i) { return (gptr)(lin + rec_elem(i, 0, L.stride)); };
-  S r0 = 0, r1 = 0;
-  if (run && !LW) {
-    gptr q1 = rec_ptr(n - 1);
-    const S a0 = q1[lane], a1 = q1[64 + tail];
-    ring[w][(n - 1) & 3][lane] = (double)a0;
-    ring[w][(n - 1) & 3][64 + lane] = (double)a1;
-    if (n >= 2) {
-      gptr q2 = rec_ptr(n - 2);
-      const S c0_ = q2[lane], c1_ = q2[64 + tail];
-      ring[w][(n - 2) & 3][lane] = (double)c0_;
-      ring[w][(n - 2) & 3][64 + lane] = (double)c1_;
-    }
-    if (n >= 3) {
-      gptr q3 = rec_ptr(n - 3);
-      r0 = q3[lane];
-      r1 = q3[64 + tail];
-    }
-  }
   __syncthreads();  // rings and constant tables are filled
   if (!run) {
     // this trajectory has nothing to do in this round: keep the block's barriers company
@@ -1504,17 +1478,6 @@ __global__ __launch_bounds__(LW ? 384 : 320) void k_backward4(ModelConsts<double
     for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
     m[0] = m_n0; m[1] = m_n1; m[2] = m_n2;
     cx[0] = cx_n0; cx[1] = cx_n1; cx[2] = cx_n2;
-    if constexpr (!LW) {
-      if (i - 2 >= 0) {
-        ring[w][(i - 2) & 3][lane] = (double)r0;
-        ring[w][(i - 2) & 3][64 + lane] = (double)r1;
-      }
-      if (i - 3 >= 0) {
-        gptr q = rec_ptr(i - 3);
-        r0 = q[lane];
-        r1 = q[64 + tail];
-      }
-    }
     QKEEP(va[0]); QKEEP(m[2]);
     QSTAMP(6);  // V_xx MFMA, next operands
     __syncthreads();
@@ -1552,191 +1515,24 @@ __global__ __launch_bounds__(64) void k_rollout(ModelConsts<S> c, BatchState st,
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_rollout2: the same rollout with TWO cooperating wavefronts per 64 trajectories (block = 128).
-// A single wavefront issues one fp64 instruction per ~9 cycles whatever the instruction-level
+// k_rollout3: the rollout with THREE cooperating wavefronts per 64 trajectories (block = 192).
+// A single wavefront issues one fp64 instruction per ~5-9 cycles whatever the instruction-level
 // parallelism (profiles/microbench), so the serial per-knot chain is split into the two halves that
-// are independent inside one knot:
+// are independent inside one knot, and the operand loads are taken off both:
 //   wave Y (pose):     T_{i+1} = T_i Exp(dt v_i), then the pose part of x_{i+1} (-) xnom_{i+1}
 //   wave X (control):  rho_i = Jl^-1 td_i, u_i = u_nom + alpha k + K dx_i, v_{i+1} = v_i + dt a(q_i, v_i, u_i)
-// They trade 11 + 6 doubles per knot through LDS (double-buffered, one barrier per knot).  The
-// arithmetic is the same sequence of operations as rollout_problem: results are bit-identical.
-// ---------------------------------------------------------------------------------------------
-template <typename S>
-__global__ __launch_bounds__(128) void k_rollout2(ModelConsts<S> c, BatchState st, int B, int n,
-                                                  int need_flag) {
-  const int lane = threadIdx.x & 63;
-  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: X, 1: Y
-  const int b = blockIdx.x * 64 + lane;
-  const bool live = (b < B) && (!need_flag || (st.flags[b < B ? b : 0] & need_flag));
-  if (__ballot(live) == 0ull) return;  // same lanes -> same trajectories in both waves: block-uniform
-  const int bs = (b < B) ? b : (B - 1);
-  const int cur = st.cur[bs];
-  const int br = bs;
-  const S *traj = (const S *)st.traj[cur] + knot_base<true>(br, n, 18);
-  const S *gains = (const S *)st.gains + knot_base<true>(br, n, 52);
-  S *out = (S *)st.traj[cur ^ 1] + knot_base<true>(bs, n, 18);
-  const S alpha = (S)st.alpha[bs];
-
-  __shared__ S sh[2][17][64];  // [parity][0..3 q | 4..6 td | 7..9 th | 10 c | 11..16 v][lane]
-
-  S pt[18];
-  load_knot<true>(traj, 0, 18, pt);
-  S t[3] = {pt[1], pt[2], pt[3]};
-  S q[4] = {pt[5], pt[6], pt[7], pt[4]};
-  S v[6];
-#pragma unroll
-  for (int a = 0; a < 6; ++a) v[a] = pt[8 + a];
-  S td[3] = {0, 0, 0}, th[3] = {0, 0, 0}, cj = 0;
-
-  if (role == 1) {
-    const S qn[4] = {pt[5], pt[6], pt[7], pt[4]};
-    se3_rminus_part1(t, q, pt + 1, qn, td, th, cj);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      sh[0][4 + a][lane] = td[a];
-      sh[0][7 + a][lane] = th[a];
-    }
-    sh[0][10][lane] = cj;
-    if (live) {
-      const S po[8] = {0, t[0], t[1], t[2], q[3], q[0], q[1], q[2]};
-#pragma unroll
-      for (int e = 1; e < 8; ++e) out[knot_elem<true>(0, e, 18)] = po[e];
-    }
-  }
-  __syncthreads();
-  if (role == 0) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      td[a] = sh[0][4 + a][lane];
-      th[a] = sh[0][7 + a][lane];
-    }
-    cj = sh[0][10][lane];
-  }
-
-  // Operands of the NEXT knot are requested before the current knot's chain starts and consumed one
-  // iteration later (two register sets, loop unrolled by two so that no copies are needed): wave X
-  // prefetches the nominal knot and the 52 gains, wave Y the nominal pose.
-  S ptA[18], ptB[18], gA[52], gB[52], pnA[8], pnB[8];
-  if (role == 0) {
-    load_knot<true>(traj, 0, 18, ptA);
-    load_knot<true>(gains, 0, 52, gA);
-  } else if (n > 1) {
-#pragma unroll
-    for (int e = 1; e < 8; ++e) pnA[e] = traj[knot_elem<true>(1, e, 18)];
-  }
-
-#ifdef QILQR_STAMPS
-  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
-#endif
-  auto knot = [&](int i, S (&ptc)[18], S (&gc)[52], S (&ptn)[18], S (&gn)[52], S (&pnc)[8], S (&pnn)[8]) {
-    const int par = (i + 1) & 1;
-    const bool more = (i + 1 < n);
-    if (role == 0) {
-      if (more) {
-        load_knot<true>(traj, i + 1, 18, ptn);
-        load_knot<true>(gains, i + 1, 52, gn);
-      }
-      QSTAMP(0);  // X: prefetch issue
-      S dx[12];
-      se3_rminus_part2(td, th, cj, dx);
-      dx[3] = th[0]; dx[4] = th[1]; dx[5] = th[2];
-#pragma unroll
-      for (int a = 0; a < 6; ++a) dx[6 + a] = v[a] - ptc[8 + a];
-      QKEEP(dx[0]); QKEEP(dx[11]);
-      QSTAMP(1);  // X: rho = Jl^-1 td, dx
-      S u[4];
-      control_law(ptc, gc, alpha, dx, u);
-      QKEEP(u[0]); QKEEP(u[3]);
-      QSTAMP(2);  // X: control law (waits for this knot's operands)
-      if (live) {
-        out[knot_elem<true>(i, 0, 18)] = ptc[0];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) out[knot_elem<true>(i, 8 + a, 18)] = v[a];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) out[knot_elem<true>(i, 14 + a, 18)] = u[a];
-      }
-      QSTAMP(3);  // X: stores
-      if (more) {
-        S acc[6];
-        body_acceleration_fast(c, q, v, u, acc);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          v[a] = v[a] + c.dt * acc[a];
-          sh[par][11 + a][lane] = v[a];
-        }
-      }
-      QSTAMP(4);  // X: acceleration, velocity update, LDS write
-    } else if (more) {
-      if (i + 2 < n) {
-#pragma unroll
-        for (int e = 1; e < 8; ++e) pnn[e] = traj[knot_elem<true>(i + 2, e, 18)];
-      }
-      S tau[6];
-#pragma unroll
-      for (int a = 0; a < 6; ++a) tau[a] = c.dt * v[a];  // pose integrates with the OLD velocity
-      QSTAMP(0);  // Y: prefetch issue
-      se3_rplus_fast(t, q, tau);
-      QKEEP(q[0]); QKEEP(t[0]);
-      QSTAMP(1);  // Y: T <- T Exp(dt v)
-      const S qn[4] = {pnc[5], pnc[6], pnc[7], pnc[4]};
-      se3_rminus_part1(t, q, pnc + 1, qn, td, th, cj);
-      QKEEP(td[0]); QKEEP(th[0]); QKEEP(cj);
-      QSTAMP(2);  // Y: pose part of x (-) xnom (waits for the nominal pose)
-#pragma unroll
-      for (int a = 0; a < 4; ++a) sh[par][a][lane] = q[a];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        sh[par][4 + a][lane] = td[a];
-        sh[par][7 + a][lane] = th[a];
-      }
-      sh[par][10][lane] = cj;
-      if (live) {
-        const S po[8] = {0, t[0], t[1], t[2], q[3], q[0], q[1], q[2]};
-#pragma unroll
-        for (int e = 1; e < 8; ++e) out[knot_elem<true>(i + 1, e, 18)] = po[e];
-      }
-    }
-    __syncthreads();
-    if (more) {
-      if (role == 0) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) q[a] = sh[par][a][lane];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          td[a] = sh[par][4 + a][lane];
-          th[a] = sh[par][7 + a][lane];
-        }
-        cj = sh[par][10][lane];
-      } else {
-#pragma unroll
-        for (int a = 0; a < 6; ++a) v[a] = sh[par][11 + a][lane];
-      }
-    }
-    QKEEP(v[0]); QKEEP(q[0]); QKEEP(cj);
-    QSTAMP(6);  // LDS read of the partner's results
-  };
-  for (int i = 0; i < n; i += 2) {
-    knot(i, ptA, gA, ptB, gB, pnA, pnB);
-    if (i + 1 < n) knot(i + 1, ptB, gB, ptA, gA, pnB, pnA);
-  }
-#ifdef QILQR_STAMPS
-  if (lane == 0 && st.stamps)
-    for (int k = 0; k < 8; ++k) st.stamps[((long)blockIdx.x * 2 + role) * 8 + k] = stamp_sum[k];
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_rollout3: k_rollout2 plus a LOADER wavefront (block = 192).  In k_rollout2 the control wave spends
-// a third of every knot issuing the 35 sixteen-byte loads of the next knot's nominal point and gains
-// (profiles/microbench/rollout_stamps.py).  Here wave L streams those operands two knots ahead
-// through registers into a double-buffered LDS image (same [pair][lane] order as the tiled global
-// layout, so its stores and the consumers' reads are conflict-free), and the nominal pose that the
-// pose wave needs one knot earlier into a second small image.  Waves X and Y read LDS only.
+//   wave L (loader):   streams the next knots' nominal point and gains (35 sixteen-byte loads per lane and
+//                      knot, whose issue alone cost the control wave a third of a knot) two knots ahead
+//                      through registers into a double-buffered LDS image (same [pair][lane] order as the
+//                      tiled global layout: conflict-free), and the nominal pose that the pose wave needs one
+//                      knot earlier into a second small image.  Waves X and Y read LDS only.
+// X and Y trade 11 + 6 scalars per knot through LDS (double-buffered).
 //   iteration i:  L: issue loads of knot i+2 (+ pose of knot i+3); write knot i+1 -> bx[(i+1)&1],
 //                    pose of knot i+2 -> by[(i+2)&1]
 //                 X: operands of knot i from bx[i&1];  Y: nominal pose of knot i+1 from by[(i+1)&1]
-//   one barrier per knot.  Same arithmetic as k_rollout / k_rollout2.
+//   one barrier per knot.  The arithmetic is the same sequence of operations as rollout_problem (k_rollout).
+// (Two re-partitions were measured in round 1 and removed from the library: the pair without the loader,
+// and a four-wave form with the pose wave cut into compose and Log -- DESIGN.md section 4.)
 // ---------------------------------------------------------------------------------------------
 template <typename S>
 __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState st, int B, int n, int need_flag) {
@@ -1762,7 +1558,7 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
   typedef S sv2 __attribute__((ext_vector_type(2)));
   __shared__ sv2 bx[2][35][64];  // [parity][pair: 0..8 nominal knot, 9..34 gains][lane]
   __shared__ sv2 by[2][4][64];   // [parity][pair 0..3 of the nominal knot = time, t, q][lane]
-  __shared__ S sh[2][17][64];    // X <-> Y exchange, as in k_rollout2
+  __shared__ S sh[2][17][64];    // X <-> Y exchange: [parity][0..3 q | 4..6 td | 7..9 th | 10 c | 11..16 v][lane]
 
   // Each role runs its own loop (so that the register allocator sees three disjoint live ranges);
   // all three execute exactly 1 + n barriers.
@@ -2000,236 +1796,6 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
 #ifdef QILQR_STAMPS
   stamp_flush();
 #endif
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_rollout4: k_rollout3 with the pose wave cut in two (block = 256).  The serial dependency of a
-// rollout is  v_k -> T_{k+1} = T_k Exp(dt v_k) -> Log(Tnom_{k+1}^-1 T_{k+1}) -> u_{k+1} -> v_{k+2}:
-// in k_rollout3 the pose wave does Exp-compose AND Log inside one knot interval, the control wave waits.
-//   wave Y (compose):  T_{k+1} = T_k Exp(dt v_k)                          in interval k
-//   wave Z (log):      td, theta, c of Tnom_k^-1 T_k                       at the start of interval k
-//   wave X (control):  interval k: what needs no Log first (operands, velocity error), then waits for Z's
-//                      flag in LDS (no barrier: the others must not stop there), rho, u_k, v_{k+1}
-//   wave L (loader):   as in k_rollout3 (the nominal pose one knot later, for Z)
-// The chain per interval is max(Y, Z + X's dependent part) instead of max(Y + Z, X) -- on paper.  Measured
-// (B = 1024, N = 100): 97 us against 87.5 us for k_rollout3; the two extra hand-offs through LDS on the chain
-// (pose to Z, Log to X with a polled flag) cost more than the overlap returns.  At B = 8192 it is 7% faster,
-// at 2048, 4096 and 16384 it is not.  Not the default; kept selectable (single_wave_rollout = 4) with its
-// parity test.  Same arithmetic as k_rollout / k_rollout2 / k_rollout3.
-// ---------------------------------------------------------------------------------------------
-template <typename S>
-__global__ __launch_bounds__(256) void k_rollout4(ModelConsts<S> c, BatchState st, int B, int n, int need_flag) {
-  const int lane = threadIdx.x & 63;
-  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: X, 1: Y, 2: Z, 3: L
-  const int b = blockIdx.x * 64 + lane;
-  const bool live = (b < B) && (!need_flag || (st.flags[b < B ? b : 0] & need_flag));
-  if (__ballot(live) == 0ull) return;  // identical in the four waves: block-uniform
-  const int bs = (b < B) ? b : (B - 1);
-  const int cur = st.cur[bs];
-  const S *traj = (const S *)st.traj[cur] + knot_base<true>(bs, n, 18);
-  const S *gains = (const S *)st.gains + knot_base<true>(bs, n, 52);
-  S *out = (S *)st.traj[cur ^ 1] + knot_base<true>(bs, n, 18);
-
-  typedef S sv2 __attribute__((ext_vector_type(2)));
-  __shared__ sv2 bx[2][35][64];  // [parity][pair: 0..8 nominal knot, 9..34 gains][lane]
-  __shared__ sv2 by[2][4][64];   // [parity][pair 0..3 of the nominal knot = time, t, q][lane]
-  __shared__ S shT[2][7][64];    // Y -> Z, X: pose of knot k in shT[k & 1]: t(3), q(x,y,z,w)
-  __shared__ S shZ[2][7][64];    // Z -> X: td(3), theta(3), c of knot k in shZ[k & 1]
-  __shared__ S shV[2][6][64];    // X -> Y: v of knot k in shV[k & 1]
-  __shared__ int zflag;          // Z: "the Log of knot zflag is in shZ"
-
-  if (role == 3) {
-    // ------------------------------------------------------------------ L: loader
-    const sv2 *tp = reinterpret_cast<const sv2 *>(traj);   // pair k of knot i: tp[(i * 9 + k) * 64]
-    const sv2 *gp = reinterpret_cast<const sv2 *>(gains);  //                   gp[(i * 26 + k) * 64]
-    sv2 ra[35], rb[35], pa[4], pb[4];
-    auto load_ops = [&](int k, sv2 (&r)[35]) {
-      if (k < n) {
-#pragma unroll
-        for (int e = 0; e < 9; ++e) r[e] = tp[((long)k * 9 + e) * 64];
-#pragma unroll
-        for (int e = 0; e < 26; ++e) r[9 + e] = gp[((long)k * 26 + e) * 64];
-      }
-    };
-    auto load_pose = [&](int k, sv2 (&r)[4]) {
-      if (k < n) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = tp[((long)k * 9 + e) * 64];
-      }
-    };
-    load_ops(0, ra);
-#pragma unroll
-    for (int e = 0; e < 35; ++e) bx[0][e][lane] = ra[e];
-    load_ops(1, ra);   // written during interval 0
-    load_pose(1, pa);  // written during interval 0, read by Z in interval 1
-    __syncthreads();
-    auto knot = [&](int i, sv2 (&rc)[35], sv2 (&rn)[35], sv2 (&pc)[4], sv2 (&pn)[4]) {
-      load_ops(i + 2, rn);   // consumed by X in interval i + 2
-      load_pose(i + 2, pn);  // consumed by Z in interval i + 2
-      if (i + 1 < n) {
-#pragma unroll
-        for (int e = 0; e < 35; ++e) bx[(i + 1) & 1][e][lane] = rc[e];  // knot i + 1
-#pragma unroll
-        for (int e = 0; e < 4; ++e) by[(i + 1) & 1][e][lane] = pc[e];   // nominal pose of knot i + 1
-      }
-      __syncthreads();
-    };
-    for (int i = 0; i < n; i += 2) {
-      knot(i, ra, rb, pa, pb);
-      if (i + 1 < n) knot(i + 1, rb, ra, pb, pa);
-    }
-    return;
-  }
-
-  S t[3], q[4], v[6];
-  {
-    S p0[18];
-    load_knot<true>(traj, 0, 18, p0);
-    t[0] = p0[1]; t[1] = p0[2]; t[2] = p0[3];
-    q[0] = p0[5]; q[1] = p0[6]; q[2] = p0[7]; q[3] = p0[4];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) v[a] = p0[8 + a];
-    if (role == 2) {
-      // Log of knot 0 (the rollout starts on the nominal trajectory's first state: exactly zero)
-      S td[3], th[3], cj;
-      const S qn[4] = {p0[5], p0[6], p0[7], p0[4]};
-      se3_rminus_part1(t, q, p0 + 1, qn, td, th, cj);
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        shZ[0][a][lane] = td[a];
-        shZ[0][3 + a][lane] = th[a];
-      }
-      shZ[0][6][lane] = cj;
-      if (lane == 0) zflag = 0;
-    }
-    if (role == 1 && live) {
-      const S po[8] = {0, t[0], t[1], t[2], q[3], q[0], q[1], q[2]};
-#pragma unroll
-      for (int e = 1; e < 8; ++e) out[knot_elem<true>(0, e, 18)] = po[e];
-    }
-  }
-  __syncthreads();
-
-  if (role == 0) {
-    // ------------------------------------------------------------------ X: control + velocity
-    const S alpha = (S)st.alpha[bs];
-    for (int i = 0; i < n; ++i) {
-      const bool more = (i + 1 < n);
-      S pt[18], g[52];
-#pragma unroll
-      for (int e = 0; e < 9; ++e) {
-        const sv2 w = bx[i & 1][e][lane];
-        pt[2 * e] = w[0];
-        pt[2 * e + 1] = w[1];
-      }
-#pragma unroll
-      for (int e = 0; e < 26; ++e) {
-        const sv2 w = bx[i & 1][9 + e][lane];
-        g[2 * e] = w[0];
-        g[2 * e + 1] = w[1];
-      }
-      if (i > 0) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) q[a] = shT[i & 1][3 + a][lane];
-      }
-      S dx[12];
-#pragma unroll
-      for (int a = 0; a < 6; ++a) dx[6 + a] = v[a] - pt[8 + a];
-      // wait for the Log of knot i (bounded: a lost flag must not hang the wave)
-      if (i > 0) {
-        int spins = 0;
-        while (__hip_atomic_load(&zflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < i && ++spins < (1 << 24)) {
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      }
-      S td[3], th[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        td[a] = shZ[i & 1][a][lane];
-        th[a] = shZ[i & 1][3 + a][lane];
-      }
-      const S cj = shZ[i & 1][6][lane];
-      se3_rminus_part2(td, th, cj, dx);
-      dx[3] = th[0]; dx[4] = th[1]; dx[5] = th[2];
-      S u[4];
-      control_law(pt, g, alpha, dx, u);
-      if (live) {
-        out[knot_elem<true>(i, 0, 18)] = pt[0];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) out[knot_elem<true>(i, 8 + a, 18)] = v[a];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) out[knot_elem<true>(i, 14 + a, 18)] = u[a];
-      }
-      if (more) {
-        S acc[6];
-        body_acceleration_fast(c, q, v, u, acc);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          v[a] = v[a] + c.dt * acc[a];
-          shV[(i + 1) & 1][a][lane] = v[a];
-        }
-      }
-      __syncthreads();
-    }
-  } else if (role == 1) {
-    // ------------------------------------------------------------------ Y: compose
-    RolloutSeries<S> sr;
-    sr.load();
-    for (int i = 0; i < n; ++i) {
-      const bool more = (i + 1 < n);
-      if (more) {
-        S tau[6];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) tau[a] = c.dt * v[a];  // pose integrates with the OLD velocity
-        se3_rplus_fast(t, q, tau, sr);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) shT[(i + 1) & 1][a][lane] = t[a];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) shT[(i + 1) & 1][3 + a][lane] = q[a];
-        if (live) {
-          const S po[8] = {0, t[0], t[1], t[2], q[3], q[0], q[1], q[2]};
-#pragma unroll
-          for (int e = 1; e < 8; ++e) out[knot_elem<true>(i + 1, e, 18)] = po[e];
-        }
-      }
-      __syncthreads();
-      if (more) {
-#pragma unroll
-        for (int a = 0; a < 6; ++a) v[a] = shV[(i + 1) & 1][a][lane];
-      }
-    }
-  } else {
-    // ------------------------------------------------------------------ Z: Log
-    RolloutSeries<S> sr;
-    sr.load();
-    for (int i = 0; i < n; ++i) {
-      if (i > 0) {
-        S tk[3], qk[4], pnm[8];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) tk[a] = shT[i & 1][a][lane];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) qk[a] = shT[i & 1][3 + a][lane];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const sv2 w = by[i & 1][e][lane];  // nominal pose of knot i
-          pnm[2 * e] = w[0];
-          pnm[2 * e + 1] = w[1];
-        }
-        S td[3], th[3], cj;
-        const S qn[4] = {pnm[5], pnm[6], pnm[7], pnm[4]};
-        se3_rminus_part1(tk, qk, pnm + 1, qn, td, th, cj, sr);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          shZ[i & 1][a][lane] = td[a];
-          shZ[i & 1][3 + a][lane] = th[a];
-        }
-        shZ[i & 1][6][lane] = cj;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&zflag, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      __syncthreads();
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
