@@ -20,6 +20,7 @@
 #ifndef QUADROTOR_ILQR_H
 #define QUADROTOR_ILQR_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -135,8 +136,13 @@ int qilqr_solve_batch(qilqr_solver *s, const double *init, const double *desired
                       int32_t *out_status, int32_t *out_iters, int32_t *out_n_bwd,
                       int32_t *out_n_fwd);
 
-/* Same, with every buffer already resident in device memory (HBM) of the solver's device.
- * Runs on the solver's own stream and returns after that stream has drained. */
+/* Same, with every buffer already resident in device memory (HBM) of the solver's device: plain contiguous
+ * B x n x 18 doubles / B doubles / B int32, caller-owned, outputs at least that large (nothing is checked on the
+ * device side; any output may be NULL).  Stream ordering: the solve runs on the solver's OWN stream (qilqr_stream,
+ * created non-blocking: it is not ordered with the null stream or with any other stream).  Inputs written by
+ * asynchronous work on another stream must be ordered first: record an event there and pass it to
+ * qilqr_stream_wait_event (or synchronise that stream).  The call returns after the solver's stream has drained,
+ * so the outputs may be read from any stream afterwards. */
 int qilqr_solve_batch_device(qilqr_solver *s, const double *d_init, const double *d_desired_batch,
                              int32_t B, int32_t n, double *d_out_traj, double *d_out_cost,
                              int32_t *d_out_status, int32_t *d_out_iters, int32_t *d_out_n_bwd,
@@ -160,7 +166,8 @@ int qilqr_line_search(qilqr_solver *s, const double *traj, const double *cost, c
 /* Cost history of the last batch solve (options.populate_debug = 1): hist is B x cap, row b holds
  * new_cost after each completed forward pass of problem b (what ILQRDebug.cost would hold, ilqr.hh:78-80;
  * trajectories are only captured by the single-problem qilqr_solve), unused entries are NaN.
- * cap = the largest number of entries any problem can have (= min(max_iters, 1e6)); returned in *out_cap
+ * cap = the largest number of entries any problem can have (= min(ceil(max_iters), 1e6): the loop of ilqr.hh:58
+ * runs while i < max_iters, a double); returned in *out_cap
  * when hist is NULL. */
 int qilqr_cost_history(qilqr_solver *s, int32_t B, double *hist, int32_t cap, int32_t *out_cap);
 
@@ -183,6 +190,13 @@ int qilqr_set_regularisation(qilqr_solver *s, double mu_init, double mu_factor, 
 /* device the solver is bound to, and the HIP stream it launches on (hipStream_t as void*) */
 int qilqr_device(const qilqr_solver *s);
 void *qilqr_stream(const qilqr_solver *s);
+/* make the solver's stream wait (on the device) for a hipEvent_t recorded on another stream */
+int qilqr_stream_wait_event(qilqr_solver *s, void *hip_event);
+
+/* Pinned host memory for the buffers handed to the host-buffer entry points (qilqr_solve_batch copies with plain
+ * hipMemcpy: direct DMA from / to pinned memory, HIP's chunked staging for pageable memory).  NULL on failure. */
+void *qilqr_host_alloc(size_t bytes);
+void qilqr_host_free(void *p);
 
 /* ABI version of this header */
 int qilqr_abi_version(void);

@@ -6,6 +6,7 @@ There is no CPU fallback: if the HIP library is missing or no GPU is present eve
 entry point raises.
 """
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -35,7 +36,7 @@ EXPORTS = (
     "qilqr_create", "qilqr_destroy", "qilqr_last_error", "qilqr_solve", "qilqr_solve_batch",
     "qilqr_solve_batch_device", "qilqr_cost_trajectory", "qilqr_backwards_pass", "qilqr_forward_sim",
     "qilqr_line_search", "qilqr_cost_history", "qilqr_profile_reset", "qilqr_profile_get", "qilqr_profile_mode", "qilqr_set_regularisation",
-    "qilqr_device", "qilqr_stream",
+    "qilqr_device", "qilqr_stream", "qilqr_stream_wait_event", "qilqr_host_alloc", "qilqr_host_free",
     "qilqr_abi_version",
 )
 
@@ -80,6 +81,9 @@ def load():
         lib = C.CDLL(LIB_PATH)
         lib.qilqr_last_error.restype = C.c_char_p
         lib.qilqr_stream.restype = C.c_void_p
+        lib.qilqr_host_alloc.restype = C.c_void_p
+        lib.qilqr_host_alloc.argtypes = [C.c_size_t]
+        lib.qilqr_host_free.argtypes = [C.c_void_p]
         _lib = lib
     return _lib
 
@@ -166,7 +170,8 @@ class QuadrotorILQRBatch:
         init = _d(init).reshape(-1, KNOT)
         n = len(init)
         out = np.zeros_like(init)
-        cap = int(max(self.options["max_iters"], 0)) if self.options.get("populate_debug") else 0
+        # the loop of ilqr.hh:58 runs while i < max_iters with max_iters a double: ceil(max_iters) entries at most
+        cap = int(min(max(math.ceil(self.options["max_iters"]), 0), 1e6)) if self.options.get("populate_debug") else 0
         dcost = np.zeros(max(cap, 1))
         dtraj = np.zeros((max(cap, 1), n, KNOT))
         cost, st, it, nd = C.c_double(), C.c_int32(), C.c_int32(), C.c_int32()
@@ -195,7 +200,41 @@ class QuadrotorILQRBatch:
     # ---- batch of problems, torch CUDA tensors already resident in HBM
     def solve_batch_device(self, init, out_traj, out_cost, out_status, out_iters, out_n_bwd, out_n_fwd,
                            desired_batch=None):
-        B, n = init.shape[0], init.shape[1]
+        """qilqr_solve_batch_device on torch tensors.  Every tensor must live on the solver's device, be
+        contiguous and have the ABI's dtype and shape (float64 (B,n,18) / (B,), int32 (B,)); outputs may be None.
+        The solve runs on the solver's own stream: it is ordered behind whatever torch has enqueued on its
+        current stream (an event recorded here, waited for on the device), and has finished when this returns."""
+        import torch
+        if init.dim() != 3 or init.shape[2] != KNOT:
+            raise TypeError("init must be (B, n, 18)")
+        B, n = int(init.shape[0]), int(init.shape[1])
+        dev_index = load().qilqr_device(self._h)
+
+        def check(t, name, dtype, shape):
+            if t is None:
+                return
+            if not t.is_cuda or t.device.index != dev_index:
+                raise TypeError(f"{name} must be a CUDA tensor on device {dev_index}")
+            if t.dtype != dtype:
+                raise TypeError(f"{name} must be {dtype}")
+            if tuple(t.shape) != shape:
+                raise TypeError(f"{name} must have shape {shape}, not {tuple(t.shape)}")
+            if not t.is_contiguous():
+                raise TypeError(f"{name} must be contiguous")
+
+        check(init, "init", torch.float64, (B, n, KNOT))
+        check(desired_batch, "desired_batch", torch.float64, (B, n, KNOT))
+        check(out_traj, "out_traj", torch.float64, (B, n, KNOT))
+        check(out_cost, "out_cost", torch.float64, (B,))
+        for t, name in ((out_status, "out_status"), (out_iters, "out_iters"), (out_n_bwd, "out_n_bwd"),
+                        (out_n_fwd, "out_n_fwd")):
+            check(t, name, torch.int32, (B,))
+        # inputs produced by asynchronous torch work on its current stream: the solver's stream waits for them
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(init.device))
+        rc = load().qilqr_stream_wait_event(self._h, C.c_void_p(ev.cuda_event))
+        if rc:
+            _raise(rc)
         vp = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
         rc = load().qilqr_solve_batch_device(self._h, vp(init), vp(desired_batch), C.c_int32(B), C.c_int32(n),
                                              vp(out_traj), vp(out_cost), vp(out_status), vp(out_iters),

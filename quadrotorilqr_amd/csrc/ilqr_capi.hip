@@ -73,8 +73,13 @@ struct qilqr_solver {
   hipEvent_t main_ready = nullptr;
   int *d_part_counters = nullptr;  // [MAX_PARTS][COUNT_WORDS]
   long total_B = 0;                // trajectories in flight on the device in this call (kernel choices go by it)
-  double *io_aos = nullptr;         // device scratch in the plain [B][n][W] layout (W <= 52), for host I/O
+  double *io_aos = nullptr;         // device scratch in the plain [B][n][W] layout (W <= 52), for host I/O (lazy)
+  size_t io_cap = 0;                // its capacity in doubles
   void *desired_tiled = nullptr;    // per-problem desired trajectories, tiled (allocated on first use)
+  // device staging of the host-buffer batch entry point (qilqr_solve_batch), kept between calls, grow-only
+  double *stage_traj = nullptr, *stage_des = nullptr, *stage_cost = nullptr;
+  int *stage_int = nullptr;
+  size_t stage_traj_cap = 0, stage_des_cap = 0, stage_B_cap = 0;
   // profiling
   std::vector<EventPair> events;
   size_t events_used = 0;
@@ -97,7 +102,11 @@ EventPair *timing_slot(qilqr_solver *s, int kind) {
   if (stride > 1 && (seen % stride) != 0) return nullptr;
   if (s->events_used == s->events.size()) {
     EventPair e;
-    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return nullptr;
+    if (hipEventCreate(&e.a) != hipSuccess) return nullptr;
+    if (hipEventCreate(&e.b) != hipSuccess) {
+      (void)hipEventDestroy(e.a);
+      return nullptr;
+    }
     s->events.push_back(e);
   }
   EventPair *ep = &s->events[s->events_used++];
@@ -130,6 +139,7 @@ void free_workspace(qilqr_solver *s) {
   s->allocs.clear();
   s->cap_B = s->cap_n = 0;
   s->io_aos = nullptr;
+  s->io_cap = 0;
   s->desired_tiled = nullptr;
 }
 
@@ -150,11 +160,16 @@ int dalloc_s(qilqr_solver *s, void **p, size_t count) {  // count elements of th
   return rc;
 }
 
+// number of ILQRIterDebug entries a solve can produce: the loop of ilqr.hh:58 runs for i = 0 .. while i < max_iters
+// with max_iters a double, i.e. ceil(max_iters) times
+inline int debug_capacity(double max_iters) { return (int)std::fmin(std::fmax(std::ceil(max_iters), 0.0), 1e6); }
+
 int ensure_workspace(qilqr_solver *s, long B, long n) {
-  const int want_hist = s->options.populate_debug ? (int)std::fmin(std::fmax(s->params.max_iters, 0.0), 1e6) : 0;
+  const int want_hist = s->options.populate_debug ? debug_capacity(s->params.max_iters) : 0;
   if (B <= s->cap_B && n <= s->cap_n && want_hist <= s->hist_cap) return QILQR_OK;
-  free_workspace(s);
+  // grow only: alternating (B, n) shapes settle on the larger of each instead of reallocating on every call
   const long cB = B > s->cap_B ? B : s->cap_B, cn = n > s->cap_n ? n : s->cap_n;
+  free_workspace(s);
   BatchState &st = s->st;
   st.layout = s->layout;
   st.ctab = s->d_ctab;
@@ -165,7 +180,8 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
     if ((rc = dalloc(s, &st.knot_cost[k], (size_t)tiled_count(cB, cn, 1)))) return rc;
   }
   if ((rc = dalloc_s(s, &st.gains, (size_t)tiled_count(cB, cn, 52)))) return rc;
-  if ((rc = dalloc(s, &s->io_aos, (size_t)cB * cn * 52))) return rc;
+  s->io_aos = nullptr;  // host-I/O scratch: allocated on first use (ensure_io), the device-resident solve needs none
+  s->io_cap = 0;
   s->desired_tiled = nullptr;
   if ((rc = dalloc(s, &st.cur, cB))) return rc;
   if ((rc = dalloc(s, &st.cost, cB))) return rc;
@@ -248,15 +264,37 @@ int begin_batch(qilqr_solver *s, long B, long n, const double *d_desired_batch) 
   launch(s, K_OTHER, k_begin, dim3(cdiv(B, 256)), dim3(256), s->st, (int)B);
   return QILQR_OK;
 }
+// the plain-layout device scratch of the host-buffer entry points, sized to what the call needs
+int ensure_io(qilqr_solver *s, size_t count) {
+  if (count <= s->io_cap) return QILQR_OK;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (s->io_aos) {
+    for (auto it = s->allocs.begin(); it != s->allocs.end(); ++it)
+      if (*it == (void *)s->io_aos) {
+        s->allocs.erase(it);
+        break;
+      }
+    (void)hipFree(s->io_aos);
+    s->io_aos = nullptr;
+    s->io_cap = 0;
+  }
+  int rc = dalloc(s, &s->io_aos, count);
+  if (rc) return rc;
+  s->io_cap = count;
+  return QILQR_OK;
+}
 // host plain array -> device tiled buffer through the io scratch
 int upload_tiled(qilqr_solver *s, const double *h_plain, void *tiled, long B, long n, int W) {
+  int rc0 = ensure_io(s, (size_t)B * n * W);
+  if (rc0) return rc0;
   HIP_TRY(hipMemcpyAsync(s->io_aos, h_plain, sizeof(double) * (size_t)B * n * W, hipMemcpyHostToDevice, s->stream));
   return to_tiled(s, s->io_aos, tiled, B, n, W);
 }
 int download_tiled(qilqr_solver *s, double *h_plain, void *t0, void *t1, const int *sel, int flip, long B, long n,
                    int W) {
-  int rc = from_tiled(s, s->io_aos, t0, t1, sel, flip, B, n, W);
+  int rc = ensure_io(s, (size_t)B * n * W);
   if (rc) return rc;
+  if ((rc = from_tiled(s, s->io_aos, t0, t1, sel, flip, B, n, W))) return rc;
   HIP_TRY(hipMemcpyAsync(h_plain, s->io_aos, sizeof(double) * (size_t)B * n * W, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return QILQR_OK;
@@ -483,10 +521,19 @@ int auto_parts(const qilqr_solver *s, long B) {
   while (want > 1 && tiles < 2 * want) --want;  // at least two tiles per part
   return want;
 }
+// streams and completion events of the first nparts sub-batches, created on first use
+int ensure_parts(qilqr_solver *s, int nparts) {
+  for (int k = 0; k < nparts; ++k) {
+    if (!s->part_stream[k]) HIP_TRY(hipStreamCreateWithFlags(&s->part_stream[k], hipStreamNonBlocking));
+    if (!s->part_done[k]) HIP_TRY(hipEventCreateWithFlags(&s->part_done[k], hipEventDisableTiming));
+  }
+  return QILQR_OK;
+}
 // The outer loop of ILQR::solve for a batch cut into parts (free-running rounds only).  On return the
 // main stream waits for every part; the caller enqueues its own work there.
 int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
   int rc;
+  if ((rc = ensure_parts(s, nparts))) return rc;
   const long tiles = (B + 63) / 64;
   std::vector<Part> parts;
   for (int p = 0; p < nparts; ++p) {
@@ -578,11 +625,35 @@ int check_quaternions(const double *traj, long count, const char *what) {
   return QILQR_OK;
 }
 
+// The batch solve on device-resident buffers.  drain = false: return with the gather enqueued, the caller puts
+// its own copies behind it and waits for the stream itself.
+int solve_batch_device_impl(qilqr_solver *s, const double *d_init, const double *d_desired_batch, int32_t B, int32_t n,
+                            double *d_out_traj, double *d_out_cost, int32_t *d_out_status, int32_t *d_out_iters,
+                            int32_t *d_out_n_bwd, int32_t *d_out_n_fwd, bool drain) {
+  if (!s || !d_init) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  int rc = begin_batch(s, B, n, d_desired_batch);
+  if (rc) return rc;
+  if ((rc = to_tiled(s, d_init, s->st.traj[0], B, n, 18))) return rc;
+  const int nparts = (s->dev.sync_every > 1) ? auto_parts(s, B) : 1;
+  if (nparts > 1) {
+    if ((rc = run_solve_parts(s, B, n, nparts))) return rc;
+  } else if ((rc = run_solve(s, B, n, s->dev.sync_every, [] { return QILQR_OK; }, false))) {
+    return rc;
+  }
+  if ((rc = gather(s, B, n, d_out_traj, d_out_cost, d_out_status, d_out_iters, d_out_n_bwd, d_out_n_fwd)))
+    return rc;
+  if (!drain) return QILQR_OK;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipGetLastError());
+  if (s->dev.profile) drain_events(s);
+  return QILQR_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
-int qilqr_abi_version(void) { return 2; }
+int qilqr_abi_version(void) { return 3; }
 
 const char *qilqr_last_error(void) { return g_last_error.c_str(); }
 
@@ -658,10 +729,7 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   }
   if (e == hipSuccess) e = hipMalloc((void **)&s->d_part_counters, sizeof(int) * COUNT_WORDS * qilqr_solver::MAX_PARTS);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->main_ready, hipEventDisableTiming);
-  for (int k = 0; k < qilqr_solver::MAX_PARTS && e == hipSuccess; ++k) {
-    e = hipStreamCreateWithFlags(&s->part_stream[k], hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->part_done[k], hipEventDisableTiming);
-  }
+  // (the streams and events of sub-batches are created when a solve first uses them: ensure_parts)
   if (e == hipSuccess) e = hipMalloc(&s->d_consts, s->f32 ? sizeof(ModelConsts<float>) : sizeof(ModelConsts<double>));
   if (e == hipSuccess)
     e = s->f32 ? hipMemcpy(s->d_consts, &s->constsf, sizeof(ModelConsts<float>), hipMemcpyHostToDevice)
@@ -692,6 +760,10 @@ void qilqr_destroy(qilqr_solver *s) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
+  if (s->stage_traj) (void)hipFree(s->stage_traj);
+  if (s->stage_des) (void)hipFree(s->stage_des);
+  if (s->stage_cost) (void)hipFree(s->stage_cost);
+  if (s->stage_int) (void)hipFree(s->stage_int);
   if (s->d_desired) (void)hipFree(s->d_desired);
   if (s->d_ctab) (void)hipFree(s->d_ctab);
   if (s->d_consts) (void)hipFree(s->d_consts);
@@ -793,25 +865,22 @@ int qilqr_profile_get(qilqr_solver *s, qilqr_profile *out) {
 int qilqr_solve_batch_device(qilqr_solver *s, const double *d_init, const double *d_desired_batch, int32_t B,
                              int32_t n, double *d_out_traj, double *d_out_cost, int32_t *d_out_status,
                              int32_t *d_out_iters, int32_t *d_out_n_bwd, int32_t *d_out_n_fwd) {
-  if (!s || !d_init) return fail(QILQR_ERR_INVALID_ARG, "null argument");
-  int rc = begin_batch(s, B, n, d_desired_batch);
-  if (rc) return rc;
-  if ((rc = to_tiled(s, d_init, s->st.traj[0], B, n, 18))) return rc;
-  const int nparts = (s->dev.sync_every > 1) ? auto_parts(s, B) : 1;
-  if (nparts > 1) {
-    if ((rc = run_solve_parts(s, B, n, nparts))) return rc;
-  } else if ((rc = run_solve(s, B, n, s->dev.sync_every, [] { return QILQR_OK; }, false))) {
-    return rc;
-  }
-  if ((rc = gather(s, B, n, d_out_traj, d_out_cost, d_out_status, d_out_iters, d_out_n_bwd, d_out_n_fwd)))
-    return rc;
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  HIP_TRY(hipGetLastError());
-  if (s->dev.profile) drain_events(s);
+  return solve_batch_device_impl(s, d_init, d_desired_batch, B, n, d_out_traj, d_out_cost, d_out_status, d_out_iters,
+                                 d_out_n_bwd, d_out_n_fwd, /*drain=*/true);
+}
+
+// Order the solver's stream behind work of another stream: the solver's stream waits (on the device, no host
+// stall) for `hip_event`, a hipEvent_t the caller recorded on the stream that produces the input buffers.
+int qilqr_stream_wait_event(qilqr_solver *s, void *hip_event) {
+  if (!s || !hip_event) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamWaitEvent(s->stream, (hipEvent_t)hip_event, 0));
   return QILQR_OK;
 }
 
-// host-buffer wrapper: stage through device scratch owned by the call
+// host-buffer wrapper: stage through device buffers the solver keeps between calls (no hipMalloc / hipFree per
+// call).  The copies are plain hipMemcpy: direct DMA when the caller's buffers are pinned (qilqr_host_alloc, or any
+// hipHostMalloc / hipHostRegister'ed memory), HIP's own chunked staging when they are pageable.
 int qilqr_solve_batch(qilqr_solver *s, const double *init, const double *desired_batch, int32_t B, int32_t n,
                       double *out_traj, double *out_cost, int32_t *out_status, int32_t *out_iters,
                       int32_t *out_n_bwd, int32_t *out_n_fwd) {
@@ -823,37 +892,61 @@ int qilqr_solve_batch(qilqr_solver *s, const double *init, const double *desired
   if ((rc = check_quaternions(init, (long)B * n, "initial trajectory"))) return rc;
   if (desired_batch && (rc = check_quaternions(desired_batch, (long)B * n, "desired trajectory"))) return rc;
   HIP_TRY(hipSetDevice(s->device));
-  const size_t tb = sizeof(double) * 18 * (size_t)B * n;
-  double *d_io = nullptr, *d_des = nullptr, *d_cost = nullptr;
-  int *d_int = nullptr;
-  auto cleanup = [&] {
-    if (d_io) (void)hipFree(d_io);
-    if (d_des) (void)hipFree(d_des);
-    if (d_cost) (void)hipFree(d_cost);
-    if (d_int) (void)hipFree(d_int);
+  const size_t cnt = 18 * (size_t)B * n, tb = sizeof(double) * cnt;
+  auto grow = [&](auto **p, size_t *cap, size_t want, size_t elem) -> hipError_t {
+    if (want <= *cap) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc((void **)p, want * elem);
+    if (e == hipSuccess) *cap = want;
+    return e;
   };
-  hipError_t e = hipMalloc((void **)&d_io, tb);
-  if (e == hipSuccess && desired_batch) e = hipMalloc((void **)&d_des, tb);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_cost, sizeof(double) * B);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_int, sizeof(int) * 4 * B);
-  if (e == hipSuccess) e = hipMemcpy(d_io, init, tb, hipMemcpyHostToDevice);
-  if (e == hipSuccess && desired_batch) e = hipMemcpy(d_des, desired_batch, tb, hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    cleanup();
-    return fail(QILQR_ERR_HIP, std::string("staging: ") + hipGetErrorString(e));
+  hipError_t e = grow(&s->stage_traj, &s->stage_traj_cap, cnt, sizeof(double));
+  if (e == hipSuccess && desired_batch) e = grow(&s->stage_des, &s->stage_des_cap, cnt, sizeof(double));
+  if (e == hipSuccess && (size_t)B > s->stage_B_cap) {
+    if (s->stage_cost) (void)hipFree(s->stage_cost);
+    if (s->stage_int) (void)hipFree(s->stage_int);
+    s->stage_cost = nullptr;
+    s->stage_int = nullptr;
+    s->stage_B_cap = 0;
+    e = hipMalloc((void **)&s->stage_cost, sizeof(double) * B);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->stage_int, sizeof(int) * 4 * B);
+    if (e == hipSuccess) s->stage_B_cap = B;
   }
-  rc = qilqr_solve_batch_device(s, d_io, d_des, B, n, d_io, d_cost, d_int, d_int + B, d_int + 2 * B, d_int + 3 * B);
-  if (rc == QILQR_OK) {
-    if (out_traj) e = hipMemcpy(out_traj, d_io, tb, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && out_cost) e = hipMemcpy(out_cost, d_cost, sizeof(double) * B, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && out_status) e = hipMemcpy(out_status, d_int, sizeof(int) * B, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && out_iters) e = hipMemcpy(out_iters, d_int + B, sizeof(int) * B, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && out_n_bwd) e = hipMemcpy(out_n_bwd, d_int + 2 * B, sizeof(int) * B, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && out_n_fwd) e = hipMemcpy(out_n_fwd, d_int + 3 * B, sizeof(int) * B, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) rc = fail(QILQR_ERR_HIP, std::string("copy back: ") + hipGetErrorString(e));
+  if (e == hipSuccess) e = hipMemcpyAsync(s->stage_traj, init, tb, hipMemcpyHostToDevice, s->stream);
+  if (e == hipSuccess && desired_batch) e = hipMemcpyAsync(s->stage_des, desired_batch, tb, hipMemcpyHostToDevice, s->stream);
+  if (e != hipSuccess) return fail(QILQR_ERR_HIP, std::string("staging: ") + hipGetErrorString(e));
+  double *d_cost = s->stage_cost;
+  int *d_int = s->stage_int;
+  rc = solve_batch_device_impl(s, s->stage_traj, desired_batch ? s->stage_des : nullptr, B, n, s->stage_traj, d_cost, d_int,
+                               d_int + B, d_int + 2 * B, d_int + 3 * B, /*drain=*/false);
+  if (rc != QILQR_OK) return rc;
+  // the copies back follow the gather on the solver's stream; one wait at the end
+  if (out_traj) e = hipMemcpyAsync(out_traj, s->stage_traj, tb, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess && out_cost) e = hipMemcpyAsync(out_cost, d_cost, sizeof(double) * B, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess && out_status) e = hipMemcpyAsync(out_status, d_int, sizeof(int) * B, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess && out_iters) e = hipMemcpyAsync(out_iters, d_int + B, sizeof(int) * B, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess && out_n_bwd) e = hipMemcpyAsync(out_n_bwd, d_int + 2 * B, sizeof(int) * B, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess && out_n_fwd) e = hipMemcpyAsync(out_n_fwd, d_int + 3 * B, sizeof(int) * B, hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (s->dev.profile) drain_events(s);
+  if (e != hipSuccess) return fail(QILQR_ERR_HIP, std::string("copy back: ") + hipGetErrorString(e));
+  return QILQR_OK;
+}
+
+// pinned host memory for callers of the host-buffer entry points (direct DMA instead of HIP's pageable staging)
+void *qilqr_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    g_last_error = "hipHostMalloc failed";
+    return nullptr;
   }
-  cleanup();
-  return rc;
+  return p;
+}
+void qilqr_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int qilqr_solve(qilqr_solver *s, const double *init, int32_t n, double *out_traj, double *out_cost,
@@ -952,9 +1045,16 @@ int qilqr_line_search(qilqr_solver *s, const double *traj, const double *cost, c
   if (!s || !traj || !cost || !gains || !terms) return fail(QILQR_ERR_INVALID_ARG, "null argument");
   int rc = begin_batch(s, B, n, nullptr);
   if (rc) return rc;
-  double *d_cost = nullptr, *d_terms = nullptr;
-  HIP_TRY(hipMalloc((void **)&d_cost, sizeof(double) * B));
-  HIP_TRY(hipMalloc((void **)&d_terms, sizeof(double) * 2 * B));
+  struct Scratch {  // freed on every return path
+    double *cost = nullptr, *terms = nullptr;
+    ~Scratch() {
+      if (cost) (void)hipFree(cost);
+      if (terms) (void)hipFree(terms);
+    }
+  } scratch;
+  HIP_TRY(hipMalloc((void **)&scratch.cost, sizeof(double) * B));
+  HIP_TRY(hipMalloc((void **)&scratch.terms, sizeof(double) * 2 * B));
+  double *const d_cost = scratch.cost, *const d_terms = scratch.terms;
   if ((rc = upload_tiled(s, traj, s->st.traj[0], B, n, 18))) return rc;
   if ((rc = upload_tiled(s, gains, s->st.gains, B, n, 52))) return rc;
   HIP_TRY(hipMemcpyAsync(d_cost, cost, sizeof(double) * B, hipMemcpyHostToDevice, s->stream));
@@ -965,8 +1065,6 @@ int qilqr_line_search(qilqr_solver *s, const double *traj, const double *cost, c
     std::vector<int> st3(B, QILQR_STATUS_LINE_SEARCH_FAILED);
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (out_status) std::memcpy(out_status, st3.data(), sizeof(int) * B);
-    (void)hipFree(d_cost);
-    (void)hipFree(d_terms);
     return QILQR_OK;
   }
   for (int t = 0; t < s->params.ls_max_iters; ++t) {
@@ -986,8 +1084,6 @@ int qilqr_line_search(qilqr_solver *s, const double *traj, const double *cost, c
   if (out_cost) HIP_TRY(hipMemcpy(out_cost, s->st.cost, sizeof(double) * B, hipMemcpyDeviceToHost));
   if (out_step) HIP_TRY(hipMemcpy(out_step, s->st.alpha, sizeof(double) * B, hipMemcpyDeviceToHost));
   if (out_traj && (rc = download_tiled(s, out_traj, s->st.traj[0], s->st.traj[1], s->st.cur, 0, B, n, 18))) return rc;
-  (void)hipFree(d_cost);
-  (void)hipFree(d_terms);
   HIP_TRY(hipGetLastError());
   return QILQR_OK;
 }

@@ -11,6 +11,7 @@
 // is not the C++ one) through src/proto_wire.h.  Errors map as the reference's exceptions do under
 // pybind11: runtime_error -> RuntimeError (inertia, line-search exhaustion with the same text),
 // out_of_range -> IndexError, invalid_argument -> ValueError, wrong array shape -> TypeError.
+#include <cmath>
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 
@@ -101,7 +102,7 @@ py::tuple solve(Solver &self, const py::object &initial_traj) {
   if (n == 0) throw py::value_error("empty initial trajectory");  // UB in the reference (ilqr.hh:156)
   std::vector<double> out(init.size());
   int cap = 0;
-  if (self.opt.populate_debug && self.opt.max_iters > 0) cap = (int)std::min(self.opt.max_iters, 1e6);
+  if (self.opt.populate_debug && self.opt.max_iters > 0) cap = (int)std::min(std::ceil(self.opt.max_iters), 1e6);  // i < max_iters, a double (ilqr.hh:58)
   std::vector<double> dcost((size_t)std::max(cap, 1)), dtraj((size_t)std::max(cap, 1) * init.size());
   double cost = 0;
   int32_t status = 0, iters = 0, n_debug = 0;

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = capi.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.qilqr_abi_version() == 2
+    assert lib.qilqr_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
