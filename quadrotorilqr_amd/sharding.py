@@ -1,7 +1,13 @@
 """Batch sharding across GPUs.  Problems are independent (nothing in ilqr.hh couples two
 trajectories), so a batch splits into contiguous shards with no data-path collective; the only
 exchange is one gather of the converged trajectories and per-problem scalars to rank 0
-(RCCL over xGMI when the backend is "nccl", which is RCCL on ROCm; gloo in the CPU tests)."""
+(RCCL over xGMI when the backend is "nccl", which is RCCL on ROCm; gloo in the CPU tests).
+
+The gather is ragged and copy-free on the root: every other rank sends its shard point to point and the
+root receives it directly into that shard's rows of the result buffer (no padding to the largest shard, no
+concatenation afterwards).  xGMI is point to point (7 links per GPU), so seven simultaneous receives on the
+root use seven different links; a ring all-gather would put eight times the bytes on every link for a
+result only the root wants."""
 import torch
 import torch.distributed as dist
 
@@ -13,6 +19,10 @@ def shard_range(B, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_sizes(B, world):
+    return [shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world)]
+
+
 def shard_of_step(rank, step, world):
     """Which shard of the global batch `rank` solves at `step` when a sequence of batches is solved: the
     assignment rotates, so that over any `world` consecutive steps every rank has solved every shard once.
@@ -21,20 +31,49 @@ def shard_of_step(rank, step, world):
     return (rank + step) % world
 
 
-def gather_to_root(t, shard_sizes, dst=0, group=None):
-    """Gather per-rank tensors (first dim = that rank's shard size) on rank `dst`; returns the
-    concatenation there and None elsewhere.  Ragged shards are padded to the largest one."""
+def gather_to_root(t, sizes, dst=0, group=None, out=None, shard_of_rank=None):
+    """Gather per-rank tensors on rank `dst` in SHARD order.
+
+    t              this rank's shard: first dimension = the size of the shard it holds
+    sizes          size of every shard, in shard order
+    shard_of_rank  which shard each rank holds (default: rank r holds shard r); with a rotating assignment
+                   (shard_of_step) pass [shard_of_step(r, step, world) for r in range(world)], so that the
+                   result is in global problem order whatever rank solved which shard
+    out            optional preallocated result on the root (sum(sizes) rows), reused between calls
+
+    Returns the gathered tensor on the root (rows of shard k at offset sum(sizes[:k])) and None elsewhere."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return t
     rank = dist.get_rank(group)
-    mx = max(shard_sizes)
-    if t.shape[0] < mx:
-        pad = torch.zeros((mx - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        t = torch.cat([t, pad], 0)
+    if shard_of_rank is None:
+        shard_of_rank = list(range(world))
+    if sorted(shard_of_rank) != list(range(world)):
+        raise ValueError("shard_of_rank must be a permutation of the ranks")
+    offs = [0]
+    for s in sizes:
+        offs.append(offs[-1] + int(s))
+    mine = shard_of_rank[rank]
+    if t.shape[0] != sizes[mine]:
+        raise ValueError(f"rank {rank} holds shard {mine} of {sizes[mine]} rows but passed {t.shape[0]}")
     t = t.contiguous()
-    bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-    dist.gather(t, bufs, dst=dst, group=group)
     if rank != dst:
+        if t.shape[0] > 0:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, dst, group)]):
+                w.wait()
         return None
-    return torch.cat([b[:s] for b, s in zip(bufs, shard_sizes)], 0)
+    if out is None:
+        out = torch.empty((offs[-1],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    elif out.shape[0] != offs[-1] or tuple(out.shape[1:]) != tuple(t.shape[1:]) or not out.is_contiguous():
+        raise ValueError("out has the wrong shape")
+    ops = []
+    for r in range(world):
+        k = shard_of_rank[r]
+        if r == dst or sizes[k] == 0:
+            continue
+        ops.append(dist.P2POp(dist.irecv, out[offs[k]:offs[k + 1]], r, group))  # a contiguous row range: received in place
+    works = dist.batch_isend_irecv(ops) if ops else []
+    out[offs[mine]:offs[mine + 1]].copy_(t)
+    for w in works:
+        w.wait()
+    return out

@@ -43,18 +43,22 @@ def test_generator_is_shard_independent():
     np.testing.assert_array_equal(whole[lo:hi], part)
 
 
-def _worker(rank, world, port, B, q):
+def _worker(rank, world, port, B, q, step):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lo, hi = sharding.shard_range(B, rank, world)
+    # the shard this rank holds at `step` of a rotating assignment (step 0: rank r holds shard r)
+    shard_of_rank = [sharding.shard_of_step(r, step, world) for r in range(world)]
+    lo, hi = sharding.shard_range(B, shard_of_rank[rank], world)
     init = pb.config2(B=hi - lo, N=6, seed=4, b0=lo)["init"]
     shard_out = torch.from_numpy(init * 2.0 + 1.0)            # stand-in for the shard's solve
     shard_cost = torch.from_numpy(init[:, :, 1:4].sum(axis=(1, 2)))
-    sizes = [sharding.shard_range(B, k, world)[1] - sharding.shard_range(B, k, world)[0] for k in range(world)]
-    traj = sharding.gather_to_root(shard_out, sizes)
-    cost = sharding.gather_to_root(shard_cost, sizes)
+    sizes = sharding.shard_sizes(B, world)
+    out_buf = torch.full((B, 6, 18), float("nan"), dtype=torch.float64) if rank == 0 else None  # reused result buffer
+    traj = sharding.gather_to_root(shard_out, sizes, out=out_buf, shard_of_rank=shard_of_rank)
+    cost = sharding.gather_to_root(shard_cost, sizes, shard_of_rank=shard_of_rank)
     if rank == 0:
+        assert traj is out_buf
         q.put((traj.numpy(), cost.numpy()))
     else:
         assert traj is None and cost is None
@@ -62,20 +66,22 @@ def _worker(rank, world, port, B, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B", [10, 11])  # even and ragged shards
-def test_two_rank_gather_reassembles_the_batch(B):
+# even and ragged shards; a step of the rotating assignment (rank r holds shard (r + step) mod world: the root must
+# put every shard back at its global offset); three ranks; more ranks than problems (an empty shard)
+@pytest.mark.parametrize("B,world,step", [(10, 2, 0), (11, 2, 0), (11, 2, 1), (10, 3, 2), (2, 3, 1)])
+def test_gather_reassembles_the_batch_in_global_order(B, world, step):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q, step)) for r in range(world)]
     for p in procs:
         p.start()
-    traj, cost = q.get(timeout=120)
+    traj, cost = q.get(timeout=180)
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=180)
         assert p.exitcode == 0
     whole = pb.config2(B=B, N=6, seed=4)["init"]
     np.testing.assert_array_equal(traj, whole * 2.0 + 1.0)
