@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- iLQR solves/sec on BASELINE.json configs[1]: B=1024 random SE(3) starts per GPU,
-100 knots, fp64, model A.
+"""bench.py -- iLQR solves/sec.
 
-One "step" = one batched solve of the whole per-GPU batch, inputs already resident in HBM.
-N>1: launched by torch.distributed.run, one rank per GPU; each rank solves its own shard of
-1024 problems (weak scaling, no data-path collective) and the converged trajectories are
-gathered on rank 0 over RCCL inside the timed region.
+Default (what the driver runs): BASELINE.json configs[1] -- B = 1024 random SE(3) starts per GPU, 100 knots, fp64,
+model A.  One "step" = one batched solve of the whole per-GPU batch, inputs already resident
+in HBM.  N > 1: launched by torch.distributed.run, one rank per GPU; each rank solves its own shard of 1024 problems
+(weak scaling, no data-path collective) and the converged trajectories are gathered on rank 0 over RCCL inside the
+timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     for the dominant kernel, from HIP events recorded on the solver's stream inside
-               the timed region (algorithmic flops/bytes from BASELINE.md section 4)
-  cpu_baseline the CPU oracle timed on this host's cores on a bounded sample of the same workload
+--config 3: BASELINE.json configs[3] as specified -- ONE batch of 65536 problems (seed 4) cut into contiguous shards
+over the N ranks (8192 per GPU at N = 8; strong scaling: the same total batch at every N), RCCL gather of the
+converged trajectories to rank 0 inside the timed region, its time also reported on its own.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline      the dominant kernel, from HIP events attached to its dispatches inside the timed region (algorithmic
+                flops / bytes from BASELINE.md section 4 times the measured pass counts)
+  cpu_baseline  the CPU oracle timed on this host's cores on a bounded sample of the same workload (N = 1 only)
+  host_to_host  the metric as SURVEY.md section 8(d) words it: host buffers in -> host buffers out through
+                qilqr_solve_batch (pinned buffers, PCIe copies included); measured after the timed region, never `value`
+  large_batch   the same solver at B = 8192 per GPU (the shard of configs[3]): solves/s and, per kernel, the average
+                launch time and the fractions of the fp64 and HBM peaks -- the saturated-machine view
+  serving       several batches in flight (independent handles): measured after the timed region, never `value`
 """
 import argparse
 import json
@@ -28,6 +37,43 @@ HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # algorithmic work per knot
 FLOP_BWD_KNOT, FLOP_FWD_KNOT = 30000.0, 1250.0
 BYTES_BWD_KNOT, BYTES_FWD_KNOT, BYTES_IO_KNOT = 86 * 8.0, 103 * 8.0, 53 * 8.0
+# The PMC summary `roofline.traffic` is read from: named explicitly, and only used when its tag is this round's
+# (profiles/run_rocprof.sh <tag> writes profiles/<tag>_rocprof_summary.json from the same bench command).
+ROUND_TAG = "r02"
+TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r02_rocprof_summary.json")
+
+
+def kernel_table(prof, n_bwd_knots, n_fwd_knots):
+    """per-kernel work and time of the timed region (HIP events attached to the dispatches)"""
+    return {
+        "k_backward": dict(ms=prof["backward_ms"], launches=prof["backward_launches"], seen=prof["backward_seen"],
+                           flops=FLOP_BWD_KNOT * n_bwd_knots, bytes=BYTES_BWD_KNOT * n_bwd_knots),
+        "k_rollout": dict(ms=prof["rollout_ms"], launches=prof["rollout_launches"], seen=prof["rollout_seen"],
+                          flops=FLOP_FWD_KNOT * n_fwd_knots, bytes=BYTES_FWD_KNOT * n_fwd_knots),
+    }
+
+
+def rates(kd):
+    """achieved TFLOP/s and GB/s of one kernel: its algorithmic work / (all its launches x the measured average
+    launch duration) -- events sample every k-th launch"""
+    sec = max(kd["ms"], 1e-9) * 1e-3 * max(kd["seen"], 1) / max(kd["launches"], 1)
+    return kd["flops"] / sec / 1e12, kd["bytes"] / sec / 1e9
+
+
+def read_traffic(dom, B, N):
+    """HBM bytes per launch of the dominant kernel from this round's committed PMC summary (FETCH_SIZE and WRITE_SIZE in
+    separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None when the summary is
+    missing, is not this round's, or was taken on another workload"""
+    if not (B == 1024 and N == 100) or not os.path.exists(TRAFFIC_SUMMARY):
+        return None, None
+    try:
+        js = json.load(open(TRAFFIC_SUMMARY))
+        if not str(js.get("tag", "")).startswith(ROUND_TAG):
+            return None, None
+        t = js["FETCH_SIZE"][dom]["bytes_per_launch_corrected"] + js["WRITE_SIZE"][dom]["bytes_per_launch_corrected"]
+        return t, os.path.basename(TRAFFIC_SUMMARY) + " (tag " + js["tag"] + ")"
+    except Exception:
+        return None, None
 
 
 def main():
@@ -35,7 +81,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
+    ap.add_argument("--config", type=int, default=1, choices=(1, 3),
+                    help="BASELINE.json configs[k]: 1 = B 1024 per GPU (weak scaling, default); 3 = one batch of 65536 sharded over the GPUs (strong scaling)")
+    ap.add_argument("--batch", type=int, default=0, help="config 1: problems per GPU (default 1024); config 3: problems in total (default 65536)")
     ap.add_argument("--knots", type=int, default=100)
     ap.add_argument("--sync-every", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -47,6 +95,8 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=300.0, help="untimed solves before the warm-up steps (clocks out of idle)")
     ap.add_argument("--no-serving", action="store_true", help="skip the extra several-batches-in-flight measurement (never part of value)")
     ap.add_argument("--serving-batches", type=int, default=18)
+    ap.add_argument("--no-host-to-host", action="store_true", help="skip the host-buffers-in / host-buffers-out measurement (never part of value)")
+    ap.add_argument("--no-large-batch", action="store_true", help="skip the B = 8192 measurement (never part of value)")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP events around the kernels (roofline = null)")
     args = ap.parse_args()
 
@@ -71,43 +121,73 @@ def main():
     dev = torch.device("cuda", local_rank if (world > 1 and not one_device_test) else 0)
     to_wire = (lambda t: t.cpu()) if one_device_test else (lambda t: t)  # gloo gathers host tensors
 
-    B, N = args.batch, args.knots
-    cfg = pb.config2(B=B, N=N, seed=2, b0=rank * B)  # counter-based generator: shard-independent
+    N = args.knots
+    strong = args.config == 3
+    if strong:
+        # configs[3]: ONE batch, contiguous shards, fixed assignment (rank r holds [lo_r, hi_r) of the global batch)
+        B_total = args.batch or 65536
+        sizes = sharding.shard_sizes(B_total, world)
+        lo, hi = sharding.shard_range(B_total, rank, world)
+        B, seed = hi - lo, 4
+        cfg = pb.config2(B=B, N=N, seed=seed, b0=lo)  # counter-based generator: keyed by the global problem index
+        shard_at = lambda step: list(range(world))
+    else:
+        # configs[1]: 1024 problems per GPU; the global batch of a step is the N shards of 1024 distinct problems
+        # (shard k = problems k*B .. (k+1)*B of the generator); rank r solves shard (r + step) mod N.  How long a shard
+        # takes is set by its slowest problem (31 to 45 rollouts over the first eight shards), so a fixed assignment
+        # would make every step wait for the same unlucky rank; rotating it evens the ranks' totals over the steps
+        # without any exchange (sharding.shard_of_step).
+        B, seed = args.batch or 1024, 2
+        B_total = B * world
+        sizes = [B] * world
+        cfg = pb.config2(B=B, N=N, seed=seed, b0=rank * B)
+        shard_at = lambda step: [sharding.shard_of_step(r, step, world) for r in range(world)]
     solver = capi.from_config(cfg, device=dev.index, profile=(0 if args.no_profile else (2 if args.profile_all else 1)), sync_every=args.sync_every,
                               force_general=args.backward, streams=args.streams, **({} if args.rollout < 0 else dict(single_wave_rollout=args.rollout)))
 
     init = torch.from_numpy(cfg["init"]).to(dev)
-    # N > 1: the global batch of a step is the N shards of 1024 distinct problems (shard k = problems
-    # k*B .. (k+1)*B of the counter-based generator); rank r solves shard (r + step) mod N.  How long a shard
-    # takes is set by its slowest problem (31 to 45 rollouts over the first eight shards), so a fixed
-    # assignment would make every step wait for the same unlucky rank; rotating it evens the ranks' totals
-    # over the steps without any exchange (sharding.shard_of_step).
-    inits = {rank: init}
-    for sh in range(world):
-        if sh not in inits:
-            inits[sh] = torch.from_numpy(pb.config2(B=B, N=N, seed=2, b0=sh * B)["init"]).to(dev)
+    inits = {rank: init}  # by shard index
+    if not strong:
+        for sh in range(world):
+            if sh not in inits:
+                inits[sh] = torch.from_numpy(pb.config2(B=B, N=N, seed=seed, b0=sh * B)["init"]).to(dev)
     # two sets of output buffers, used alternately: with N > 1 the gather of step s (RCCL, torch's stream) runs
     # while the solver's own stream is already solving step s + 1
     out_traj = [torch.empty_like(init) for _ in range(2)]
     out_cost = [torch.empty(B, dtype=torch.float64, device=dev) for _ in range(2)]
     out_i = [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(4)]  # status, iters, n_bwd, n_fwd
-    sizes = [B] * world
+    # the gathered batch on rank 0, in global problem order, allocated once
+    if world > 1 and rank == 0:
+        wire_dev = torch.device("cpu") if one_device_test else dev
+        g_traj = torch.empty((B_total, N, 18), dtype=torch.float64, device=wire_dev)
+        g_cost = torch.empty(B_total, dtype=torch.float64, device=wire_dev)
+    else:
+        g_traj = g_cost = None
     step_no = [0]
-
     gathered = [None, None]  # per output buffer set: event after its last gather (N > 1)
+    pass_knots = torch.zeros(2, dtype=torch.float64, device=dev)  # sum over the timed steps of n_bwd, n_fwd (this rank)
+    count_passes = [False]
+
+    def gather(k, step):
+        sor = shard_at(step)
+        sharding.gather_to_root(to_wire(out_traj[k]), sizes, out=g_traj, shard_of_rank=sor)
+        sharding.gather_to_root(to_wire(out_cost[k]), sizes, out=g_cost, shard_of_rank=sor)
 
     def step():
         k = step_no[0] & 1
-        sh = sharding.shard_of_step(rank, step_no[0], world)
-        step_no[0] += 1
+        sh = shard_at(step_no[0])[rank]
         if gathered[k] is not None:
             gathered[k].synchronize()  # the gather that read this buffer set two steps ago has finished
-        solver.solve_batch_device(inits[sh], out_traj[k], out_cost[k], out_i[0], out_i[1], out_i[2], out_i[3])
+        # (static inputs; the gather still in flight on torch's stream reads the OTHER buffer set: no ordering needed)
+        solver.solve_batch_device(inits[sh], out_traj[k], out_cost[k], out_i[0], out_i[1], out_i[2], out_i[3],
+                                  wait_current_stream=False)
+        if count_passes[0] and world > 1:  # rotating shards: the pass counts differ from step to step
+            pass_knots.add_(torch.stack([out_i[2].sum(), out_i[3].sum()]).to(torch.float64))
         if world > 1:  # the one exchange of the path: converged trajectories to rank 0
-            sharding.gather_to_root(to_wire(out_traj[k]), sizes)
-            sharding.gather_to_root(to_wire(out_cost[k]), sizes)
+            gather(k, step_no[0])
             gathered[k] = torch.cuda.Event()
             gathered[k].record()
+        step_no[0] += 1
 
     def fence():
         if world > 1:
@@ -130,71 +210,70 @@ def main():
     if not args.no_profile and not args.profile_all and args.warmup > 0:
         solver.profile_mode((3 if calib["backward_ms"] >= calib["rollout_ms"] else 4) | (args.event_stride << 8))
     solver.profile_reset()
+    count_passes[0] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    count_passes[0] = False
     if world > 1:
         tt = to_wire(torch.tensor([dt], dtype=torch.float64, device=dev))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     prof = solver.profile_get()
 
+    # the gather on its own (after the timed region): every rank's shard of the last step to rank 0, waited for
+    gather_ms = None
+    if world > 1:
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            gather((step_no[0] - 1) & 1, step_no[0] - 1)
+        fence()
+        tg = to_wire(torch.tensor([(time.perf_counter() - t1) / 3], dtype=torch.float64, device=dev))
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        gather_ms = float(tg.item()) * 1e3
+
     status, iters, n_bwd, n_fwd = (t.cpu().numpy() for t in out_i)
-    total = B * world * args.steps
+    total = B_total * args.steps
     value = total / dt
+    if world > 1:
+        knots_bwd, knots_fwd = (float(v) * N for v in pass_knots.cpu().numpy())
+        all_knots = to_wire(pass_knots.clone())
+        dist.all_reduce(all_knots, op=dist.ReduceOp.SUM)
+        knot_steps = float(all_knots.sum().item()) * N
+    else:  # one shard, the same every step
+        knots_bwd, knots_fwd = float(n_bwd.sum()) * N * args.steps, float(n_fwd.sum()) * N * args.steps
+        knot_steps = knots_bwd + knots_fwd
 
     if rank == 0:
         # ---- roofline of the dominant kernel (this rank's launches, timed region only)
-        knots_bwd = float(n_bwd.sum()) * N * args.steps
-        knots_fwd = float(n_fwd.sum()) * N * args.steps
-        # ms / launches: the launches that carried events (every event_stride-th launch of the dominant kernel);
-        # seen: all its launches in the timed region.  Work is per launch: total work / all launches.
-        kern = {
-            "k_backward": dict(ms=prof["backward_ms"], launches=prof["backward_launches"], seen=prof["backward_seen"],
-                               flops=FLOP_BWD_KNOT * knots_bwd, bytes=BYTES_BWD_KNOT * knots_bwd),
-            "k_rollout": dict(ms=prof["rollout_ms"], launches=prof["rollout_launches"], seen=prof["rollout_seen"],
-                              flops=FLOP_FWD_KNOT * knots_fwd, bytes=BYTES_FWD_KNOT * knots_fwd),
-        }
-        dom = max(kern, key=lambda k: kern[k]["ms"])
-        kd = kern[dom]
-        # time all launches would take at the measured average launch duration
-        sec = max(kd["ms"], 1e-9) * 1e-3 * max(kd["seen"], 1) / max(kd["launches"], 1)
-        tflops = kd["flops"] / sec / 1e12
-        gbs = kd["bytes"] / sec / 1e9
-        # HBM bytes per launch of that kernel from the latest committed PMC summary (profiles/, produced by
-        # profiles/run_rocprof.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
-        # MI355X_MICROARCH.md prescribes for gfx950); null when no summary is present
-        traffic, traffic_src = None, None
-        import glob
-        summaries = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.json")))
-        if summaries and B == 1024 and N == 100:
-            try:
-                js = json.load(open(summaries[-1]))
-                traffic = (js["FETCH_SIZE"][dom]["bytes_per_launch_corrected"]
-                           + js["WRITE_SIZE"][dom]["bytes_per_launch_corrected"])
-                traffic_src = os.path.basename(summaries[-1])
-            except Exception:
-                traffic = None
-        # k_backward is matrix-core work (fp64 MFMA); k_rollout has none: its bound is the bytes it moves
-        if dom == "k_backward":
-            bound = dict(bound="mfma", achieved=tflops, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=tflops / FP64_PEAK_TFLOPS)
-        else:
-            bound = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
-        roofline = {
-            "kernel": dom, **bound, "traffic": traffic, "traffic_source": traffic_src,
-            "avg_launch_us": kd["ms"] * 1e3 / max(kd["launches"], 1), "launches": kd["seen"],
-            "timed_launches": kd["launches"],
-            "alg_flops_per_launch": kd["flops"] / max(kd["seen"], 1),
-            "alg_bytes_per_launch": kd["bytes"] / max(kd["seen"], 1),
-            "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
-            "flops": {"achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS},
-            "kernels_ms": {k: round(v["ms"], 3) for k, v in kern.items()}
-                          | {"k_linearize": round(prof["linearize_ms"], 3), "other": round(prof["other_ms"], 3)},
-            "warmup_avg_launch_us": {k: round(calib[k + "_ms"] * 1e3 / max(calib[k + "_launches"], 1), 2)
-                                     for k in ("backward", "rollout")},
-        }
+        roofline = None
+        if not args.no_profile:
+            kern = kernel_table(prof, knots_bwd, knots_fwd)
+            dom = max(kern, key=lambda k: kern[k]["ms"])
+            kd = kern[dom]
+            tflops, gbs = rates(kd)
+            traffic, traffic_src = read_traffic(dom, B, N)
+            # k_backward is matrix-core work (fp64 MFMA); k_rollout has none: its bound is the bytes it moves
+            if dom == "k_backward":
+                bound = dict(bound="mfma", achieved=tflops, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=tflops / FP64_PEAK_TFLOPS)
+            else:
+                bound = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
+            roofline = {
+                "kernel": dom, **bound, "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_us": kd["ms"] * 1e3 / max(kd["launches"], 1), "launches": kd["seen"],
+                "timed_launches": kd["launches"],
+                "alg_flops_per_launch": kd["flops"] / max(kd["seen"], 1),
+                "alg_bytes_per_launch": kd["bytes"] / max(kd["seen"], 1),
+                "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+                "flops": {"achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS},
+                "kernels_ms": {k: round(v["ms"], 3) for k, v in kern.items()}
+                              | {"k_linearize": round(prof["linearize_ms"], 3), "other": round(prof["other_ms"], 3)},
+                "warmup_avg_launch_us": {k: round(calib[k + "_ms"] * 1e3 / max(calib[k + "_launches"], 1), 2)
+                                         for k in ("backward", "rollout")},
+            }
         # ---- CPU baseline: the oracle on this host's cores, bounded sample of the same workload
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
@@ -218,11 +297,76 @@ def main():
                    "sample": f"first {sample} of the {B} problems of rank 0 x {reps} repeats, {cores} threads, {tc:.2f} s; "
                              f"single thread: {16 / t1c:.1f} solves/s on 16 problems",
                    "parity_max_rel_cost_err": float(np.max(np.abs(got - r["cost"]) / np.abs(r["cost"])))}
+        # ---- the metric as SURVEY.md section 8(d) defines it: host buffers in -> host buffers out (never `value`)
+        h2h = None
+        if not args.no_host_to_host and world == 1:
+            hin = capi.host_array(cfg["init"].shape)
+            hin[...] = cfg["init"]
+            hout = dict(traj=capi.host_array(cfg["init"].shape), cost=capi.host_array((B,)),
+                        **{k: capi.host_array((B,), np.int32) for k in ("status", "iters", "n_bwd", "n_fwd")})
+            plain = capi.from_config(cfg, device=dev.index, sync_every=args.sync_every)
+            plain.solve_batch(hin, out=hout)
+            reps = max(3, min(args.steps, 10))
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                plain.solve_batch(hin, out=hout)
+            th = (time.perf_counter() - t1) / reps
+            pg = cfg["init"].copy()  # the same through pageable buffers (HIP stages the copies itself)
+            plain.solve_batch(pg)
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                plain.solve_batch(pg)
+            tp = (time.perf_counter() - t1) / reps
+            h2h = {"value": B / th, "unit": "solves/s", "ms_per_solve": th * 1e3,
+                   "what": f"qilqr_solve_batch, B = {B}: quaternion checks + H2D + solve + D2H, pinned host buffers, {reps} repeats",
+                   "bytes_in": int(cfg["init"].nbytes), "bytes_out": int(cfg["init"].nbytes + B * 24),
+                   "pageable_buffers": {"value": B / tp, "ms_per_solve": tp * 1e3},
+                   "parity_with_device_path": bool(np.array_equal(hout["cost"], out_cost[(step_no[0] - 1) & 1].cpu().numpy()))}
+            plain.close()
+        # ---- the saturated machine: the shard one GPU solves in configs[3] (never `value`)
+        large = None
+        if not args.no_large_batch and world == 1 and not strong:
+            LB = 8192
+            lcfg = pb.config2(B=LB, N=N, seed=4)
+            ls = capi.from_config(lcfg, device=dev.index, profile=2, sync_every=args.sync_every)
+            linit = torch.from_numpy(lcfg["init"]).to(dev)
+            lbuf = (torch.empty_like(linit), torch.empty(LB, dtype=torch.float64, device=dev),
+                    [torch.empty(LB, dtype=torch.int32, device=dev) for _ in range(4)])
+            ls.solve_batch_device(linit, lbuf[0], lbuf[1], *lbuf[2])
+            ls.profile_reset()
+            reps = 3
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                ls.solve_batch_device(linit, lbuf[0], lbuf[1], *lbuf[2])
+            tl = (time.perf_counter() - t1) / reps
+            lp = ls.profile_get()
+            lb_, lf_ = float(lbuf[2][2].sum().item()) * N * reps, float(lbuf[2][3].sum().item()) * N * reps
+            lk = kernel_table(lp, lb_, lf_)
+            per = {}
+            for k, kd in lk.items():
+                tf, gb = rates(kd)
+                per[k] = {"avg_launch_us": kd["ms"] * 1e3 / max(kd["launches"], 1), "launches": kd["launches"],
+                          "fp64_frac": tf / FP64_PEAK_TFLOPS, "hbm_frac": gb / HBM_PEAK_GBS}
+            per["k_linearize"] = {"avg_launch_us": lp["linearize_ms"] * 1e3 / max(lp["linearize_launches"], 1),
+                                  "launches": lp["linearize_launches"]}
+            ls.profile_mode(0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                ls.solve_batch_device(linit, lbuf[0], lbuf[1], *lbuf[2])
+            tl0 = (time.perf_counter() - t1) / reps
+            large = {"what": f"B = {LB}, N = {N}, fp64, seed 4 (the shard one GPU solves in configs[3]); device-resident, {reps} repeats",
+                     "value": LB / tl0, "unit": "solves/s", "ms_per_solve": tl0 * 1e3,
+                     "ms_per_solve_with_every_kernel_timed": tl * 1e3, "kernels": per,
+                     "status_counts": np.bincount(lbuf[2][0].cpu().numpy(), minlength=4).tolist()}
+            ls.close()
+            del linit, lbuf
         # ---- extra, outside the timed region and never `value`: a stream of such batches with several in flight
         # (one solver handle and one host thread per batch in flight): the tail of one batch -- a few trajectories
         # still iterating on an almost idle chip -- overlaps the head of the next
         serving = None
-        if not args.no_serving and world == 1:
+        if not args.no_serving and world == 1 and not strong:
             import threading
             serving = {"what": f"solves/s over {args.serving_batches} batches of {B} with k batches in flight "
                                "(independent handles, streams and host threads); k = 1 is `value`'s configuration"}
@@ -238,7 +382,7 @@ def main():
 
                 def drive(w):
                     for _ in range(per):
-                        w[0].solve_batch_device(init, w[1][0], w[1][1], *w[1][2])
+                        w[0].solve_batch_device(init, w[1][0], w[1][1], *w[1][2], wait_current_stream=False)
 
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
@@ -251,20 +395,28 @@ def main():
                 serving[f"in_flight_{k}"] = per * k * B / (time.perf_counter() - t1)
                 for w in ws:
                     w[0].close()
+        if strong:
+            workload = (f"BASELINE.json configs[3]: ONE batch of {B_total} random SE(3) starts -> hover, {N} knots, fp64, model A, "
+                        f"seed 4, contiguous shards of {sizes[0]} per GPU")
+            conf = {"workload": workload, "batch_total": B_total, "batch_per_gpu": sizes[0], "knots": N,
+                    "parallelism": f"batch-shard x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
+                    "shard_assignment": "contiguous, fixed: rank r solves problems [lo_r, hi_r)"}
+        else:
+            workload = f"BASELINE.json configs[1]: batch={B}/GPU random SE(3) starts -> hover, {N} knots, fp64, model A, seed 2"
+            conf = {"workload": workload, "batch_per_gpu": B, "knots": N,
+                    "parallelism": f"batch-shard x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
+                    "shard_assignment": ("one shard" if world == 1 else
+                                         f"{world} shards of {B} distinct problems per step; rank r solves shard (r + step) mod {world}")}
         line = {
             "metric": "iLQR solves/sec (batch, 100-knot SE(3) quadrotor)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: batch={B}/GPU random SE(3) starts -> hover, "
-                                   f"{N} knots, fp64, model A, seed 2", "batch_per_gpu": B, "knots": N,
-                       "parallelism": f"batch-shard x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
-                       "shard_assignment": ("one shard" if world == 1 else
-                                            f"{world} shards of {B} distinct problems per step; rank r solves shard (r + step) mod {world}")},
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic", "config": conf,
             "iters_mean": float(iters.mean()), "iters_max": int(iters.max()),
             "status_counts": np.bincount(status, minlength=4).tolist(),
-            "knot_steps_per_s": float((n_bwd.sum() + n_fwd.sum()) * N * world * args.steps / dt),
-            "roofline": roofline, "cpu_baseline": cpu, "serving": serving,
+            "knot_steps_per_s": knot_steps / dt,
+            "gather_ms": gather_ms,
+            "roofline": roofline, "cpu_baseline": cpu, "host_to_host": h2h, "large_batch": large, "serving": serving,
         }
         print(json.dumps(line))
     if world > 1:

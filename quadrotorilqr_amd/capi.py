@@ -184,26 +184,36 @@ class QuadrotorILQRBatch:
                          debug_trajs=dtraj[:k].copy())
 
     # ---- batch of problems, host buffers
-    def solve_batch(self, init, desired_batch=None):
+    def solve_batch(self, init, desired_batch=None, out=None):
+        """qilqr_solve_batch.  `out` (optional): a dict of preallocated result arrays (keys traj, cost, status, iters,
+        n_bwd, n_fwd; C-contiguous float64 / int32) that is filled and returned -- with pinned arrays (host_array) the
+        copies are direct DMA."""
         init = _d(init)
         B, n = init.shape[0], init.shape[1]
         des = None if desired_batch is None else _d(desired_batch)
-        out = np.zeros_like(init)
-        cost = np.zeros(B)
-        st, it, nb, nf = (np.zeros(B, dtype=np.int32) for _ in range(4))
-        rc = load().qilqr_solve_batch(self._h, _p(init), _p(des), C.c_int32(B), C.c_int32(n), _p(out), _p(cost),
-                                      _ip(st), _ip(it), _ip(nb), _ip(nf))
+        if out is None:
+            out = dict(traj=np.zeros_like(init), cost=np.zeros(B), **{k: np.zeros(B, dtype=np.int32) for k in ("status", "iters", "n_bwd", "n_fwd")})
+        else:
+            for k, dt, shape in (("traj", np.float64, init.shape), ("cost", np.float64, (B,)), ("status", np.int32, (B,)),
+                                 ("iters", np.int32, (B,)), ("n_bwd", np.int32, (B,)), ("n_fwd", np.int32, (B,))):
+                a = out[k]
+                if a.dtype != dt or a.shape != shape or not a.flags["C_CONTIGUOUS"]:
+                    raise TypeError(f"out[{k!r}] must be a C-contiguous {np.dtype(dt).name} array of shape {shape}")
+        rc = load().qilqr_solve_batch(self._h, _p(init), _p(des), C.c_int32(B), C.c_int32(n), _p(out["traj"]), _p(out["cost"]),
+                                      _ip(out["status"]), _ip(out["iters"]), _ip(out["n_bwd"]), _ip(out["n_fwd"]))
         if rc:
             _raise(rc)
-        return dict(traj=out, cost=cost, status=st, iters=it, n_bwd=nb, n_fwd=nf)
+        return out
 
     # ---- batch of problems, torch CUDA tensors already resident in HBM
     def solve_batch_device(self, init, out_traj, out_cost, out_status, out_iters, out_n_bwd, out_n_fwd,
-                           desired_batch=None):
+                           desired_batch=None, wait_current_stream=True):
         """qilqr_solve_batch_device on torch tensors.  Every tensor must live on the solver's device, be
         contiguous and have the ABI's dtype and shape (float64 (B,n,18) / (B,), int32 (B,)); outputs may be None.
         The solve runs on the solver's own stream: it is ordered behind whatever torch has enqueued on its
-        current stream (an event recorded here, waited for on the device), and has finished when this returns."""
+        current stream (an event recorded here, waited for on the device), and has finished when this returns.
+        wait_current_stream=False skips that ordering: only for inputs that are known to be complete (bench.py:
+        static inputs, and a gather of the OTHER buffer set still in flight on torch's stream)."""
         import torch
         if init.dim() != 3 or init.shape[2] != KNOT:
             raise TypeError("init must be (B, n, 18)")
@@ -230,11 +240,12 @@ class QuadrotorILQRBatch:
                         (out_n_fwd, "out_n_fwd")):
             check(t, name, torch.int32, (B,))
         # inputs produced by asynchronous torch work on its current stream: the solver's stream waits for them
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(init.device))
-        rc = load().qilqr_stream_wait_event(self._h, C.c_void_p(ev.cuda_event))
-        if rc:
-            _raise(rc)
+        if wait_current_stream:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(init.device))
+            rc = load().qilqr_stream_wait_event(self._h, C.c_void_p(ev.cuda_event))
+            if rc:
+                _raise(rc)
         vp = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
         rc = load().qilqr_solve_batch_device(self._h, vp(init), vp(desired_batch), C.c_int32(B), C.c_int32(n),
                                              vp(out_traj), vp(out_cost), vp(out_status), vp(out_iters),
@@ -323,6 +334,20 @@ class QuadrotorILQRBatch:
         if rc:
             _raise(rc)
         return {f: getattr(p, f) for f, _ in Profile._fields_}
+
+
+def host_array(shape, dtype=np.float64):
+    """A NumPy array in pinned host memory (qilqr_host_alloc): hipMemcpy to / from it is direct DMA.  The memory is
+    released when the array (and every view of it) is garbage collected."""
+    import weakref
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = load().qilqr_host_alloc(C.c_size_t(max(n, 1)))
+    if not p:
+        raise MemoryError(load().qilqr_last_error().decode())
+    buf = (C.c_char * max(n, 1)).from_address(p)
+    a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    weakref.finalize(buf, load().qilqr_host_free, C.c_void_p(p))
+    return a
 
 
 def from_config(cfg, **kw):

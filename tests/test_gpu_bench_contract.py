@@ -37,6 +37,15 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["value"] > 0 and c["parity_max_rel_cost_err"] < 1e-9
+    # the metric as SURVEY.md section 8(d) words it (host buffers in -> host buffers out), beside `value`, never it
+    h = j["host_to_host"]
+    assert h["unit"] == "solves/s" and 0 < h["value"] < j["value"] * 1.05 and h["parity_with_device_path"] is True
+    assert h["bytes_in"] == 1024 * 100 * 18 * 8 and h["pageable_buffers"]["value"] > 0
+    # the saturated machine: B = 8192 in the same run, per-kernel launch times and roofline fractions
+    lb = j["large_batch"]
+    assert lb["value"] > j["value"] and lb["status_counts"][2] == 0 and lb["status_counts"][3] == 0
+    for k in ("k_backward", "k_rollout"):
+        assert lb["kernels"][k]["avg_launch_us"] > 1.0 and 0 < lb["kernels"][k]["fp64_frac"] < 1 and 0 < lb["kernels"][k]["hbm_frac"] < 1
 
 
 @pytest.mark.gpu
@@ -63,3 +72,30 @@ def test_two_rank_code_path_on_one_gpu():
     assert abs(j["value"] - 2 * 1024 * 1e3 / j["ms_per_step"]) / j["value"] < 1e-6
     assert "shard (r + step) mod 2" in j["config"]["shard_assignment"]
     assert j["status_counts"][2] == 0 and j["status_counts"][3] == 0  # every problem of the last shard converged
+    assert j["gather_ms"] > 0 and j["host_to_host"] is None and j["large_batch"] is None
+
+
+@pytest.mark.gpu
+def test_config3_strong_scaling_code_path_on_one_gpu():
+    """bench.py --config 3 (BASELINE.json configs[3]: ONE batch cut into contiguous shards, strong scaling) with two
+    ranks on GPU 0 over gloo, at a reduced total batch: the value counts the whole batch once per step, the gather
+    is timed on its own too."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, QILQR_BENCH_ONE_DEVICE_TEST="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "3", "--batch", "2050"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong"
+    assert j["config"]["batch_total"] == 2050 and j["config"]["batch_per_gpu"] == 1025
+    assert abs(j["value"] - 2050 * 1e3 / j["ms_per_step"]) / j["value"] < 1e-6
+    assert "configs[3]" in j["config"]["workload"] and j["gather_ms"] > 0
+    assert j["status_counts"][2] == 0 and j["status_counts"][3] == 0
