@@ -82,9 +82,10 @@ typedef struct {
                             per trajectory beyond); 1: the general kernel even when Q, R are symmetric; 2: the
                             one-wavefront kernel for symmetric weights (k_backward<true>); 3: k_backward2;
                             4: k_backward4 */
-  int32_t single_wave_rollout; /* rollout kernel: 0 (default) = pose wave + control wave + loader wave per 64
-                                  trajectories (k_rollout3); 1 = one wavefront (k_rollout, always used above 16384
-                                  trajectories) */
+  int32_t single_wave_rollout; /* rollout kernel: 0 (default) = by the batch: sixteen lanes per trajectory, four
+                                  trajectories per block (k_rollout16) up to 4096 trajectories, a lane per trajectory
+                                  in three cooperating wavefronts (k_rollout3) up to 16384, in one wavefront (k_rollout)
+                                  beyond; 1 = k_rollout; 2 = k_rollout3; 3 = k_rollout16 */
   int32_t precision; /* 0: fp64 everywhere (reference parity).  1: mixed: trajectories, gains and knot records
                         stored in fp32, rollout and linearisation computed in fp32, Riccati recursion on the fp64
                         matrix core, cost sums / Armijo / convergence tests in fp64 (BASELINE.json configs[2]) */

@@ -215,6 +215,7 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
 }
 
 inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+constexpr long R16_MAX_B = 4096;  // k_rollout16 up to this many trajectories (launch_rollout)
 // largest number of consecutive restarts lm_restart (ilqr_kernels.h) can grant one iteration
 inline double max_restarts(const SolveParams &p) {
   if (!(p.mu_init > 0.0) || !(p.mu_init <= p.mu_max)) return 0.0;
@@ -354,15 +355,23 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
   return QILQR_OK;
 }
 int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
-  // the cooperating pair shortens one trajectory's chain; with more tiles than the chip has room for
-  // pairs (1 pair per SIMD at 256 VGPRs) the single-wave form gives the higher throughput
-  if (s->dev.single_wave_rollout == 1 || std::max(B, s->total_B) > 16384) {
+  // Which rollout kernel, by how many trajectories share the chip (qilqr_device_config.single_wave_rollout):
+  //   k_rollout16  sixteen lanes per trajectory, four trajectories per block: the shortest chain per trajectory and a
+  //                block on every CU from 1024 trajectories on; up to R16_MAX_B trajectories
+  //   k_rollout3   a lane per trajectory, three cooperating wavefronts per 64 trajectories
+  //   k_rollout    a lane per trajectory, one wavefront: the highest throughput, above 16384 trajectories
+  const long load_B = std::max(B, s->total_B);
+  const int choice = s->dev.single_wave_rollout;
+  if (choice == 1 || (choice != 3 && load_B > 16384)) {
     if (s->f32)
-      launch(s, K_ROLLOUT, k_rollout<float>, dim3(cdiv(B, 64)), dim3(64), s->constsf, s->st, (int)B, (int)n,
-                         need_flag);
+      launch(s, K_ROLLOUT, k_rollout<float>, dim3(cdiv(B, 64)), dim3(64), s->constsf, s->st, (int)B, (int)n, need_flag);
     else
-      launch(s, K_ROLLOUT, k_rollout<double>, dim3(cdiv(B, 64)), dim3(64), s->consts, s->st, (int)B, (int)n,
-                         need_flag);
+      launch(s, K_ROLLOUT, k_rollout<double>, dim3(cdiv(B, 64)), dim3(64), s->consts, s->st, (int)B, (int)n, need_flag);
+  } else if (choice == 3 || (choice == 0 && load_B <= R16_MAX_B)) {
+    if (s->f32)
+      launch(s, K_ROLLOUT, k_rollout16<float>, dim3(cdiv(B, 4)), dim3(128), s->consts, s->st, (int)B, (int)n, need_flag);
+    else
+      launch(s, K_ROLLOUT, k_rollout16<double>, dim3(cdiv(B, 4)), dim3(128), s->consts, s->st, (int)B, (int)n, need_flag);
   } else {
     if (s->f32)
       launch(s, K_ROLLOUT, k_rollout3<float>, dim3(cdiv(B, 64)), dim3(192), s->constsf, s->st, (int)B, (int)n, need_flag);

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "backward_layout.h"
+#include "rollout16.h"
 #include "se3_math.h"
 
 namespace qilqr {
@@ -1795,6 +1796,203 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
   }
 #ifdef QILQR_STAMPS
   stamp_flush();
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rollout16: SIXTEEN LANES PER TRAJECTORY (rollout16.h): block = 128 = rollout wavefront R + operand wavefront P
+// for four trajectories (b0 = 4 blockIdx.x; row r of 16 lanes <-> trajectory b0 + r).  At B = 1024 that is 256
+// blocks -- one per CU -- instead of the 16 blocks of k_rollout3, and about a third of its instructions per knot.
+//   P: for knot k (running up to R16_RING - 1 knots ahead of R): loads the nominal knot and the gains (tiled global
+//      layout, per-lane element indices), forms the 23 operand registers (r16::p_make_ops) and writes them to ring
+//      slot k % R16_RING as [register][lane]; copies the time column to the output trajectory.
+//   R: waits for slot i, reads its lane's 23 values, runs r16::r_knot, stores the knot (two masked stores).
+// The two waves never meet at a barrier inside the loop: P publishes "knots produced", R "knots consumed" in two LDS
+// words (LDS operations of a wavefront execute in order, so a flag written after the data is seen after the data);
+// every spin is bounded, so a lost flag ends the kernel instead of hanging it.
+// Trajectories of the block that are not being rolled out this round alias the block's first live trajectory (their
+// rows compute a duplicate that nobody stores): no row wanders onto a slow branch, no extra memory traffic.
+// S = storage precision of trajectories and gains; the arithmetic is fp64 in either mode.
+// ---------------------------------------------------------------------------------------------
+struct DevWave {
+  typedef double V;
+  typedef bool M;
+  typedef int I;
+  template <class F> static __device__ __forceinline__ V vconst(F f) { return f((int)(threadIdx.x & 63)); }
+  template <class F> static __device__ __forceinline__ M mconst(F f) { return f((int)(threadIdx.x & 63)); }
+  // element indices of a knot become offsets into the tiled layout, (e / 2) * 128 + e % 2 (se3_math.h, knot_elem): the
+  // loads of wavefront P are then a wave-uniform knot pointer plus a 32-bit lane offset, no address arithmetic per knot
+  static __device__ __forceinline__ I iuni(int e) { return (e >> 1) * 128 + (e & 1); }
+  template <class F> static __device__ __forceinline__ I iconst(F f) { return iuni(f((int)(threadIdx.x & 63))); }
+  // value of lane L of the caller's row of 16 (v_mov_b64_dpp row_newbcast)
+  template <int L> static __device__ __forceinline__ V bc(V x) { return __builtin_amdgcn_mov_dpp(x, 0x150 + L, 0xf, 0xf, false); }
+  // acc + x[lane L of the row] * m
+  template <int L> static __device__ __forceinline__ V fm(V acc, V src, V m) {
+#ifdef QILQR_R16_ASM_FMAC
+    // one v_fmac_f64_dpp; s_nop 1 = the two wait states a DPP read needs behind a VALU write of its source (the
+    // compiler does not see the DPP read inside the asm)
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(L));
+    return acc;
+#else
+    return __builtin_fma(bc<L>(src), m, acc);
+#endif
+  }
+  // permutation inside every quad of four lanes (two v_mov_b32_dpp quad_perm: fp64 DPP has row_newbcast only)
+  template <int CTRL> static __device__ __forceinline__ V qperm(V x) {
+    const long long v = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(v >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+  }
+  static __device__ __forceinline__ V rot1(V x) { return qperm<0xC9>(x); }  // lane j <- j + 1 (mod 3), j = 3 stays
+  static __device__ __forceinline__ V fma(V a, V b, V c) { return __builtin_fma(a, b, c); }
+  static __device__ __forceinline__ bool any(M m) { return __ballot(m) != 0ull; }
+  static __device__ __forceinline__ V sel(M m, V a, V b) { return m ? a : b; }
+  static __device__ __forceinline__ M gt(V a, V b) { return a > b; }
+  static __device__ __forceinline__ M lt(V a, V b) { return a < b; }
+  static __device__ __forceinline__ M land(M a, M b) { return a && b; }
+  static __device__ __forceinline__ M lor(M a, M b) { return a || b; }
+  static __device__ __forceinline__ M lnot(M a) { return !a; }
+  static __device__ __forceinline__ V abs_(V a) { return fabs(a); }
+  static __device__ __forceinline__ V sqrt_(V a) { return sqrt(a); }
+  static __device__ __forceinline__ V sin_(V a) { return sin(a); }
+  static __device__ __forceinline__ V cos_(V a) { return cos(a); }
+  static __device__ __forceinline__ V atan2_(V a, V b) { return atan2(a, b); }
+};
+
+constexpr int R16_RING = 4;
+constexpr int R16_SPIN_MAX = 1 << 22;
+template <typename S>
+__global__ __launch_bounds__(128) void k_rollout16(ModelConsts<double> c, BatchState st, int B, int n, int need_flag) {
+  using namespace r16;
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: R, 1: P
+  const int row = lane >> 4;
+  const int b = blockIdx.x * 4 + row;
+  const bool live = (b < B) && (!need_flag || (st.flags[b < B ? b : 0] & need_flag));
+  const unsigned long long livemask = __ballot(live);
+  if (livemask == 0ull) return;  // identical in both waves: block-uniform
+  const int bs = live ? b : blockIdx.x * 4 + ((__ffsll((long long)livemask) - 1) >> 4);  // dead rows alias the first live one
+  const int cur = st.cur[bs];
+  const S *traj = (const S *)st.traj[cur] + knot_base<true>(bs, n, 18);
+  const S *gains = (const S *)st.gains + knot_base<true>(bs, n, 52);
+  S *out = (S *)st.traj[cur ^ 1] + knot_base<true>(bs, n, 18);
+
+  __shared__ double ops[R16_RING][NOPS][64];
+  __shared__ int flags[2];  // [0]: knots produced by P, [1]: knots consumed by R
+  if (threadIdx.x < 2) flags[threadIdx.x] = 0;
+  __syncthreads();
+  // The LDS executes the operations of one wavefront in the order they were issued, so a flag written after the data
+  // (or after the reads of a slot) is seen after them: no s_waitcnt, and no workgroup fence -- a release fence would wait
+  // for the wavefront's outstanding GLOBAL loads and stores too (vmcnt(0)), i.e. for P's prefetch and R's knot stores, on
+  // every knot.  The asm statements only keep the compiler from moving LDS accesses across the flag.
+  auto flag_read = [&](int which) -> int { return __hip_atomic_load(&flags[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  auto flag_wait = [&](int which, int target, int seen) -> bool {
+    if (seen >= target) return true;  // already observed (read ahead, one knot ago)
+    for (int spins = 0; spins < R16_SPIN_MAX; ++spins) {
+      if (flag_read(which) >= target) {
+        asm volatile("" ::: "memory");
+        return true;
+      }
+    }
+    return false;
+  };
+  auto flag_post = [&](int which, int value) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&flags[which], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+
+  if (role == 1) {
+    // ------------------------------------------------------------------ P: operand registers
+    PConsts<DevWave> pc;
+    make_pconsts(pc);
+    const double alpha = st.alpha[bs];
+    // The loads of knot k + 1 are requested before knot k is converted and written (two register sets, loop unrolled
+    // by two: no copies).  A knot is 30 loads per lane: a wave-uniform knot pointer plus the lane's 32-bit offset.
+    // The requests are unconditional (past the end the last knot is requested again): a branch around them makes the
+    // compiler wait for vmcnt(0) at every use, i.e. for the requests it has just issued.
+    S rawA[NRAW], rawB[NRAW], tmA, tmB;
+    auto request = [&](int k, S (&raw)[NRAW], S &tm) {
+      const int kk = k < n ? k : n - 1;
+      const S *tk = traj + (long)kk * (9 * 128), *gk = gains + (long)kk * (26 * 128);
+      tm = tk[0];  // time_s: the oldest request of the knot
+      auto ld = [&](int off) -> S { return tk[off]; };
+      auto lg = [&](int off) -> S { return gk[off]; };
+      p_load<DevWave>(pc, ld, lg, raw);
+    };
+    bool ok = true;
+#ifdef QILQR_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+    auto knot = [&](int k, S (&rc)[NRAW], S &tmc, S (&rn)[NRAW], S &tmn) {
+      request(k + 1, rn, tmn);
+      QSTAMP(0);  // P: requests
+      double op[NOPS];
+      p_compute<DevWave>(pc, rc, alpha, op);
+      QKEEP(op[0]); QKEEP(op[22]); QKEEP(op[10]);
+      QSTAMP(1);  // P: wait for the loads, operand registers
+      if (k >= R16_RING && !flag_wait(1, k - R16_RING + 1, -1)) ok = false;  // slot k % R16_RING is free once R has read knot k - R16_RING
+      QSTAMP(2);  // P: wait for a free slot
+#pragma unroll
+      for (int r = 0; r < NOPS; ++r) ops[k % R16_RING][r][lane] = op[r];
+      flag_post(0, k + 1);
+      if (live && (lane & 15) == 0) out[knot_elem<true>(k, 0, 18)] = tmc;  // time_s passes through (ilqr.hh:164)
+      QSTAMP(3);  // P: LDS writes, flag, time store
+    };
+    request(0, rawA, tmA);
+    for (int k = 0; k < n && ok; k += 2) {
+      knot(k, rawA, tmA, rawB, tmB);
+      if (k + 1 < n && ok) knot(k + 1, rawB, tmB, rawA, tmA);
+    }
+#ifdef QILQR_STAMPS
+    if (lane == 0 && st.stamps)
+      for (int k = 0; k < 8; ++k) st.stamps[((long)blockIdx.x * 2 + 1) * 8 + k] = stamp_sum[k];
+#endif
+    return;
+  }
+
+  // -------------------------------------------------------------------- R: rollout
+  RConsts<DevWave> kc;
+  make_rconsts(c, kc);
+  RState<DevWave> s;
+  {
+    auto ld0 = [&](int e) -> double { return e >= 0 ? (double)traj[knot_elem<true>(0, e, 18)] : 0.0; };
+    s.TT = ld0(tt_elem(lane));
+    s.QQ = ld0(qq_elem(lane));
+    s.VL = ld0(vl_elem(lane));
+    s.VW = ld0(vw_elem(lane));
+  }
+  // the two masked stores of a knot: a wave-uniform knot pointer plus the lane's offset in the tiled layout
+  const int e1 = st1_elem(lane), e2 = st2_elem(lane);
+  const bool w1 = live && e1 >= 0, w2 = live && e2 >= 0;
+  const int o1 = DevWave::iuni(e1 >= 0 ? e1 : 0), o2 = DevWave::iuni(e2 >= 0 ? e2 : 0);
+#ifdef QILQR_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+  int seen = -1;  // P's progress as last read
+  for (int i = 0; i < n; ++i) {
+    if (!flag_wait(0, i + 1, seen)) return;
+    QSTAMP(0);  // R: wait for P's slot
+    double op[NOPS];
+#pragma unroll
+    for (int r = 0; r < NOPS; ++r) op[r] = ops[i % R16_RING][r][lane];
+    seen = flag_read(0);  // for the next knot: P is normally several knots ahead, and this read's latency is covered by the knot
+    QSTAMP(1);  // R: operand reads issued
+    double st1, st2;
+    r_knot<DevWave>(kc, s, op, i + 1 < n, st1, st2);
+    flag_post(1, i + 1);  // the slot's values have been read: P may refill it
+    QKEEP(st1); QKEEP(s.QQ); QKEEP(s.TT); QKEEP(s.VL);
+    QSTAMP(2);  // R: the knot
+    S *ok_ = out + (long)i * (9 * 128);
+    if (w1) ok_[o1] = (S)st1;
+    if (w2) ok_[o2] = (S)st2;
+    QSTAMP(3);  // R: stores
+  }
+#ifdef QILQR_STAMPS
+  if (lane == 0 && st.stamps)
+    for (int k = 0; k < 8; ++k) st.stamps[((long)blockIdx.x * 2 + 0) * 8 + k] = stamp_sum[k];
 #endif
 }
 

@@ -1,0 +1,434 @@
+// rollout16.h -- the closed-loop forward simulation (ILQR::forward_sim, ilqr.hh:149-172) with SIXTEEN LANES PER
+// TRAJECTORY: one wavefront rolls out four trajectories, one per row of 16 lanes.
+//
+// Why.  With a lane per trajectory (k_rollout3) a knot is ~600 fp64 instructions spread over two cooperating
+// wavefronts, and a lone wavefront issues one fp64 instruction per ~6.8 cycles whatever the exec mask: ~2000
+// cycles per knot on 16 of the chip's 256 CUs at B = 1024.  Spending the idle lanes on the INSIDE of a trajectory
+// cuts the instruction count of the knot to about a third on ONE wavefront:
+//   * every product with a matrix that does not depend on the state -- the nominal rotation R_n^T, the left
+//     multiplication by conj(q_n), the 4 x 12 feedback gain, I, dt I^-1, dt I^-1 arms -- is one
+//     v_fmac_f64_dpp row_newbcast per INPUT component (the lane holds its row of the matrix, the broadcast brings
+//     the component): 4 x 12 gains = 12 instructions instead of 52, a nominal quaternion product 4 instead of 28;
+//   * the seven polynomials of the knot (cos, sinc, two Jacobian coefficients of Exp; the two halves of asin for
+//     Log) are evaluated side by side in different lanes with per-lane coefficient registers (one Estrin pass);
+//   * cross products are done four at a time: three-vectors sit in lanes 0..2 of a quad, a x b = a' b'' - a'' b'
+//     with ' a rotation inside every quad (two v_mov_b32_dpp quad_perm per 64-bit value -- fp64 DPP itself has
+//     only row_newbcast on gfx950), so th x td (Log), theta_e x rho_e (Exp) and omega x I omega (gyroscopic term)
+//     share one set of rotations;
+//   * elementwise vector operations are one instruction instead of three to six.
+// Everything that depends only on the nominal trajectory and the gains is prepared by a second wavefront P, one
+// knot ring ahead, as 23 "operand registers" per knot in LDS; the rollout wavefront R reads its lane's 23 values.
+//
+// The arithmetic is the reference's (se3_math.h: se3_rminus_fast / se3_rplus_fast / control_law /
+// body_acceleration_fast) with other summation orders: results agree with the oracle to rounding (1e-12).
+//
+// The code is written once against a "wave" policy W (value-per-lane type V, predicate M, cross-lane operations):
+// DevWave maps it to registers and DPP on gfx950; tests/host_harness.cpp maps it to arrays of 64 lanes so that the
+// CPU suite checks the lane maps, the operand preparation and the arithmetic against the oracle without a GPU.
+//
+// Lane map of a row (16 lanes = quads Q0..Q3, j = lane & 3):
+//   three-vectors live in lanes j = 0..2 of a quad; the quaternion (x, y, z, w) in j = 0..3 of every quad
+//   TT  translation in Q1          QQ  quaternion in every quad        VL, VW  linear / angular velocity in every quad
+//   Log works in Q0 (td, theta, rho), Exp in Q1 (theta_e, rho_e, p), the gyroscopic term in Q2, the control in Q3.
+#pragma once
+#include "se3_math.h"
+
+namespace qilqr {
+namespace r16 {
+
+// ---------------------------------------------------------------------------------------------------------------
+// operand registers prepared by P for one knot (value per lane; rows of matrices live in the lanes that consume them)
+enum {
+  OP_RT = 0,    // 3: column c of R_n^T as rows in Q0: lane (Q0, j) holds R_n[c][j]
+  OP_TN = 3,    // nominal translation in Q1 (j < 3)
+  OP_LQ = 4,    // 4: column c of the left-multiplication matrix of conj(q_n), rows (x, y, z, w) in Q0
+  OP_K = 8,     // 12: column c of the feedback gain K (4 x 12), rows in Q3
+  OP_U0 = 20,   // u_nom + alpha k in Q3
+  OP_VNL = 21,  // nominal linear velocity (j < 3 of every quad)
+  OP_VNW = 22,  // nominal angular velocity
+  NOPS = 23
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// lane constants of the rollout wavefront (built once per launch)
+template <class W>
+struct RConsts {
+  typedef typename W::V V;
+  typedef typename W::M M;
+  double dt;
+  V SA, SB1;           // packing scales: A1 = th + SA VW, B1 = TI + SB1 VL
+  V IC[3];             // column c of the inertia, rows in Q2
+  V NI[3];             // column c of -dt I^-1, rows in every quad
+  V GLz;               // dt / m at j = 2
+  V GW[4];             // column a of dt I^-1 arms, rows in every quad
+  V GRAVC, S1, S2;     // gravity: -g dt e_z, and the signed scales of the two quaternion permutations
+  V MH0, MQ0, MQ1, MQ1_3, MW, M03;
+  V MQ0_3, MQ2_3;      // store assembly
+  V PC[8];             // per-lane polynomial coefficients (lane-in-row 0..5)
+  M L0, L1, L2, L3;    // lane-in-row == 0..3 (patching the Exp coefficients on the closed-form path)
+};
+
+template <class W>
+QILQR_HD void make_rconsts(const ModelConsts<double> &c, RConsts<W> &k) {
+  const double dt = c.dt;
+  k.dt = dt;
+  auto q = [](int l) { return (l >> 2) & 3; };
+  auto j = [](int l) { return l & 3; };
+  k.SA = W::vconst([&](int l) { return (j(l) < 3) ? (q(l) == 1 ? dt : (q(l) == 2 ? 1.0 : 0.0)) : 0.0; });
+  k.SB1 = W::vconst([&](int l) { return (j(l) < 3 && q(l) == 1) ? dt : 0.0; });
+  for (int cc = 0; cc < 3; ++cc) {
+    k.IC[cc] = W::vconst([&](int l) { return (j(l) < 3 && q(l) == 2) ? c.inertia[3 * j(l) + cc] : 0.0; });
+    k.NI[cc] = W::vconst([&](int l) { return (j(l) < 3) ? -dt * c.inertia_inv[3 * j(l) + cc] : 0.0; });
+  }
+  k.GLz = W::vconst([&](int l) { return j(l) == 2 ? c.Bu[8 * 4] : 0.0; });  // row 8 of J_u: dt / m (the same for every rotor)
+  for (int a = 0; a < 4; ++a) k.GW[a] = W::vconst([&](int l) { return (j(l) < 3) ? c.Bu[(9 + j(l)) * 4 + a] : 0.0; });
+  k.GRAVC = W::vconst([&](int l) { return j(l) == 2 ? -c.g * dt : 0.0; });
+  // R^T e_z = (2(xz - yw), 2(yz + xw), 1 - 2(x^2 + y^2)) = x (2z, 2w, -2x) + y (-2w, 2z, -2y) + e_z
+  k.S1 = W::vconst([&](int l) { return -c.g * dt * (j(l) == 0 ? 2.0 : (j(l) == 1 ? 2.0 : (j(l) == 2 ? -2.0 : 0.0))); });
+  k.S2 = W::vconst([&](int l) { return -c.g * dt * (j(l) == 0 ? -2.0 : (j(l) == 1 ? 2.0 : (j(l) == 2 ? -2.0 : 0.0))); });
+  k.MH0 = W::vconst([&](int l) { return q(l) == 0 ? -0.5 : 0.0; });
+  k.MQ0 = W::vconst([&](int l) { return q(l) == 0 ? 1.0 : 0.0; });
+  k.MQ1 = W::vconst([&](int l) { return q(l) == 1 ? 1.0 : 0.0; });
+  k.MQ1_3 = W::vconst([&](int l) { return (q(l) == 1 && j(l) < 3) ? 1.0 : 0.0; });
+  k.MW = W::vconst([&](int l) { return j(l) == 3 ? 1.0 : 0.0; });
+  k.M03 = W::vconst([&](int l) { return (l & 15) < 4 ? 1.0 : 0.0; });
+  k.MQ0_3 = W::vconst([&](int l) { return (q(l) == 0 && j(l) < 3) ? 1.0 : 0.0; });
+  k.MQ2_3 = W::vconst([&](int l) { return (q(l) == 2 && j(l) < 3) ? 1.0 : 0.0; });
+  for (int e = 0; e < 8; ++e)
+    k.PC[e] = W::vconst([&](int l) {
+      switch (l & 15) {
+        case 0: return Series<double>::cos_half[e];
+        case 1: return Series<double>::sin_half_over[e];
+        case 2: return Series<double>::jac_a[e];
+        case 3: return Series<double>::jac_b[e];
+        case 4: return 2.0 * Series<double>::asin_lo[e];   // Log's coefficient is 2 asin(s) / s
+        case 5: return 2.0 * Series<double>::asin_hi[e];
+        default: return 0.0;
+      }
+    });
+  k.L0 = W::mconst([](int l) { return (l & 15) == 0; });
+  k.L1 = W::mconst([](int l) { return (l & 15) == 1; });
+  k.L2 = W::mconst([](int l) { return (l & 15) == 2; });
+  k.L3 = W::mconst([](int l) { return (l & 15) == 3; });
+}
+
+// state of the four trajectories of a wavefront
+template <class W>
+struct RState {
+  typename W::V TT, QQ, VL, VW;
+};
+
+// a x b for three-vectors in lanes j = 0..2 of every quad, given the rotations a' (j <- j + 1) and a'' (j <- j + 2) of a;
+// lane j = 3 of every quad comes out as a[3] b[3] - a[3] b[3] = 0
+template <class W>
+QILQR_HD typename W::V cross_rot(typename W::V ap, typename W::V app, typename W::V b) {
+  const typename W::V bp = W::rot1(b), bpp = W::rot1(bp);
+  return W::fma(ap, bpp, -(app * bp));
+}
+
+// One knot of the rollout for the four trajectories of the wavefront.
+//   in:  state s (knot i), operand registers op[NOPS] of knot i
+//   out: u (control of knot i, Q3 lanes), st1 / st2 (the knot's state as it is stored: see r_store_elems), and, when
+//        `advance`, the state of knot i + 1 in s
+template <class W>
+QILQR_HD void r_knot(const RConsts<W> &k, RState<W> &s, const typename W::V *op, bool advance, typename W::V &st1,
+                     typename W::V &st2) {
+  typedef typename W::V V;
+  typedef typename W::M M;
+  const V TT = s.TT, QQ = s.QQ, VL = s.VL, VW = s.VW;
+  const double eps = Eps<double>::manif;
+
+  // ---- Log, rotation part: qd = conj(q_n) q in Q0 (x, y, z, w)
+  V qd = W::template bc<0>(QQ) * op[OP_LQ + 0];
+  qd = W::template fm<1>(qd, QQ, op[OP_LQ + 1]);
+  qd = W::template fm<2>(qd, QQ, op[OP_LQ + 2]);
+  qd = W::template fm<3>(qd, QQ, op[OP_LQ + 3]);
+  V sq = qd * qd;
+  V s2 = W::template bc<0>(sq) + W::template bc<1>(sq);
+  s2 = s2 + W::template bc<2>(sq);
+  {
+    const V nn = s2 + W::template bc<3>(sq);
+    const M off = W::gt(W::abs_(nn - 1.0), eps);  // manif's compose renormalisation
+    if (W::any(off)) {
+      const V sc = W::sel(off, 2.0 / (1.0 + nn), V(1.0));
+      qd = qd * sc;
+      sq = qd * qd;
+      s2 = W::template bc<0>(sq) + W::template bc<1>(sq);
+      s2 = s2 + W::template bc<2>(sq);
+    }
+  }
+  const V wq = W::template bc<3>(qd);
+
+  // ---- Exp scalars: theta_e = dt omega (the pose integrates with the OLD velocity)
+  const V THE = k.dt * VW;
+  const V sqe = THE * THE;
+  V th2e = W::template bc<0>(sqe) + W::template bc<1>(sqe);
+  th2e = th2e + W::template bc<2>(sqe);
+
+  // ---- the six polynomials, side by side: lanes 0..3 of a row at theta_e^2 (cos(th/2), sin(th/2)/th, (1 - cos th)/th^2,
+  // (th - sin th)/th^3), lanes 4, 5 at s2 (the two halves of 2 asin(s)/s)
+  V P1;
+  {
+    const V x = W::fma(k.M03, th2e - s2, s2);
+    const V x2 = x * x, x4 = x2 * x2;
+    const V p01 = W::fma(k.PC[1], x, k.PC[0]), p23 = W::fma(k.PC[3], x, k.PC[2]), p45 = W::fma(k.PC[5], x, k.PC[4]),
+            p67 = W::fma(k.PC[7], x, k.PC[6]);
+    P1 = W::fma(W::fma(p67, x2, p45), x4, W::fma(p23, x2, p01));
+  }
+  V coeff;
+  {
+    const V y2 = s2 * s2, y4 = y2 * y2, y8 = y4 * y4;
+    coeff = W::template fm<5>(W::template bc<4>(P1), P1, y8);
+    // manif's branches of Log (so3_log): small angle, and the atan2 form outside the series' range / for w <= 0
+    const M small = W::lnot(W::gt(s2, eps));
+    const M series = W::land(W::gt(wq, 0.0), W::lnot(W::gt(s2, Series<double>::LOG_MAX)));
+    const M closed = W::land(W::lnot(small), W::lnot(series));
+    if (W::any(closed)) {
+      const V ss = W::sqrt_(W::sel(closed, s2, V(1.0)));
+      const M neg = W::lt(wq, 0.0);
+      const V at = W::atan2_(W::sel(neg, -ss, ss), W::sel(neg, -wq, wq));
+      coeff = W::sel(closed, 2.0 * at / ss, coeff);
+    }
+    coeff = W::sel(small, V(2.0), coeff);
+  }
+  {
+    // manif's branches of Exp: small angle, closed forms beyond the series' range; patch lanes 0..3 of P1.  The closed
+    // forms (sqrt, two sin, two cos) run only when some row is beyond the series' range, the small-angle constants only
+    // when some row is at rest: a converging solve takes neither branch.
+    const M small = W::lnot(W::gt(th2e, eps));
+    const M closed = W::gt(th2e, Series<double>::EXP_MAX);
+    if (W::any(closed)) {
+      const V x = W::sel(closed, th2e, V(1.0));
+      const V theta = W::sqrt_(x), ha = 0.5 * theta;
+      const V sn = W::sin_(ha), cs = W::cos_(ha), st = W::sin_(theta), ct = W::cos_(theta);
+      P1 = W::sel(W::land(closed, k.L0), cs, P1);
+      P1 = W::sel(W::land(closed, k.L1), sn / theta, P1);
+      P1 = W::sel(W::land(closed, k.L2), (1.0 - ct) / x, P1);
+      P1 = W::sel(W::land(closed, k.L3), (theta - st) / (x * theta), P1);
+    }
+    if (W::any(small)) {
+      P1 = W::sel(W::land(small, k.L0), V(1.0), P1);
+      P1 = W::sel(W::land(small, W::lor(k.L1, k.L2)), V(0.5), P1);
+      P1 = W::sel(W::land(small, k.L3), V(0.0), P1);
+    }
+  }
+  const V th = coeff * qd;  // Q0: theta (lane j = 3 holds coeff w: finite, never used)
+  const V th2 = (coeff * coeff) * s2;
+  V cJ;  // 1/th^2 - (1 + cos th)/(2 th sin th)
+  {
+    const double *jc = Series<double>::jinv_c;
+    const V x2 = th2 * th2, x4 = x2 * x2;
+    const V p01 = W::fma(V(jc[1]), th2, V(jc[0])), p23 = W::fma(V(jc[3]), th2, V(jc[2])), p45 = W::fma(V(jc[5]), th2, V(jc[4])),
+            p67 = W::fma(V(jc[7]), th2, V(jc[6]));
+    cJ = W::fma(W::fma(p67, x2, p45), x4, W::fma(p23, x2, p01));
+  }
+  {
+    const M small = W::lnot(W::gt(th2, eps));  // a rollout that has converged onto its nominal trajectory is here at every knot
+    const M closed = W::gt(th2, Series<double>::JINV_MAX);
+    if (W::any(closed)) {
+      const V x = W::sel(closed, th2, V(1.0));
+      const V theta = W::sqrt_(x);
+      cJ = W::sel(closed, 1.0 / x - (1.0 + W::cos_(theta)) / (2.0 * theta * W::sin_(theta)), cJ);
+    }
+    cJ = W::sel(small, V(0.0), cJ);
+  }
+
+  // ---- td = R_n^T (t - t_n) in Q0 and I omega in Q2, in one accumulator
+  const V dT = TT - op[OP_TN];
+  V TI = W::template bc<4>(dT) * op[OP_RT + 0];
+  TI = W::template fm<5>(TI, dT, op[OP_RT + 1]);
+  TI = W::template fm<6>(TI, dT, op[OP_RT + 2]);
+  TI = W::template fm<0>(TI, VW, k.IC[0]);
+  TI = W::template fm<1>(TI, VW, k.IC[1]);
+  TI = W::template fm<2>(TI, VW, k.IC[2]);
+
+  // ---- cross products, four quads at a time
+  const V A1 = W::fma(k.SA, VW, th);    // [theta | theta_e | omega | 0]
+  const V B1 = W::fma(k.SB1, VL, TI);   // [td    | rho_e   | I omega | 0]
+  const V A1p = W::rot1(A1), A1pp = W::rot1(A1p);
+  const V C1 = cross_rot<W>(A1p, A1pp, B1);  // [theta x td | theta_e x rho_e | omega x I omega | 0]
+  const V C2 = cross_rot<W>(A1p, A1pp, C1);  // [theta x (theta x td) | theta_e x (theta_e x rho_e) | . | 0]
+  // rho = td - theta x td / 2 + c theta x (theta x td) in Q0;  p = rho_e + a w1 + b w2 in Q1
+  const V CA = W::fma(k.MQ1, W::template bc<2>(P1), k.MH0);
+  const V CB = W::template fm<3>(k.MQ0 * cJ, P1, k.MQ1);
+  const V RP = W::fma(CB, C2, W::fma(CA, C1, B1));
+
+  // ---- control (ilqr.hh:158-161): u = (u_nom + alpha k) + K [rho ; theta ; v - v_nom], rows in Q3
+  const V dvl = VL - op[OP_VNL], dvw = VW - op[OP_VNW];
+  V u0 = W::template fm<0>(op[OP_U0], RP, op[OP_K + 0]);
+  V u1 = W::template bc<0>(th) * op[OP_K + 3];
+  V u2 = W::template bc<0>(dvl) * op[OP_K + 6];
+  V u3 = W::template bc<0>(dvw) * op[OP_K + 9];
+  u0 = W::template fm<1>(u0, RP, op[OP_K + 1]);
+  u1 = W::template fm<1>(u1, th, op[OP_K + 4]);
+  u2 = W::template fm<1>(u2, dvl, op[OP_K + 7]);
+  u3 = W::template fm<1>(u3, dvw, op[OP_K + 10]);
+  u0 = W::template fm<2>(u0, RP, op[OP_K + 2]);
+  u1 = W::template fm<2>(u1, th, op[OP_K + 5]);
+  u2 = W::template fm<2>(u2, dvl, op[OP_K + 8]);
+  u3 = W::template fm<2>(u3, dvw, op[OP_K + 11]);
+  const V UU = (u0 + u1) + (u2 + u3);
+
+  // ---- what is stored for knot i: [v_lin | t | omega | u] and the quaternion
+  st1 = W::fma(k.MQ2_3, VW, W::fma(k.MQ0_3, VL, TT)) + UU;
+  st2 = QQ;
+  if (!advance) return;  // the reference's step after the last knot is computed and discarded (ilqr.hh:168)
+
+  // ---- velocity: v + dt a(q, v, u) (quadrotor_model.cc:65-78)
+  V aL = VL + k.GRAVC;
+  aL = W::template fm<0>(aL, QQ, k.S1 * W::template qperm<0xCE>(QQ));  // (z, w, x, .)
+  aL = W::template fm<1>(aL, QQ, k.S2 * W::template qperm<0xDB>(QQ));  // (w, z, y, .)
+  V aW = VW;
+  {
+    V l1 = W::template bc<12>(UU) * k.GLz;
+    V w1 = W::template bc<12>(UU) * k.GW[0];
+    l1 = W::template fm<13>(l1, UU, k.GLz);
+    w1 = W::template fm<13>(w1, UU, k.GW[1]);
+    aL = W::template fm<14>(aL, UU, k.GLz);
+    aW = W::template fm<14>(aW, UU, k.GW[2]);
+    l1 = W::template fm<15>(l1, UU, k.GLz);
+    w1 = W::template fm<15>(w1, UU, k.GW[3]);
+    aL = aL + l1;
+    aW = aW + w1;
+  }
+  {
+    V g1 = W::template bc<8>(C1) * k.NI[0];  // -dt I^-1 (omega x I omega)
+    g1 = W::template fm<9>(g1, C1, k.NI[1]);
+    aW = W::template fm<10>(aW, C1, k.NI[2]);
+    aW = aW + g1;
+  }
+
+  // ---- pose: T <- T Exp(dt v):  t += R(q) p,  q <- q (sh theta_e, ch)
+  const V QQp = W::rot1(QQ), QQpp = W::rot1(QQp);
+  const V C3 = cross_rot<W>(QQp, QQpp, RP);   // Q1: u x p
+  const V C4 = cross_rot<W>(QQp, QQpp, C3);   // Q1: u x (u x p)
+  const V Wq = W::template bc<3>(QQ);
+  const V Rp = W::fma(V(2.0), C4, W::fma(Wq + Wq, C3, RP));
+  const V TTn = W::fma(k.MQ1_3, Rp, TT);
+  const V ZX = cross_rot<W>(QQp, QQpp, THE);  // u x theta_e in every quad
+  const V z = W::fma(Wq, THE, ZX);
+  const V CH = W::template bc<0>(P1), SH = W::template bc<1>(P1);
+  const V ov = W::fma(SH, z, CH * QQ);
+  const V prod = QQ * THE;
+  V dq = W::template bc<0>(prod) + W::template bc<1>(prod);
+  dq = dq + W::template bc<2>(prod);
+  V QQn = W::fma(-(k.MW * SH), dq, ov);
+  {
+    const V sqq = QQn * QQn;
+    V nq = (W::template bc<0>(sqq) + W::template bc<1>(sqq)) + (W::template bc<2>(sqq) + W::template bc<3>(sqq));
+    const M off = W::gt(W::abs_(nq - 1.0), eps);
+    if (W::any(off)) QQn = QQn * W::sel(off, 2.0 / (1.0 + nq), V(1.0));
+  }
+  s.TT = TTn;
+  s.QQ = QQn;
+  s.VL = aL;
+  s.VW = aW;
+}
+
+// Which element of the 18-double knot a lane of st1 / st2 holds (-1: none).  st1 = [v_lin | t | omega | u], st2 = the
+// quaternion in Q0 (x, y, z, w -> elements 5, 6, 7, 4).
+QILQR_HD int st1_elem(int l) {
+  const int q = (l >> 2) & 3, j = l & 3;
+  if (q == 3) return 14 + j;
+  if (j == 3) return -1;
+  return q == 0 ? 8 + j : (q == 1 ? 1 + j : 11 + j);
+}
+QILQR_HD int st2_elem(int l) {
+  const int q = (l >> 2) & 3, j = l & 3;
+  if (q != 0) return -1;
+  return j == 3 ? 4 : 5 + j;
+}
+// the state of knot 0: which element a lane loads into TT / QQ / VL / VW (-1: zero)
+QILQR_HD int tt_elem(int l) { return (((l >> 2) & 3) == 1 && (l & 3) < 3) ? 1 + (l & 3) : -1; }
+QILQR_HD int qq_elem(int l) { return (l & 3) == 3 ? 4 : 5 + (l & 3); }
+QILQR_HD int vl_elem(int l) { return (l & 3) < 3 ? 8 + (l & 3) : -1; }
+QILQR_HD int vw_elem(int l) { return (l & 3) < 3 ? 11 + (l & 3) : -1; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Operand preparation (wavefront P).  `ld(e)` returns element e of the nominal knot (18 doubles: time, t, q(w,x,y,z),
+// v, u) of this lane's trajectory as a value per lane -- e may differ from lane to lane; `lg(e)` the same for the 52
+// gains [k(4) | K column-major].  `alpha` is the trajectory's step size (value per lane, uniform in a row).
+template <class W>
+struct PConsts {
+  typedef typename W::V V;
+  typename W::I e_uj, e_h[3], e_lq[4], e_tn, e_vl, e_vw, e_un, e_k, e_K[12];  // element indices per lane
+  V s_h[3], s_lq[4], d_c[3], mQ0_3, mQ0, mQ1_3, mQ3, m3;                      // signs / masks per lane
+};
+template <class W>
+QILQR_HD void make_pconsts(PConsts<W> &p) {
+  auto q = [](int l) { return (l >> 2) & 3; };
+  auto j = [](int l) { return l & 3; };
+  // elements of the knot: 1..3 t, 4 qw, 5..7 q(x, y, z), 8..10 v_lin, 11..13 omega, 14..17 u
+  p.e_uj = W::iconst([&](int l) { return 5 + (j(l) < 3 ? j(l) : 0); });
+  // row c of hat(u): H[c][j] = sign * u_idx:   row 0 = (0, -z, y), row 1 = (z, 0, -x), row 2 = (-y, x, 0)
+  const int hidx[3][3] = {{0, 2, 1}, {2, 0, 0}, {1, 0, 0}};
+  const double hsgn[3][3] = {{0, -1, 1}, {1, 0, -1}, {-1, 1, 0}};
+  for (int c = 0; c < 3; ++c) {
+    p.e_h[c] = W::iconst([&](int l) { return 5 + hidx[c][j(l) < 3 ? j(l) : 0]; });
+    p.s_h[c] = W::vconst([&](int l) { return (q(l) == 0 && j(l) < 3) ? hsgn[c][j(l)] : 0.0; });
+    p.d_c[c] = W::vconst([&](int l) { return (q(l) == 0 && j(l) == c) ? 1.0 : 0.0; });
+  }
+  // left multiplication by a = conj(q_n) = (-x, -y, -z, w): rows (o_x, o_y, o_z, o_w), columns (b_x, b_y, b_z, b_w)
+  //   o_x: ( aw, -az,  ay, ax)   o_y: ( az, aw, -ax, ay)   o_z: (-ay, ax, aw, az)   o_w: (-ax, -ay, -az, aw)
+  // in terms of q_n (x, y, z, w) = elements (5, 6, 7, 4): a_v = -q_v
+  const int lidx[4][4] = {{4, 7, 6, 5}, {7, 4, 5, 6}, {6, 5, 4, 7}, {5, 6, 7, 4}};      // [row][col] -> element
+  const double lsgn[4][4] = {{1, 1, -1, -1}, {-1, 1, 1, -1}, {1, -1, 1, -1}, {1, 1, 1, 1}};
+  for (int c = 0; c < 4; ++c) {
+    p.e_lq[c] = W::iconst([&](int l) { return lidx[j(l)][c]; });
+    p.s_lq[c] = W::vconst([&](int l) { return q(l) == 0 ? lsgn[j(l)][c] : 0.0; });
+  }
+  p.e_tn = W::iconst([&](int l) { return 1 + (j(l) < 3 ? j(l) : 0); });
+  p.e_vl = W::iconst([&](int l) { return 8 + (j(l) < 3 ? j(l) : 0); });
+  p.e_vw = W::iconst([&](int l) { return 11 + (j(l) < 3 ? j(l) : 0); });
+  p.e_un = W::iconst([&](int l) { return 14 + j(l); });
+  p.e_k = W::iconst([&](int l) { return j(l); });
+  for (int c = 0; c < 12; ++c) p.e_K[c] = W::iconst([&](int l) { return 4 + 4 * c + j(l); });
+  p.mQ0_3 = W::vconst([&](int l) { return (q(l) == 0 && j(l) < 3) ? 1.0 : 0.0; });
+  p.mQ0 = W::vconst([&](int l) { return q(l) == 0 ? 1.0 : 0.0; });
+  p.mQ1_3 = W::vconst([&](int l) { return (q(l) == 1 && j(l) < 3) ? 1.0 : 0.0; });
+  p.mQ3 = W::vconst([&](int l) { return q(l) == 3 ? 1.0 : 0.0; });
+  p.m3 = W::vconst([&](int l) { return j(l) < 3 ? 1.0 : 0.0; });
+}
+
+// raw values a lane of P loads for one knot (its own element of each group), in the storage type of the loader
+enum { RAW_X = 0, RAW_Y, RAW_Z, RAW_W, RAW_UJ, RAW_H = 5, RAW_TN = 8, RAW_LQ = 9, RAW_K = 13, RAW_KFF = 25, RAW_UN, RAW_VL, RAW_VW, NRAW };
+// phase 1: request the loads (nothing here uses a loaded value: on the device the requests of knot k + 1 are in flight
+// while knot k is being converted and written)
+template <class W, class RAWT, class LD, class LG>
+QILQR_HD void p_load(const PConsts<W> &p, LD ld, LG lg, RAWT *raw) {
+  raw[RAW_X] = ld(W::iuni(5)); raw[RAW_Y] = ld(W::iuni(6)); raw[RAW_Z] = ld(W::iuni(7)); raw[RAW_W] = ld(W::iuni(4));
+  raw[RAW_UJ] = ld(p.e_uj);
+  for (int c = 0; c < 3; ++c) raw[RAW_H + c] = ld(p.e_h[c]);
+  raw[RAW_TN] = ld(p.e_tn);
+  for (int c = 0; c < 4; ++c) raw[RAW_LQ + c] = ld(p.e_lq[c]);
+  for (int c = 0; c < 12; ++c) raw[RAW_K + c] = lg(p.e_K[c]);
+  raw[RAW_KFF] = lg(p.e_k);
+  raw[RAW_UN] = ld(p.e_un);
+  raw[RAW_VL] = ld(p.e_vl);
+  raw[RAW_VW] = ld(p.e_vw);
+}
+// phase 2: the operand registers from the raw values
+template <class W, class RAWT>
+QILQR_HD void p_compute(const PConsts<W> &p, const RAWT *raw, typename W::V alpha, typename W::V *op) {
+  typedef typename W::V V;
+  // nominal rotation R_n = I + 2 w hat(u) + 2 hat(u)^2, row c as a lane vector over j:
+  //   R_n[c][j] = 2 u_c u_j + 2 w hat(u)[c][j] + delta_cj (1 - 2 |u|^2)
+  const V x = V(raw[RAW_X]), y = V(raw[RAW_Y]), z = V(raw[RAW_Z]), w = V(raw[RAW_W]);
+  const V uj = V(raw[RAW_UJ]) * p.mQ0_3;
+  const V dd = 1.0 - 2.0 * ((x * x + y * y) + z * z);
+  const V w2 = w + w;
+  const V uc[3] = {x + x, y + y, z + z};
+  for (int c = 0; c < 3; ++c) {
+    const V h = V(raw[RAW_H + c]) * p.s_h[c];
+    op[OP_RT + c] = W::fma(uc[c], uj, W::fma(w2, h, p.d_c[c] * dd));
+  }
+  op[OP_TN] = V(raw[RAW_TN]) * p.mQ1_3;
+  for (int c = 0; c < 4; ++c) op[OP_LQ + c] = V(raw[RAW_LQ + c]) * p.s_lq[c];
+  for (int c = 0; c < 12; ++c) op[OP_K + c] = V(raw[RAW_K + c]) * p.mQ3;
+  op[OP_U0] = W::fma(alpha, V(raw[RAW_KFF]), V(raw[RAW_UN])) * p.mQ3;
+  op[OP_VNL] = V(raw[RAW_VL]) * p.m3;
+  op[OP_VNW] = V(raw[RAW_VW]) * p.m3;
+}
+
+}  // namespace r16
+}  // namespace qilqr

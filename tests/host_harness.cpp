@@ -5,11 +5,13 @@
 // are emulated from their documented lane maps) so that `pytest -m "not gpu"` can check the
 // knot records, the rollout and the operand layout of the backward pass against the oracle
 // before anything runs on a GPU.
+#include <cmath>
 #include <cstring>
 #include <vector>
 
 #include "../quadrotorilqr_amd/csrc/backward_layout.h"
 #include "../quadrotorilqr_amd/csrc/host_model.h"
+#include "../quadrotorilqr_amd/csrc/rollout16.h"
 #include "../quadrotorilqr_amd/csrc/se3_math.h"
 
 using namespace qilqr;
@@ -32,6 +34,51 @@ void mfma_f64_16x16x4(const double a[64], const double b[64], double acc[64][4])
   for (int l = 0; l < 64; ++l)
     for (int r = 0; r < 4; ++r) acc[l][r] = D[4 * r + (l >> 4)][l & 15];
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// A wavefront on the CPU for rollout16.h: 64 lanes per value, the cross-lane operations from their definitions
+// (row_newbcast: lane L of the caller's row of 16; quad_perm: lane 4q + i reads lane 4q + ((ctrl >> 2 i) & 3)).
+struct HV {
+  double v[64];
+  HV() { for (double &x : v) x = 0.0; }
+  HV(double s) { for (double &x : v) x = s; }
+};
+struct HM { bool b[64]; };
+struct HI { int v[64]; };
+#define HV_BIN(op)                                                                                       \
+  inline HV operator op(const HV &a, const HV &b) { HV r; for (int l = 0; l < 64; ++l) r.v[l] = a.v[l] op b.v[l]; return r; } \
+  inline HV operator op(const HV &a, double b) { HV r; for (int l = 0; l < 64; ++l) r.v[l] = a.v[l] op b; return r; }         \
+  inline HV operator op(double a, const HV &b) { HV r; for (int l = 0; l < 64; ++l) r.v[l] = a op b.v[l]; return r; }
+HV_BIN(+) HV_BIN(-) HV_BIN(*) HV_BIN(/)
+inline HV operator-(const HV &a) { HV r; for (int l = 0; l < 64; ++l) r.v[l] = -a.v[l]; return r; }
+struct HostWave {
+  typedef HV V;
+  typedef HM M;
+  typedef HI I;
+  template <class F> static V vconst(F f) { V r; for (int l = 0; l < 64; ++l) r.v[l] = f(l); return r; }
+  template <class F> static M mconst(F f) { M r; for (int l = 0; l < 64; ++l) r.b[l] = f(l); return r; }
+  template <class F> static I iconst(F f) { I r; for (int l = 0; l < 64; ++l) r.v[l] = f(l); return r; }
+  static I iuni(int e) { I r; for (int l = 0; l < 64; ++l) r.v[l] = e; return r; }
+  template <int L> static V bc(const V &x) { V r; for (int l = 0; l < 64; ++l) r.v[l] = x.v[(l & ~15) + L]; return r; }
+  template <int L> static V fm(const V &acc, const V &src, const V &m) { return fma(bc<L>(src), m, acc); }
+  template <int CTRL> static V qperm(const V &x) {
+    V r;
+    for (int l = 0; l < 64; ++l) r.v[l] = x.v[(l & ~3) + ((CTRL >> (2 * (l & 3))) & 3)];
+    return r;
+  }
+  static V rot1(const V &x) { return qperm<0xC9>(x); }
+  static V fma(const V &a, const V &b, const V &c) { V r; for (int l = 0; l < 64; ++l) r.v[l] = std::fma(a.v[l], b.v[l], c.v[l]); return r; }
+  static bool any(const M &m) { for (bool x : m.b) if (x) return true; return false; }
+  static V sel(const M &m, const V &a, const V &b) { V r; for (int l = 0; l < 64; ++l) r.v[l] = m.b[l] ? a.v[l] : b.v[l]; return r; }
+  static M gt(const V &a, const V &b) { M r; for (int l = 0; l < 64; ++l) r.b[l] = a.v[l] > b.v[l]; return r; }
+  static M lt(const V &a, const V &b) { M r; for (int l = 0; l < 64; ++l) r.b[l] = a.v[l] < b.v[l]; return r; }
+  static M land(const M &a, const M &b) { M r; for (int l = 0; l < 64; ++l) r.b[l] = a.b[l] && b.b[l]; return r; }
+  static M lor(const M &a, const M &b) { M r; for (int l = 0; l < 64; ++l) r.b[l] = a.b[l] || b.b[l]; return r; }
+  static M lnot(const M &a) { M r; for (int l = 0; l < 64; ++l) r.b[l] = !a.b[l]; return r; }
+#define HV_FUN(name, fn) static V name(const V &a) { V r; for (int l = 0; l < 64; ++l) r.v[l] = fn(a.v[l]); return r; }
+  HV_FUN(abs_, std::fabs) HV_FUN(sqrt_, std::sqrt) HV_FUN(sin_, std::sin) HV_FUN(cos_, std::cos)
+  static V atan2_(const V &a, const V &b) { V r; for (int l = 0; l < 64; ++l) r.v[l] = std::atan2(a.v[l], b.v[l]); return r; }
+};
 }  // namespace
 
 extern "C" {
@@ -125,6 +172,48 @@ void hh_rollout_tiled(const ModelConsts<double> *c, const double *traj, const do
   for (long b = 0; b < B; ++b)
     for (long i = 0; i < n; ++i)
       for (int e = 0; e < 18; ++e) out[(b * n + i) * 18 + e] = to[knot_base<true>(b, n, 18) + knot_elem<true>(i, e, 18)];
+}
+
+// k_rollout16 on the CPU: one wavefront = four trajectories (plain [4][n][18] / [4][n][52] arrays), the operand
+// registers of every knot prepared by r16::p_make_ops and consumed by r16::r_knot exactly as the two device
+// wavefronts do (the LDS ring and its flags are plumbing, not arithmetic: not re-enacted).  ops_out (optional):
+// the 23 x 64 operand values of knot `ops_knot`.
+void hh_rollout16(const ModelConsts<double> *c, const double *traj, const double *gains, const double *alpha, double *out,
+                  int n, int ops_knot, double *ops_out) {
+  using namespace r16;
+  RConsts<HostWave> kc;
+  make_rconsts(*c, kc);
+  PConsts<HostWave> pc;
+  make_pconsts(pc);
+  auto T = [&](int l, int i, int e) { return traj[((long)(l >> 4) * n + i) * 18 + e]; };
+  auto G = [&](int l, int i, int e) { return gains[((long)(l >> 4) * n + i) * 52 + e]; };
+  RState<HostWave> s;
+  for (int l = 0; l < 64; ++l) {
+    s.TT.v[l] = tt_elem(l) >= 0 ? T(l, 0, tt_elem(l)) : 0.0;
+    s.QQ.v[l] = T(l, 0, qq_elem(l));
+    s.VL.v[l] = vl_elem(l) >= 0 ? T(l, 0, vl_elem(l)) : 0.0;
+    s.VW.v[l] = vw_elem(l) >= 0 ? T(l, 0, vw_elem(l)) : 0.0;
+  }
+  HV al;
+  for (int l = 0; l < 64; ++l) al.v[l] = alpha[l >> 4];
+  for (int i = 0; i < n; ++i) {
+    auto ld = [&](const HI &e) { HV r; for (int l = 0; l < 64; ++l) r.v[l] = T(l, i, e.v[l]); return r; };
+    auto lg = [&](const HI &e) { HV r; for (int l = 0; l < 64; ++l) r.v[l] = G(l, i, e.v[l]); return r; };
+    HV op[NOPS], raw[NRAW];
+    p_load<HostWave>(pc, ld, lg, raw);
+    p_compute<HostWave>(pc, raw, al, op);
+    if (ops_out && i == ops_knot)
+      for (int r = 0; r < NOPS; ++r)
+        for (int l = 0; l < 64; ++l) ops_out[r * 64 + l] = op[r].v[l];
+    HV st1, st2;
+    r_knot<HostWave>(kc, s, op, i + 1 < n, st1, st2);
+    for (int l = 0; l < 64; ++l) {
+      double *o = out + ((long)(l >> 4) * n + i) * 18;
+      if ((l & 15) == 0) o[0] = T(l, i, 0);
+      if (st1_elem(l) >= 0) o[st1_elem(l)] = st1.v[l];
+      if (st2_elem(l) >= 0) o[st2_elem(l)] = st2.v[l];
+    }
+  }
 }
 // dense J_x (12x12) and J_u (12x4) rebuilt from a knot record through m_source()
 void hh_dense_jacobians(const ModelConsts<double> *c, const double *rec, double *Jx, double *Ju) {

@@ -22,7 +22,7 @@ def hh():
     so = os.path.join(HERE, "libhost_harness.so")
     src = os.path.join(HERE, "host_harness.cpp")
     hdrs = [os.path.join(HERE, "..", "quadrotorilqr_amd", "csrc", h)
-            for h in ("se3_math.h", "backward_layout.h", "host_model.h")]
+            for h in ("se3_math.h", "backward_layout.h", "host_model.h", "rollout16.h")]
     if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src, "-lm"])
     return C.CDLL(so)
@@ -284,3 +284,137 @@ def test_tiled_layout_rollout_equals_plain_layout(hh):
             hh.hh_rollout(P(c), P(np.ascontiguousarray(traj[b])), P(np.ascontiguousarray(gains[b])),
                           C.c_double(alpha[b]), P(out), C.c_int(n))
             np.testing.assert_array_equal(out_t[b], out)
+
+
+# ------------------------------------------------------------------ sixteen lanes per trajectory (rollout16.h)
+def _random_cfg16(seed, n, dense=False):
+    """model, weights and four random trajectories (random_problem's generator, four times)"""
+    model, Q, R, t0, desired = random_problem(seed, n=n, dense=dense)
+    trajs = np.stack([t0] + [random_problem(seed + 100 * k, n=n, dense=dense)[3] for k in (1, 2, 3)])
+    cfg = dict(model=model, Q=Q, R=R, dt=0.1, desired=desired, options=dict(pb.OPTIONS_DEMO, populate_debug=False))
+    return cfg, trajs
+
+
+def _rollout16(hh, c, trajs, gains, alpha, ops_knot=-1):
+    """four trajectories through the CPU re-enactment of k_rollout16's two wavefronts"""
+    trajs, gains, alpha = (np.ascontiguousarray(a, dtype=float) for a in (trajs, gains, alpha))
+    out = np.zeros_like(trajs)
+    ops = np.zeros((23, 64))
+    hh.hh_rollout16(P(c), P(trajs), P(gains), P(alpha), P(out), C.c_int(trajs.shape[1]), C.c_int(ops_knot), P(ops))
+    return out, ops
+
+
+def _pose_close(a, b, atol):
+    """knots compared as the reference's tests do (ilqr_test.cc:38-53): poses up to the quaternion's sign"""
+    a = a.copy()
+    flip = np.sum(a[..., 4:8] * b[..., 4:8], axis=-1) < 0
+    a[flip, 4:8] *= -1
+    np.testing.assert_allclose(a, b, rtol=1e-10, atol=atol)
+
+
+def test_rollout16_operand_registers(hh):
+    """what wavefront P prepares for a knot, against the definitions: R_n^T rows in Q0, the nominal translation in
+    Q1, the left-multiplication matrix of conj(q_n) in Q0, the gain columns and u_nom + alpha k in Q3, zeros in
+    every lane that owns nothing"""
+    cfg, trajs = _random_cfg16(41, 5)
+    c = consts(hh, cfg["model"], cfg["Q"], cfg["R"], cfg["dt"])
+    r = np.random.default_rng(5)
+    tr = trajs[:4]
+    gains = r.uniform(-1, 1, (4, 5, 52))
+    alpha = np.array([1.0, 0.5, 0.25, 0.125])
+    _, ops = _rollout16(hh, c, tr, gains, alpha, ops_knot=2)
+    for row in range(4):
+        p = tr[row][2]
+        w, x, y, z = p[4:8]
+        if True:
+            Rn = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                           [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                           [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        L = np.array([[w, z, -y, -x], [-z, w, x, -y], [y, -x, w, -z], [x, y, z, w]])  # conj(q_n) (x) . on (x, y, z, w)
+        k, K = orc.gains_to_kK(gains[row][2:3])
+        for l in range(16):
+            lane, q, j = 16 * row + l, l >> 2, l & 3
+            for cc in range(3):
+                np.testing.assert_allclose(ops[cc, lane], Rn[cc, j] if (q == 0 and j < 3) else 0.0, atol=1e-15)
+            np.testing.assert_allclose(ops[3, lane], p[1 + j] if (q == 1 and j < 3) else 0.0)
+            for cc in range(4):
+                np.testing.assert_allclose(ops[4 + cc, lane], L[j, cc] if q == 0 else 0.0)
+            for cc in range(12):
+                np.testing.assert_allclose(ops[8 + cc, lane], K[0][j, cc] if q == 3 else 0.0)
+            np.testing.assert_allclose(ops[20, lane], p[14 + j] + alpha[row] * k[0][j] if q == 3 else 0.0, rtol=1e-15)
+            np.testing.assert_allclose(ops[21, lane], p[8 + j] if j < 3 else 0.0)
+            np.testing.assert_allclose(ops[22, lane], p[11 + j] if j < 3 else 0.0)
+
+
+@pytest.mark.parametrize("seed,dense", [(51, False), (52, True)])
+def test_rollout16_matches_oracle_on_random_trajectories(hh, seed, dense):
+    """random nominal trajectories (rotations up to 1.5 rad per axis away from anything: the closed-form branches of
+    Log and of its Jacobian), small random gains, four different step sizes in the four rows"""
+    cfg, trajs = _random_cfg16(seed, 14, dense)
+    c = consts(hh, cfg["model"], cfg["Q"], cfg["R"], cfg["dt"])
+    ref = orc.OracleSolver(orc.model_params(**cfg["model"]), cfg["Q"], cfg["R"], cfg["desired"], cfg["dt"],
+                           orc.options(**cfg["options"]))
+    r = np.random.default_rng(seed)
+    tr = trajs[:4]
+    gains = 0.05 * r.uniform(-1, 1, (4, 14, 52))
+    alpha = np.array([1.0, 0.5, 0.25, 1.0])
+    out, _ = _rollout16(hh, c, tr, gains, alpha)
+    for b in range(4):
+        _pose_close(out[b], ref.forward_sim(tr[b], gains[b], alpha[b]), atol=1e-10)
+        np.testing.assert_array_equal(out[b][:, 0], tr[b][:, 0])          # time_s passes through
+        np.testing.assert_array_equal(out[b][0, 1:14], tr[b][0, 1:14])    # knot 0 is the input's state
+
+
+def test_rollout16_matches_oracle_along_a_converging_solve(hh):
+    """the series branches: rollouts of a converging solve (small relative rotations), four trajectories at once"""
+    cfg = pb.config2(B=4, N=40)
+    c = consts(hh, cfg["model"], cfg["Q"], cfg["R"], cfg["dt"])
+    s = orc.OracleSolver(orc.model_params(**cfg["model"]), cfg["Q"], cfg["R"], cfg["desired"], cfg["dt"],
+                         orc.options(**cfg["options"]))
+    trajs = cfg["init"].copy()
+    for it in range(4):
+        gains = np.stack([s.backwards_pass(t)[0] for t in trajs])
+        for alpha in (np.array([1.0, 1.0, 1.0, 1.0]), np.array([0.5, 1.0, 0.25, 0.125])):
+            out, _ = _rollout16(hh, c, trajs, gains, alpha)
+            for b in range(4):
+                np.testing.assert_allclose(out[b], s.forward_sim(trajs[b], gains[b], alpha[b]), rtol=1e-10, atol=1e-11)
+        trajs = np.stack([s.forward_sim(trajs[b], gains[b], 1.0) for b in range(4)])
+
+
+def test_rollout16_branches(hh):
+    """(a) a rollout that stays ON the nominal trajectory (zero gains, nominal = a feasible rollout): relative rotation
+    zero -> manif's small-angle branches of Log and of its Jacobian; zero angular velocity -> small-angle Exp;
+    (b) fast spin (|dt omega| > 0.5 rad) -> the closed forms of Exp; (c) the demo's desired trajectory, whose roll
+    reaches pi (w = 0 exactly: the atan2 branch of Log with w <= 0)"""
+    cfg = pb.config2(B=4, N=12)
+    c = consts(hh, cfg["model"], cfg["Q"], cfg["R"], cfg["dt"])
+    s = orc.OracleSolver(orc.model_params(**cfg["model"]), cfg["Q"], cfg["R"], cfg["desired"], cfg["dt"],
+                         orc.options(**cfg["options"]))
+    zero = np.zeros((12, 52))
+    init = cfg["init"].copy()
+    init[0, 0, 11:14] = 0.0                      # (a) no angular velocity at all in row 0
+    init[1, 0, 11:14] = [9.0, -4.0, 2.0]         # (b) |dt omega| ~ 1 rad
+    feas = np.stack([s.forward_sim(init[b], zero, 1.0) for b in range(4)])   # feasible nominal trajectories
+    out, _ = _rollout16(hh, c, feas, np.zeros((4, 12, 52)), np.ones(4))
+    for b in range(4):
+        np.testing.assert_allclose(out[b], s.forward_sim(feas[b], zero, 1.0), rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(out[b], feas[b], rtol=1e-9, atol=1e-10)   # it re-traces the nominal trajectory
+    r = np.random.default_rng(3)
+    gains = 0.05 * r.uniform(-1, 1, (4, 12, 52))
+    out, _ = _rollout16(hh, c, init, gains, np.array([1.0, 1.0, 0.5, 0.5]))
+    for b in range(4):
+        np.testing.assert_allclose(out[b], s.forward_sim(init[b], gains[b], [1.0, 1.0, 0.5, 0.5][b]), rtol=1e-10, atol=1e-11)
+    # (c) the demo's box climb, 40 knots, first iterations of its solve
+    cfg1 = pb.config1(4.0)
+    c1 = consts(hh, cfg1["model"], cfg1["Q"], cfg1["R"], cfg1["dt"])
+    s1 = orc.OracleSolver(orc.model_params(**cfg1["model"]), cfg1["Q"], cfg1["R"], cfg1["desired"], cfg1["dt"],
+                          orc.options(**cfg1["options"]))
+    traj = cfg1["init"][0]
+    for it in range(3):
+        g, _ = s1.backwards_pass(traj)
+        four = np.stack([traj] * 4)
+        al = np.array([1.0, 0.5, 0.25, 0.125])
+        out, _ = _rollout16(hh, c1, four, np.stack([g] * 4), al)
+        for b in range(4):
+            _pose_close(out[b], s1.forward_sim(traj, g, al[b]), atol=1e-9)
+        traj = s1.forward_sim(traj, g, 1.0)

@@ -61,10 +61,11 @@ def test_config3_full_size_mixed_precision():
     # (iteration counts differ by up to 3), which leaves sqrt(1e-5 cost / R) ~ 0.1 of freedom in a control
     np.testing.assert_allclose(o150["traj"][:, :, 14:], ref["traj"][:, :, 14:], atol=1e-1)
     assert np.abs(o150["iters"].astype(int) - ref["iters"]).max() <= 3
-    # independence of position in the batch: a different batch size, the same per-problem bits
-    again = s32.solve_batch(cfg["init"][:2048])
-    np.testing.assert_array_equal(again["traj"], out["traj"][:2048])
-    np.testing.assert_array_equal(again["iters"], out["iters"][:2048])
+    # independence of position in the batch: a different batch size (on the same side of the kernel-selection
+    # thresholds: the rollout kernel changes at 4096 trajectories), the same per-problem bits
+    again = s32.solve_batch(cfg["init"][:5000])
+    np.testing.assert_array_equal(again["traj"], out["traj"][:5000])
+    np.testing.assert_array_equal(again["iters"], out["iters"][:5000])
 
 
 def test_config4_one_gpu_shard_full_size():

@@ -261,24 +261,34 @@ def test_sub_batches_on_their_own_streams_give_identical_results():
             np.testing.assert_array_equal(np.nan_to_num(one.cost_history(B)), np.nan_to_num(many.cost_history(B)))
 
 
-def test_three_wave_rollout_matches_single_wave():
-    """k_rollout3 (pose wave + control wave + loader wave) performs the same operations as k_rollout; the
-    compiler may contract multiply-adds differently in the two kernels, so agreement is to rounding (1e-12)"""
-    for B, n in [(70, 33), (5, 1), (64, 2)]:
+def test_rollout_kernels_agree():
+    """The three rollout kernels on the same inputs.  k_rollout3 (pose wave + control wave + loader wave) performs the
+    operations of k_rollout (one wave, a lane per trajectory): agreement to 1e-12 (the compiler may contract
+    multiply-adds differently).  k_rollout16 (sixteen lanes per trajectory, rollout16.h) sums in other orders:
+    1e-10, the per-pass tolerance.  Ragged batches (B not a multiple of 4 or 64), horizons 1 and 2, four different
+    step sizes inside one block, and both storage precisions."""
+    for B, n in [(70, 33), (5, 1), (64, 2), (3, 7)]:
         cfg = pb.config2(B=B, N=n, seed=7)
-        three = capi.from_config(cfg)                        # pose wave + control wave + loader wave (k_rollout3)
-        one = capi.from_config(cfg, single_wave_rollout=1)   # one wave (k_rollout)
         r = np.random.default_rng(B)
         gains = 0.05 * r.uniform(-1, 1, (B, n, 52))
         alpha = 0.5 ** r.integers(0, 4, B)
         trajs = cfg["init"] + 0.0
         trajs[:, :, 8:14] += 0.3 * r.standard_normal((B, n, 6))
-        np.testing.assert_allclose(three.forward_sim(trajs, gains, alpha), one.forward_sim(trajs, gains, alpha),
-                                   rtol=1e-12, atol=1e-12)
+        one = capi.from_config(cfg, single_wave_rollout=1).forward_sim(trajs, gains, alpha)     # k_rollout
+        three = capi.from_config(cfg, single_wave_rollout=2).forward_sim(trajs, gains, alpha)   # k_rollout3
+        sixteen = capi.from_config(cfg, single_wave_rollout=3).forward_sim(trajs, gains, alpha)  # k_rollout16
+        np.testing.assert_allclose(three, one, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(sixteen, one, rtol=1e-10, atol=1e-11)
+        np.testing.assert_array_equal(sixteen[:, :, 0], trajs[:, :, 0])
+        np.testing.assert_array_equal(sixteen[:, 0, 1:14], trajs[:, 0, 1:14])
+        s32 = capi.from_config(cfg, single_wave_rollout=3, precision="f32").forward_sim(trajs, gains, alpha)
+        np.testing.assert_allclose(s32, one, rtol=2e-5, atol=2e-5)
     cfg = pb.config2(B=96, N=40)
-    a, b = capi.from_config(cfg).solve_batch(cfg["init"]), capi.from_config(cfg, single_wave_rollout=True).solve_batch(cfg["init"])
-    np.testing.assert_allclose(a["traj"], b["traj"], atol=1e-8)
-    np.testing.assert_array_equal(a["iters"], b["iters"])
+    outs = [capi.from_config(cfg, single_wave_rollout=k).solve_batch(cfg["init"]) for k in (1, 2, 3, 0)]
+    for o in outs[1:]:
+        np.testing.assert_allclose(o["traj"], outs[0]["traj"], atol=1e-8)
+        np.testing.assert_array_equal(o["iters"], outs[0]["iters"])
+        np.testing.assert_array_equal(o["n_fwd"], outs[0]["n_fwd"])
 
 
 # ------------------------------------------------------------------ full solves
