@@ -19,11 +19,12 @@ for _ in range(3):
 out = np.zeros((B, 8), dtype=np.uint64)
 capi.load().qilqr_debug_stamps(s._h, out.ctypes.data_as(C.c_void_p), C.c_int32(B))
 blocks = B // 4
-st = out.reshape(-1)[: blocks * 16].reshape(blocks, 2, 8).astype(np.float64)
-names = {0: ["wait for P's slot", "operand reads + flag", "the knot (r_knot)", "stores"],
-         1: ["requests", "wait for loads + operand registers", "wait for a free slot", "LDS writes, flag, time store"]}
-for role in (0, 1):
+st = out.reshape(-1)[: blocks * 24].reshape(blocks, 3, 8).astype(np.float64)
+names = {0: ["wait for P's slot, operand reads issued", "wait for (t, q)_i", "Log, control, stores", "wait for F_i", "velocity, hand-off"],
+         1: ["wait for v_i", "the knot (free velocity, Exp, compose)"],
+         2: ["requests", "wait for loads + operand registers", "wait for a free slot", "LDS writes, flag, time store"]}
+for role in (0, 1, 2):
     med = np.median(st[:, role, :], axis=0) / N
-    print("wave", ["R (rollout)", "P (operands)"][role], " total %.0f cycles/knot" % med.sum())
+    print("wave", ["A (control)", "B (pose)", "P (operands)"][role], " total %.0f cycles/knot" % med.sum())
     for n_, m in zip(names[role], med):
-        print(f"   {n_:38s} {m:8.0f}  {100 * m / med.sum():5.1f} %")
+        print(f"   {n_:42s} {m:8.0f}  {100 * m / med.sum():5.1f} %")

@@ -369,9 +369,9 @@ int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
       launch(s, K_ROLLOUT, k_rollout<double>, dim3(cdiv(B, 64)), dim3(64), s->consts, s->st, (int)B, (int)n, need_flag);
   } else if (choice == 3 || (choice == 0 && load_B <= R16_MAX_B)) {
     if (s->f32)
-      launch(s, K_ROLLOUT, k_rollout16<float>, dim3(cdiv(B, 4)), dim3(128), s->consts, s->st, (int)B, (int)n, need_flag);
+      launch(s, K_ROLLOUT, k_rollout16<float>, dim3(cdiv(B, 4)), dim3(192), s->consts, s->st, (int)B, (int)n, need_flag);
     else
-      launch(s, K_ROLLOUT, k_rollout16<double>, dim3(cdiv(B, 4)), dim3(128), s->consts, s->st, (int)B, (int)n, need_flag);
+      launch(s, K_ROLLOUT, k_rollout16<double>, dim3(cdiv(B, 4)), dim3(192), s->consts, s->st, (int)B, (int)n, need_flag);
   } else {
     if (s->f32)
       launch(s, K_ROLLOUT, k_rollout3<float>, dim3(cdiv(B, 64)), dim3(192), s->constsf, s->st, (int)B, (int)n, need_flag);

@@ -1800,16 +1800,20 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_rollout16: SIXTEEN LANES PER TRAJECTORY (rollout16.h): block = 128 = rollout wavefront R + operand wavefront P
-// for four trajectories (b0 = 4 blockIdx.x; row r of 16 lanes <-> trajectory b0 + r).  At B = 1024 that is 256
-// blocks -- one per CU -- instead of the 16 blocks of k_rollout3, and about a third of its instructions per knot.
-//   P: for knot k (running up to R16_RING - 1 knots ahead of R): loads the nominal knot and the gains (tiled global
-//      layout, per-lane element indices), forms the 23 operand registers (r16::p_make_ops) and writes them to ring
-//      slot k % R16_RING as [register][lane]; copies the time column to the output trajectory.
-//   R: waits for slot i, reads its lane's 23 values, runs r16::r_knot, stores the knot (two masked stores).
-// The two waves never meet at a barrier inside the loop: P publishes "knots produced", R "knots consumed" in two LDS
-// words (LDS operations of a wavefront execute in order, so a flag written after the data is seen after the data);
-// every spin is bounded, so a lost flag ends the kernel instead of hanging it.
+// k_rollout16: SIXTEEN LANES PER TRAJECTORY (rollout16.h): block = 192 = control wavefront A + pose wavefront B +
+// operand wavefront P for four trajectories (b0 = 4 blockIdx.x; row r of 16 lanes <-> trajectory b0 + r).  At B = 1024
+// that is 256 blocks -- one per CU -- instead of the 16 blocks of k_rollout3, and about a third of its instructions
+// per knot, cut into the two halves that are independent inside a knot:
+//   A (r16::a_control, a_velocity): Log of the pose error, control law, thrust -> u_i, v_{i+1}; stores knot i
+//   B (r16::b_knot): gravity and gyroscopic terms ("free" velocity F_i, handed to A in the same knot), Exp, pose
+//      composition -> (t, q)_{i+1}
+//   P (r16::p_load, p_compute): for knot k (running up to R16_RING - 1 knots ahead of A): loads the nominal knot and the
+//      gains (tiled global layout, per-lane element offsets), forms the 23 operand registers and writes them to ring slot
+//      k % R16_RING as [register][lane]; copies the time column to the output trajectory.
+// The waves never meet at a barrier inside the loop.  Five LDS words carry progress: knots produced by P / consumed by
+// A, and "v_k ready" (A), "(t, q)_k ready", "F_k ready" (B); the values themselves go through double-buffered LDS slots.
+// LDS operations of a wavefront execute in order, so a flag written after the data is seen after the data; every spin
+// is bounded, so a lost flag ends the kernel instead of hanging it.
 // Trajectories of the block that are not being rolled out this round alias the block's first live trajectory (their
 // rows compute a duplicate that nobody stores): no row wanders onto a slow branch, no extra memory traffic.
 // S = storage precision of trajectories and gains; the arithmetic is fp64 in either mode.
@@ -1862,16 +1866,17 @@ struct DevWave {
 
 constexpr int R16_RING = 4;
 constexpr int R16_SPIN_MAX = 1 << 22;
+enum { R16_F_PROD = 0, R16_F_CONS, R16_F_V, R16_F_T, R16_F_F, R16_NFLAGS };
 template <typename S>
-__global__ __launch_bounds__(128) void k_rollout16(ModelConsts<double> c, BatchState st, int B, int n, int need_flag) {
+__global__ __launch_bounds__(192) void k_rollout16(ModelConsts<double> c, BatchState st, int B, int n, int need_flag) {
   using namespace r16;
   const int lane = threadIdx.x & 63;
-  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: R, 1: P
+  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: A, 1: B, 2: P
   const int row = lane >> 4;
   const int b = blockIdx.x * 4 + row;
   const bool live = (b < B) && (!need_flag || (st.flags[b < B ? b : 0] & need_flag));
   const unsigned long long livemask = __ballot(live);
-  if (livemask == 0ull) return;  // identical in both waves: block-uniform
+  if (livemask == 0ull) return;  // identical in the three waves: block-uniform
   const int bs = live ? b : blockIdx.x * 4 + ((__ffsll((long long)livemask) - 1) >> 4);  // dead rows alias the first live one
   const int cur = st.cur[bs];
   const S *traj = (const S *)st.traj[cur] + knot_base<true>(bs, n, 18);
@@ -1879,12 +1884,14 @@ __global__ __launch_bounds__(128) void k_rollout16(ModelConsts<double> c, BatchS
   S *out = (S *)st.traj[cur ^ 1] + knot_base<true>(bs, n, 18);
 
   __shared__ double ops[R16_RING][NOPS][64];
-  __shared__ int flags[2];  // [0]: knots produced by P, [1]: knots consumed by R
-  if (threadIdx.x < 2) flags[threadIdx.x] = 0;
+  __shared__ double xch[3][2][2][64];  // hand-off slots [X_T (t, q) | X_V v | X_F free velocity][parity of the knot][register][lane]
+  enum { X_T = 0, X_V = 1, X_F = 2 };
+  __shared__ int flags[R16_NFLAGS];
+  if (threadIdx.x < R16_NFLAGS) flags[threadIdx.x] = 0;
   __syncthreads();
   // The LDS executes the operations of one wavefront in the order they were issued, so a flag written after the data
   // (or after the reads of a slot) is seen after them: no s_waitcnt, and no workgroup fence -- a release fence would wait
-  // for the wavefront's outstanding GLOBAL loads and stores too (vmcnt(0)), i.e. for P's prefetch and R's knot stores, on
+  // for the wavefront's outstanding GLOBAL loads and stores too (vmcnt(0)), i.e. for P's prefetch and A's knot stores, on
   // every knot.  The asm statements only keep the compiler from moving LDS accesses across the flag.
   auto flag_read = [&](int which) -> int { return __hip_atomic_load(&flags[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
   auto flag_wait = [&](int which, int target, int seen) -> bool {
@@ -1901,8 +1908,26 @@ __global__ __launch_bounds__(128) void k_rollout16(ModelConsts<double> c, BatchS
     asm volatile("" ::: "memory");
     if (lane == 0) __hip_atomic_store(&flags[which], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
+  // A hand-off read in ONE LDS round trip: the flag and the two values are requested back to back (the LDS serves a
+  // wavefront's requests in order, so values read after a flag that shows `target` are the published ones); if the
+  // flag is not there yet, poll and read again.
+  auto read_handoff = [&](int which, int target, int kind, int par, double &d0, double &d1) -> bool {
+    for (int spins = 0; spins < R16_SPIN_MAX; ++spins) {
+      asm volatile("" ::: "memory");  // read again, every time round
+      const int f = flag_read(which);
+      const double a0 = xch[kind][par][0][lane], a1 = xch[kind][par][1][lane];  // (indexed directly: LDS addressing, not flat)
+      if (f >= target) {
+        d0 = a0;
+        d1 = a1;
+        asm volatile("" ::: "memory");
+        return true;
+      }
+    }
+    return false;
+  };
+  auto ld0 = [&](int e) -> double { return e >= 0 ? (double)traj[knot_elem<true>(0, e, 18)] : 0.0; };
 
-  if (role == 1) {
+  if (role == 2) {
     // ------------------------------------------------------------------ P: operand registers
     PConsts<DevWave> pc;
     make_pconsts(pc);
@@ -1932,11 +1957,11 @@ __global__ __launch_bounds__(128) void k_rollout16(ModelConsts<double> c, BatchS
       p_compute<DevWave>(pc, rc, alpha, op);
       QKEEP(op[0]); QKEEP(op[22]); QKEEP(op[10]);
       QSTAMP(1);  // P: wait for the loads, operand registers
-      if (k >= R16_RING && !flag_wait(1, k - R16_RING + 1, -1)) ok = false;  // slot k % R16_RING is free once R has read knot k - R16_RING
+      if (k >= R16_RING && !flag_wait(R16_F_CONS, k - R16_RING + 1, -1)) ok = false;  // slot k % R16_RING is free once A has used knot k - R16_RING
       QSTAMP(2);  // P: wait for a free slot
 #pragma unroll
       for (int r = 0; r < NOPS; ++r) ops[k % R16_RING][r][lane] = op[r];
-      flag_post(0, k + 1);
+      flag_post(R16_F_PROD, k + 1);
       if (live && (lane & 15) == 0) out[knot_elem<true>(k, 0, 18)] = tmc;  // time_s passes through (ilqr.hh:164)
       QSTAMP(3);  // P: LDS writes, flag, time store
     };
@@ -1947,52 +1972,83 @@ __global__ __launch_bounds__(128) void k_rollout16(ModelConsts<double> c, BatchS
     }
 #ifdef QILQR_STAMPS
     if (lane == 0 && st.stamps)
-      for (int k = 0; k < 8; ++k) st.stamps[((long)blockIdx.x * 2 + 1) * 8 + k] = stamp_sum[k];
+      for (int k = 0; k < 8; ++k) st.stamps[((long)blockIdx.x * 3 + 2) * 8 + k] = stamp_sum[k];
 #endif
     return;
   }
 
-  // -------------------------------------------------------------------- R: rollout
   RConsts<DevWave> kc;
   make_rconsts(c, kc);
-  RState<DevWave> s;
-  {
-    auto ld0 = [&](int e) -> double { return e >= 0 ? (double)traj[knot_elem<true>(0, e, 18)] : 0.0; };
-    s.TT = ld0(tt_elem(lane));
-    s.QQ = ld0(qq_elem(lane));
-    s.VL = ld0(vl_elem(lane));
-    s.VW = ld0(vw_elem(lane));
-  }
-  // the two masked stores of a knot: a wave-uniform knot pointer plus the lane's offset in the tiled layout
-  const int e1 = st1_elem(lane), e2 = st2_elem(lane);
-  const bool w1 = live && e1 >= 0, w2 = live && e2 >= 0;
-  const int o1 = DevWave::iuni(e1 >= 0 ? e1 : 0), o2 = DevWave::iuni(e2 >= 0 ? e2 : 0);
+  double TT = ld0(tt_elem(lane)), QQ = ld0(qq_elem(lane)), VL = ld0(vl_elem(lane)), VW = ld0(vw_elem(lane));
 #ifdef QILQR_STAMPS
   unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
+
+  if (role == 1) {
+    // ------------------------------------------------------------------ B: pose
+    for (int i = 0; i + 1 < n; ++i) {
+      if (i > 0 && !read_handoff(R16_F_V, i, X_V, i & 1, VL, VW)) return;
+      QSTAMP(0);  // B: wait for v_i
+      double TTn, QQn;
+      b_knot<DevWave>(kc, TT, QQ, VL, VW,
+                      [&](double FL, double FW) {
+                        xch[X_F][i & 1][0][lane] = FL;
+                        xch[X_F][i & 1][1][lane] = FW;
+                        flag_post(R16_F_F, i + 1);
+                      },
+                      TTn, QQn);
+      TT = TTn;
+      QQ = QQn;
+      xch[X_T][(i + 1) & 1][0][lane] = TT;
+      xch[X_T][(i + 1) & 1][1][lane] = QQ;
+      flag_post(R16_F_T, i + 1);
+      QSTAMP(1);  // B: the knot
+    }
+#ifdef QILQR_STAMPS
+    if (lane == 0 && st.stamps)
+      for (int k = 0; k < 8; ++k) st.stamps[((long)blockIdx.x * 3 + 1) * 8 + k] = stamp_sum[k];
+#endif
+    return;
+  }
+
+  // -------------------------------------------------------------------- A: control, velocity, stores
+  // the two masked stores of a knot: a wave-uniform knot pointer plus the lane's offset in the tiled layout
+  const int e1 = st1_elem(lane), e2 = st2_elem(lane);
+  const bool w1 = live && e1 >= 0, w2 = live && e2 >= 0;
+  const int o1 = DevWave::iuni(e1 >= 0 ? e1 : 0), o2 = DevWave::iuni(e2 >= 0 ? e2 : 0);
   int seen = -1;  // P's progress as last read
   for (int i = 0; i < n; ++i) {
-    if (!flag_wait(0, i + 1, seen)) return;
-    QSTAMP(0);  // R: wait for P's slot
+    if (!flag_wait(R16_F_PROD, i + 1, seen)) return;
     double op[NOPS];
 #pragma unroll
     for (int r = 0; r < NOPS; ++r) op[r] = ops[i % R16_RING][r][lane];
-    seen = flag_read(0);  // for the next knot: P is normally several knots ahead, and this read's latency is covered by the knot
-    QSTAMP(1);  // R: operand reads issued
+    seen = flag_read(R16_F_PROD);  // for the next knot: P is normally several knots ahead, and this read's latency is covered by the knot
+    QSTAMP(0);  // A: wait for P's slot, operand reads issued
+    if (i > 0 && !read_handoff(R16_F_T, i, X_T, i & 1, TT, QQ)) return;
+    QSTAMP(1);  // A: wait for (t, q)_i
     double st1, st2;
-    r_knot<DevWave>(kc, s, op, i + 1 < n, st1, st2);
-    flag_post(1, i + 1);  // the slot's values have been read: P may refill it
-    QKEEP(st1); QKEEP(s.QQ); QKEEP(s.TT); QKEEP(s.VL);
-    QSTAMP(2);  // R: the knot
+    const double UU = a_control<DevWave>(kc, TT, QQ, VL, VW, op, st1, st2);
+    flag_post(R16_F_CONS, i + 1);  // the slot's values have been used: P may refill it
     S *ok_ = out + (long)i * (9 * 128);
     if (w1) ok_[o1] = (S)st1;
     if (w2) ok_[o2] = (S)st2;
-    QSTAMP(3);  // R: stores
+    QKEEP(UU);
+    QSTAMP(2);  // A: Log, control, stores
+    if (i + 1 < n) {  // the reference's step after the last knot is computed and discarded (ilqr.hh:168)
+      double FL, FW;
+      if (!read_handoff(R16_F_F, i + 1, X_F, i & 1, FL, FW)) return;
+      QSTAMP(3);  // A: wait for F_i
+      a_velocity<DevWave>(kc, UU, FL, FW, VL, VW);
+      xch[X_V][(i + 1) & 1][0][lane] = VL;
+      xch[X_V][(i + 1) & 1][1][lane] = VW;
+      flag_post(R16_F_V, i + 1);
+      QSTAMP(4);  // A: velocity
+    }
   }
 #ifdef QILQR_STAMPS
   if (lane == 0 && st.stamps)
-    for (int k = 0; k < 8; ++k) st.stamps[((long)blockIdx.x * 2 + 0) * 8 + k] = stamp_sum[k];
+    for (int k = 0; k < 8; ++k) st.stamps[((long)blockIdx.x * 3 + 0) * 8 + k] = stamp_sum[k];
 #endif
 }
 

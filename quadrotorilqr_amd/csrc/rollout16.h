@@ -56,13 +56,13 @@ struct RConsts {
   typedef typename W::V V;
   typedef typename W::M M;
   double dt;
-  V SA, SB1;           // packing scales: A1 = th + SA VW, B1 = TI + SB1 VL
+  V SA, SB1;           // packing scales of the pose wave: A1 = SA VW, B1 = I omega + SB1 VL
   V IC[3];             // column c of the inertia, rows in Q2
   V NI[3];             // column c of -dt I^-1, rows in every quad
   V GLz;               // dt / m at j = 2
   V GW[4];             // column a of dt I^-1 arms, rows in every quad
   V GRAVC, S1, S2;     // gravity: -g dt e_z, and the signed scales of the two quaternion permutations
-  V MH0, MQ0, MQ1, MQ1_3, MW, M03;
+  V MQ1, MQ1_3, MW;
   V MQ0_3, MQ2_3;      // store assembly
   V PC[8];             // per-lane polynomial coefficients (lane-in-row 0..5)
   M L0, L1, L2, L3;    // lane-in-row == 0..3 (patching the Exp coefficients on the closed-form path)
@@ -86,12 +86,9 @@ QILQR_HD void make_rconsts(const ModelConsts<double> &c, RConsts<W> &k) {
   // R^T e_z = (2(xz - yw), 2(yz + xw), 1 - 2(x^2 + y^2)) = x (2z, 2w, -2x) + y (-2w, 2z, -2y) + e_z
   k.S1 = W::vconst([&](int l) { return -c.g * dt * (j(l) == 0 ? 2.0 : (j(l) == 1 ? 2.0 : (j(l) == 2 ? -2.0 : 0.0))); });
   k.S2 = W::vconst([&](int l) { return -c.g * dt * (j(l) == 0 ? -2.0 : (j(l) == 1 ? 2.0 : (j(l) == 2 ? -2.0 : 0.0))); });
-  k.MH0 = W::vconst([&](int l) { return q(l) == 0 ? -0.5 : 0.0; });
-  k.MQ0 = W::vconst([&](int l) { return q(l) == 0 ? 1.0 : 0.0; });
   k.MQ1 = W::vconst([&](int l) { return q(l) == 1 ? 1.0 : 0.0; });
   k.MQ1_3 = W::vconst([&](int l) { return (q(l) == 1 && j(l) < 3) ? 1.0 : 0.0; });
   k.MW = W::vconst([&](int l) { return j(l) == 3 ? 1.0 : 0.0; });
-  k.M03 = W::vconst([&](int l) { return (l & 15) < 4 ? 1.0 : 0.0; });
   k.MQ0_3 = W::vconst([&](int l) { return (q(l) == 0 && j(l) < 3) ? 1.0 : 0.0; });
   k.MQ2_3 = W::vconst([&](int l) { return (q(l) == 2 && j(l) < 3) ? 1.0 : 0.0; });
   for (int e = 0; e < 8; ++e)
@@ -112,12 +109,6 @@ QILQR_HD void make_rconsts(const ModelConsts<double> &c, RConsts<W> &k) {
   k.L3 = W::mconst([](int l) { return (l & 15) == 3; });
 }
 
-// state of the four trajectories of a wavefront
-template <class W>
-struct RState {
-  typename W::V TT, QQ, VL, VW;
-};
-
 // a x b for three-vectors in lanes j = 0..2 of every quad, given the rotations a' (j <- j + 1) and a'' (j <- j + 2) of a;
 // lane j = 3 of every quad comes out as a[3] b[3] - a[3] b[3] = 0
 template <class W>
@@ -126,18 +117,106 @@ QILQR_HD typename W::V cross_rot(typename W::V ap, typename W::V app, typename W
   return W::fma(ap, bpp, -(app * bp));
 }
 
-// One knot of the rollout for the four trajectories of the wavefront.
-//   in:  state s (knot i), operand registers op[NOPS] of knot i
-//   out: u (control of knot i, Q3 lanes), st1 / st2 (the knot's state as it is stored: see r_store_elems), and, when
-//        `advance`, the state of knot i + 1 in s
-template <class W>
-QILQR_HD void r_knot(const RConsts<W> &k, RState<W> &s, const typename W::V *op, bool advance, typename W::V &st1,
-                     typename W::V &st2) {
+// One knot of the rollout for four trajectories, cut into the two halves that are independent inside a knot; two
+// wavefronts run them side by side and trade (t, q) and v once per knot:
+//   a_knot  (control wave A): Log of the pose error, control law, thrust -> u_i, v_{i+1}, and what is stored for knot i
+//   b_knot  (pose wave B):    gravity and gyroscopic terms of the velocity update ("free" velocity F_i, handed to A in
+//                             the same knot), then Exp and the pose composition -> (t, q)_{i+1}
+// Both take the state of knot i: TT, QQ (written by B), VL, VW (written by A).
+
+// the pose wave.  post_f(FL, FW) is called as soon as the free velocity is final (the device publishes it to A there).
+template <class W, class POSTF>
+QILQR_HD void b_knot(const RConsts<W> &k, typename W::V TT, typename W::V QQ, typename W::V VL, typename W::V VW,
+                     POSTF post_f, typename W::V &TTn, typename W::V &QQn) {
   typedef typename W::V V;
   typedef typename W::M M;
-  const V TT = s.TT, QQ = s.QQ, VL = s.VL, VW = s.VW;
   const double eps = Eps<double>::manif;
+  // ---- theta_e = dt omega and rho_e = dt v (the pose integrates with the OLD velocity); I omega in Q2
+  V IW = W::template bc<0>(VW) * k.IC[0];
+  IW = W::template fm<1>(IW, VW, k.IC[1]);
+  IW = W::template fm<2>(IW, VW, k.IC[2]);
+  const V A1 = k.SA * VW;                 // [0 | theta_e | omega   | 0]
+  const V B1 = W::fma(k.SB1, VL, IW);     // [0 | rho_e   | I omega | 0]
+  const V A1p = W::rot1(A1), A1pp = W::rot1(A1p);
+  const V C1 = cross_rot<W>(A1p, A1pp, B1);  // [0 | theta_e x rho_e | omega x I omega | 0]
+  // ---- the free velocity: v + dt (gravity in the body frame - I^-1 (omega x I omega))  (quadrotor_model.cc:65-78)
+  {
+    V FL = VL + k.GRAVC;
+    FL = W::template fm<0>(FL, QQ, k.S1 * W::template qperm<0xCE>(QQ));  // (z, w, x, .)
+    FL = W::template fm<1>(FL, QQ, k.S2 * W::template qperm<0xDB>(QQ));  // (w, z, y, .)
+    V g1 = W::template bc<8>(C1) * k.NI[0];  // -dt I^-1 (omega x I omega)
+    g1 = W::template fm<9>(g1, C1, k.NI[1]);
+    V FW = W::template fm<10>(VW, C1, k.NI[2]);
+    FW = FW + g1;
+    post_f(FL, FW);
+  }
+  // ---- Exp coefficients: cos(th/2), sin(th/2)/th, (1 - cos th)/th^2, (th - sin th)/th^3 in lanes 0..3 of a row
+  const V THE = k.dt * VW;
+  const V sqe = THE * THE;
+  V th2e = W::template bc<0>(sqe) + W::template bc<1>(sqe);
+  th2e = th2e + W::template bc<2>(sqe);
+  V P1;
+  {
+    const V x = th2e, x2 = x * x, x4 = x2 * x2;
+    const V p01 = W::fma(k.PC[1], x, k.PC[0]), p23 = W::fma(k.PC[3], x, k.PC[2]), p45 = W::fma(k.PC[5], x, k.PC[4]),
+            p67 = W::fma(k.PC[7], x, k.PC[6]);
+    P1 = W::fma(W::fma(p67, x2, p45), x4, W::fma(p23, x2, p01));
+    // manif's branches of Exp: small angle, closed forms beyond the series' range; patch lanes 0..3 of P1.  The closed
+    // forms (sqrt, two sin, two cos) run only when some row is beyond the series' range, the small-angle constants only
+    // when some row is at rest: a converging solve takes neither branch.
+    const M small = W::lnot(W::gt(th2e, eps));
+    const M closed = W::gt(th2e, Series<double>::EXP_MAX);
+    if (W::any(closed)) {
+      const V xc = W::sel(closed, th2e, V(1.0));
+      const V theta = W::sqrt_(xc), ha = 0.5 * theta;
+      const V sn = W::sin_(ha), cs = W::cos_(ha), st = W::sin_(theta), ct = W::cos_(theta);
+      P1 = W::sel(W::land(closed, k.L0), cs, P1);
+      P1 = W::sel(W::land(closed, k.L1), sn / theta, P1);
+      P1 = W::sel(W::land(closed, k.L2), (1.0 - ct) / xc, P1);
+      P1 = W::sel(W::land(closed, k.L3), (theta - st) / (xc * theta), P1);
+    }
+    if (W::any(small)) {
+      P1 = W::sel(W::land(small, k.L0), V(1.0), P1);
+      P1 = W::sel(W::land(small, W::lor(k.L1, k.L2)), V(0.5), P1);
+      P1 = W::sel(W::land(small, k.L3), V(0.0), P1);
+    }
+  }
+  // ---- p = rho_e + a theta_e x rho_e + b theta_e x (theta_e x rho_e) in Q1
+  const V C2 = cross_rot<W>(A1p, A1pp, C1);
+  const V CA = W::template bc<2>(P1) * k.MQ1, CB = W::template bc<3>(P1) * k.MQ1;
+  const V PP = W::fma(CB, C2, W::fma(CA, C1, B1));  // Q1: p (Q2: I omega, never used)
+  // ---- pose: T <- T Exp(dt v):  t += R(q) p,  q <- q (sh theta_e, ch)
+  const V QQp = W::rot1(QQ), QQpp = W::rot1(QQp);
+  const V C3 = cross_rot<W>(QQp, QQpp, PP);   // Q1: u x p
+  const V C4 = cross_rot<W>(QQp, QQpp, C3);   // Q1: u x (u x p)
+  const V Wq = W::template bc<3>(QQ);
+  const V Rp = W::fma(V(2.0), C4, W::fma(Wq + Wq, C3, PP));
+  TTn = W::fma(k.MQ1_3, Rp, TT);
+  const V ZX = cross_rot<W>(QQp, QQpp, THE);  // u x theta_e in every quad
+  const V z = W::fma(Wq, THE, ZX);
+  const V CH = W::template bc<0>(P1), SH = W::template bc<1>(P1);
+  const V ov = W::fma(SH, z, CH * QQ);
+  const V prod = QQ * THE;
+  V dq = W::template bc<0>(prod) + W::template bc<1>(prod);
+  dq = dq + W::template bc<2>(prod);
+  V Qn = W::fma(-(k.MW * SH), dq, ov);
+  {
+    const V sqq = Qn * Qn;
+    V nq = (W::template bc<0>(sqq) + W::template bc<1>(sqq)) + (W::template bc<2>(sqq) + W::template bc<3>(sqq));
+    const M off = W::gt(W::abs_(nq - 1.0), eps);  // manif's compose renormalisation
+    if (W::any(off)) Qn = Qn * W::sel(off, 2.0 / (1.0 + nq), V(1.0));
+  }
+  QQn = Qn;
+}
 
+// the control wave, first part: everything up to the control u_i (rows in Q3) and what is stored for knot i
+// (st1 = [v_lin | t | omega | u], st2 = the quaternion: see st1_elem / st2_elem)
+template <class W>
+QILQR_HD typename W::V a_control(const RConsts<W> &k, typename W::V TT, typename W::V QQ, typename W::V VL, typename W::V VW,
+                                 const typename W::V *op, typename W::V &st1, typename W::V &st2) {
+  typedef typename W::V V;
+  typedef typename W::M M;
+  const double eps = Eps<double>::manif;
   // ---- Log, rotation part: qd = conj(q_n) q in Q0 (x, y, z, w)
   V qd = W::template bc<0>(QQ) * op[OP_LQ + 0];
   qd = W::template fm<1>(qd, QQ, op[OP_LQ + 1]);
@@ -158,26 +237,14 @@ QILQR_HD void r_knot(const RConsts<W> &k, RState<W> &s, const typename W::V *op,
     }
   }
   const V wq = W::template bc<3>(qd);
-
-  // ---- Exp scalars: theta_e = dt omega (the pose integrates with the OLD velocity)
-  const V THE = k.dt * VW;
-  const V sqe = THE * THE;
-  V th2e = W::template bc<0>(sqe) + W::template bc<1>(sqe);
-  th2e = th2e + W::template bc<2>(sqe);
-
-  // ---- the six polynomials, side by side: lanes 0..3 of a row at theta_e^2 (cos(th/2), sin(th/2)/th, (1 - cos th)/th^2,
-  // (th - sin th)/th^3), lanes 4, 5 at s2 (the two halves of 2 asin(s)/s)
-  V P1;
-  {
-    const V x = W::fma(k.M03, th2e - s2, s2);
-    const V x2 = x * x, x4 = x2 * x2;
-    const V p01 = W::fma(k.PC[1], x, k.PC[0]), p23 = W::fma(k.PC[3], x, k.PC[2]), p45 = W::fma(k.PC[5], x, k.PC[4]),
-            p67 = W::fma(k.PC[7], x, k.PC[6]);
-    P1 = W::fma(W::fma(p67, x2, p45), x4, W::fma(p23, x2, p01));
-  }
+  // ---- 2 asin(s)/s: its two halves side by side in lanes 4, 5 of a row
   V coeff;
   {
-    const V y2 = s2 * s2, y4 = y2 * y2, y8 = y4 * y4;
+    const V x = s2, x2 = x * x, x4 = x2 * x2;
+    const V p01 = W::fma(k.PC[1], x, k.PC[0]), p23 = W::fma(k.PC[3], x, k.PC[2]), p45 = W::fma(k.PC[5], x, k.PC[4]),
+            p67 = W::fma(k.PC[7], x, k.PC[6]);
+    const V P1 = W::fma(W::fma(p67, x2, p45), x4, W::fma(p23, x2, p01));
+    const V y8 = x4 * x4;
     coeff = W::template fm<5>(W::template bc<4>(P1), P1, y8);
     // manif's branches of Log (so3_log): small angle, and the atan2 form outside the series' range / for w <= 0
     const M small = W::lnot(W::gt(s2, eps));
@@ -191,27 +258,6 @@ QILQR_HD void r_knot(const RConsts<W> &k, RState<W> &s, const typename W::V *op,
     }
     coeff = W::sel(small, V(2.0), coeff);
   }
-  {
-    // manif's branches of Exp: small angle, closed forms beyond the series' range; patch lanes 0..3 of P1.  The closed
-    // forms (sqrt, two sin, two cos) run only when some row is beyond the series' range, the small-angle constants only
-    // when some row is at rest: a converging solve takes neither branch.
-    const M small = W::lnot(W::gt(th2e, eps));
-    const M closed = W::gt(th2e, Series<double>::EXP_MAX);
-    if (W::any(closed)) {
-      const V x = W::sel(closed, th2e, V(1.0));
-      const V theta = W::sqrt_(x), ha = 0.5 * theta;
-      const V sn = W::sin_(ha), cs = W::cos_(ha), st = W::sin_(theta), ct = W::cos_(theta);
-      P1 = W::sel(W::land(closed, k.L0), cs, P1);
-      P1 = W::sel(W::land(closed, k.L1), sn / theta, P1);
-      P1 = W::sel(W::land(closed, k.L2), (1.0 - ct) / x, P1);
-      P1 = W::sel(W::land(closed, k.L3), (theta - st) / (x * theta), P1);
-    }
-    if (W::any(small)) {
-      P1 = W::sel(W::land(small, k.L0), V(1.0), P1);
-      P1 = W::sel(W::land(small, W::lor(k.L1, k.L2)), V(0.5), P1);
-      P1 = W::sel(W::land(small, k.L3), V(0.0), P1);
-    }
-  }
   const V th = coeff * qd;  // Q0: theta (lane j = 3 holds coeff w: finite, never used)
   const V th2 = (coeff * coeff) * s2;
   V cJ;  // 1/th^2 - (1 + cos th)/(2 th sin th)
@@ -221,8 +267,6 @@ QILQR_HD void r_knot(const RConsts<W> &k, RState<W> &s, const typename W::V *op,
     const V p01 = W::fma(V(jc[1]), th2, V(jc[0])), p23 = W::fma(V(jc[3]), th2, V(jc[2])), p45 = W::fma(V(jc[5]), th2, V(jc[4])),
             p67 = W::fma(V(jc[7]), th2, V(jc[6]));
     cJ = W::fma(W::fma(p67, x2, p45), x4, W::fma(p23, x2, p01));
-  }
-  {
     const M small = W::lnot(W::gt(th2, eps));  // a rollout that has converged onto its nominal trajectory is here at every knot
     const M closed = W::gt(th2, Series<double>::JINV_MAX);
     if (W::any(closed)) {
@@ -232,97 +276,49 @@ QILQR_HD void r_knot(const RConsts<W> &k, RState<W> &s, const typename W::V *op,
     }
     cJ = W::sel(small, V(0.0), cJ);
   }
-
-  // ---- td = R_n^T (t - t_n) in Q0 and I omega in Q2, in one accumulator
+  // ---- td = R_n^T (t - t_n) in Q0;  rho = td - theta x td / 2 + c theta x (theta x td)
   const V dT = TT - op[OP_TN];
-  V TI = W::template bc<4>(dT) * op[OP_RT + 0];
-  TI = W::template fm<5>(TI, dT, op[OP_RT + 1]);
-  TI = W::template fm<6>(TI, dT, op[OP_RT + 2]);
-  TI = W::template fm<0>(TI, VW, k.IC[0]);
-  TI = W::template fm<1>(TI, VW, k.IC[1]);
-  TI = W::template fm<2>(TI, VW, k.IC[2]);
-
-  // ---- cross products, four quads at a time
-  const V A1 = W::fma(k.SA, VW, th);    // [theta | theta_e | omega | 0]
-  const V B1 = W::fma(k.SB1, VL, TI);   // [td    | rho_e   | I omega | 0]
-  const V A1p = W::rot1(A1), A1pp = W::rot1(A1p);
-  const V C1 = cross_rot<W>(A1p, A1pp, B1);  // [theta x td | theta_e x rho_e | omega x I omega | 0]
-  const V C2 = cross_rot<W>(A1p, A1pp, C1);  // [theta x (theta x td) | theta_e x (theta_e x rho_e) | . | 0]
-  // rho = td - theta x td / 2 + c theta x (theta x td) in Q0;  p = rho_e + a w1 + b w2 in Q1
-  const V CA = W::fma(k.MQ1, W::template bc<2>(P1), k.MH0);
-  const V CB = W::template fm<3>(k.MQ0 * cJ, P1, k.MQ1);
-  const V RP = W::fma(CB, C2, W::fma(CA, C1, B1));
-
+  V td = W::template bc<4>(dT) * op[OP_RT + 0];
+  td = W::template fm<5>(td, dT, op[OP_RT + 1]);
+  td = W::template fm<6>(td, dT, op[OP_RT + 2]);
+  const V thp = W::rot1(th), thpp = W::rot1(thp);
+  const V C1 = cross_rot<W>(thp, thpp, td);
+  const V C2 = cross_rot<W>(thp, thpp, C1);
+  const V RH = W::fma(cJ, C2, W::fma(V(-0.5), C1, td));
   // ---- control (ilqr.hh:158-161): u = (u_nom + alpha k) + K [rho ; theta ; v - v_nom], rows in Q3
   const V dvl = VL - op[OP_VNL], dvw = VW - op[OP_VNW];
-  V u0 = W::template fm<0>(op[OP_U0], RP, op[OP_K + 0]);
-  V u1 = W::template bc<0>(th) * op[OP_K + 3];
   V u2 = W::template bc<0>(dvl) * op[OP_K + 6];
   V u3 = W::template bc<0>(dvw) * op[OP_K + 9];
-  u0 = W::template fm<1>(u0, RP, op[OP_K + 1]);
-  u1 = W::template fm<1>(u1, th, op[OP_K + 4]);
+  V u1 = W::template bc<0>(th) * op[OP_K + 3];
+  V u0 = W::template fm<0>(op[OP_U0], RH, op[OP_K + 0]);
   u2 = W::template fm<1>(u2, dvl, op[OP_K + 7]);
   u3 = W::template fm<1>(u3, dvw, op[OP_K + 10]);
-  u0 = W::template fm<2>(u0, RP, op[OP_K + 2]);
-  u1 = W::template fm<2>(u1, th, op[OP_K + 5]);
+  u1 = W::template fm<1>(u1, th, op[OP_K + 4]);
+  u0 = W::template fm<1>(u0, RH, op[OP_K + 1]);
   u2 = W::template fm<2>(u2, dvl, op[OP_K + 8]);
   u3 = W::template fm<2>(u3, dvw, op[OP_K + 11]);
+  u1 = W::template fm<2>(u1, th, op[OP_K + 5]);
+  u0 = W::template fm<2>(u0, RH, op[OP_K + 2]);
   const V UU = (u0 + u1) + (u2 + u3);
-
-  // ---- what is stored for knot i: [v_lin | t | omega | u] and the quaternion
   st1 = W::fma(k.MQ2_3, VW, W::fma(k.MQ0_3, VL, TT)) + UU;
   st2 = QQ;
-  if (!advance) return;  // the reference's step after the last knot is computed and discarded (ilqr.hh:168)
-
-  // ---- velocity: v + dt a(q, v, u) (quadrotor_model.cc:65-78)
-  V aL = VL + k.GRAVC;
-  aL = W::template fm<0>(aL, QQ, k.S1 * W::template qperm<0xCE>(QQ));  // (z, w, x, .)
-  aL = W::template fm<1>(aL, QQ, k.S2 * W::template qperm<0xDB>(QQ));  // (w, z, y, .)
-  V aW = VW;
-  {
-    V l1 = W::template bc<12>(UU) * k.GLz;
-    V w1 = W::template bc<12>(UU) * k.GW[0];
-    l1 = W::template fm<13>(l1, UU, k.GLz);
-    w1 = W::template fm<13>(w1, UU, k.GW[1]);
-    aL = W::template fm<14>(aL, UU, k.GLz);
-    aW = W::template fm<14>(aW, UU, k.GW[2]);
-    l1 = W::template fm<15>(l1, UU, k.GLz);
-    w1 = W::template fm<15>(w1, UU, k.GW[3]);
-    aL = aL + l1;
-    aW = aW + w1;
-  }
-  {
-    V g1 = W::template bc<8>(C1) * k.NI[0];  // -dt I^-1 (omega x I omega)
-    g1 = W::template fm<9>(g1, C1, k.NI[1]);
-    aW = W::template fm<10>(aW, C1, k.NI[2]);
-    aW = aW + g1;
-  }
-
-  // ---- pose: T <- T Exp(dt v):  t += R(q) p,  q <- q (sh theta_e, ch)
-  const V QQp = W::rot1(QQ), QQpp = W::rot1(QQp);
-  const V C3 = cross_rot<W>(QQp, QQpp, RP);   // Q1: u x p
-  const V C4 = cross_rot<W>(QQp, QQpp, C3);   // Q1: u x (u x p)
-  const V Wq = W::template bc<3>(QQ);
-  const V Rp = W::fma(V(2.0), C4, W::fma(Wq + Wq, C3, RP));
-  const V TTn = W::fma(k.MQ1_3, Rp, TT);
-  const V ZX = cross_rot<W>(QQp, QQpp, THE);  // u x theta_e in every quad
-  const V z = W::fma(Wq, THE, ZX);
-  const V CH = W::template bc<0>(P1), SH = W::template bc<1>(P1);
-  const V ov = W::fma(SH, z, CH * QQ);
-  const V prod = QQ * THE;
-  V dq = W::template bc<0>(prod) + W::template bc<1>(prod);
-  dq = dq + W::template bc<2>(prod);
-  V QQn = W::fma(-(k.MW * SH), dq, ov);
-  {
-    const V sqq = QQn * QQn;
-    V nq = (W::template bc<0>(sqq) + W::template bc<1>(sqq)) + (W::template bc<2>(sqq) + W::template bc<3>(sqq));
-    const M off = W::gt(W::abs_(nq - 1.0), eps);
-    if (W::any(off)) QQn = QQn * W::sel(off, 2.0 / (1.0 + nq), V(1.0));
-  }
-  s.TT = TTn;
-  s.QQ = QQn;
-  s.VL = aL;
-  s.VW = aW;
+  return UU;
+}
+// the control wave, second part: v_{i+1} = F_i + dt (thrust, torques)  (J_u u: rows 8..11 of the constant control Jacobian)
+template <class W>
+QILQR_HD void a_velocity(const RConsts<W> &k, typename W::V UU, typename W::V FL, typename W::V FW, typename W::V &VLn,
+                         typename W::V &VWn) {
+  typedef typename W::V V;
+  V l1 = W::template bc<12>(UU) * k.GLz;
+  V w1 = W::template bc<12>(UU) * k.GW[0];
+  l1 = W::template fm<13>(l1, UU, k.GLz);
+  w1 = W::template fm<13>(w1, UU, k.GW[1]);
+  FL = W::template fm<14>(FL, UU, k.GLz);
+  FW = W::template fm<14>(FW, UU, k.GW[2]);
+  l1 = W::template fm<15>(l1, UU, k.GLz);
+  w1 = W::template fm<15>(w1, UU, k.GW[3]);
+  VLn = FL + l1;
+  VWn = FW + w1;
 }
 
 // Which element of the 18-double knot a lane of st1 / st2 holds (-1: none).  st1 = [v_lin | t | omega | u], st2 = the

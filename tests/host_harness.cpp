@@ -175,8 +175,8 @@ void hh_rollout_tiled(const ModelConsts<double> *c, const double *traj, const do
 }
 
 // k_rollout16 on the CPU: one wavefront = four trajectories (plain [4][n][18] / [4][n][52] arrays), the operand
-// registers of every knot prepared by r16::p_make_ops and consumed by r16::r_knot exactly as the two device
-// wavefronts do (the LDS ring and its flags are plumbing, not arithmetic: not re-enacted).  ops_out (optional):
+// registers of every knot prepared by r16::p_load / p_compute and consumed by r16::a_control / b_knot / a_velocity
+// exactly as the three device wavefronts do (the LDS ring and its flags are plumbing, not arithmetic: not re-enacted).  ops_out (optional):
 // the 23 x 64 operand values of knot `ops_knot`.
 void hh_rollout16(const ModelConsts<double> *c, const double *traj, const double *gains, const double *alpha, double *out,
                   int n, int ops_knot, double *ops_out) {
@@ -187,12 +187,12 @@ void hh_rollout16(const ModelConsts<double> *c, const double *traj, const double
   make_pconsts(pc);
   auto T = [&](int l, int i, int e) { return traj[((long)(l >> 4) * n + i) * 18 + e]; };
   auto G = [&](int l, int i, int e) { return gains[((long)(l >> 4) * n + i) * 52 + e]; };
-  RState<HostWave> s;
+  HV TT, QQ, VL, VW;
   for (int l = 0; l < 64; ++l) {
-    s.TT.v[l] = tt_elem(l) >= 0 ? T(l, 0, tt_elem(l)) : 0.0;
-    s.QQ.v[l] = T(l, 0, qq_elem(l));
-    s.VL.v[l] = vl_elem(l) >= 0 ? T(l, 0, vl_elem(l)) : 0.0;
-    s.VW.v[l] = vw_elem(l) >= 0 ? T(l, 0, vw_elem(l)) : 0.0;
+    TT.v[l] = tt_elem(l) >= 0 ? T(l, 0, tt_elem(l)) : 0.0;
+    QQ.v[l] = T(l, 0, qq_elem(l));
+    VL.v[l] = vl_elem(l) >= 0 ? T(l, 0, vl_elem(l)) : 0.0;
+    VW.v[l] = vw_elem(l) >= 0 ? T(l, 0, vw_elem(l)) : 0.0;
   }
   HV al;
   for (int l = 0; l < 64; ++l) al.v[l] = alpha[l >> 4];
@@ -206,12 +206,18 @@ void hh_rollout16(const ModelConsts<double> *c, const double *traj, const double
       for (int r = 0; r < NOPS; ++r)
         for (int l = 0; l < 64; ++l) ops_out[r * 64 + l] = op[r].v[l];
     HV st1, st2;
-    r_knot<HostWave>(kc, s, op, i + 1 < n, st1, st2);
+    const HV UU = a_control<HostWave>(kc, TT, QQ, VL, VW, op, st1, st2);   // wave A
     for (int l = 0; l < 64; ++l) {
       double *o = out + ((long)(l >> 4) * n + i) * 18;
       if ((l & 15) == 0) o[0] = T(l, i, 0);
       if (st1_elem(l) >= 0) o[st1_elem(l)] = st1.v[l];
       if (st2_elem(l) >= 0) o[st2_elem(l)] = st2.v[l];
+    }
+    if (i + 1 < n) {  // the reference's step after the last knot is computed and discarded (ilqr.hh:168)
+      HV FL, FW, TTn, QQn, VLn, VWn;
+      b_knot<HostWave>(kc, TT, QQ, VL, VW, [&](const HV &l_, const HV &w_) { FL = l_; FW = w_; }, TTn, QQn);  // wave B
+      a_velocity<HostWave>(kc, UU, FL, FW, VLn, VWn);                                                        // wave A
+      TT = TTn; QQ = QQn; VL = VLn; VW = VWn;
     }
   }
 }
