@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libquadrotor_ilqr.so")
+# (QILQR_LIB: another build of the same library, for A/B measurements -- profiles/microbench)
+LIB_PATH = os.environ.get("QILQR_LIB") or os.path.join(_HERE, "lib", "libquadrotor_ilqr.so")
 
 KNOT = 18
 GAIN = 52

@@ -1044,16 +1044,295 @@ __device__ __forceinline__ double bw4_dot_step(double acc, double m, double vx) 
   asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(vx), "v"(m), "n"(R));
   return acc;
 }
+// ---- the three roles of the backward pass over FOUR trajectories per block (k_backward4 and the persistent k_solve4).
+// LDS: ring[trajectory][slot] = knot record followed by the constant operand table; kf[trajectory][parity] = K and the
+// LDL^T factors handed from a matrix wave to the gradient wave.  Every role executes exactly 1 + n block barriers.
+template <typename S>
+__device__ __forceinline__ void bw4_fill_ctab(double (&ring)[4][4][BW2_BUF], const void *ctab, int nthreads) {
+  // constant operand table behind every ring slot
+  for (int t = threadIdx.x; t < CTAB_SIZE; t += nthreads) {
+    const double v = (double)((const S *)ctab)[t];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      ring[g][0][BW2_REC + t] = v;
+      ring[g][1][BW2_REC + t] = v;
+      ring[g][2][BW2_REC + t] = v;
+      ring[g][3][BW2_REC + t] = v;
+    }
+  }
+}
+// G: gradients of four trajectories, one row of 16 lanes each (lane = 16 g + j).  gains / dump4: the gains of the row's
+// trajectory (tiled) and its four-element dump slot; grun: the row's trajectory is being solved.  Returns Q_u^T k summed
+// over the knots (every lane of the row holds it).
+template <typename S>
+__device__ __forceinline__ double bw4_gradient_wave(double (&ring)[4][4][BW2_BUF], double (&kf)[4][2][80], const RecLayout &L,
+                                                    S *gains, S *dump4, bool grun, int n, int lane) {
+  typedef typename GA<S>::v2 sv2;
+  typedef typename GA<S>::ptr2 gptr2;
+  const int g = lane >> 4, j = lane & 15;
+  // operand addresses of lane (g, j) in ring slot 0: column j of M (12 rows) and entry j of [C_x ; C_u]
+  // (the slot is a compile-time constant in gradient_step, so it folds into the ds_read offset field)
+  const double *mp[12];
+#pragma unroll
+  for (int r = 0; r < 12; ++r) {
+    const int src = m_source_tab(r, j);
+    mp[r] = &ring[g][0][(src >= 0) ? src : BW2_REC + (-1 - src)];
+  }
+  const double *gp = &ring[g][0][L.off_g + j];
+  const bool kowner = grun && (j == 0);
+  gptr2 kdst0 = (gptr2)(kowner ? gains + knot_elem<true>(n - 1, 0, 52) : dump4);
+  gptr2 kdst1 = (gptr2)(kowner ? gains + knot_elem<true>(n - 1, 2, 52) : dump4 + 2);
+  const long kst = kowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
+  double vx = 0.0;  // V_x[j] (lanes j < 12)
+  double QuTk = 0.0;
+  __syncthreads();
+  auto gradient_slot = [&](int q, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const double *f = kf[g][q & 1];
+    // every LDS read of the step first, in the order of use (LDS returns in order): one exposed round trip
+    double m[12];
+#pragma unroll
+    for (int r = 0; r < 12; ++r) m[r] = mp[r][SLOT * BW2_BUF];
+    const double gcj = gp[SLOT * BW2_BUF];
+    asm volatile("" ::: "memory");
+    const double c0 = f[4 * j], c1 = f[4 * j + 1], c2 = f[4 * j + 2], c3 = f[4 * j + 3];  // K[:, j]
+    const double l10 = f[64], l20 = f[65], l30 = f[66], l21 = f[67], l31 = f[68], l32 = f[69], i0 = f[70],
+                 i1 = f[71], i2 = f[72], i3 = f[73];
+    asm volatile("" ::: "memory");
+    // [Q_x ; Q_u][j] = [C_x ; C_u][j] + sum_r M[r][j] V_x[r], three partial sums of four rows.  (Not the
+    // summation order of k_backward / k_backward2 -- rows kk, 4 + kk, 8 + kk chained, then a butterfly: that
+    // order was tried here for bit-identical results across batch sizes, costs 3% and still differs in the
+    // last bit elsewhere.  Results agree to ~1e-15 relative; the tests state it.)
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+    p0 = bw4_dot_step<0>(p0, m[0], vx); p1 = bw4_dot_step<4>(p1, m[4], vx); p2 = bw4_dot_step<8>(p2, m[8], vx);
+    p0 = bw4_dot_step<1>(p0, m[1], vx); p1 = bw4_dot_step<5>(p1, m[5], vx); p2 = bw4_dot_step<9>(p2, m[9], vx);
+    p0 = bw4_dot_step<2>(p0, m[2], vx); p1 = bw4_dot_step<6>(p1, m[6], vx); p2 = bw4_dot_step<10>(p2, m[10], vx);
+    p0 = bw4_dot_step<3>(p0, m[3], vx); p1 = bw4_dot_step<7>(p1, m[7], vx); p2 = bw4_dot_step<11>(p2, m[11], vx);
+    const double ghat = gcj + ((p0 + p1) + p2);
+    const double Qu0 = row_bcast<12>(ghat), Qu1 = row_bcast<13>(ghat), Qu2 = row_bcast<14>(ghat),
+                 Qu3 = row_bcast<15>(ghat);
+    vx = ghat + ((c0 * Qu0 + c1 * Qu1) + (c2 * Qu2 + c3 * Qu3));  // V_x = Q_x + K^T Q_u: the recurrence ends here
+    const double y0 = Qu0, y1 = Qu1 - l10 * y0, y2 = Qu2 - l20 * y0 - l21 * y1,
+                 y3 = Qu3 - l30 * y0 - l31 * y1 - l32 * y2;
+    const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
+                 x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
+    const double k0 = -x0, k1 = -x1, k2 = -x2, k3 = -x3;  // feed-forward (ilqr.hh:128)
+    const sv2 w0 = {(S)k0, (S)k1}, w1 = {(S)k2, (S)k3};
+    *kdst0 = w0;
+    *kdst1 = w1;
+    kdst0 -= kst;
+    kdst1 -= kst;
+    QuTk += Qu0 * k0 + Qu1 * k1 + Qu2 * k2 + Qu3 * k3;
+  };
+  auto gradient_step = [&](int q) {
+    switch (q & 3) {
+      case 0: gradient_slot(q, std::integral_constant<int, 0>()); break;
+      case 1: gradient_slot(q, std::integral_constant<int, 1>()); break;
+      case 2: gradient_slot(q, std::integral_constant<int, 2>()); break;
+      default: gradient_slot(q, std::integral_constant<int, 3>()); break;
+    }
+  };
+  // interval i: issue the loads of record i-3 (set B), gradient step of knot i+1, record i-2 (set A, loaded
+  // one interval ago) into the ring; the two sets swap roles every interval
+  for (int i = n - 1; i >= 0; --i) {
+    if (i + 1 <= n - 1) gradient_step(i + 1);
+    __syncthreads();
+  }
+  gradient_step(0);
+  return QuTk;
+}
+// L: streams the knot records of the block's four trajectories (rec0..rec3: their record bases) into the rings
+template <typename S>
+__device__ __forceinline__ void bw4_loader_wave(double (&ring)[4][4][BW2_BUF], const RecLayout &L, const S *rec0, const S *rec1,
+                                                const S *rec2, const S *rec3, int n, int lane) {
+  const int tl = (L.stride - 65 < lane) ? L.stride - 65 : lane;  // second load: elements 64 .. stride-1, clamped
+  typename GA<S>::cptr lp[4] = {(typename GA<S>::cptr)rec0, (typename GA<S>::cptr)rec1, (typename GA<S>::cptr)rec2,
+                               (typename GA<S>::cptr)rec3};
+  S q0[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {  // (trajectories with nothing to do are streamed too: no branches in this wave)
+    typename GA<S>::cptr a = lp[g] + rec_elem(n - 1, 0, L.stride);
+    const S a0 = a[lane], a1 = a[64 + tl];
+    S b0_ = 0, b1_ = 0;
+    if (n >= 2) {
+      typename GA<S>::cptr b2 = lp[g] + rec_elem(n - 2, 0, L.stride);
+      b0_ = b2[lane];
+      b1_ = b2[64 + tl];
+    }
+    if (n >= 3) {
+      typename GA<S>::cptr c3 = lp[g] + rec_elem(n - 3, 0, L.stride);
+      q0[g] = c3[lane];
+      q1[g] = c3[64 + tl];
+    }
+    ring[g][(n - 1) & 3][lane] = (double)a0;
+    ring[g][(n - 1) & 3][64 + lane] = (double)a1;
+    if (n >= 2) {
+      ring[g][(n - 2) & 3][lane] = (double)b0_;
+      ring[g][(n - 2) & 3][64 + lane] = (double)b1_;
+    }
+  }
+  __syncthreads();  // rings and constant tables are filled
+  for (int i = n - 1; i >= 0; --i) {
+    // first the four records requested one interval ago, then the next four requests: the wait in front of
+    // the LDS writes is for loads that are all older than anything in flight
+    if (i - 2 >= 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        ring[g][(i - 2) & 3][lane] = (double)q0[g];
+        ring[g][(i - 2) & 3][64 + lane] = (double)q1[g];
+      }
+    }
+    if (i - 3 >= 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        typename GA<S>::cptr a = lp[g] + rec_elem(i - 3, 0, L.stride);
+        q0[g] = a[lane];
+        q1[g] = a[64 + tl];
+      }
+    }
+    __syncthreads();
+  }
+}
+// M_w: the matrix recursion of one trajectory (ring / kf row w).  cuu: the lane's entry of C_uu = 2 R (+ mu on the diagonal,
+// lm_restart) in accumulator register 3 (row 12 + kk, column j >= 12), zero elsewhere.
+template <typename S>
+__device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], double (&kf)[4][2][80], const RecLayout &L, int w,
+                                                bool run, S *gains, S *dump4, double cuu, int n, int lane,
+                                                unsigned long long *stamps_out) {
+  typedef typename GA<S>::v2 sv2;
+  typedef typename GA<S>::ptr2 gptr2;
+  const int j = lane & 15, kk = lane >> 4;
+  int off[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int src;
+    if (k < 3) src = m_source_tab(4 * k + kk, j);
+    else src = (j < 12) ? cxx_source_tab(L, 4 * (k - 3) + kk, j) : -1 - CTAB_ZERO;
+    off[k] = (src >= 0) ? src : BW2_REC + (-1 - src);
+  }
+  const bool gowner = run && (kk == 0 && j < 12);
+  const int ge0 = 4 + 4 * j;
+  gptr2 gdst0 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0, 52) : dump4);
+  gptr2 gdst1 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0 + 2, 52) : dump4 + 2);
+  const long gstep = gowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
+  double va[3] = {0.0, 0.0, 0.0};  // V_xx[j][4 kc + kk]  (A operand)
+  __syncthreads();  // rings and constant tables are filled
+  if (!run) {
+    // this trajectory has nothing to do in this round: keep the block's barriers company
+    for (int i = n - 1; i >= 0; --i) __syncthreads();
+    return;
+  }
+  double m[3], cx[3];
+  {
+    const double *buf = ring[w][(n - 1) & 3];
+    m[0] = buf[off[0]]; m[1] = buf[off[1]]; m[2] = buf[off[2]];
+    cx[0] = buf[off[3]]; cx[1] = buf[off[4]]; cx[2] = buf[off[5]];
+  }
+  // The knot loop is sensitive to where its instruction stream sits: the same code shifted by 4 bytes (mod 8) runs 7 %
+  // slower (71.5 -> 77 us per launch at B = 1024; MI355X_MICROARCH.md, "code-placement sensitivity").  Pin it to a
+  // 64-byte boundary.
+#ifndef QILQR_BW4_PHASE
+#define QILQR_BW4_PHASE 1  // s_nop s behind the boundary: the phase measured fastest of 0..7 (71.6 us; the others 72.0 - 73.6)
+#endif
+  asm volatile(".p2align 6\n\t.rept %0\n\ts_nop 0\n\t.endr" ::"n"(QILQR_BW4_PHASE));
+#ifdef QILQR_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev, real0;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real0)::"memory");
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+  for (int i = n - 1; i >= 0; --i) {
+    // operands of knot i-1, for the next iteration (the slot was filled during the previous interval)
+    const double *nb = ring[w][(i > 0 ? i - 1 : 0) & 3];
+    const double m_n0 = nb[off[0]], m_n1 = nb[off[1]], m_n2 = nb[off[2]], cx_n0 = nb[off[3]], cx_n1 = nb[off[4]],
+                 cx_n2 = nb[off[5]];
+    d4 T = {0.0, 0.0, 0.0, 0.0};
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0], m[0], T, 0, 0, 0);
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1], m[1], T, 0, 0, 0);
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2], m[2], T, 0, 0, 0);
+    QKEEP(T[0]); QKEEP(T[3]);
+    QSTAMP(0);  // ring reads issued, T = V M
+    d4 H = {cx[0], cx[1], cx[2], cuu};
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
+    QKEEP(H[0]); QKEEP(H[3]);
+    QSTAMP(1);  // H = C + M^T T
+    double Quu[16], Qu_unused[4], col[4];
+    gather_rows(H[3], col);
+    bcast_quu_row<0>(col, 0.0, Quu, Qu_unused);
+    bcast_quu_row<1>(col, 0.0, Quu, Qu_unused);
+    bcast_quu_row<2>(col, 0.0, Quu, Qu_unused);
+    bcast_quu_row<3>(col, 0.0, Quu, Qu_unused);
+    QKEEP(Quu[0]); QKEEP(Quu[15]); QKEEP(col[3]);
+    QSTAMP(2);  // gather + Q_uu broadcast
+    // LDL^T of the lower triangle of Q_uu (ilqr.hh:126), as in k_backward
+    const double i0 = rcp_nr(Quu[0]);
+    const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
+    const double d1 = Quu[5] - l10 * Quu[4];
+    const double i1 = rcp_nr(d1);
+    const double c21 = Quu[9] - l20 * Quu[4], c31 = Quu[13] - l30 * Quu[4];
+    const double l21 = c21 * i1, l31 = c31 * i1;
+    const double d2 = Quu[10] - l20 * Quu[8] - l21 * c21;
+    const double i2 = rcp_nr(d2);
+    const double c32 = Quu[14] - l30 * Quu[8] - l31 * c21;
+    const double l32 = c32 * i2;
+    const double d3 = Quu[15] - l30 * Quu[12] - l31 * c31 - l32 * c32;
+    const double i3 = rcp_nr(d3);
+    double kcol[4];
+    {
+      const double y0 = col[0], y1 = col[1] - l10 * y0, y2 = col[2] - l20 * y0 - l21 * y1,
+                   y3 = col[3] - l30 * y0 - l31 * y1 - l32 * y2;
+      const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
+                   x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
+      kcol[0] = -x0; kcol[1] = -x1; kcol[2] = -x2; kcol[3] = -x3;  // K[:, j] (ilqr.hh:127)
+    }
+    QKEEP(kcol[0]); QKEEP(kcol[3]);
+    QSTAMP(4);  // LDL^T + solve
+    {
+      const sv2 w0 = {(S)kcol[0], (S)kcol[1]}, w1 = {(S)kcol[2], (S)kcol[3]};
+      *gdst0 = w0;
+      *gdst1 = w1;
+      gdst0 -= gstep;
+      gdst1 -= gstep;
+    }
+    // hand K and the factors to G (the four lanes of a column hold the same K[:, j]: same address, same data)
+    double *f = kf[w][i & 1];
+    f[4 * j] = kcol[0]; f[4 * j + 1] = kcol[1]; f[4 * j + 2] = kcol[2]; f[4 * j + 3] = kcol[3];
+    if (lane == 0) {
+      f[64] = l10; f[65] = l20; f[66] = l30; f[67] = l21; f[68] = l31; f[69] = l32;
+      f[70] = i0; f[71] = i1; f[72] = i2; f[73] = i3;
+    }
+    QSTAMP(5);  // gain stores, hand-off to G
+    // V_xx = Q_xx + Q_xu K: A[j][kk] = Q_xu[j][kk] = H[12 + kk][j] is accumulator register 3
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(H[3], sel4(kcol, kk), H, 0, 0, 0);
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
+    m[0] = m_n0; m[1] = m_n1; m[2] = m_n2;
+    cx[0] = cx_n0; cx[1] = cx_n1; cx[2] = cx_n2;
+    QKEEP(va[0]); QKEEP(m[2]);
+    QSTAMP(6);  // V_xx MFMA, next operands
+    __syncthreads();
+    QSTAMP(7);  // barrier
+  }
+#ifdef QILQR_STAMPS
+  {
+    // slot 3 (no section of wave M uses it): the loop's duration on the constant 100 MHz clock, so that
+    // cycles / time gives the shader clock the loop ran at
+    unsigned long long real1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real1)::"memory");
+    stamp_sum[3] = (real1 - real0) & 0xfffffull;
+  }
+  if (lane == 0 && stamps_out)
+    for (int k = 0; k < 8; ++k) stamps_out[k] = stamp_sum[k];
+#endif
+}
+
 template <typename S>
 __global__ __launch_bounds__(384) void k_backward4(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n,
                                                    int force) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0..3: matrix wave of trajectory b0 + w; 4: G; 5: L
   const int b0 = blockIdx.x * 4;
-#ifdef QILQR_STAMPS
-  unsigned long long real_entry, real_loaded = 0, real_settled = 0, real_bar1 = 0;
-  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real_entry)::"memory");
-#endif
   __shared__ int s_run[4], s_cur[4], s_iters[4], s_act[4];
   __shared__ double s_cost[4];
   // four slots per trajectory: in interval i the matrix wave reads slot (i-1) & 3 and writes slot (i-2) & 3
@@ -1089,9 +1368,6 @@ __global__ __launch_bounds__(384) void k_backward4(ModelConsts<double> c, SolveP
           const int i = 64 * h + lane;
           kc_early[k][h] = (i < n) ? st.knot_cost[k][cost_index(b, i, n)] : 0.0;
         }
-#ifdef QILQR_STAMPS
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real_loaded)::"memory");
-#endif
       bool restart = false;
       bool settle = false, accept = false, count_active = false, known = true;
       int status = -1;
@@ -1186,13 +1462,7 @@ __global__ __launch_bounds__(384) void k_backward4(ModelConsts<double> c, SolveP
       s_cost[w] = cost_now;
     }
   }
-#ifdef QILQR_STAMPS
-  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real_settled)::"memory");
-#endif
   __syncthreads();
-#ifdef QILQR_STAMPS
-  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real_bar1)::"memory");
-#endif
   // one add per block, and where nobody waits for it: here for a block that has no recursion to run, at the
   // end of the gradient wave otherwise
   const int block_act = s_act[0] + s_act[1] + s_act[2] + s_act[3];
@@ -1201,95 +1471,14 @@ __global__ __launch_bounds__(384) void k_backward4(ModelConsts<double> c, SolveP
     return;
   }
 
-  // constant operand table behind every ring slot
-  for (int t = threadIdx.x; t < CTAB_SIZE; t += 384) {
-    const double v = (double)((const S *)st.ctab)[t];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      ring[g][0][BW2_REC + t] = v;
-      ring[g][1][BW2_REC + t] = v;
-      ring[g][2][BW2_REC + t] = v;
-      ring[g][3][BW2_REC + t] = v;
-    }
-  }
-  typedef typename GA<S>::v2 sv2;
-  typedef typename GA<S>::ptr2 gptr2;
-
+  bw4_fill_ctab<S>(ring, st.ctab, 384);
   if (w == 4) {
-    // ------------------------------------------------------------------ G: records + gradients of four trajectories
+    // ------------------------------------------------------------------ G: gradients of four trajectories
     const int g = lane >> 4, j = lane & 15;
     const int bg = (b0 + g < B) ? b0 + g : B - 1;  // a valid stand-in for a missing trajectory (never stored)
     const bool grun = s_run[g] != 0;
-    // operand addresses of lane (g, j) in ring slot 0: column j of M (12 rows) and entry j of [C_x ; C_u]
-    // (the slot is a compile-time constant in gradient_step, so it folds into the ds_read offset field)
-    const double *mp[12];
-#pragma unroll
-    for (int r = 0; r < 12; ++r) {
-      const int src = m_source_tab(r, j);
-      mp[r] = &ring[g][0][(src >= 0) ? src : BW2_REC + (-1 - src)];
-    }
-    const double *gp = &ring[g][0][L.off_g + j];
-    S *gains = (S *)st.gains + knot_base<true>(bg, n, 52);
-    const bool kowner = grun && (j == 0);
-    gptr2 kdst0 = (gptr2)(kowner ? gains + knot_elem<true>(n - 1, 0, 52) : (S *)st.dump + 4 * (long)bg);
-    gptr2 kdst1 = (gptr2)(kowner ? gains + knot_elem<true>(n - 1, 2, 52) : (S *)st.dump + 4 * (long)bg + 2);
-    const long kst = kowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
-    double vx = 0.0;  // V_x[j] (lanes j < 12)
-    double QuTk = 0.0;
-    __syncthreads();
-    auto gradient_slot = [&](int q, auto slot_tag) {
-      constexpr int SLOT = decltype(slot_tag)::value;
-      const double *f = kf[g][q & 1];
-      // every LDS read of the step first, in the order of use (LDS returns in order): one exposed round trip
-      double m[12];
-#pragma unroll
-      for (int r = 0; r < 12; ++r) m[r] = mp[r][SLOT * BW2_BUF];
-      const double gcj = gp[SLOT * BW2_BUF];
-      asm volatile("" ::: "memory");
-      const double c0 = f[4 * j], c1 = f[4 * j + 1], c2 = f[4 * j + 2], c3 = f[4 * j + 3];  // K[:, j]
-      const double l10 = f[64], l20 = f[65], l30 = f[66], l21 = f[67], l31 = f[68], l32 = f[69], i0 = f[70],
-                   i1 = f[71], i2 = f[72], i3 = f[73];
-      asm volatile("" ::: "memory");
-      // [Q_x ; Q_u][j] = [C_x ; C_u][j] + sum_r M[r][j] V_x[r], three partial sums of four rows.  (Not the
-      // summation order of k_backward / k_backward2 -- rows kk, 4 + kk, 8 + kk chained, then a butterfly: that
-      // order was tried here for bit-identical results across batch sizes, costs 3% and still differs in the
-      // last bit elsewhere.  Results agree to ~1e-15 relative; the tests state it.)
-      double p0 = 0.0, p1 = 0.0, p2 = 0.0;
-      p0 = bw4_dot_step<0>(p0, m[0], vx); p1 = bw4_dot_step<4>(p1, m[4], vx); p2 = bw4_dot_step<8>(p2, m[8], vx);
-      p0 = bw4_dot_step<1>(p0, m[1], vx); p1 = bw4_dot_step<5>(p1, m[5], vx); p2 = bw4_dot_step<9>(p2, m[9], vx);
-      p0 = bw4_dot_step<2>(p0, m[2], vx); p1 = bw4_dot_step<6>(p1, m[6], vx); p2 = bw4_dot_step<10>(p2, m[10], vx);
-      p0 = bw4_dot_step<3>(p0, m[3], vx); p1 = bw4_dot_step<7>(p1, m[7], vx); p2 = bw4_dot_step<11>(p2, m[11], vx);
-      const double ghat = gcj + ((p0 + p1) + p2);
-      const double Qu0 = row_bcast<12>(ghat), Qu1 = row_bcast<13>(ghat), Qu2 = row_bcast<14>(ghat),
-                   Qu3 = row_bcast<15>(ghat);
-      vx = ghat + ((c0 * Qu0 + c1 * Qu1) + (c2 * Qu2 + c3 * Qu3));  // V_x = Q_x + K^T Q_u: the recurrence ends here
-      const double y0 = Qu0, y1 = Qu1 - l10 * y0, y2 = Qu2 - l20 * y0 - l21 * y1,
-                   y3 = Qu3 - l30 * y0 - l31 * y1 - l32 * y2;
-      const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
-                   x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
-      const double k0 = -x0, k1 = -x1, k2 = -x2, k3 = -x3;  // feed-forward (ilqr.hh:128)
-      const sv2 w0 = {(S)k0, (S)k1}, w1 = {(S)k2, (S)k3};
-      *kdst0 = w0;
-      *kdst1 = w1;
-      kdst0 -= kst;
-      kdst1 -= kst;
-      QuTk += Qu0 * k0 + Qu1 * k1 + Qu2 * k2 + Qu3 * k3;
-    };
-    auto gradient_step = [&](int q) {
-      switch (q & 3) {
-        case 0: gradient_slot(q, std::integral_constant<int, 0>()); break;
-        case 1: gradient_slot(q, std::integral_constant<int, 1>()); break;
-        case 2: gradient_slot(q, std::integral_constant<int, 2>()); break;
-        default: gradient_slot(q, std::integral_constant<int, 3>()); break;
-      }
-    };
-    // interval i: issue the loads of record i-3 (set B), gradient step of knot i+1, record i-2 (set A, loaded
-    // one interval ago) into the ring; the two sets swap roles every interval
-    for (int i = n - 1; i >= 0; --i) {
-      if (i + 1 <= n - 1) gradient_step(i + 1);
-      __syncthreads();
-    }
-    gradient_step(0);
+    const double QuTk = bw4_gradient_wave<S>(ring, kf, L, (S *)st.gains + knot_base<true>(bg, n, 52), (S *)st.dump + 4 * (long)bg, grun,
+                                             n, lane);
     if (j == 0 && grun) {
       const int b = b0 + g;
       st.terms[2 * b] = QuTk;
@@ -1317,187 +1506,25 @@ __global__ __launch_bounds__(384) void k_backward4(ModelConsts<double> c, SolveP
   }
 
   if (w == 5) {
-    // ---------------------------------------------------------------- L: knot records of four trajectories
-    const int tl = (L.stride - 65 < lane) ? L.stride - 65 : lane;  // second load: elements 64 .. stride-1, clamped
-    typename GA<S>::cptr lp[4];
-    S q0[4], q1[4];
+    // ------------------------------------------------------------------ L: knot records of four trajectories
+    const S *rec[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int bg = (b0 + g < B) ? b0 + g : B - 1;
-      lp[g] = (typename GA<S>::cptr)((const S *)st.lin[s_cur[g]] + rec_base(bg, n, L.stride));
-      q0[g] = 0; q1[g] = 0;
+      rec[g] = (const S *)st.lin[s_cur[g]] + rec_base(bg, n, L.stride);
     }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {  // (trajectories with nothing to do are streamed too: no branches in this wave)
-      typename GA<S>::cptr a = lp[g] + rec_elem(n - 1, 0, L.stride);
-      const S a0 = a[lane], a1 = a[64 + tl];
-      S b0_ = 0, b1_ = 0;
-      if (n >= 2) {
-        typename GA<S>::cptr b2 = lp[g] + rec_elem(n - 2, 0, L.stride);
-        b0_ = b2[lane];
-        b1_ = b2[64 + tl];
-      }
-      if (n >= 3) {
-        typename GA<S>::cptr c3 = lp[g] + rec_elem(n - 3, 0, L.stride);
-        q0[g] = c3[lane];
-        q1[g] = c3[64 + tl];
-      }
-      ring[g][(n - 1) & 3][lane] = (double)a0;
-      ring[g][(n - 1) & 3][64 + lane] = (double)a1;
-      if (n >= 2) {
-        ring[g][(n - 2) & 3][lane] = (double)b0_;
-        ring[g][(n - 2) & 3][64 + lane] = (double)b1_;
-      }
-    }
-    __syncthreads();  // rings and constant tables are filled
-    for (int i = n - 1; i >= 0; --i) {
-      // first the four records requested one interval ago, then the next four requests: the wait in front of
-      // the LDS writes is for loads that are all older than anything in flight
-      if (i - 2 >= 0) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          ring[g][(i - 2) & 3][lane] = (double)q0[g];
-          ring[g][(i - 2) & 3][64 + lane] = (double)q1[g];
-        }
-      }
-      if (i - 3 >= 0) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          typename GA<S>::cptr a = lp[g] + rec_elem(i - 3, 0, L.stride);
-          q0[g] = a[lane];
-          q1[g] = a[64 + tl];
-        }
-      }
-      __syncthreads();
-    }
+    bw4_loader_wave<S>(ring, L, rec[0], rec[1], rec[2], rec[3], n, lane);
     return;
   }
   // -------------------------------------------------------------------- M_w: matrix recursion of trajectory b0 + w
-  const bool run = s_run[w] != 0;
-  const int b = (b0 + w < B) ? b0 + w : B - 1;
-  const int j = lane & 15, kk = lane >> 4;
-  int off[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    int src;
-    if (k < 3) src = m_source_tab(4 * k + kk, j);
-    else src = (j < 12) ? cxx_source_tab(L, 4 * (k - 3) + kk, j) : -1 - CTAB_ZERO;
-    off[k] = (src >= 0) ? src : BW2_REC + (-1 - src);
-  }
-  S *gains = (S *)st.gains + knot_base<true>(b, n, 52);
-  const bool gowner = run && (kk == 0 && j < 12);
-  const int ge0 = 4 + 4 * j;
-  gptr2 gdst0 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0, 52) : (S *)st.dump + 4 * (long)b);
-  gptr2 gdst1 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0 + 2, 52) : (S *)st.dump + 4 * (long)b + 2);
-  const long gstep = gowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
-  // register 3 <-> row 12 + kk: C_uu = 2 R (+ mu on the diagonal, lm_restart)
-  const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] + ((j - 12 == kk) ? mu : 0.0) : 0.0;
-  double va[3] = {0.0, 0.0, 0.0};  // V_xx[j][4 kc + kk]  (A operand)
-  __syncthreads();  // rings and constant tables are filled
-  if (!run) {
-    // this trajectory has nothing to do in this round: keep the block's barriers company
-    for (int i = n - 1; i >= 0; --i) __syncthreads();
-    return;
-  }
-  double m[3], cx[3];
   {
-    const double *buf = ring[w][(n - 1) & 3];
-    m[0] = buf[off[0]]; m[1] = buf[off[1]]; m[2] = buf[off[2]];
-    cx[0] = buf[off[3]]; cx[1] = buf[off[4]]; cx[2] = buf[off[5]];
+    const int b = (b0 + w < B) ? b0 + w : B - 1;
+    const int j = lane & 15, kk = lane >> 4;
+    // register 3 <-> row 12 + kk: C_uu = 2 R (+ mu on the diagonal, lm_restart)
+    const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] + ((j - 12 == kk) ? mu : 0.0) : 0.0;
+    bw4_matrix_wave<S>(ring, kf, L, w, s_run[w] != 0, (S *)st.gains + knot_base<true>(b, n, 52), (S *)st.dump + 4 * (long)b, cuu, n,
+                       lane, st.stamps ? st.stamps + (long)(b0 + w) * 8 : nullptr);
   }
-#ifdef QILQR_STAMPS
-  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev, real0;
-  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real0)::"memory");
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
-#endif
-  for (int i = n - 1; i >= 0; --i) {
-    // operands of knot i-1, for the next iteration (the slot was filled during the previous interval)
-    const double *nb = ring[w][(i > 0 ? i - 1 : 0) & 3];
-    const double m_n0 = nb[off[0]], m_n1 = nb[off[1]], m_n2 = nb[off[2]], cx_n0 = nb[off[3]], cx_n1 = nb[off[4]],
-                 cx_n2 = nb[off[5]];
-    d4 T = {0.0, 0.0, 0.0, 0.0};
-    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0], m[0], T, 0, 0, 0);
-    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1], m[1], T, 0, 0, 0);
-    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2], m[2], T, 0, 0, 0);
-    QKEEP(T[0]); QKEEP(T[3]);
-    QSTAMP(0);  // ring reads issued, T = V M
-    d4 H = {cx[0], cx[1], cx[2], cuu};
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
-    QKEEP(H[0]); QKEEP(H[3]);
-    QSTAMP(1);  // H = C + M^T T
-    double Quu[16], Qu_unused[4], col[4];
-    gather_rows(H[3], col);
-    bcast_quu_row<0>(col, 0.0, Quu, Qu_unused);
-    bcast_quu_row<1>(col, 0.0, Quu, Qu_unused);
-    bcast_quu_row<2>(col, 0.0, Quu, Qu_unused);
-    bcast_quu_row<3>(col, 0.0, Quu, Qu_unused);
-    QKEEP(Quu[0]); QKEEP(Quu[15]); QKEEP(col[3]);
-    QSTAMP(2);  // gather + Q_uu broadcast
-    // LDL^T of the lower triangle of Q_uu (ilqr.hh:126), as in k_backward
-    const double i0 = rcp_nr(Quu[0]);
-    const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
-    const double d1 = Quu[5] - l10 * Quu[4];
-    const double i1 = rcp_nr(d1);
-    const double c21 = Quu[9] - l20 * Quu[4], c31 = Quu[13] - l30 * Quu[4];
-    const double l21 = c21 * i1, l31 = c31 * i1;
-    const double d2 = Quu[10] - l20 * Quu[8] - l21 * c21;
-    const double i2 = rcp_nr(d2);
-    const double c32 = Quu[14] - l30 * Quu[8] - l31 * c21;
-    const double l32 = c32 * i2;
-    const double d3 = Quu[15] - l30 * Quu[12] - l31 * c31 - l32 * c32;
-    const double i3 = rcp_nr(d3);
-    double kcol[4];
-    {
-      const double y0 = col[0], y1 = col[1] - l10 * y0, y2 = col[2] - l20 * y0 - l21 * y1,
-                   y3 = col[3] - l30 * y0 - l31 * y1 - l32 * y2;
-      const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
-                   x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
-      kcol[0] = -x0; kcol[1] = -x1; kcol[2] = -x2; kcol[3] = -x3;  // K[:, j] (ilqr.hh:127)
-    }
-    QKEEP(kcol[0]); QKEEP(kcol[3]);
-    QSTAMP(4);  // LDL^T + solve
-    {
-      const sv2 w0 = {(S)kcol[0], (S)kcol[1]}, w1 = {(S)kcol[2], (S)kcol[3]};
-      *gdst0 = w0;
-      *gdst1 = w1;
-      gdst0 -= gstep;
-      gdst1 -= gstep;
-    }
-    // hand K and the factors to G (the four lanes of a column hold the same K[:, j]: same address, same data)
-    double *f = kf[w][i & 1];
-    f[4 * j] = kcol[0]; f[4 * j + 1] = kcol[1]; f[4 * j + 2] = kcol[2]; f[4 * j + 3] = kcol[3];
-    if (lane == 0) {
-      f[64] = l10; f[65] = l20; f[66] = l30; f[67] = l21; f[68] = l31; f[69] = l32;
-      f[70] = i0; f[71] = i1; f[72] = i2; f[73] = i3;
-    }
-    QSTAMP(5);  // gain stores, hand-off to G
-    // V_xx = Q_xx + Q_xu K: A[j][kk] = Q_xu[j][kk] = H[12 + kk][j] is accumulator register 3
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(H[3], sel4(kcol, kk), H, 0, 0, 0);
-#pragma unroll
-    for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
-    m[0] = m_n0; m[1] = m_n1; m[2] = m_n2;
-    cx[0] = cx_n0; cx[1] = cx_n1; cx[2] = cx_n2;
-    QKEEP(va[0]); QKEEP(m[2]);
-    QSTAMP(6);  // V_xx MFMA, next operands
-    __syncthreads();
-    QSTAMP(7);  // barrier
-  }
-#ifdef QILQR_STAMPS
-  {
-    // slot 3 (no section of wave M uses it): the loop's duration on the constant 100 MHz clock, so that
-    // cycles / time gives the shader clock the loop ran at
-    unsigned long long real1;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real1)::"memory");
-    // loop (16 bits, 10 ns units... 32 bits) | entry -> loads arrived | -> settled | -> first barrier | -> loop
-    stamp_sum[3] = ((real1 - real0) & 0xfffffull) | (((real_loaded - real_entry) & 0x7ffull) << 20) |
-                   (((real_settled - real_loaded) & 0x7ffull) << 31) | (((real_bar1 - real_settled) & 0x7ffull) << 42) |
-                   (((real0 - real_bar1) & 0x7ffull) << 53);
-  }
-  if (lane == 0 && st.stamps)
-    for (int k = 0; k < 8; ++k) st.stamps[(long)(b0 + w) * 8 + k] = stamp_sum[k];
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1866,7 +1893,196 @@ struct DevWave {
 
 constexpr int R16_RING = 4;
 constexpr int R16_SPIN_MAX = 1 << 22;
-enum { R16_F_PROD = 0, R16_F_CONS, R16_F_V, R16_F_T, R16_F_F, R16_NFLAGS };
+constexpr int R16_CHUNK = 16;  // knots per "stored and visible" announcement of wave A (k_solve4's linearisation follows it)
+enum { R16_F_PROD = 0, R16_F_CONS, R16_F_V, R16_F_T, R16_F_F, R16_F_K, R16_F_ABORT, R16_NFLAGS };
+enum { X_T = 0, X_V = 1, X_F = 2 };
+// LDS of the three rollout roles
+struct R16Lds {
+  double ops[R16_RING][r16::NOPS][64];  // operand registers of R16_RING knots, [register][lane]
+  double xch[3][2][2][64];             // hand-off slots [X_T (t, q) | X_V v | X_F free velocity][parity of the knot][register][lane]
+  int flags[R16_NFLAGS];               // knots produced by P / used by A; v_k, (t, q)_k, F_k ready; knots stored; abort
+};
+// The LDS executes the operations of one wavefront in the order they were issued, so a flag written after the data (or
+// after the reads of a slot) is seen after them: no s_waitcnt, and no workgroup fence -- a release fence would wait for the
+// wavefront's outstanding GLOBAL loads and stores too (vmcnt(0)), i.e. for P's prefetch and A's knot stores, on every
+// knot.  The asm statements only keep the compiler from moving LDS accesses across the flag.
+__device__ __forceinline__ int r16_flag_read(R16Lds &sh, int which) {
+  return __hip_atomic_load(&sh.flags[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void r16_flag_post(R16Lds &sh, int which, int value, int lane) {
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_store(&sh.flags[which], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// false: the flag never came (a bounded spin: the kernel ends instead of hanging); the abort word tells the other roles
+__device__ __forceinline__ bool r16_flag_wait(R16Lds &sh, int which, int target, int seen, int lane) {
+  if (seen >= target) return true;  // already observed (read ahead, one knot ago)
+  for (int spins = 0; spins < R16_SPIN_MAX; ++spins) {
+    if (r16_flag_read(sh, which) >= target) {
+      asm volatile("" ::: "memory");
+      return true;
+    }
+    if ((spins & 255) == 255 && r16_flag_read(sh, R16_F_ABORT)) break;
+  }
+  r16_flag_post(sh, R16_F_ABORT, 1, lane);
+  return false;
+}
+// A hand-off read in ONE LDS round trip: the flag and the two values are requested back to back (the LDS serves a
+// wavefront's requests in order, so values read after a flag that shows `target` are the published ones); if the flag is not
+// there yet, poll and read again.
+__device__ __forceinline__ bool r16_read_handoff(R16Lds &sh, int which, int target, int kind, int par, double &d0, double &d1, int lane) {
+  for (int spins = 0; spins < R16_SPIN_MAX; ++spins) {
+    asm volatile("" ::: "memory");  // read again, every time round
+    const int f = r16_flag_read(sh, which);
+    const double a0 = sh.xch[kind][par][0][lane], a1 = sh.xch[kind][par][1][lane];
+    if (f >= target) {
+      d0 = a0;
+      d1 = a1;
+      asm volatile("" ::: "memory");
+      return true;
+    }
+    if ((spins & 255) == 255 && r16_flag_read(sh, R16_F_ABORT)) break;
+  }
+  r16_flag_post(sh, R16_F_ABORT, 1, lane);
+  return false;
+}
+
+// P: operand registers.  traj / gains: the nominal trajectory and the gains of the lane's trajectory (tiled); out: its
+// candidate trajectory (the time column is copied there when `live`).
+template <typename S>
+__device__ __forceinline__ void r16_wave_P(R16Lds &sh, const S *traj, const S *gains, S *out, double alpha, bool live, int n, int lane,
+                                           unsigned long long *stamps_out) {
+  using namespace r16;
+  PConsts<DevWave> pc;
+  make_pconsts(pc);
+  // The loads of knot k + 1 are requested before knot k is converted and written (two register sets, loop unrolled
+  // by two: no copies).  A knot is 30 loads per lane: a wave-uniform knot pointer plus the lane's 32-bit offset.
+  // The requests are unconditional (past the end the last knot is requested again): a branch around them makes the
+  // compiler wait for vmcnt(0) at every use, i.e. for the requests it has just issued.
+  S rawA[NRAW], rawB[NRAW], tmA, tmB;
+  auto request = [&](int k, S (&raw)[NRAW], S &tm) {
+    const int kk = k < n ? k : n - 1;
+    const S *tk = traj + (long)kk * (9 * 128), *gk = gains + (long)kk * (26 * 128);
+    tm = tk[0];  // time_s: the oldest request of the knot
+    auto ld = [&](int off) -> S { return tk[off]; };
+    auto lg = [&](int off) -> S { return gk[off]; };
+    p_load<DevWave>(pc, ld, lg, raw);
+  };
+  bool ok = true;
+#ifdef QILQR_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+  auto knot = [&](int k, S (&rc)[NRAW], S &tmc, S (&rn)[NRAW], S &tmn) {
+    request(k + 1, rn, tmn);
+    QSTAMP(0);  // P: requests
+    double op[NOPS];
+    p_compute<DevWave>(pc, rc, alpha, op);
+    QKEEP(op[0]); QKEEP(op[22]); QKEEP(op[10]);
+    QSTAMP(1);  // P: wait for the loads, operand registers
+    if (k >= R16_RING && !r16_flag_wait(sh, R16_F_CONS, k - R16_RING + 1, -1, lane)) ok = false;  // slot k % R16_RING is free once A has used knot k - R16_RING
+    QSTAMP(2);  // P: wait for a free slot
+#pragma unroll
+    for (int r = 0; r < NOPS; ++r) sh.ops[k % R16_RING][r][lane] = op[r];
+    r16_flag_post(sh, R16_F_PROD, k + 1, lane);
+    if (live && (lane & 15) == 0) out[knot_elem<true>(k, 0, 18)] = tmc;  // time_s passes through (ilqr.hh:164)
+    QSTAMP(3);  // P: LDS writes, flag, time store
+  };
+  request(0, rawA, tmA);
+  for (int k = 0; k < n && ok; k += 2) {
+    knot(k, rawA, tmA, rawB, tmB);
+    if (k + 1 < n && ok) knot(k + 1, rawB, tmB, rawA, tmA);
+  }
+#ifdef QILQR_STAMPS
+  if (lane == 0 && stamps_out)
+    for (int k = 0; k < 8; ++k) stamps_out[k] = stamp_sum[k];
+#endif
+}
+
+// B: pose.  (TT, QQ, VL, VW): the state of knot 0.
+__device__ __forceinline__ void r16_wave_B(R16Lds &sh, const r16::RConsts<DevWave> &kc, double TT, double QQ, double VL, double VW, int n,
+                                           int lane, unsigned long long *stamps_out) {
+  using namespace r16;
+#ifdef QILQR_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+  for (int i = 0; i + 1 < n; ++i) {
+    if (i > 0 && !r16_read_handoff(sh, R16_F_V, i, X_V, i & 1, VL, VW, lane)) return;
+    QSTAMP(0);  // B: wait for v_i
+    double TTn, QQn;
+    b_knot<DevWave>(kc, TT, QQ, VL, VW,
+                    [&](double FL, double FW) {
+                      sh.xch[X_F][i & 1][0][lane] = FL;
+                      sh.xch[X_F][i & 1][1][lane] = FW;
+                      r16_flag_post(sh, R16_F_F, i + 1, lane);
+                    },
+                    TTn, QQn);
+    TT = TTn;
+    QQ = QQn;
+    sh.xch[X_T][(i + 1) & 1][0][lane] = TT;
+    sh.xch[X_T][(i + 1) & 1][1][lane] = QQ;
+    r16_flag_post(sh, R16_F_T, i + 1, lane);
+    QSTAMP(1);  // B: the knot
+  }
+#ifdef QILQR_STAMPS
+  if (lane == 0 && stamps_out)
+    for (int k = 0; k < 8; ++k) stamps_out[k] = stamp_sum[k];
+#endif
+}
+
+// A: control, velocity, stores.  PUBLISH: announce "knots [0, k) stored and visible to the block" every R16_CHUNK knots
+// (the stores have left the wavefront: s_waitcnt vmcnt(0), one wait per chunk) -- k_solve4's linearisation follows it.
+template <typename S, bool PUBLISH>
+__device__ __forceinline__ void r16_wave_A(R16Lds &sh, const r16::RConsts<DevWave> &kc, double TT, double QQ, double VL, double VW, S *out,
+                                           bool live, int n, int lane, unsigned long long *stamps_out) {
+  using namespace r16;
+  // the two masked stores of a knot: a wave-uniform knot pointer plus the lane's offset in the tiled layout
+  const int e1 = st1_elem(lane), e2 = st2_elem(lane);
+  const bool w1 = live && e1 >= 0, w2 = live && e2 >= 0;
+  const int o1 = DevWave::iuni(e1 >= 0 ? e1 : 0), o2 = DevWave::iuni(e2 >= 0 ? e2 : 0);
+#ifdef QILQR_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+  int seen = -1;  // P's progress as last read
+  for (int i = 0; i < n; ++i) {
+    if (!r16_flag_wait(sh, R16_F_PROD, i + 1, seen, lane)) return;
+    double op[NOPS];
+#pragma unroll
+    for (int r = 0; r < NOPS; ++r) op[r] = sh.ops[i % R16_RING][r][lane];
+    seen = r16_flag_read(sh, R16_F_PROD);  // for the next knot: P is normally several knots ahead, and this read's latency is covered by the knot
+    QSTAMP(0);  // A: wait for P's slot, operand reads issued
+    if (i > 0 && !r16_read_handoff(sh, R16_F_T, i, X_T, i & 1, TT, QQ, lane)) return;
+    QSTAMP(1);  // A: wait for (t, q)_i
+    double st1, st2;
+    const double UU = a_control<DevWave>(kc, TT, QQ, VL, VW, op, st1, st2);
+    r16_flag_post(sh, R16_F_CONS, i + 1, lane);  // the slot's values have been used: P may refill it
+    S *ok_ = out + (long)i * (9 * 128);
+    if (w1) ok_[o1] = (S)st1;
+    if (w2) ok_[o2] = (S)st2;
+    if (PUBLISH && (((i + 1) % R16_CHUNK) == 0 || i + 1 == n)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      r16_flag_post(sh, R16_F_K, i + 1, lane);
+    }
+    QKEEP(UU);
+    QSTAMP(2);  // A: Log, control, stores
+    if (i + 1 < n) {  // the reference's step after the last knot is computed and discarded (ilqr.hh:168)
+      double FL, FW;
+      if (!r16_read_handoff(sh, R16_F_F, i + 1, X_F, i & 1, FL, FW, lane)) return;
+      QSTAMP(3);  // A: wait for F_i
+      a_velocity<DevWave>(kc, UU, FL, FW, VL, VW);
+      sh.xch[X_V][(i + 1) & 1][0][lane] = VL;
+      sh.xch[X_V][(i + 1) & 1][1][lane] = VW;
+      r16_flag_post(sh, R16_F_V, i + 1, lane);
+      QSTAMP(4);  // A: velocity
+    }
+  }
+#ifdef QILQR_STAMPS
+  if (lane == 0 && stamps_out)
+    for (int k = 0; k < 8; ++k) stamps_out[k] = stamp_sum[k];
+#endif
+}
+
 template <typename S>
 __global__ __launch_bounds__(192) void k_rollout16(ModelConsts<double> c, BatchState st, int B, int n, int need_flag) {
   using namespace r16;
@@ -1882,174 +2098,20 @@ __global__ __launch_bounds__(192) void k_rollout16(ModelConsts<double> c, BatchS
   const S *traj = (const S *)st.traj[cur] + knot_base<true>(bs, n, 18);
   const S *gains = (const S *)st.gains + knot_base<true>(bs, n, 52);
   S *out = (S *)st.traj[cur ^ 1] + knot_base<true>(bs, n, 18);
-
-  __shared__ double ops[R16_RING][NOPS][64];
-  __shared__ double xch[3][2][2][64];  // hand-off slots [X_T (t, q) | X_V v | X_F free velocity][parity of the knot][register][lane]
-  enum { X_T = 0, X_V = 1, X_F = 2 };
-  __shared__ int flags[R16_NFLAGS];
-  if (threadIdx.x < R16_NFLAGS) flags[threadIdx.x] = 0;
+  __shared__ R16Lds sh;
+  if (threadIdx.x < R16_NFLAGS) sh.flags[threadIdx.x] = 0;
   __syncthreads();
-  // The LDS executes the operations of one wavefront in the order they were issued, so a flag written after the data
-  // (or after the reads of a slot) is seen after them: no s_waitcnt, and no workgroup fence -- a release fence would wait
-  // for the wavefront's outstanding GLOBAL loads and stores too (vmcnt(0)), i.e. for P's prefetch and A's knot stores, on
-  // every knot.  The asm statements only keep the compiler from moving LDS accesses across the flag.
-  auto flag_read = [&](int which) -> int { return __hip_atomic_load(&flags[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-  auto flag_wait = [&](int which, int target, int seen) -> bool {
-    if (seen >= target) return true;  // already observed (read ahead, one knot ago)
-    for (int spins = 0; spins < R16_SPIN_MAX; ++spins) {
-      if (flag_read(which) >= target) {
-        asm volatile("" ::: "memory");
-        return true;
-      }
-    }
-    return false;
-  };
-  auto flag_post = [&](int which, int value) {
-    asm volatile("" ::: "memory");
-    if (lane == 0) __hip_atomic_store(&flags[which], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  };
-  // A hand-off read in ONE LDS round trip: the flag and the two values are requested back to back (the LDS serves a
-  // wavefront's requests in order, so values read after a flag that shows `target` are the published ones); if the
-  // flag is not there yet, poll and read again.
-  auto read_handoff = [&](int which, int target, int kind, int par, double &d0, double &d1) -> bool {
-    for (int spins = 0; spins < R16_SPIN_MAX; ++spins) {
-      asm volatile("" ::: "memory");  // read again, every time round
-      const int f = flag_read(which);
-      const double a0 = xch[kind][par][0][lane], a1 = xch[kind][par][1][lane];  // (indexed directly: LDS addressing, not flat)
-      if (f >= target) {
-        d0 = a0;
-        d1 = a1;
-        asm volatile("" ::: "memory");
-        return true;
-      }
-    }
-    return false;
-  };
-  auto ld0 = [&](int e) -> double { return e >= 0 ? (double)traj[knot_elem<true>(0, e, 18)] : 0.0; };
-
+  unsigned long long *stamps = st.stamps ? st.stamps + ((long)blockIdx.x * 3 + (role == 2 ? 2 : role)) * 8 : nullptr;
   if (role == 2) {
-    // ------------------------------------------------------------------ P: operand registers
-    PConsts<DevWave> pc;
-    make_pconsts(pc);
-    const double alpha = st.alpha[bs];
-    // The loads of knot k + 1 are requested before knot k is converted and written (two register sets, loop unrolled
-    // by two: no copies).  A knot is 30 loads per lane: a wave-uniform knot pointer plus the lane's 32-bit offset.
-    // The requests are unconditional (past the end the last knot is requested again): a branch around them makes the
-    // compiler wait for vmcnt(0) at every use, i.e. for the requests it has just issued.
-    S rawA[NRAW], rawB[NRAW], tmA, tmB;
-    auto request = [&](int k, S (&raw)[NRAW], S &tm) {
-      const int kk = k < n ? k : n - 1;
-      const S *tk = traj + (long)kk * (9 * 128), *gk = gains + (long)kk * (26 * 128);
-      tm = tk[0];  // time_s: the oldest request of the knot
-      auto ld = [&](int off) -> S { return tk[off]; };
-      auto lg = [&](int off) -> S { return gk[off]; };
-      p_load<DevWave>(pc, ld, lg, raw);
-    };
-    bool ok = true;
-#ifdef QILQR_STAMPS
-    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
-#endif
-    auto knot = [&](int k, S (&rc)[NRAW], S &tmc, S (&rn)[NRAW], S &tmn) {
-      request(k + 1, rn, tmn);
-      QSTAMP(0);  // P: requests
-      double op[NOPS];
-      p_compute<DevWave>(pc, rc, alpha, op);
-      QKEEP(op[0]); QKEEP(op[22]); QKEEP(op[10]);
-      QSTAMP(1);  // P: wait for the loads, operand registers
-      if (k >= R16_RING && !flag_wait(R16_F_CONS, k - R16_RING + 1, -1)) ok = false;  // slot k % R16_RING is free once A has used knot k - R16_RING
-      QSTAMP(2);  // P: wait for a free slot
-#pragma unroll
-      for (int r = 0; r < NOPS; ++r) ops[k % R16_RING][r][lane] = op[r];
-      flag_post(R16_F_PROD, k + 1);
-      if (live && (lane & 15) == 0) out[knot_elem<true>(k, 0, 18)] = tmc;  // time_s passes through (ilqr.hh:164)
-      QSTAMP(3);  // P: LDS writes, flag, time store
-    };
-    request(0, rawA, tmA);
-    for (int k = 0; k < n && ok; k += 2) {
-      knot(k, rawA, tmA, rawB, tmB);
-      if (k + 1 < n && ok) knot(k + 1, rawB, tmB, rawA, tmA);
-    }
-#ifdef QILQR_STAMPS
-    if (lane == 0 && st.stamps)
-      for (int k = 0; k < 8; ++k) st.stamps[((long)blockIdx.x * 3 + 2) * 8 + k] = stamp_sum[k];
-#endif
+    r16_wave_P<S>(sh, traj, gains, out, st.alpha[bs], live, n, lane, stamps);
     return;
   }
-
   RConsts<DevWave> kc;
   make_rconsts(c, kc);
-  double TT = ld0(tt_elem(lane)), QQ = ld0(qq_elem(lane)), VL = ld0(vl_elem(lane)), VW = ld0(vw_elem(lane));
-#ifdef QILQR_STAMPS
-  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
-#endif
-
-  if (role == 1) {
-    // ------------------------------------------------------------------ B: pose
-    for (int i = 0; i + 1 < n; ++i) {
-      if (i > 0 && !read_handoff(R16_F_V, i, X_V, i & 1, VL, VW)) return;
-      QSTAMP(0);  // B: wait for v_i
-      double TTn, QQn;
-      b_knot<DevWave>(kc, TT, QQ, VL, VW,
-                      [&](double FL, double FW) {
-                        xch[X_F][i & 1][0][lane] = FL;
-                        xch[X_F][i & 1][1][lane] = FW;
-                        flag_post(R16_F_F, i + 1);
-                      },
-                      TTn, QQn);
-      TT = TTn;
-      QQ = QQn;
-      xch[X_T][(i + 1) & 1][0][lane] = TT;
-      xch[X_T][(i + 1) & 1][1][lane] = QQ;
-      flag_post(R16_F_T, i + 1);
-      QSTAMP(1);  // B: the knot
-    }
-#ifdef QILQR_STAMPS
-    if (lane == 0 && st.stamps)
-      for (int k = 0; k < 8; ++k) st.stamps[((long)blockIdx.x * 3 + 1) * 8 + k] = stamp_sum[k];
-#endif
-    return;
-  }
-
-  // -------------------------------------------------------------------- A: control, velocity, stores
-  // the two masked stores of a knot: a wave-uniform knot pointer plus the lane's offset in the tiled layout
-  const int e1 = st1_elem(lane), e2 = st2_elem(lane);
-  const bool w1 = live && e1 >= 0, w2 = live && e2 >= 0;
-  const int o1 = DevWave::iuni(e1 >= 0 ? e1 : 0), o2 = DevWave::iuni(e2 >= 0 ? e2 : 0);
-  int seen = -1;  // P's progress as last read
-  for (int i = 0; i < n; ++i) {
-    if (!flag_wait(R16_F_PROD, i + 1, seen)) return;
-    double op[NOPS];
-#pragma unroll
-    for (int r = 0; r < NOPS; ++r) op[r] = ops[i % R16_RING][r][lane];
-    seen = flag_read(R16_F_PROD);  // for the next knot: P is normally several knots ahead, and this read's latency is covered by the knot
-    QSTAMP(0);  // A: wait for P's slot, operand reads issued
-    if (i > 0 && !read_handoff(R16_F_T, i, X_T, i & 1, TT, QQ)) return;
-    QSTAMP(1);  // A: wait for (t, q)_i
-    double st1, st2;
-    const double UU = a_control<DevWave>(kc, TT, QQ, VL, VW, op, st1, st2);
-    flag_post(R16_F_CONS, i + 1);  // the slot's values have been used: P may refill it
-    S *ok_ = out + (long)i * (9 * 128);
-    if (w1) ok_[o1] = (S)st1;
-    if (w2) ok_[o2] = (S)st2;
-    QKEEP(UU);
-    QSTAMP(2);  // A: Log, control, stores
-    if (i + 1 < n) {  // the reference's step after the last knot is computed and discarded (ilqr.hh:168)
-      double FL, FW;
-      if (!read_handoff(R16_F_F, i + 1, X_F, i & 1, FL, FW)) return;
-      QSTAMP(3);  // A: wait for F_i
-      a_velocity<DevWave>(kc, UU, FL, FW, VL, VW);
-      xch[X_V][(i + 1) & 1][0][lane] = VL;
-      xch[X_V][(i + 1) & 1][1][lane] = VW;
-      flag_post(R16_F_V, i + 1);
-      QSTAMP(4);  // A: velocity
-    }
-  }
-#ifdef QILQR_STAMPS
-  if (lane == 0 && st.stamps)
-    for (int k = 0; k < 8; ++k) st.stamps[((long)blockIdx.x * 3 + 0) * 8 + k] = stamp_sum[k];
-#endif
+  auto ld0 = [&](int e) -> double { return e >= 0 ? (double)traj[knot_elem<true>(0, e, 18)] : 0.0; };
+  const double TT = ld0(tt_elem(lane)), QQ = ld0(qq_elem(lane)), VL = ld0(vl_elem(lane)), VW = ld0(vw_elem(lane));
+  if (role == 1) r16_wave_B(sh, kc, TT, QQ, VL, VW, n, lane, stamps);
+  else r16_wave_A<S, false>(sh, kc, TT, QQ, VL, VW, out, live, n, lane, stamps);
 }
 
 // ---------------------------------------------------------------------------------------------
