@@ -44,7 +44,12 @@ TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r02_rocprof_summary.json")
 
 
 def kernel_table(prof, n_bwd_knots, n_fwd_knots):
-    """per-kernel work and time of the timed region (HIP events attached to the dispatches)"""
+    """per-kernel work and time of the timed region (HIP events attached to the dispatches).  With the persistent solve
+    (k_solve4: the whole solve is one launch) there is one kernel, and its work is all the backward and forward knots."""
+    if prof.get("solve_launches", 0) > 0:
+        return {"k_solve4": dict(ms=prof["solve_ms"], launches=prof["solve_launches"], seen=prof["solve_seen"],
+                                 flops=FLOP_BWD_KNOT * n_bwd_knots + FLOP_FWD_KNOT * n_fwd_knots,
+                                 bytes=BYTES_BWD_KNOT * n_bwd_knots + BYTES_FWD_KNOT * n_fwd_knots)}
     return {
         "k_backward": dict(ms=prof["backward_ms"], launches=prof["backward_launches"], seen=prof["backward_seen"],
                            flops=FLOP_BWD_KNOT * n_bwd_knots, bytes=BYTES_BWD_KNOT * n_bwd_knots),
@@ -90,6 +95,7 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="HIP events around every kernel, not only the two candidates for dominant kernel")
     ap.add_argument("--rollout", type=int, default=-1, help="rollout kernel: 0 pose + control + loader waves, 1 single wave (default: library default)")
     ap.add_argument("--backward", type=int, default=0, help="diagnostic: backward kernel (qilqr_device_config.force_general: 0 automatic, 1 general, 2 one wavefront per trajectory)")
+    ap.add_argument("--persistent", type=int, default=0, help="qilqr_device_config.persistent: 0 by the batch, 1 the solve as one launch (k_solve4), 2 rounds of three launches")
     ap.add_argument("--streams", type=int, default=0, help="sub-batches on their own streams (qilqr_device_config.streams; 0 automatic)")
     ap.add_argument("--event-stride", type=int, default=4, help="time every k-th launch of the dominant kernel in the timed region (a timed dispatch costs the stream about 6 us)")
     ap.add_argument("--settle-ms", type=float, default=300.0, help="untimed solves before the warm-up steps (clocks out of idle)")
@@ -143,7 +149,8 @@ def main():
         cfg = pb.config2(B=B, N=N, seed=seed, b0=rank * B)
         shard_at = lambda step: [sharding.shard_of_step(r, step, world) for r in range(world)]
     solver = capi.from_config(cfg, device=dev.index, profile=(0 if args.no_profile else (2 if args.profile_all else 1)), sync_every=args.sync_every,
-                              force_general=args.backward, streams=args.streams, **({} if args.rollout < 0 else dict(single_wave_rollout=args.rollout)))
+                              force_general=args.backward, streams=args.streams, persistent=args.persistent,
+                              **({} if args.rollout < 0 else dict(single_wave_rollout=args.rollout)))
 
     init = torch.from_numpy(cfg["init"]).to(dev)
     inits = {rank: init}  # by shard index
@@ -208,7 +215,7 @@ def main():
     # perturbation of the rounds being measured).
     calib = solver.profile_get()
     if not args.no_profile and not args.profile_all and args.warmup > 0:
-        solver.profile_mode((3 if calib["backward_ms"] >= calib["rollout_ms"] else 4) | (args.event_stride << 8))
+        solver.profile_mode((3 if calib["backward_ms"] >= calib["rollout_ms"] else 4) | (args.event_stride << 8))  # (k_solve4 is timed in every mode)
     solver.profile_reset()
     count_passes[0] = True
     t0 = time.perf_counter()
@@ -256,8 +263,9 @@ def main():
             kd = kern[dom]
             tflops, gbs = rates(kd)
             traffic, traffic_src = read_traffic(dom, B, N)
-            # k_backward is matrix-core work (fp64 MFMA); k_rollout has none: its bound is the bytes it moves
-            if dom == "k_backward":
+            # k_backward (and the persistent solve, which contains it) is matrix-core work (fp64 MFMA); k_rollout has none:
+            # its bound is the bytes it moves
+            if dom in ("k_backward", "k_solve4"):
                 bound = dict(bound="mfma", achieved=tflops, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=tflops / FP64_PEAK_TFLOPS)
             else:
                 bound = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
@@ -272,7 +280,7 @@ def main():
                 "kernels_ms": {k: round(v["ms"], 3) for k, v in kern.items()}
                               | {"k_linearize": round(prof["linearize_ms"], 3), "other": round(prof["other_ms"], 3)},
                 "warmup_avg_launch_us": {k: round(calib[k + "_ms"] * 1e3 / max(calib[k + "_launches"], 1), 2)
-                                         for k in ("backward", "rollout")},
+                                         for k in ("backward", "rollout", "solve")},
             }
         # ---- CPU baseline: the oracle on this host's cores, bounded sample of the same workload
         cpu = None
@@ -345,11 +353,14 @@ def main():
             lk = kernel_table(lp, lb_, lf_)
             per = {}
             for k, kd in lk.items():
+                if kd["launches"] == 0:
+                    continue
                 tf, gb = rates(kd)
                 per[k] = {"avg_launch_us": kd["ms"] * 1e3 / max(kd["launches"], 1), "launches": kd["launches"],
                           "fp64_frac": tf / FP64_PEAK_TFLOPS, "hbm_frac": gb / HBM_PEAK_GBS}
-            per["k_linearize"] = {"avg_launch_us": lp["linearize_ms"] * 1e3 / max(lp["linearize_launches"], 1),
-                                  "launches": lp["linearize_launches"]}
+            if lp["linearize_launches"]:
+                per["k_linearize"] = {"avg_launch_us": lp["linearize_ms"] * 1e3 / max(lp["linearize_launches"], 1),
+                                      "launches": lp["linearize_launches"]}
             ls.profile_mode(0)
             torch.cuda.synchronize()
             t1 = time.perf_counter()

@@ -56,7 +56,7 @@ class Options(C.Structure):
 class DeviceConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("profile", C.c_int32), ("sync_every", C.c_int32),
                 ("force_general", C.c_int32), ("single_wave_rollout", C.c_int32), ("precision", C.c_int32),
-                ("streams", C.c_int32)]
+                ("streams", C.c_int32), ("persistent", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -65,7 +65,7 @@ class Profile(C.Structure):
                 ("linearize_ms", C.c_double), ("linearize_launches", C.c_int32),
                 ("other_ms", C.c_double), ("other_launches", C.c_int32),
                 ("backward_seen", C.c_int32), ("rollout_seen", C.c_int32), ("linearize_seen", C.c_int32),
-                ("other_seen", C.c_int32)]
+                ("other_seen", C.c_int32), ("solve_ms", C.c_double), ("solve_launches", C.c_int32), ("solve_seen", C.c_int32)]
 
 
 _lib = None
@@ -121,7 +121,7 @@ class QuadrotorILQRBatch:
 
     def __init__(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired,
                  dt_s, options, device=0, profile=0, sync_every=2, force_general=False,
-                 single_wave_rollout=False, precision="f64", streams=0):
+                 single_wave_rollout=False, precision="f64", streams=0, persistent=0):
         lib = load()
         m = Model()
         m.mass_kg = mass_kg
@@ -147,7 +147,7 @@ class QuadrotorILQRBatch:
         self.options = dict(options)
         self.desired = _d(desired).reshape(-1, KNOT)
         dc = DeviceConfig(int(device), int(profile), int(sync_every), int(force_general),
-                          int(single_wave_rollout), {"f64": 0, "f32": 1}[precision], int(streams))
+                          int(single_wave_rollout), {"f64": 0, "f32": 1}[precision], int(streams), int(persistent))
         self._h = C.c_void_p()
         rc = lib.qilqr_create(C.byref(m), _p(Q), _p(R), _p(self.desired), C.c_int32(len(self.desired)),
                               C.c_double(dt_s), C.byref(o), C.byref(dc), C.byref(self._h))

@@ -33,7 +33,7 @@ int fail(int code, const std::string &msg) {
       return fail(QILQR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));         \
   } while (0)
 
-enum Kind { K_BACKWARD = 0, K_ROLLOUT = 1, K_LINEARIZE = 2, K_OTHER = 3, K_KINDS = 4 };
+enum Kind { K_BACKWARD = 0, K_ROLLOUT = 1, K_LINEARIZE = 2, K_OTHER = 3, K_SOLVE = 4, K_KINDS = 5 };
 
 struct EventPair {
   hipEvent_t a, b;
@@ -83,9 +83,10 @@ struct qilqr_solver {
   // profiling
   std::vector<EventPair> events;
   size_t events_used = 0;
-  double prof_ms[K_KINDS] = {0, 0, 0, 0};
-  unsigned prof_seen[K_KINDS] = {0, 0, 0, 0};  // launches of each kind seen by the sampler
-  int prof_n[K_KINDS] = {0, 0, 0, 0};
+  double prof_ms[K_KINDS] = {0, 0, 0, 0, 0};
+  unsigned prof_seen[K_KINDS] = {0, 0, 0, 0, 0};  // launches of each kind seen by the sampler
+  int prof_n[K_KINDS] = {0, 0, 0, 0, 0};
+  int num_cus = 256;  // compute units of the device (grid of the persistent solve)
 };
 
 namespace {
@@ -95,11 +96,13 @@ EventPair *timing_slot(qilqr_solver *s, int kind) {
   const int mode = s->dev.profile & 0xff, stride = (s->dev.profile >> 8) & 0xff;
   if (!mode) return nullptr;
   const unsigned seen = s->prof_seen[kind]++;  // every launch of the kind since the last reset
-  if (mode == 1 && kind != K_BACKWARD && kind != K_ROLLOUT) return nullptr;
-  if (mode == 3 && kind != K_BACKWARD) return nullptr;
-  if (mode == 4 && kind != K_ROLLOUT) return nullptr;
-  // sampling: every stride-th launch of a kind carries events (a timed dispatch costs the stream ~6 us)
-  if (stride > 1 && (seen % stride) != 0) return nullptr;
+  if (kind != K_SOLVE) {  // (the one launch of a persistent solve is always timed)
+    if (mode == 1 && kind != K_BACKWARD && kind != K_ROLLOUT) return nullptr;
+    if (mode == 3 && kind != K_BACKWARD) return nullptr;
+    if (mode == 4 && kind != K_ROLLOUT) return nullptr;
+    // sampling: every stride-th launch of a kind carries events (a timed dispatch costs the stream ~6 us)
+    if (stride > 1 && (seen % stride) != 0) return nullptr;
+  }
   if (s->events_used == s->events.size()) {
     EventPair e;
     if (hipEventCreate(&e.a) != hipSuccess) return nullptr;
@@ -223,23 +226,24 @@ inline double max_restarts(const SolveParams &p) {
 }
 
 // plain [B][n][W] fp64 (device) -> tiled, storage precision
-int to_tiled(qilqr_solver *s, const double *d_plain, void *tiled, long B, long n, int W) {
+// (zero_word: an int the same launch sets to zero -- the group queue of a persistent solve that follows)
+int to_tiled(qilqr_solver *s, const double *d_plain, void *tiled, long B, long n, int W, int *zero_word = nullptr) {
   if (s->f32)
     launch(s, K_OTHER, k_retile<float>, dim3(cdiv(B * n * W, 256)), dim3(256), d_plain, (double *)nullptr,
-                       (float *)tiled, (float *)tiled, (const int *)nullptr, 0, (int)B, (int)n, W, 1);
+                       (float *)tiled, (float *)tiled, (const int *)nullptr, 0, (int)B, (int)n, W, 1, zero_word);
   else
     launch(s, K_OTHER, k_retile<double>, dim3(cdiv(B * n * W, 256)), dim3(256), d_plain,
-                       (double *)nullptr, (double *)tiled, (double *)tiled, (const int *)nullptr, 0, (int)B, (int)n, W, 1);
+                       (double *)nullptr, (double *)tiled, (double *)tiled, (const int *)nullptr, 0, (int)B, (int)n, W, 1, zero_word);
   return QILQR_OK;
 }
 // tiled -> plain [B][n][W] fp64 (device); sel/flip choose between t0 and t1 per trajectory
 int from_tiled(qilqr_solver *s, double *d_plain, void *t0, void *t1, const int *sel, int flip, long B, long n, int W) {
   if (s->f32)
     launch(s, K_OTHER, k_retile<float>, dim3(cdiv(B * n * W, 256)), dim3(256), (const double *)nullptr,
-                       d_plain, (float *)t0, (float *)t1, sel, flip, (int)B, (int)n, W, 0);
+                       d_plain, (float *)t0, (float *)t1, sel, flip, (int)B, (int)n, W, 0, (int *)nullptr);
   else
     launch(s, K_OTHER, k_retile<double>, dim3(cdiv(B * n * W, 256)), dim3(256), (const double *)nullptr,
-                       d_plain, (double *)t0, (double *)t1, sel, flip, (int)B, (int)n, W, 0);
+                       d_plain, (double *)t0, (double *)t1, sel, flip, (int)B, (int)n, W, 0, (int *)nullptr);
   return QILQR_OK;
 }
 
@@ -634,6 +638,32 @@ int check_quaternions(const double *traj, long count, const char *what) {
   return QILQR_OK;
 }
 
+// The persistent solve (solve4.h): every trajectory from its first linearisation to its exit status in ONE launch.
+// Requirements: symmetric weights (the matrix-core recursion of k_backward4), no per-round host visibility (debug capture
+// of trajectories uses the rounds).  qilqr_device_config.persistent: 0 = by the batch, 1 = always, 2 = never.
+constexpr long PERSIST_MAX_B = 4096;
+bool use_persistent(const qilqr_solver *s, long B) {
+  if (!s->symmetric || s->dev.persistent == 2) return false;
+  if (s->dev.persistent == 1) return true;
+  return s->dev.sync_every > 1 && B <= PERSIST_MAX_B;
+}
+int launch_solve4(qilqr_solver *s, long B, long n) {
+  const unsigned groups = cdiv(B, 4);
+  const unsigned grid = std::min<unsigned>(groups, (unsigned)s->num_cus);  // one block per CU (256 VGPRs, 105 KB of LDS); the rest queue
+#define QILQR_LAUNCH_S4(S, LK) \
+  launch(s, K_SOLVE, k_solve4<S, LK>, dim3(grid), dim3(384), s->consts, (const ModelConsts<S> *)s->d_consts, s->params, s->st, (int)B, (int)n, 0u)
+  switch (layout_kind(s->layout) + (s->f32 ? 3 : 0)) {
+    case 0: QILQR_LAUNCH_S4(double, 0); break;
+    case 1: QILQR_LAUNCH_S4(double, 1); break;
+    case 2: QILQR_LAUNCH_S4(double, 2); break;
+    case 3: QILQR_LAUNCH_S4(float, 0); break;
+    case 4: QILQR_LAUNCH_S4(float, 1); break;
+    default: QILQR_LAUNCH_S4(float, 2); break;
+  }
+#undef QILQR_LAUNCH_S4
+  return QILQR_OK;
+}
+
 // The batch solve on device-resident buffers.  drain = false: return with the gather enqueued, the caller puts
 // its own copies behind it and waits for the stream itself.
 int solve_batch_device_impl(qilqr_solver *s, const double *d_init, const double *d_desired_batch, int32_t B, int32_t n,
@@ -642,9 +672,12 @@ int solve_batch_device_impl(qilqr_solver *s, const double *d_init, const double 
   if (!s || !d_init) return fail(QILQR_ERR_INVALID_ARG, "null argument");
   int rc = begin_batch(s, B, n, d_desired_batch);
   if (rc) return rc;
-  if ((rc = to_tiled(s, d_init, s->st.traj[0], B, n, 18))) return rc;
+  const bool persistent = use_persistent(s, B);
+  if ((rc = to_tiled(s, d_init, s->st.traj[0], B, n, 18, persistent ? s->st.counters : nullptr))) return rc;
   const int nparts = (s->dev.sync_every > 1) ? auto_parts(s, B) : 1;
-  if (nparts > 1) {
+  if (persistent) {
+    if ((rc = launch_solve4(s, B, n))) return rc;
+  } else if (nparts > 1) {
     if ((rc = run_solve_parts(s, B, n, nparts))) return rc;
   } else if ((rc = run_solve(s, B, n, s->dev.sync_every, [] { return QILQR_OK; }, false))) {
     return rc;
@@ -683,7 +716,7 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(QILQR_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
-  qilqr_device_config dc = {0, 0, 2, 0, 0, 0, 0};
+  qilqr_device_config dc = {0, 0, 2, 0, 0, 0, 0, 0};
   if (dev) dc = *dev;
   if (dc.device < 0 || dc.device >= ndev) return fail(QILQR_ERR_INVALID_ARG, "bad device ordinal");
   if (dc.sync_every < 1) dc.sync_every = 1;
@@ -715,6 +748,10 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   s->n_desired = n_desired;
 
   hipError_t e = hipSetDevice(s->device);
+  if (e == hipSuccess) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device) == hipSuccess && cus > 0) s->num_cus = cus;
+  }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
   const size_t es = s->f32 ? sizeof(float) : sizeof(double);
   if (e == hipSuccess) e = hipMalloc(&s->d_desired, es * 18 * (n_desired > 0 ? n_desired : 1));
@@ -868,6 +905,9 @@ int qilqr_profile_get(qilqr_solver *s, qilqr_profile *out) {
   out->rollout_seen = (int32_t)s->prof_seen[K_ROLLOUT];
   out->linearize_seen = (int32_t)s->prof_seen[K_LINEARIZE];
   out->other_seen = (int32_t)s->prof_seen[K_OTHER];
+  out->solve_ms = s->prof_ms[K_SOLVE];
+  out->solve_launches = s->prof_n[K_SOLVE];
+  out->solve_seen = (int32_t)s->prof_seen[K_SOLVE];
   return QILQR_OK;
 }
 

@@ -1926,6 +1926,19 @@ __device__ __forceinline__ bool r16_flag_wait(R16Lds &sh, int which, int target,
   r16_flag_post(sh, R16_F_ABORT, 1, lane);
   return false;
 }
+// the same for a wavefront that is in no hurry (the linearisation waits a chunk of knots at a time): sleeps between polls
+__device__ __forceinline__ bool r16_flag_wait_relaxed(R16Lds &sh, int which, int target, int lane) {
+  for (int spins = 0; spins < R16_SPIN_MAX; ++spins) {
+    if (r16_flag_read(sh, which) >= target) {
+      asm volatile("" ::: "memory");
+      return true;
+    }
+    if (r16_flag_read(sh, R16_F_ABORT)) return false;
+    __builtin_amdgcn_s_sleep(16);
+  }
+  r16_flag_post(sh, R16_F_ABORT, 1, lane);
+  return false;
+}
 // A hand-off read in ONE LDS round trip: the flag and the two values are requested back to back (the LDS serves a
 // wavefront's requests in order, so values read after a flag that shows `target` are the published ones); if the flag is not
 // there yet, poll and read again.
@@ -1999,9 +2012,11 @@ __device__ __forceinline__ void r16_wave_P(R16Lds &sh, const S *traj, const S *g
 }
 
 // B: pose.  (TT, QQ, VL, VW): the state of knot 0.
-__device__ __forceinline__ void r16_wave_B(R16Lds &sh, const r16::RConsts<DevWave> &kc, double TT, double QQ, double VL, double VW, int n,
+__device__ __forceinline__ void r16_wave_B(R16Lds &sh, const ModelConsts<double> &c, double TT, double QQ, double VL, double VW, int n,
                                            int lane, unsigned long long *stamps_out) {
   using namespace r16;
+  RConsts<DevWave> kc;  // (built here: what the pose wave does not use is never computed, nor kept in registers)
+  make_rconsts(c, kc);
 #ifdef QILQR_STAMPS
   unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
@@ -2033,9 +2048,11 @@ __device__ __forceinline__ void r16_wave_B(R16Lds &sh, const r16::RConsts<DevWav
 // A: control, velocity, stores.  PUBLISH: announce "knots [0, k) stored and visible to the block" every R16_CHUNK knots
 // (the stores have left the wavefront: s_waitcnt vmcnt(0), one wait per chunk) -- k_solve4's linearisation follows it.
 template <typename S, bool PUBLISH>
-__device__ __forceinline__ void r16_wave_A(R16Lds &sh, const r16::RConsts<DevWave> &kc, double TT, double QQ, double VL, double VW, S *out,
+__device__ __forceinline__ void r16_wave_A(R16Lds &sh, const ModelConsts<double> &c, double TT, double QQ, double VL, double VW, S *out,
                                            bool live, int n, int lane, unsigned long long *stamps_out) {
   using namespace r16;
+  RConsts<DevWave> kc;  // (built here: what the control wave does not use is never computed, nor kept in registers)
+  make_rconsts(c, kc);
   // the two masked stores of a knot: a wave-uniform knot pointer plus the lane's offset in the tiled layout
   const int e1 = st1_elem(lane), e2 = st2_elem(lane);
   const bool w1 = live && e1 >= 0, w2 = live && e2 >= 0;
@@ -2106,12 +2123,10 @@ __global__ __launch_bounds__(192) void k_rollout16(ModelConsts<double> c, BatchS
     r16_wave_P<S>(sh, traj, gains, out, st.alpha[bs], live, n, lane, stamps);
     return;
   }
-  RConsts<DevWave> kc;
-  make_rconsts(c, kc);
   auto ld0 = [&](int e) -> double { return e >= 0 ? (double)traj[knot_elem<true>(0, e, 18)] : 0.0; };
   const double TT = ld0(tt_elem(lane)), QQ = ld0(qq_elem(lane)), VL = ld0(vl_elem(lane)), VW = ld0(vw_elem(lane));
-  if (role == 1) r16_wave_B(sh, kc, TT, QQ, VL, VW, n, lane, stamps);
-  else r16_wave_A<S, false>(sh, kc, TT, QQ, VL, VW, out, live, n, lane, stamps);
+  if (role == 1) r16_wave_B(sh, c, TT, QQ, VL, VW, n, lane, stamps);
+  else r16_wave_A<S, false>(sh, c, TT, QQ, VL, VW, out, live, n, lane, stamps);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2203,8 +2218,9 @@ __global__ void k_gather(BatchState st, int B, int n, double *out_traj, double *
 // tiled buffer t0 / t1 (the current-trajectory selector), xor'ed with flip.
 template <typename S>
 __global__ void k_retile(const double *plain_in, double *plain_out, S *t0, S *t1, const int *sel,
-                         int flip, int B, int n, int W, int to_tiled) {
+                         int flip, int B, int n, int W, int to_tiled, int *zero_word) {
   const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id == 0 && zero_word) *zero_word = 0;  // the group queue of the k_solve4 launch that follows
   const long per = (long)n * W;
   if (id >= (long)B * per) return;
   const long b = id / per;
@@ -2233,3 +2249,5 @@ __global__ void k_seed_search(BatchState st, int B, const double *cost, const do
 }
 
 }  // namespace qilqr
+
+#include "solve4.h"

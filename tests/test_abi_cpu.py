@@ -34,8 +34,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(capi.Model) == 13 * 8
     assert C.sizeof(capi.Options) == 56      # 2 doubles, int32 + pad, 3 doubles, int32 + pad
     assert capi.Options.rtol.offset == 24 and capi.Options.populate_debug.offset == 48
-    assert C.sizeof(capi.DeviceConfig) == 28  # seven int32 (ABI version 2 added `streams`)
-    assert C.sizeof(capi.Profile) == 80  # four (double, int32 + pad) pairs and four int32 counts
+    assert C.sizeof(capi.DeviceConfig) == 32  # eight int32 (ABI version 2 added `streams`, version 3 `persistent`)
+    assert C.sizeof(capi.Profile) == 96  # four (double, int32 + pad) pairs, four int32 counts, (double, int32, int32)
 
 
 def test_bad_inertia_raises_runtime_error_with_reference_text():
