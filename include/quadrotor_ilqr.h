@@ -92,9 +92,10 @@ typedef struct {
   int32_t streams; /* batch solves with sync_every > 1: number of contiguous sub-batches that run their rounds on
                       their own HIP streams (their kernels are bound by different resources and overlap);
                       0 = automatic (2 from 4096 trajectories on, else 1: see auto_parts in ilqr_capi.hip), at most 8 */
-  int32_t persistent; /* the solve as ONE launch (k_solve4: blocks of six wavefronts own four trajectories each from the
+  int32_t persistent; /* the solve as ONE launch (k_solve4: blocks of eight wavefronts own four trajectories each from the
                          first linearisation to the exit status, no rounds, no host in the loop; symmetric weights only):
-                         0 = by the batch (up to 4096 trajectories), 1 = always, 2 = never (rounds of three launches) */
+                         0 = whichever measures faster (today the rounds, at every batch size: DESIGN.md), 1 = always,
+                         2 = never (rounds of three launches) */
 } qilqr_device_config;
 
 /* A handle owns its device workspace and stream: use it from one thread at a time (different handles are

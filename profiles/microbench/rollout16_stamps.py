@@ -8,7 +8,7 @@ from quadrotorilqr_amd import capi, problems as pb  # noqa: E402
 capi.LIB_PATH = os.path.join(ROOT, "quadrotorilqr_amd", "lib", "libquadrotor_ilqr_stamps.so")
 B, N = 1024, 100
 cfg = pb.config2(B=B, N=N)
-s = capi.from_config(cfg, single_wave_rollout=3)
+s = capi.from_config(cfg, single_wave_rollout=3, profile=2)
 tr = cfg["init"]
 for _ in range(3):
     gains, _ = s.backwards_pass(tr)
@@ -16,12 +16,17 @@ for _ in range(3):
 gains, _ = s.backwards_pass(tr_prev)
 for _ in range(3):
     s.forward_sim(tr_prev, gains, 1.0)
+s.profile_reset()
+for _ in range(5):
+    s.forward_sim(tr_prev, gains, 1.0)
+p = s.profile_get()
+print("stamps build: k_rollout16 %.2f us per launch" % (1e3 * p["rollout_ms"] / p["rollout_launches"]))
 out = np.zeros((B, 8), dtype=np.uint64)
 capi.load().qilqr_debug_stamps(s._h, out.ctypes.data_as(C.c_void_p), C.c_int32(B))
 blocks = B // 4
 st = out.reshape(-1)[: blocks * 24].reshape(blocks, 3, 8).astype(np.float64)
-names = {0: ["wait for P's slot, operand reads issued", "wait for (t, q)_i", "Log, control, stores", "wait for F_i", "velocity, hand-off"],
-         1: ["wait for v_i", "the knot (free velocity, Exp, compose)"],
+names = {0: ["operand reads, velocity terms", "wait for the Log of knot i", "control, velocity", "Exp, hand-off", "store"],
+         1: ["Log, hand-off", "requests, stores", "wait for E_i", "compose"],
          2: ["requests", "wait for loads + operand registers", "wait for a free slot", "LDS writes, flag, time store"]}
 for role in (0, 1, 2):
     med = np.median(st[:, role, :], axis=0) / N

@@ -640,18 +640,21 @@ int check_quaternions(const double *traj, long count, const char *what) {
 
 // The persistent solve (solve4.h): every trajectory from its first linearisation to its exit status in ONE launch.
 // Requirements: symmetric weights (the matrix-core recursion of k_backward4), no per-round host visibility (debug capture
-// of trajectories uses the rounds).  qilqr_device_config.persistent: 0 = by the batch, 1 = always, 2 = never.
-constexpr long PERSIST_MAX_B = 4096;
+// of trajectories uses the rounds).  qilqr_device_config.persistent: 0 = by measurement, 1 = always, 2 = never.
+// By measurement (profiles/microbench/persistent_sweep.py, MI355X, N = 100, device-resident) the rounds are the faster path
+// at every batch size -- 256: 4.35 vs 4.67 ms, 1024: 5.90 vs 6.00, 2048: 8.3 vs 9.9, 8192: 22.0 vs 28.8 -- since the rollout
+// kernel of the rounds got its sixteen lanes per trajectory: both paths are bound by (iterations of the slowest trajectory) x
+// (latency of one iteration), and inside k_solve4 the forward phase ends one linearisation task (~15 us) after the rollout.
+// So 0 selects the rounds; the persistent solve stays selectable and tested.
 bool use_persistent(const qilqr_solver *s, long B) {
-  if (!s->symmetric || s->dev.persistent == 2) return false;
-  if (s->dev.persistent == 1) return true;
-  return s->dev.sync_every > 1 && B <= PERSIST_MAX_B;
+  (void)B;
+  return s->symmetric && s->dev.persistent == 1;
 }
 int launch_solve4(qilqr_solver *s, long B, long n) {
   const unsigned groups = cdiv(B, 4);
   const unsigned grid = std::min<unsigned>(groups, (unsigned)s->num_cus);  // one block per CU (256 VGPRs, 105 KB of LDS); the rest queue
 #define QILQR_LAUNCH_S4(S, LK) \
-  launch(s, K_SOLVE, k_solve4<S, LK>, dim3(grid), dim3(384), s->consts, (const ModelConsts<S> *)s->d_consts, s->params, s->st, (int)B, (int)n, 0u)
+  launch(s, K_SOLVE, k_solve4<S, LK>, dim3(grid), dim3(S4_THREADS), s->consts, (const ModelConsts<S> *)s->d_consts, s->params, s->st, (int)B, (int)n, 0u)
   switch (layout_kind(s->layout) + (s->f32 ? 3 : 0)) {
     case 0: QILQR_LAUNCH_S4(double, 0); break;
     case 1: QILQR_LAUNCH_S4(double, 1); break;

@@ -1831,14 +1831,16 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
 // operand wavefront P for four trajectories (b0 = 4 blockIdx.x; row r of 16 lanes <-> trajectory b0 + r).  At B = 1024
 // that is 256 blocks -- one per CU -- instead of the 16 blocks of k_rollout3, and about a third of its instructions
 // per knot, cut into the two halves that are independent inside a knot:
-//   A (r16::a_control, a_velocity): Log of the pose error, control law, thrust -> u_i, v_{i+1}; stores knot i
-//   B (r16::b_knot): gravity and gyroscopic terms ("free" velocity F_i, handed to A in the same knot), Exp, pose
-//      composition -> (t, q)_{i+1}
+//   A (r16::a_pre, a_post, a_exp): u_i = u_nom + alpha k + K [tau_i ; v_i - v_nom], v_{i+1} = v_i + dt a(q_i, v_i, u_i), and
+//      E_{i+1} = Exp(dt v_{i+1}); stores v_i, u_i
+//   B (r16::b_compose, b_log): T_{i+1} = T_i E_i, then the pose error tau_{i+1} = Log(T_nom^-1 T_{i+1}); stores the poses
+//      (the recurrence spans two knots -- Log_i -> u_i -> v_{i+1} -> E_{i+1} -> T_{i+2} -> Log_{i+2} -- so the two waves work on
+//      alternate knots at the same time, with two hand-offs per two knots and about the same instruction count each)
 //   P (r16::p_load, p_compute): for knot k (running up to R16_RING - 1 knots ahead of A): loads the nominal knot and the
 //      gains (tiled global layout, per-lane element offsets), forms the 23 operand registers and writes them to ring slot
 //      k % R16_RING as [register][lane]; copies the time column to the output trajectory.
-// The waves never meet at a barrier inside the loop.  Five LDS words carry progress: knots produced by P / consumed by
-// A, and "v_k ready" (A), "(t, q)_k ready", "F_k ready" (B); the values themselves go through double-buffered LDS slots.
+// The waves never meet at a barrier inside the loop.  LDS words carry progress: knots produced by P / used by A / by B,
+// "E_k ready" (A), "tau_k ready" (B); the values themselves go through double-buffered LDS slots.
 // LDS operations of a wavefront execute in order, so a flag written after the data is seen after the data; every spin
 // is bounded, so a lost flag ends the kernel instead of hanging it.
 // Trajectories of the block that are not being rolled out this round alias the block's first live trajectory (their
@@ -1868,6 +1870,27 @@ struct DevWave {
     return __builtin_fma(bc<L>(src), m, acc);
 #endif
   }
+  // acc + sum_c src[lane L0 + c of the row] * m_c as a chain of v_fmac_f64_dpp (one instruction per term; the compiler
+  // itself emits v_mov_b64_dpp + v_fma_f64, two).  The compiler's hazard recogniser does not look inside the asm, so the block
+  // carries its own wait states on both sides: a DPP read needs two behind the VALU write of its source -- `src` may have
+  // just been written, and `acc` may be the source of a DPP read right after.
+#define QILQR_FMAC_DPP(m, l) "v_fmac_f64_dpp %0, %1, " m " row_newbcast:" l " row_mask:0xf bank_mask:0xf\n\t"
+  template <int L0> static __device__ __forceinline__ V dot2(V acc, V src, V m0, V m1) {
+    asm("s_nop 1\n\t" QILQR_FMAC_DPP("%2", "%4") QILQR_FMAC_DPP("%3", "%5") "s_nop 1"
+        : "+v"(acc) : "v"(src), "v"(m0), "v"(m1), "n"(L0), "n"(L0 + 1));
+    return acc;
+  }
+  template <int L0> static __device__ __forceinline__ V dot3(V acc, V src, V m0, V m1, V m2) {
+    asm("s_nop 1\n\t" QILQR_FMAC_DPP("%2", "%5") QILQR_FMAC_DPP("%3", "%6") QILQR_FMAC_DPP("%4", "%7") "s_nop 1"
+        : "+v"(acc) : "v"(src), "v"(m0), "v"(m1), "v"(m2), "n"(L0), "n"(L0 + 1), "n"(L0 + 2));
+    return acc;
+  }
+  template <int L0> static __device__ __forceinline__ V dot4(V acc, V src, V m0, V m1, V m2, V m3) {
+    asm("s_nop 1\n\t" QILQR_FMAC_DPP("%2", "%6") QILQR_FMAC_DPP("%3", "%7") QILQR_FMAC_DPP("%4", "%8") QILQR_FMAC_DPP("%5", "%9") "s_nop 1"
+        : "+v"(acc) : "v"(src), "v"(m0), "v"(m1), "v"(m2), "v"(m3), "n"(L0), "n"(L0 + 1), "n"(L0 + 2), "n"(L0 + 3));
+    return acc;
+  }
+#undef QILQR_FMAC_DPP
   // permutation inside every quad of four lanes (two v_mov_b32_dpp quad_perm: fp64 DPP has row_newbcast only)
   template <int CTRL> static __device__ __forceinline__ V qperm(V x) {
     const long long v = __double_as_longlong(x);
@@ -1889,22 +1912,34 @@ struct DevWave {
   static __device__ __forceinline__ V sin_(V a) { return sin(a); }
   static __device__ __forceinline__ V cos_(V a) { return cos(a); }
   static __device__ __forceinline__ V atan2_(V a, V b) { return atan2(a, b); }
+  // the closed forms beyond the series' ranges: rarely taken and large (sin, cos, atan2 in fp64), so out of line -- the knot
+  // loops stay short and the closed forms' registers are not the loops'
+  static __device__ __attribute__((noinline)) V exp_closed(M c, V x, V p, M l0, M l1, M l2, M l3) {
+    return r16::exp_closed_forms<DevWave>(c, x, p, l0, l1, l2, l3);
+  }
+  static __device__ __attribute__((noinline)) V log_closed(M c, V s2, V wq, V coeff) { return r16::log_closed_forms<DevWave>(c, s2, wq, coeff); }
+  static __device__ __attribute__((noinline)) V jinv_closed(M c, V th2, V cJ) { return r16::jinv_closed_forms<DevWave>(c, th2, cJ); }
 };
 
+// s_waitcnt vmcnt(0) as an instruction the compiler's wait-count pass sees (gfx9 encoding: vmcnt in bits 3:0 and 15:14,
+// expcnt 6:4 = 7 and lgkmcnt 11:8 = 15 left open).  Placed after the loads of a role's initial state: otherwise the pass may
+// keep "a load is outstanding" alive around the knot loop and wait for vmcnt(0) INSIDE it -- which, the counter being shared,
+// also waits for the knot's own stores, every knot.
+#define R16_LOADS_DONE() __builtin_amdgcn_s_waitcnt(0x0F70)
 constexpr int R16_RING = 4;
 constexpr int R16_SPIN_MAX = 1 << 22;
 constexpr int R16_CHUNK = 16;  // knots per "stored and visible" announcement of wave A (k_solve4's linearisation follows it)
-enum { R16_F_PROD = 0, R16_F_CONS, R16_F_V, R16_F_T, R16_F_F, R16_F_K, R16_F_ABORT, R16_NFLAGS };
-enum { X_T = 0, X_V = 1, X_F = 2 };
+enum { R16_F_PROD = 0, R16_F_CONS_A, R16_F_CONS_B, R16_F_E, R16_F_L, R16_F_KA, R16_F_KB, R16_F_ABORT, R16_NFLAGS };
+enum { X_L = 0, X_E = 1 };
 // LDS of the three rollout roles
 struct R16Lds {
   double ops[R16_RING][r16::NOPS][64];  // operand registers of R16_RING knots, [register][lane]
-  double xch[3][2][2][64];             // hand-off slots [X_T (t, q) | X_V v | X_F free velocity][parity of the knot][register][lane]
-  int flags[R16_NFLAGS];               // knots produced by P / used by A; v_k, (t, q)_k, F_k ready; knots stored; abort
+  double xch[2][2][3][64];             // hand-off slots [X_L (theta | c, td, q) of knot k | X_E (dq, p) of Exp(dt v_k)][parity of k][register][lane]
+  int flags[R16_NFLAGS];               // knots produced by P / used by A, by B; E_k ready (A); Log_k ready (B); knots stored (A, B); abort
 };
 // The LDS executes the operations of one wavefront in the order they were issued, so a flag written after the data (or
 // after the reads of a slot) is seen after them: no s_waitcnt, and no workgroup fence -- a release fence would wait for the
-// wavefront's outstanding GLOBAL loads and stores too (vmcnt(0)), i.e. for P's prefetch and A's knot stores, on every
+// wavefront's outstanding GLOBAL loads and stores too (vmcnt(0)), i.e. for P's prefetch and the knot stores, on every
 // knot.  The asm statements only keep the compiler from moving LDS accesses across the flag.
 __device__ __forceinline__ int r16_flag_read(R16Lds &sh, int which) {
   return __hip_atomic_load(&sh.flags[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1915,7 +1950,7 @@ __device__ __forceinline__ void r16_flag_post(R16Lds &sh, int which, int value, 
 }
 // false: the flag never came (a bounded spin: the kernel ends instead of hanging); the abort word tells the other roles
 __device__ __forceinline__ bool r16_flag_wait(R16Lds &sh, int which, int target, int seen, int lane) {
-  if (seen >= target) return true;  // already observed (read ahead, one knot ago)
+  if (__builtin_expect(seen >= target, 1)) return true;  // already observed (read ahead, one knot ago)
   for (int spins = 0; spins < R16_SPIN_MAX; ++spins) {
     if (r16_flag_read(sh, which) >= target) {
       asm volatile("" ::: "memory");
@@ -1939,17 +1974,20 @@ __device__ __forceinline__ bool r16_flag_wait_relaxed(R16Lds &sh, int which, int
   r16_flag_post(sh, R16_F_ABORT, 1, lane);
   return false;
 }
-// A hand-off read in ONE LDS round trip: the flag and the two values are requested back to back (the LDS serves a
+// A hand-off read in ONE LDS round trip: the flag and the NV values are requested back to back (the LDS serves a
 // wavefront's requests in order, so values read after a flag that shows `target` are the published ones); if the flag is not
 // there yet, poll and read again.
-__device__ __forceinline__ bool r16_read_handoff(R16Lds &sh, int which, int target, int kind, int par, double &d0, double &d1, int lane) {
+template <int NV>
+__device__ __forceinline__ bool r16_read_handoff(R16Lds &sh, int which, int target, int kind, int par, double (&d)[NV], int lane) {
   for (int spins = 0; spins < R16_SPIN_MAX; ++spins) {
     asm volatile("" ::: "memory");  // read again, every time round
     const int f = r16_flag_read(sh, which);
-    const double a0 = sh.xch[kind][par][0][lane], a1 = sh.xch[kind][par][1][lane];
-    if (f >= target) {
-      d0 = a0;
-      d1 = a1;
+    double a[NV];
+#pragma unroll
+    for (int r = 0; r < NV; ++r) a[r] = sh.xch[kind][par][r][lane];
+    if (__builtin_expect(f >= target, 1)) {
+#pragma unroll
+      for (int r = 0; r < NV; ++r) d[r] = a[r];
       asm volatile("" ::: "memory");
       return true;
     }
@@ -1957,6 +1995,35 @@ __device__ __forceinline__ bool r16_read_handoff(R16Lds &sh, int which, int targ
   }
   r16_flag_post(sh, R16_F_ABORT, 1, lane);
   return false;
+}
+// the first attempt of r16_read_handoff split off, so that its LDS latency can be covered by other work: request the flag
+// and the values here, do the other work, then r16_handoff_finish (which polls only if the first attempt came too early)
+template <int NV>
+__device__ __forceinline__ void r16_handoff_request(R16Lds &sh, int which, int kind, int par, int &f, double (&a)[NV], int lane) {
+  asm volatile("" ::: "memory");
+  f = r16_flag_read(sh, which);
+#pragma unroll
+  for (int r = 0; r < NV; ++r) a[r] = sh.xch[kind][par][r][lane];
+  asm volatile("" ::: "memory");
+}
+template <int NV>
+__device__ __forceinline__ bool r16_handoff_finish(R16Lds &sh, int which, int target, int kind, int par, int f, double (&a)[NV], int lane) {
+  if (__builtin_expect(f >= target, 1)) return true;
+  return r16_read_handoff<NV>(sh, which, target, kind, par, a, lane);
+}
+// "knots [0, k) are stored and visible to the block": a wavefront whose only vector-memory operations are its knot stores
+// (PER per knot) announces, every R16_CHUNK / 2 knots, the knots whose stores are older than its PER * R16_CHUNK / 2 youngest
+// (s_waitcnt vmcnt(N) waits for all but the N youngest: nearly free), and everything after its last knot (vmcnt(0), once)
+template <int PER>
+__device__ __forceinline__ void r16_publish_stores(R16Lds &sh, int which, int i, int n, int lane) {
+  constexpr int LAG = R16_CHUNK / 2;
+  if (i + 1 == n) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    r16_flag_post(sh, which, n, lane);
+  } else if (((i + 1) % LAG) == 0 && i + 1 > LAG) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * LAG) : "memory");
+    r16_flag_post(sh, which, i + 1 - LAG, lane);
+  }
 }
 
 // P: operand registers.  traj / gains: the nominal trajectory and the gains of the lane's trajectory (tiled); out: its
@@ -1992,7 +2059,9 @@ __device__ __forceinline__ void r16_wave_P(R16Lds &sh, const S *traj, const S *g
     p_compute<DevWave>(pc, rc, alpha, op);
     QKEEP(op[0]); QKEEP(op[22]); QKEEP(op[10]);
     QSTAMP(1);  // P: wait for the loads, operand registers
-    if (k >= R16_RING && !r16_flag_wait(sh, R16_F_CONS, k - R16_RING + 1, -1, lane)) ok = false;  // slot k % R16_RING is free once A has used knot k - R16_RING
+    // slot k % R16_RING is free once A and B have used knot k - R16_RING
+    if (k >= R16_RING && !(r16_flag_wait(sh, R16_F_CONS_A, k - R16_RING + 1, -1, lane) && r16_flag_wait(sh, R16_F_CONS_B, k - R16_RING + 1, -1, lane)))
+      ok = false;
     QSTAMP(2);  // P: wait for a free slot
 #pragma unroll
     for (int r = 0; r < NOPS; ++r) sh.ops[k % R16_RING][r][lane] = op[r];
@@ -2011,88 +2080,146 @@ __device__ __forceinline__ void r16_wave_P(R16Lds &sh, const S *traj, const S *g
 #endif
 }
 
-// B: pose.  (TT, QQ, VL, VW): the state of knot 0.
-__device__ __forceinline__ void r16_wave_B(R16Lds &sh, const ModelConsts<double> &c, double TT, double QQ, double VL, double VW, int n,
+// B: pose.  T_{i+1} = T_i E_i (E_i = Exp(dt v_i) from A), then tau_{i+1} = Log(T_nom^-1 T_{i+1}) for A; stores the pose of every
+// knot.  (TT, QQ): the pose of knot 0.  PUBLISH: announce the stored knots (k_solve4's linearisation follows them).
+template <typename S, bool PUBLISH>
+__device__ __forceinline__ void r16_wave_B(R16Lds &sh, const ModelConsts<double> &c, double TT, double QQ, S *out, bool live, int n,
                                            int lane, unsigned long long *stamps_out) {
   using namespace r16;
   RConsts<DevWave> kc;  // (built here: what the pose wave does not use is never computed, nor kept in registers)
   make_rconsts(c, kc);
+  const int et = stt_elem(lane), eq = stq_elem(lane);
+  const bool wt = live && et >= 0, wq = live && eq >= 0;
+  const int ot = DevWave::iuni(et >= 0 ? et : 0), oq = DevWave::iuni(eq >= 0 ? eq : 0);
 #ifdef QILQR_STAMPS
   unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
-  for (int i = 0; i + 1 < n; ++i) {
-    if (i > 0 && !r16_read_handoff(sh, R16_F_V, i, X_V, i & 1, VL, VW, lane)) return;
-    QSTAMP(0);  // B: wait for v_i
+  if (!r16_flag_wait(sh, R16_F_PROD, 1, -1, lane)) return;
+  double op[OP_K];  // R_n^T (3), t_n, the conj(q_n) matrix (4): registers 0..7 of the knot's slot
+#pragma unroll
+  for (int r = 0; r < OP_K; ++r) op[r] = sh.ops[0][r][lane];
+  int seen = r16_flag_read(sh, R16_F_PROD);  // P's progress as last read
+  // Log_i and its hand-off; then the pose stores (after the hand-off: the control wave is waiting for it)
+  auto log_knot = [&](int i, double TT, double QQ, const double *op) {
+    double TH4, TD;
+    b_log<DevWave>(kc, TT, QQ, op, TH4, TD);
+    sh.xch[X_L][i & 1][0][lane] = TH4;
+    sh.xch[X_L][i & 1][1][lane] = TD;
+    sh.xch[X_L][i & 1][2][lane] = QQ;
+    r16_flag_post(sh, R16_F_L, i + 1, lane);
+    r16_flag_post(sh, R16_F_CONS_B, i + 1, lane);
+  };
+  auto store_knot = [&](int i, double TT, double QQ) {
+    S *ok_ = out + (long)i * (9 * 128);
+    if (wt) ok_[ot] = (S)TT;
+    if (wq) ok_[oq] = (S)QQ;
+    if (PUBLISH) r16_publish_stores<2>(sh, R16_F_KB, i, n, lane);
+  };
+  for (int i = 0; i + 1 < n; ++i) {  // iteration i: the pose of knot i is in (TT, QQ), its operands in op
+    log_knot(i, TT, QQ, op);
+    QSTAMP(0);  // B: Log, hand-off
+    // E_i and the operands of knot i + 1 are requested now and used after the stores, which cover the LDS round trip (A posted
+    // E_i while this wave was in Log_i, P is normally several knots ahead)
+    if (__builtin_expect(!r16_flag_wait(sh, R16_F_PROD, i + 2, seen, lane), 0)) return;
+    double opn[OP_K];
+#pragma unroll
+    for (int r = 0; r < OP_K; ++r) opn[r] = sh.ops[(i + 1) % R16_RING][r][lane];
+    seen = r16_flag_read(sh, R16_F_PROD);
+    int fe;
+    double e[2];
+    r16_handoff_request<2>(sh, R16_F_E, X_E, i & 1, fe, e, lane);
+    store_knot(i, TT, QQ);
+    QSTAMP(1);  // B: requests, stores
+    if (__builtin_expect(!r16_handoff_finish<2>(sh, R16_F_E, i + 1, X_E, i & 1, fe, e, lane), 0)) return;
+    QSTAMP(2);  // B: wait for E_i
     double TTn, QQn;
-    b_knot<DevWave>(kc, TT, QQ, VL, VW,
-                    [&](double FL, double FW) {
-                      sh.xch[X_F][i & 1][0][lane] = FL;
-                      sh.xch[X_F][i & 1][1][lane] = FW;
-                      r16_flag_post(sh, R16_F_F, i + 1, lane);
-                    },
-                    TTn, QQn);
+    b_compose<DevWave>(kc, TT, QQ, e[0], e[1], TTn, QQn);
     TT = TTn;
     QQ = QQn;
-    sh.xch[X_T][(i + 1) & 1][0][lane] = TT;
-    sh.xch[X_T][(i + 1) & 1][1][lane] = QQ;
-    r16_flag_post(sh, R16_F_T, i + 1, lane);
-    QSTAMP(1);  // B: the knot
+#pragma unroll
+    for (int r = 0; r < OP_K; ++r) op[r] = opn[r];
+    QSTAMP(3);  // B: compose
   }
+  log_knot(n - 1, TT, QQ, op);  // the last knot: the reference's step after it is computed and discarded (ilqr.hh:168)
+  store_knot(n - 1, TT, QQ);
 #ifdef QILQR_STAMPS
   if (lane == 0 && stamps_out)
     for (int k = 0; k < 8; ++k) stamps_out[k] = stamp_sum[k];
 #endif
 }
 
-// A: control, velocity, stores.  PUBLISH: announce "knots [0, k) stored and visible to the block" every R16_CHUNK knots
-// (the stores have left the wavefront: s_waitcnt vmcnt(0), one wait per chunk) -- k_solve4's linearisation follows it.
+// A: control, velocity, Exp; stores v_i, u_i.  (VL, VW): the velocity of knot 0.
 template <typename S, bool PUBLISH>
-__device__ __forceinline__ void r16_wave_A(R16Lds &sh, const ModelConsts<double> &c, double TT, double QQ, double VL, double VW, S *out,
-                                           bool live, int n, int lane, unsigned long long *stamps_out) {
+__device__ __forceinline__ void r16_wave_A(R16Lds &sh, const ModelConsts<double> &c, double VL, double VW, S *out, bool live, int n,
+                                           int lane, unsigned long long *stamps_out) {
   using namespace r16;
   RConsts<DevWave> kc;  // (built here: what the control wave does not use is never computed, nor kept in registers)
   make_rconsts(c, kc);
-  // the two masked stores of a knot: a wave-uniform knot pointer plus the lane's offset in the tiled layout
-  const int e1 = st1_elem(lane), e2 = st2_elem(lane);
-  const bool w1 = live && e1 >= 0, w2 = live && e2 >= 0;
-  const int o1 = DevWave::iuni(e1 >= 0 ? e1 : 0), o2 = DevWave::iuni(e2 >= 0 ? e2 : 0);
+  const int ea = sta_elem(lane);
+  const bool wa = live && ea >= 0;
+  const int oa = DevWave::iuni(ea >= 0 ? ea : 0);
 #ifdef QILQR_STAMPS
   unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
+  if (n > 1) {  // E_0 = Exp(dt v_0): the pose wave's first compose
+    double DQ, PP;
+    a_exp<DevWave>(kc, VL, VW, DQ, PP);
+    sh.xch[X_E][0][0][lane] = DQ;
+    sh.xch[X_E][0][1][lane] = PP;
+    r16_flag_post(sh, R16_F_E, 1, lane);
+  }
   int seen = -1;  // P's progress as last read
-  for (int i = 0; i < n; ++i) {
+  for (int i = 0; i + 1 < n; ++i) {
+    if (__builtin_expect(!r16_flag_wait(sh, R16_F_PROD, i + 1, seen, lane), 0)) return;
+    double op[NOPS];  // the gain columns, u_nom + alpha k, v_nom: registers 8..22 of the knot's slot
+#pragma unroll
+    for (int r = OP_K; r < NOPS; ++r) op[r] = sh.ops[i % R16_RING][r][lane];
+    seen = r16_flag_read(sh, R16_F_PROD);  // for the next knot: P is normally several knots ahead, and this read's latency is covered by the knot
+    int fl;
+    double l[3];
+    r16_handoff_request<3>(sh, R16_F_L, X_L, i & 1, fl, l, lane);  // (if the pose wave is ahead: no second round trip)
+    APre<DevWave> pre;
+    a_pre<DevWave>(kc, VL, VW, op, pre);  // what needs only v_i: runs while the pose wave is still in Log_i
+    QSTAMP(0);  // A: operand reads, velocity terms
+    if (__builtin_expect(!r16_handoff_finish<3>(sh, R16_F_L, i + 1, X_L, i & 1, fl, l, lane), 0)) return;
+    QSTAMP(1);  // A: wait for the Log of knot i
+    double VLn, VWn;
+    const double st = a_post<DevWave>(kc, pre, l[0], l[1], l[2], VL, op, true, VLn, VWn);
+    r16_flag_post(sh, R16_F_CONS_A, i + 1, lane);  // the slot's values have been used
+    QSTAMP(2);  // A: control, velocity
+    if (__builtin_expect(i + 2 < n, 1)) {  // E_{i+1} for the pose of knot i + 2
+      double DQ, PP;
+      a_exp<DevWave>(kc, VLn, VWn, DQ, PP);
+      sh.xch[X_E][(i + 1) & 1][0][lane] = DQ;
+      sh.xch[X_E][(i + 1) & 1][1][lane] = PP;
+      r16_flag_post(sh, R16_F_E, i + 2, lane);
+    }
+    QSTAMP(3);  // A: Exp, hand-off
+    S *ok_ = out + (long)i * (9 * 128);
+    if (wa) ok_[oa] = (S)st;
+    if (PUBLISH) r16_publish_stores<1>(sh, R16_F_KA, i, n, lane);
+    VL = VLn;
+    VW = VWn;
+    QSTAMP(4);  // A: store
+  }
+  {  // the last knot: its control only -- the reference's step after it is computed and discarded (ilqr.hh:168)
+    const int i = n - 1;
     if (!r16_flag_wait(sh, R16_F_PROD, i + 1, seen, lane)) return;
     double op[NOPS];
 #pragma unroll
-    for (int r = 0; r < NOPS; ++r) op[r] = sh.ops[i % R16_RING][r][lane];
-    seen = r16_flag_read(sh, R16_F_PROD);  // for the next knot: P is normally several knots ahead, and this read's latency is covered by the knot
-    QSTAMP(0);  // A: wait for P's slot, operand reads issued
-    if (i > 0 && !r16_read_handoff(sh, R16_F_T, i, X_T, i & 1, TT, QQ, lane)) return;
-    QSTAMP(1);  // A: wait for (t, q)_i
-    double st1, st2;
-    const double UU = a_control<DevWave>(kc, TT, QQ, VL, VW, op, st1, st2);
-    r16_flag_post(sh, R16_F_CONS, i + 1, lane);  // the slot's values have been used: P may refill it
+    for (int r = OP_K; r < NOPS; ++r) op[r] = sh.ops[i % R16_RING][r][lane];
+    APre<DevWave> pre;
+    a_pre<DevWave>(kc, VL, VW, op, pre);
+    double l[3];
+    if (!r16_read_handoff<3>(sh, R16_F_L, i + 1, X_L, i & 1, l, lane)) return;
+    double VLn, VWn;
+    const double st = a_post<DevWave>(kc, pre, l[0], l[1], l[2], VL, op, false, VLn, VWn);
+    r16_flag_post(sh, R16_F_CONS_A, i + 1, lane);
     S *ok_ = out + (long)i * (9 * 128);
-    if (w1) ok_[o1] = (S)st1;
-    if (w2) ok_[o2] = (S)st2;
-    if (PUBLISH && (((i + 1) % R16_CHUNK) == 0 || i + 1 == n)) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      r16_flag_post(sh, R16_F_K, i + 1, lane);
-    }
-    QKEEP(UU);
-    QSTAMP(2);  // A: Log, control, stores
-    if (i + 1 < n) {  // the reference's step after the last knot is computed and discarded (ilqr.hh:168)
-      double FL, FW;
-      if (!r16_read_handoff(sh, R16_F_F, i + 1, X_F, i & 1, FL, FW, lane)) return;
-      QSTAMP(3);  // A: wait for F_i
-      a_velocity<DevWave>(kc, UU, FL, FW, VL, VW);
-      sh.xch[X_V][(i + 1) & 1][0][lane] = VL;
-      sh.xch[X_V][(i + 1) & 1][1][lane] = VW;
-      r16_flag_post(sh, R16_F_V, i + 1, lane);
-      QSTAMP(4);  // A: velocity
-    }
+    if (wa) ok_[oa] = (S)st;
+    if (PUBLISH) r16_publish_stores<1>(sh, R16_F_KA, i, n, lane);
   }
 #ifdef QILQR_STAMPS
   if (lane == 0 && stamps_out)
@@ -2118,15 +2245,16 @@ __global__ __launch_bounds__(192) void k_rollout16(ModelConsts<double> c, BatchS
   __shared__ R16Lds sh;
   if (threadIdx.x < R16_NFLAGS) sh.flags[threadIdx.x] = 0;
   __syncthreads();
-  unsigned long long *stamps = st.stamps ? st.stamps + ((long)blockIdx.x * 3 + (role == 2 ? 2 : role)) * 8 : nullptr;
+  unsigned long long *stamps = st.stamps ? st.stamps + ((long)blockIdx.x * 3 + role) * 8 : nullptr;
   if (role == 2) {
     r16_wave_P<S>(sh, traj, gains, out, st.alpha[bs], live, n, lane, stamps);
     return;
   }
   auto ld0 = [&](int e) -> double { return e >= 0 ? (double)traj[knot_elem<true>(0, e, 18)] : 0.0; };
-  const double TT = ld0(tt_elem(lane)), QQ = ld0(qq_elem(lane)), VL = ld0(vl_elem(lane)), VW = ld0(vw_elem(lane));
-  if (role == 1) r16_wave_B(sh, c, TT, QQ, VL, VW, n, lane, stamps);
-  else r16_wave_A<S, false>(sh, c, TT, QQ, VL, VW, out, live, n, lane, stamps);
+  const double s0 = ld0(role == 1 ? tt_elem(lane) : vl_elem(lane)), s1 = ld0(role == 1 ? qq_elem(lane) : vw_elem(lane));
+  R16_LOADS_DONE();
+  if (role == 1) r16_wave_B<S, false>(sh, c, s0, s1, out, live, n, lane, stamps);
+  else r16_wave_A<S, false>(sh, c, s0, s1, out, live, n, lane, stamps);
 }
 
 // ---------------------------------------------------------------------------------------------

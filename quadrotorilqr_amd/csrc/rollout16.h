@@ -33,6 +33,10 @@
 #pragma once
 #include "se3_math.h"
 
+// branches a converging solve does not take: laid out off the knot loop's straight line (a taken branch costs a lone
+// wavefront an instruction refetch)
+#define QILQR_RARE(x) __builtin_expect(!!(x), 0)
+
 namespace qilqr {
 namespace r16 {
 
@@ -56,7 +60,7 @@ struct RConsts {
   typedef typename W::V V;
   typedef typename W::M M;
   double dt;
-  V SA, SB1;           // packing scales of the pose wave: A1 = SA VW, B1 = I omega + SB1 VL
+  V SA, SB1;           // scales: SA VW = [0 | theta_e | omega | 0], SB1 VL = [0 | rho_e | 0 | 0]
   V IC[3];             // column c of the inertia, rows in Q2
   V NI[3];             // column c of -dt I^-1, rows in every quad
   V GLz;               // dt / m at j = 2
@@ -64,6 +68,7 @@ struct RConsts {
   V GRAVC, S1, S2;     // gravity: -g dt e_z, and the signed scales of the two quaternion permutations
   V MQ1, MQ1_3, MW;
   V MQ0_3, MQ2_3;      // store assembly
+  V M3;                // 1 in lanes j < 3
   V PC[8];             // per-lane polynomial coefficients (lane-in-row 0..5)
   M L0, L1, L2, L3;    // lane-in-row == 0..3 (patching the Exp coefficients on the closed-form path)
 };
@@ -91,6 +96,7 @@ QILQR_HD void make_rconsts(const ModelConsts<double> &c, RConsts<W> &k) {
   k.MW = W::vconst([&](int l) { return j(l) == 3 ? 1.0 : 0.0; });
   k.MQ0_3 = W::vconst([&](int l) { return (q(l) == 0 && j(l) < 3) ? 1.0 : 0.0; });
   k.MQ2_3 = W::vconst([&](int l) { return (q(l) == 2 && j(l) < 3) ? 1.0 : 0.0; });
+  k.M3 = W::vconst([&](int l) { return j(l) < 3 ? 1.0 : 0.0; });
   for (int e = 0; e < 8; ++e)
     k.PC[e] = W::vconst([&](int l) {
       switch (l & 15) {
@@ -117,39 +123,22 @@ QILQR_HD typename W::V cross_rot(typename W::V ap, typename W::V app, typename W
   return W::fma(ap, bpp, -(app * bp));
 }
 
-// One knot of the rollout for four trajectories, cut into the two halves that are independent inside a knot; two
-// wavefronts run them side by side and trade (t, q) and v once per knot:
-//   a_knot  (control wave A): Log of the pose error, control law, thrust -> u_i, v_{i+1}, and what is stored for knot i
-//   b_knot  (pose wave B):    gravity and gyroscopic terms of the velocity update ("free" velocity F_i, handed to A in
-//                             the same knot), then Exp and the pose composition -> (t, q)_{i+1}
-// Both take the state of knot i: TT, QQ (written by B), VL, VW (written by A).
+// One knot of the rollout for four trajectories.  The recurrence has a two-knot period -- the pose of knot i + 2 needs
+// v_{i+1}, which needs u_i, which needs the pose of knot i:  Log_i -> u_i -> v_{i+1} -> Exp(dt v_{i+1}) -> T_{i+2} -> Log_{i+2}
+// -- so two wavefronts share a knot with TWO hand-offs per period and about the same number of instructions each (a lone
+// wavefront is bound by instruction issue, ~2.4 ns per VALU instruction, not by dependences):
+//   control wave A:  a_pre (what needs only v_i), then with tau_i from B:  a_post: u_i, v_{i+1};  a_exp: E_{i+1} = Exp(dt v_{i+1})
+//   pose wave B:     b_compose: T_{i+1} = T_i E_i;  b_log: tau_{i+1} = Log(T_nom^-1 T_{i+1}) less its last two cross products
+//                    (a_rho, in A: the pose wave's instructions are the dearer ones -- longer dependent DPP chains)
+// v never leaves A; the pose never leaves B except as (rho, theta, q) for the control law and gravity.
 
-// the pose wave.  post_f(FL, FW) is called as soon as the free velocity is final (the device publishes it to A there).
-template <class W, class POSTF>
-QILQR_HD void b_knot(const RConsts<W> &k, typename W::V TT, typename W::V QQ, typename W::V VL, typename W::V VW,
-                     POSTF post_f, typename W::V &TTn, typename W::V &QQn) {
+// control wave, Exp(dt v) (quadrotor_model.cc:33-49, 174-200 -- the pose integrates with the OLD velocity): the quaternion
+// increment DQ = (sin(th/2)/th theta_e ; cos(th/2)) as (x, y, z, w) in every quad, the translation increment PP in Q1
+template <class W>
+QILQR_HD void a_exp(const RConsts<W> &k, typename W::V VL, typename W::V VW, typename W::V &DQ, typename W::V &PP) {
   typedef typename W::V V;
   typedef typename W::M M;
   const double eps = Eps<double>::manif;
-  // ---- theta_e = dt omega and rho_e = dt v (the pose integrates with the OLD velocity); I omega in Q2
-  V IW = W::template bc<0>(VW) * k.IC[0];
-  IW = W::template fm<1>(IW, VW, k.IC[1]);
-  IW = W::template fm<2>(IW, VW, k.IC[2]);
-  const V A1 = k.SA * VW;                 // [0 | theta_e | omega   | 0]
-  const V B1 = W::fma(k.SB1, VL, IW);     // [0 | rho_e   | I omega | 0]
-  const V A1p = W::rot1(A1), A1pp = W::rot1(A1p);
-  const V C1 = cross_rot<W>(A1p, A1pp, B1);  // [0 | theta_e x rho_e | omega x I omega | 0]
-  // ---- the free velocity: v + dt (gravity in the body frame - I^-1 (omega x I omega))  (quadrotor_model.cc:65-78)
-  {
-    V FL = VL + k.GRAVC;
-    FL = W::template fm<0>(FL, QQ, k.S1 * W::template qperm<0xCE>(QQ));  // (z, w, x, .)
-    FL = W::template fm<1>(FL, QQ, k.S2 * W::template qperm<0xDB>(QQ));  // (w, z, y, .)
-    V g1 = W::template bc<8>(C1) * k.NI[0];  // -dt I^-1 (omega x I omega)
-    g1 = W::template fm<9>(g1, C1, k.NI[1]);
-    V FW = W::template fm<10>(VW, C1, k.NI[2]);
-    FW = FW + g1;
-    post_f(FL, FW);
-  }
   // ---- Exp coefficients: cos(th/2), sin(th/2)/th, (1 - cos th)/th^2, (th - sin th)/th^3 in lanes 0..3 of a row
   const V THE = k.dt * VW;
   const V sqe = THE * THE;
@@ -166,69 +155,86 @@ QILQR_HD void b_knot(const RConsts<W> &k, typename W::V TT, typename W::V QQ, ty
     // when some row is at rest: a converging solve takes neither branch.
     const M small = W::lnot(W::gt(th2e, eps));
     const M closed = W::gt(th2e, Series<double>::EXP_MAX);
-    if (W::any(closed)) {
-      const V xc = W::sel(closed, th2e, V(1.0));
-      const V theta = W::sqrt_(xc), ha = 0.5 * theta;
-      const V sn = W::sin_(ha), cs = W::cos_(ha), st = W::sin_(theta), ct = W::cos_(theta);
-      P1 = W::sel(W::land(closed, k.L0), cs, P1);
-      P1 = W::sel(W::land(closed, k.L1), sn / theta, P1);
-      P1 = W::sel(W::land(closed, k.L2), (1.0 - ct) / xc, P1);
-      P1 = W::sel(W::land(closed, k.L3), (theta - st) / (xc * theta), P1);
-    }
-    if (W::any(small)) {
+    if (QILQR_RARE(W::any(closed))) P1 = W::exp_closed(closed, th2e, P1, k.L0, k.L1, k.L2, k.L3);
+    if (QILQR_RARE(W::any(small))) {
       P1 = W::sel(W::land(small, k.L0), V(1.0), P1);
       P1 = W::sel(W::land(small, W::lor(k.L1, k.L2)), V(0.5), P1);
       P1 = W::sel(W::land(small, k.L3), V(0.0), P1);
     }
   }
   // ---- p = rho_e + a theta_e x rho_e + b theta_e x (theta_e x rho_e) in Q1
+  const V A1 = k.SA * VW;    // [0 | theta_e | . | 0]
+  const V B1 = k.SB1 * VL;   // [0 | rho_e   | 0 | 0]
+  const V A1p = W::rot1(A1), A1pp = W::rot1(A1p);
+  const V C1 = cross_rot<W>(A1p, A1pp, B1);
   const V C2 = cross_rot<W>(A1p, A1pp, C1);
   const V CA = W::template bc<2>(P1) * k.MQ1, CB = W::template bc<3>(P1) * k.MQ1;
-  const V PP = W::fma(CB, C2, W::fma(CA, C1, B1));  // Q1: p (Q2: I omega, never used)
-  // ---- pose: T <- T Exp(dt v):  t += R(q) p,  q <- q (sh theta_e, ch)
+  PP = W::fma(CB, C2, W::fma(CA, C1, B1));
+  const V CH = W::template bc<0>(P1), SH = W::template bc<1>(P1);
+  DQ = W::fma(k.M3, SH * THE, k.MW * CH);
+}
+// the closed forms of a_exp (out of line on the device: rarely taken, and large)
+template <class W>
+QILQR_HD typename W::V exp_closed_forms(typename W::M closed, typename W::V th2e, typename W::V P1, typename W::M L0, typename W::M L1,
+                                        typename W::M L2, typename W::M L3) {
+  typedef typename W::V V;
+  const V xc = W::sel(closed, th2e, V(1.0));
+  const V theta = W::sqrt_(xc), ha = 0.5 * theta;
+  const V sn = W::sin_(ha), cs = W::cos_(ha), st = W::sin_(theta), ct = W::cos_(theta);
+  P1 = W::sel(W::land(closed, L0), cs, P1);
+  P1 = W::sel(W::land(closed, L1), sn / theta, P1);
+  P1 = W::sel(W::land(closed, L2), (1.0 - ct) / xc, P1);
+  return W::sel(W::land(closed, L3), (theta - st) / (xc * theta), P1);
+}
+
+// pose wave, first half: T <- T E with E = (DQ, PP) from a_exp:  t += R(q) p,  q <- q DQ
+template <class W>
+QILQR_HD void b_compose(const RConsts<W> &k, typename W::V TT, typename W::V QQ, typename W::V DQ, typename W::V PP,
+                        typename W::V &TTn, typename W::V &QQn) {
+  typedef typename W::V V;
+  typedef typename W::M M;
+  const double eps = Eps<double>::manif;
   const V QQp = W::rot1(QQ), QQpp = W::rot1(QQp);
   const V C3 = cross_rot<W>(QQp, QQpp, PP);   // Q1: u x p
   const V C4 = cross_rot<W>(QQp, QQpp, C3);   // Q1: u x (u x p)
   const V Wq = W::template bc<3>(QQ);
   const V Rp = W::fma(V(2.0), C4, W::fma(Wq + Wq, C3, PP));
   TTn = W::fma(k.MQ1_3, Rp, TT);
-  const V ZX = cross_rot<W>(QQp, QQpp, THE);  // u x theta_e in every quad
-  const V z = W::fma(Wq, THE, ZX);
-  const V CH = W::template bc<0>(P1), SH = W::template bc<1>(P1);
-  const V ov = W::fma(SH, z, CH * QQ);
-  const V prod = QQ * THE;
+  // q d = (w d_v + d_w u + u x d_v ; w d_w - u . d_v)
+  const V ZX = cross_rot<W>(QQp, QQpp, DQ);  // u x d_v in every quad (0 in lane j = 3)
+  const V DW = W::template bc<3>(DQ);
+  const V ov = W::fma(Wq, DQ, W::fma(DW, k.M3 * QQ, ZX));
+  const V prod = QQ * DQ;
   V dq = W::template bc<0>(prod) + W::template bc<1>(prod);
   dq = dq + W::template bc<2>(prod);
-  V Qn = W::fma(-(k.MW * SH), dq, ov);
+  V Qn = W::fma(-k.MW, dq, ov);
   {
     const V sqq = Qn * Qn;
     V nq = (W::template bc<0>(sqq) + W::template bc<1>(sqq)) + (W::template bc<2>(sqq) + W::template bc<3>(sqq));
     const M off = W::gt(W::abs_(nq - 1.0), eps);  // manif's compose renormalisation
-    if (W::any(off)) Qn = Qn * W::sel(off, 2.0 / (1.0 + nq), V(1.0));
+    if (QILQR_RARE(W::any(off))) Qn = Qn * W::sel(off, 2.0 / (1.0 + nq), V(1.0));
   }
   QQn = Qn;
 }
 
-// the control wave, first part: everything up to the control u_i (rows in Q3) and what is stored for knot i
-// (st1 = [v_lin | t | omega | u], st2 = the quaternion: see st1_elem / st2_elem)
+// the pose wave, second half: the pose error tau = Log(T_nom^-1 T) = [rho ; theta] (quadrotor_model.cc:215-219;
+// se3_rminus_fast) up to the last two cross products, which the control wave does (a_rho): TH4 = theta in lanes j < 3 of Q0 and
+// the Jacobian coefficient c in lane j = 3, TD = R_n^T (t - t_n) in Q0
 template <class W>
-QILQR_HD typename W::V a_control(const RConsts<W> &k, typename W::V TT, typename W::V QQ, typename W::V VL, typename W::V VW,
-                                 const typename W::V *op, typename W::V &st1, typename W::V &st2) {
+QILQR_HD void b_log(const RConsts<W> &k, typename W::V TT, typename W::V QQ, const typename W::V *op, typename W::V &TH4,
+                    typename W::V &TD) {
   typedef typename W::V V;
   typedef typename W::M M;
   const double eps = Eps<double>::manif;
-  // ---- Log, rotation part: qd = conj(q_n) q in Q0 (x, y, z, w)
-  V qd = W::template bc<0>(QQ) * op[OP_LQ + 0];
-  qd = W::template fm<1>(qd, QQ, op[OP_LQ + 1]);
-  qd = W::template fm<2>(qd, QQ, op[OP_LQ + 2]);
-  qd = W::template fm<3>(qd, QQ, op[OP_LQ + 3]);
+  // ---- rotation part: qd = conj(q_n) q in Q0 (x, y, z, w)
+  V qd = W::template dot4<0>(V(0.0), QQ, op[OP_LQ + 0], op[OP_LQ + 1], op[OP_LQ + 2], op[OP_LQ + 3]);
   V sq = qd * qd;
   V s2 = W::template bc<0>(sq) + W::template bc<1>(sq);
   s2 = s2 + W::template bc<2>(sq);
   {
     const V nn = s2 + W::template bc<3>(sq);
     const M off = W::gt(W::abs_(nn - 1.0), eps);  // manif's compose renormalisation
-    if (W::any(off)) {
+    if (QILQR_RARE(W::any(off))) {
       const V sc = W::sel(off, 2.0 / (1.0 + nn), V(1.0));
       qd = qd * sc;
       sq = qd * qd;
@@ -250,12 +256,7 @@ QILQR_HD typename W::V a_control(const RConsts<W> &k, typename W::V TT, typename
     const M small = W::lnot(W::gt(s2, eps));
     const M series = W::land(W::gt(wq, 0.0), W::lnot(W::gt(s2, Series<double>::LOG_MAX)));
     const M closed = W::land(W::lnot(small), W::lnot(series));
-    if (W::any(closed)) {
-      const V ss = W::sqrt_(W::sel(closed, s2, V(1.0)));
-      const M neg = W::lt(wq, 0.0);
-      const V at = W::atan2_(W::sel(neg, -ss, ss), W::sel(neg, -wq, wq));
-      coeff = W::sel(closed, 2.0 * at / ss, coeff);
-    }
+    if (QILQR_RARE(W::any(closed))) coeff = W::log_closed(closed, s2, wq, coeff);
     coeff = W::sel(small, V(2.0), coeff);
   }
   const V th = coeff * qd;  // Q0: theta (lane j = 3 holds coeff w: finite, never used)
@@ -269,67 +270,93 @@ QILQR_HD typename W::V a_control(const RConsts<W> &k, typename W::V TT, typename
     cJ = W::fma(W::fma(p67, x2, p45), x4, W::fma(p23, x2, p01));
     const M small = W::lnot(W::gt(th2, eps));  // a rollout that has converged onto its nominal trajectory is here at every knot
     const M closed = W::gt(th2, Series<double>::JINV_MAX);
-    if (W::any(closed)) {
-      const V x = W::sel(closed, th2, V(1.0));
-      const V theta = W::sqrt_(x);
-      cJ = W::sel(closed, 1.0 / x - (1.0 + W::cos_(theta)) / (2.0 * theta * W::sin_(theta)), cJ);
-    }
+    if (QILQR_RARE(W::any(closed))) cJ = W::jinv_closed(closed, th2, cJ);
     cJ = W::sel(small, V(0.0), cJ);
   }
-  // ---- td = R_n^T (t - t_n) in Q0;  rho = td - theta x td / 2 + c theta x (theta x td)
+  // ---- td = R_n^T (t - t_n) in Q0
   const V dT = TT - op[OP_TN];
-  V td = W::template bc<4>(dT) * op[OP_RT + 0];
-  td = W::template fm<5>(td, dT, op[OP_RT + 1]);
-  td = W::template fm<6>(td, dT, op[OP_RT + 2]);
-  const V thp = W::rot1(th), thpp = W::rot1(thp);
-  const V C1 = cross_rot<W>(thp, thpp, td);
-  const V C2 = cross_rot<W>(thp, thpp, C1);
-  const V RH = W::fma(cJ, C2, W::fma(V(-0.5), C1, td));
-  // ---- control (ilqr.hh:158-161): u = (u_nom + alpha k) + K [rho ; theta ; v - v_nom], rows in Q3
-  const V dvl = VL - op[OP_VNL], dvw = VW - op[OP_VNW];
-  V u2 = W::template bc<0>(dvl) * op[OP_K + 6];
-  V u3 = W::template bc<0>(dvw) * op[OP_K + 9];
-  V u1 = W::template bc<0>(th) * op[OP_K + 3];
-  V u0 = W::template fm<0>(op[OP_U0], RH, op[OP_K + 0]);
-  u2 = W::template fm<1>(u2, dvl, op[OP_K + 7]);
-  u3 = W::template fm<1>(u3, dvw, op[OP_K + 10]);
-  u1 = W::template fm<1>(u1, th, op[OP_K + 4]);
-  u0 = W::template fm<1>(u0, RH, op[OP_K + 1]);
-  u2 = W::template fm<2>(u2, dvl, op[OP_K + 8]);
-  u3 = W::template fm<2>(u3, dvw, op[OP_K + 11]);
-  u1 = W::template fm<2>(u1, th, op[OP_K + 5]);
-  u0 = W::template fm<2>(u0, RH, op[OP_K + 2]);
-  const V UU = (u0 + u1) + (u2 + u3);
-  st1 = W::fma(k.MQ2_3, VW, W::fma(k.MQ0_3, VL, TT)) + UU;
-  st2 = QQ;
-  return UU;
+  TD = W::template dot3<4>(V(0.0), dT, op[OP_RT + 0], op[OP_RT + 1], op[OP_RT + 2]);
+  TH4 = W::fma(k.M3, th, k.MW * cJ);
 }
-// the control wave, second part: v_{i+1} = F_i + dt (thrust, torques)  (J_u u: rows 8..11 of the constant control Jacobian)
+// control wave: rho = td - theta x td / 2 + c theta x (theta x td) in Q0, from the pose wave's (TH4, TD)
 template <class W>
-QILQR_HD void a_velocity(const RConsts<W> &k, typename W::V UU, typename W::V FL, typename W::V FW, typename W::V &VLn,
-                         typename W::V &VWn) {
+QILQR_HD typename W::V a_rho(typename W::V TH4, typename W::V TD) {
   typedef typename W::V V;
-  V l1 = W::template bc<12>(UU) * k.GLz;
-  V w1 = W::template bc<12>(UU) * k.GW[0];
-  l1 = W::template fm<13>(l1, UU, k.GLz);
-  w1 = W::template fm<13>(w1, UU, k.GW[1]);
-  FL = W::template fm<14>(FL, UU, k.GLz);
-  FW = W::template fm<14>(FW, UU, k.GW[2]);
-  l1 = W::template fm<15>(l1, UU, k.GLz);
-  w1 = W::template fm<15>(w1, UU, k.GW[3]);
-  VLn = FL + l1;
-  VWn = FW + w1;
+  const V cJ = W::template bc<3>(TH4);
+  const V thp = W::rot1(TH4), thpp = W::rot1(thp);  // (rot1 leaves lane j = 3 in place: it never reaches lanes j < 3)
+  const V C1 = cross_rot<W>(thp, thpp, TD);
+  const V C2 = cross_rot<W>(thp, thpp, C1);
+  return W::fma(cJ, C2, W::fma(V(-0.5), C1, TD));
 }
 
-// Which element of the 18-double knot a lane of st1 / st2 holds (-1: none).  st1 = [v_lin | t | omega | u], st2 = the
-// quaternion in Q0 (x, y, z, w -> elements 5, 6, 7, 4).
-QILQR_HD int st1_elem(int l) {
+// the closed forms of b_log (out of line on the device)
+template <class W>
+QILQR_HD typename W::V log_closed_forms(typename W::M closed, typename W::V s2, typename W::V wq, typename W::V coeff) {
+  typedef typename W::V V;
+  typedef typename W::M M;
+  const V ss = W::sqrt_(W::sel(closed, s2, V(1.0)));
+  const M neg = W::lt(wq, 0.0);
+  const V at = W::atan2_(W::sel(neg, -ss, ss), W::sel(neg, -wq, wq));
+  return W::sel(closed, 2.0 * at / ss, coeff);
+}
+template <class W>
+QILQR_HD typename W::V jinv_closed_forms(typename W::M closed, typename W::V th2, typename W::V cJ) {
+  typedef typename W::V V;
+  const V x = W::sel(closed, th2, V(1.0));
+  const V theta = W::sqrt_(x);
+  return W::sel(closed, 1.0 / x - (1.0 + W::cos_(theta)) / (2.0 * theta * W::sin_(theta)), cJ);
+}
+
+// control wave, the part of knot i that needs only v_i and the operands (it runs while the pose wave is still in Log_i):
+// the velocity terms of the control law, the gyroscopic term, the velocity lanes of the stored knot
+template <class W>
+struct APre {
+  typename W::V u2, u3, aW, st0;
+};
+template <class W>
+QILQR_HD void a_pre(const RConsts<W> &k, typename W::V VL, typename W::V VW, const typename W::V *op, APre<W> &r) {
+  typedef typename W::V V;
+  const V dvl = VL - op[OP_VNL], dvw = VW - op[OP_VNW];
+  r.u2 = W::template dot3<0>(V(0.0), dvl, op[OP_K + 6], op[OP_K + 7], op[OP_K + 8]);
+  r.u3 = W::template dot3<0>(V(0.0), dvw, op[OP_K + 9], op[OP_K + 10], op[OP_K + 11]);
+  r.st0 = W::fma(k.MQ2_3, VW, k.MQ0_3 * VL);
+  const V IW = W::template dot3<0>(V(0.0), VW, k.IC[0], k.IC[1], k.IC[2]);  // I omega in Q2
+  const V A1 = k.SA * VW;  // [0 | . | omega | 0]
+  const V A1p = W::rot1(A1), A1pp = W::rot1(A1p);
+  const V C1 = cross_rot<W>(A1p, A1pp, IW);  // Q2: omega x I omega
+  r.aW = W::template dot3<8>(VW, C1, k.NI[0], k.NI[1], k.NI[2]);  // omega - dt I^-1 (omega x I omega)
+}
+// control wave, with (theta | c, td) of tau_i and q_i from the pose wave: u_i (ilqr.hh:158-161; rows in Q3), v_{i+1} = v_i + dt a(q_i,
+// v_i, u_i) (quadrotor_model.cc:65-78), and what the wave stores for knot i: st = [v_lin | 0 | omega | u]
+template <class W>
+QILQR_HD typename W::V a_post(const RConsts<W> &k, const APre<W> &r, typename W::V TH, typename W::V TD, typename W::V QQ,
+                              typename W::V VL, const typename W::V *op, bool advance, typename W::V &VLn, typename W::V &VWn) {
+  typedef typename W::V V;
+  const V RH = a_rho<W>(TH, TD);  // (lane j = 3 of TH holds the Jacobian coefficient: the control law broadcasts lanes 0..2 only)
+  const V u1 = W::template dot3<0>(V(0.0), TH, op[OP_K + 3], op[OP_K + 4], op[OP_K + 5]);
+  const V u0 = W::template dot3<0>(op[OP_U0], RH, op[OP_K + 0], op[OP_K + 1], op[OP_K + 2]);
+  const V UU = (u0 + u1) + (r.u2 + r.u3);
+  const V st = r.st0 + UU;
+  if (!advance) return st;  // the reference's step after the last knot is computed and discarded (ilqr.hh:168)
+  // gravity in the body frame: (z, w, x, .) and (w, z, y, .) of q
+  const V aL = W::template dot2<0>(VL + k.GRAVC, QQ, k.S1 * W::template qperm<0xCE>(QQ), k.S2 * W::template qperm<0xDB>(QQ));
+  // J_u u: rows 8..11 of the constant control Jacobian (thrust along body z, torques)
+  VLn = W::template dot4<12>(aL, UU, k.GLz, k.GLz, k.GLz, k.GLz);
+  VWn = W::template dot4<12>(r.aW, UU, k.GW[0], k.GW[1], k.GW[2], k.GW[3]);
+  return st;
+}
+
+// Which element of the 18-double knot a lane of a stored register holds (-1: none).  The control wave stores
+// st = [v_lin | - | omega | u]; the pose wave stores the translation TT (Q1) and the quaternion QQ (its Q0 copy:
+// x, y, z, w -> elements 5, 6, 7, 4).
+QILQR_HD int sta_elem(int l) {
   const int q = (l >> 2) & 3, j = l & 3;
   if (q == 3) return 14 + j;
-  if (j == 3) return -1;
-  return q == 0 ? 8 + j : (q == 1 ? 1 + j : 11 + j);
+  if (j == 3 || q == 1) return -1;
+  return q == 0 ? 8 + j : 11 + j;
 }
-QILQR_HD int st2_elem(int l) {
+QILQR_HD int stt_elem(int l) { return (((l >> 2) & 3) == 1 && (l & 3) < 3) ? 1 + (l & 3) : -1; }
+QILQR_HD int stq_elem(int l) {
   const int q = (l >> 2) & 3, j = l & 3;
   if (q != 0) return -1;
   return j == 3 ? 4 : 5 + j;

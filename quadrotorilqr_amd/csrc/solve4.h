@@ -1,6 +1,6 @@
 // solve4.h -- k_solve4: the WHOLE of ILQR::solve (ilqr.hh:53-87) for a batch in ONE launch.
 //
-// A block of six wavefronts owns four trajectories from their first linearisation to their exit status and then takes the
+// A block of eight wavefronts owns four trajectories from their first linearisation to their exit status and then takes the
 // next four from a queue (one atomic ticket per group), so
 //   * there are no rounds: a trajectory that has converged costs nothing more, a block that is done starts other work, and
 //     the step is no longer (number of rounds of the slowest trajectory) x (three launches);
@@ -13,11 +13,11 @@
 //   settle    waves 0..3, one trajectory each: cost of the pending candidate (left-to-right sum of its knot costs,
 //             ilqr.hh:89-95), Armijo test (ilqr.hh:186), convergence tests (ilqr.hh:196-205), step-size update,
 //             Levenberg-Marquardt restart -- the per-trajectory state machine of k_backward4's prologue, with the state in LDS
-//   backward  waves 0..3 matrix recursions M_g, wave 4 gradients G, wave 5 record loader L (bw4_*); then the expected
+//   backward  waves 0..3 matrix recursions M_g, wave 4 gradients G, wave 5 record loader L (bw4_*; waves 6, 7 idle); then the expected
 //             reduction test of ilqr.hh:64-68
-//   forward   wave 0 control A, wave 1 pose B, wave 5 operands P (r16_*: sixteen lanes per trajectory); waves 2 and 3
-//             linearise the candidate's knots -- dynamics blocks / cost differentials, a lane per (trajectory, knot) --
-//             in chunks of sixteen as A announces them stored
+//   forward   wave 0 control A, wave 1 pose B, wave 2 operands P (r16_*: sixteen lanes per trajectory; a SIMD each); waves 3, 6
+//             and 7 linearise the candidate's knots -- dynamics blocks / cost differentials, a lane per (trajectory, knot) --
+//             in chunks of sixteen as A and B announce them stored
 // A trajectory that is back-tracking skips the backward phase, one that has converged skips both; the block leaves the
 // loop when its four trajectories have an exit status.
 #pragma once
@@ -38,6 +38,7 @@ __shared__ double s4_ring[4][4][BW2_BUF];
 __shared__ double s4_kf[4][2][80];
 __shared__ R16Lds s4_r16;
 __shared__ Solve4Slot s4_slot[4];
+__shared__ int s4_task;  // next (chunk, half) of the candidate's linearisation (forward phase)
 
 template <typename S>
 __device__ __attribute__((noinline)) double s4_gradient(const RecLayout &L, S *gains, S *dump4, bool grun, int n, int lane) {
@@ -56,16 +57,20 @@ __device__ __attribute__((noinline)) void s4_operands(const S *traj, const S *ga
   r16_wave_P<S>(s4_r16, traj, gains, out, alpha, live, n, lane, nullptr);
 }
 template <typename S>
-__device__ __attribute__((noinline)) void s4_pose(const ModelConsts<double> &c, const S *traj, int n, int lane) {
+__device__ __attribute__((noinline)) void s4_pose(const ModelConsts<double> &c, const S *traj, S *out, bool live, int n, int lane) {
   using namespace r16;
   auto ld0 = [&](int e) -> double { return e >= 0 ? (double)traj[knot_elem<true>(0, e, 18)] : 0.0; };
-  r16_wave_B(s4_r16, c, ld0(tt_elem(lane)), ld0(qq_elem(lane)), ld0(vl_elem(lane)), ld0(vw_elem(lane)), n, lane, nullptr);
+  const double TT = ld0(tt_elem(lane)), QQ = ld0(qq_elem(lane));
+  R16_LOADS_DONE();
+  r16_wave_B<S, true>(s4_r16, c, TT, QQ, out, live, n, lane, nullptr);
 }
 template <typename S>
 __device__ __attribute__((noinline)) void s4_control(const ModelConsts<double> &c, const S *traj, S *out, bool live, int n, int lane) {
   using namespace r16;
   auto ld0 = [&](int e) -> double { return e >= 0 ? (double)traj[knot_elem<true>(0, e, 18)] : 0.0; };
-  r16_wave_A<S, true>(s4_r16, c, ld0(tt_elem(lane)), ld0(qq_elem(lane)), ld0(vl_elem(lane)), ld0(vw_elem(lane)), out, live, n, lane, nullptr);
+  const double VL = ld0(vl_elem(lane)), VW = ld0(vw_elem(lane));
+  R16_LOADS_DONE();
+  r16_wave_A<S, true>(s4_r16, c, VL, VW, out, live, n, lane, nullptr);
 }
 
 // one lane's share of a linearisation: the dynamics blocks (half = 0) or the cost differentials and the knot cost (half = 1)
@@ -87,24 +92,37 @@ __device__ __forceinline__ void solve4_linearize_lane(const ModelConsts<S> &cl, 
   st.knot_cost[buf][cost_index(b, i, n)] = (double)cost;  // summed in fp64 (settle)
 }
 
-// the candidate's linearisation, sixteen knots behind the rollout (forward phase, waves 2 and 3): half 0 the dynamics
-// blocks, half 1 the cost differentials and knot costs; lane = (row, knot of the chunk)
+// the candidate's linearisation, sixteen knots behind the rollout (forward phase, the follower waves): tasks (chunk of
+// sixteen knots, half) are taken from a counter in LDS in the order the rollout produces them -- half 0 the dynamics blocks,
+// half 1 the cost differentials and knot costs; lane = (row, knot of the chunk).  A lane's share is a long serial computation
+// (~35 000 cycles): the phase ends one task after the rollout, and three waves keep up with it where two do not.
 template <typename S, int LK>
 __device__ __attribute__((noinline)) void s4_follow(const ModelConsts<S> *cp, const S *qr, const BatchState &st, int b, int buf, bool live,
-                                                    int half, int n, int lane) {
-  for (int k0 = 0; k0 < n; k0 += R16_CHUNK) {
+                                                    int n, int lane) {
+  const int ntasks = 2 * ((n + R16_CHUNK - 1) / R16_CHUNK);
+  for (;;) {
+    int t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(&s4_task, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= ntasks) break;
+    const int k0 = (t >> 1) * R16_CHUNK, half = t & 1;
     const int need = (k0 + R16_CHUNK < n) ? k0 + R16_CHUNK : n;
-    if (!r16_flag_wait_relaxed(s4_r16, R16_F_K, need, lane)) break;
+    if (!(r16_flag_wait_relaxed(s4_r16, R16_F_KA, need, lane) && r16_flag_wait_relaxed(s4_r16, R16_F_KB, need, lane))) break;
     const int i = k0 + (lane & 15);
     if (live && i < n) solve4_linearize_lane<S, LK>(*cp, qr, st, b, i, n, buf, half);
   }
 }
 // first linearisation of the four trajectories of a group (ilqr.hh:56 needs their cost; the first backward pass their
 // records): every lane of the block takes (trajectory, knot) pairs, dynamics halves first, then cost halves
+constexpr int S4_WAVES = 8, S4_THREADS = 64 * S4_WAVES;
+// forward-phase roles by wave (waves w and w + 4 share SIMD w % 4): the control wave A and the pose wave B have a SIMD each;
+// the operand wave P shares its SIMD with one follower, the other two followers share the fourth
+constexpr int S4_W_A = 0, S4_W_B = 1, S4_W_P = 2;
+__device__ __forceinline__ bool s4_is_follower(int w) { return w == 3 || w == 7 || w == 6; }
 template <typename S, int LK>
 __device__ __attribute__((noinline)) void s4_first(const ModelConsts<S> *cp, const S *qr, const BatchState &st, int b0, int B, int n) {
   const int per = 4 * n;
-  for (int t = threadIdx.x; t < 2 * per; t += 384) {
+  for (int t = threadIdx.x; t < 2 * per; t += S4_THREADS) {
     const int half = t >= per, r = half ? t - per : t;
     const int g = r / n, i = r - g * n;
     if (b0 + g < B) solve4_linearize_lane<S, LK>(*cp, qr, st, b0 + g, i, n, 0, half);
@@ -112,7 +130,7 @@ __device__ __attribute__((noinline)) void s4_first(const ModelConsts<S> *cp, con
 }
 
 template <typename S, int LK>
-__global__ __launch_bounds__(384) void k_solve4(ModelConsts<double> c, const ModelConsts<S> *__restrict__ cp, SolveParams p, BatchState st,
+__global__ __launch_bounds__(S4_THREADS) void k_solve4(ModelConsts<double> c, const ModelConsts<S> *__restrict__ cp, SolveParams p, BatchState st,
                                                 int B, int n, unsigned ticket_base) {
   using namespace r16;
   const int lane = threadIdx.x & 63;
@@ -123,8 +141,8 @@ __global__ __launch_bounds__(384) void k_solve4(ModelConsts<double> c, const Mod
   __shared__ S qr[160];  // the weights Q (144) and R (16) in storage precision, for the cost half of the linearisation
   __shared__ int s_group;
   const RecLayout L = st.layout;
-  for (int k = threadIdx.x; k < 160; k += 384) qr[k] = (k < 144) ? cp->Q[k] : cp->R[k - 144];
-  bw4_fill_ctab<S>(ring, st.ctab, 384);
+  for (int k = threadIdx.x; k < 160; k += S4_THREADS) qr[k] = (k < 144) ? cp->Q[k] : cp->R[k - 144];
+  bw4_fill_ctab<S>(ring, st.ctab, S4_THREADS);
   const int ngroups = (B + 3) / 4;
 #ifdef QILQR_STAMPS
   // diagnostic build: cycles of wave `w` per phase, summed over the block's life: [0] first linearisation, [1] settle,
@@ -274,6 +292,8 @@ __global__ __launch_bounds__(384) void k_solve4(ModelConsts<double> c, const Mod
             rec[g] = (const S *)st.lin[sl[g].cur] + rec_base(bg, n, L.stride);
           }
           s4_loader<S>(L, rec[0], rec[1], rec[2], rec[3], n, lane);
+        } else if (w >= 6) {
+          for (int i = n; i >= 0; --i) __syncthreads();  // no role in this phase: keep the knot barriers of bw4_* company (one + n)
         } else {
           const int bg = sl[w].b >= 0 ? sl[w].b : sl[0].b;
           const int j = lane & 15, kk = lane >> 4;
@@ -289,6 +309,7 @@ __global__ __launch_bounds__(384) void k_solve4(ModelConsts<double> c, const Mod
       const int search = (sl[0].fl | sl[1].fl | sl[2].fl | sl[3].fl) & F_SEARCH;
       if (search) {  // block-uniform
         if (threadIdx.x < R16_NFLAGS) rsh.flags[threadIdx.x] = 0;
+        if (threadIdx.x == 0) s4_task = 0;
         __syncthreads();
         const int row = lane >> 4;
         const bool live = (sl[row].fl & F_SEARCH) != 0;
@@ -298,10 +319,11 @@ __global__ __launch_bounds__(384) void k_solve4(ModelConsts<double> c, const Mod
         const S *traj = (const S *)st.traj[cur] + knot_base<true>(bs, n, 18);
         const S *gains = (const S *)st.gains + knot_base<true>(bs, n, 52);
         S *out = (S *)st.traj[cur ^ 1] + knot_base<true>(bs, n, 18);
-        if (w == 5) s4_operands<S>(traj, gains, out, sl[lrow].alpha, live, n, lane);
-        else if (w == 1) s4_pose<S>(c, traj, n, lane);
-        else if (w == 0) s4_control<S>(c, traj, out, live, n, lane);
-        else if (w < 4) s4_follow<S, LK>(cp, qr, st, sl[row].b, sl[row].cur ^ 1, live, w - 2, n, lane);
+        // a wavefront per SIMD for the three rollout roles (waves w, w + 4 share SIMD w % 4); the two linearising waves share the fourth
+        if (w == S4_W_A) s4_control<S>(c, traj, out, live, n, lane);
+        else if (w == S4_W_B) s4_pose<S>(c, traj, out, live, n, lane);
+        else if (w == S4_W_P) s4_operands<S>(traj, gains, out, sl[lrow].alpha, live, n, lane);
+        else if (s4_is_follower(w)) s4_follow<S, LK>(cp, qr, st, sl[row].b, sl[row].cur ^ 1, live, n, lane);
         QSTAMP(3);
         __syncthreads();
         QSTAMP(4);
@@ -333,8 +355,8 @@ __global__ __launch_bounds__(384) void k_solve4(ModelConsts<double> c, const Mod
       if (p.mu_init > 0.0) st.mu[b] = s.mu;
     }
 #ifdef QILQR_STAMPS
-    if (lane == 0 && st.stamps && blockIdx.x * 6 + w < B)  // (B x 8 words are allocated)
-      for (int k = 0; k < 8; ++k) st.stamps[((long)blockIdx.x * 6 + w) * 8 + k] = stamp_sum[k];
+    if (lane == 0 && st.stamps && blockIdx.x * S4_WAVES + w < B)  // (B x 8 words are allocated)
+      for (int k = 0; k < 8; ++k) st.stamps[((long)blockIdx.x * S4_WAVES + w) * 8 + k] = stamp_sum[k];
 #endif
   }
 }

@@ -61,6 +61,14 @@ struct HostWave {
   static I iuni(int e) { I r; for (int l = 0; l < 64; ++l) r.v[l] = e; return r; }
   template <int L> static V bc(const V &x) { V r; for (int l = 0; l < 64; ++l) r.v[l] = x.v[(l & ~15) + L]; return r; }
   template <int L> static V fm(const V &acc, const V &src, const V &m) { return fma(bc<L>(src), m, acc); }
+  // acc + sum_c src[lane L0 + c of the row] * m_c, accumulated in this order (on the device: a chain of v_fmac_f64_dpp)
+  template <int L0> static V dot2(const V &acc, const V &src, const V &m0, const V &m1) { return fm<L0 + 1>(fm<L0>(acc, src, m0), src, m1); }
+  template <int L0> static V dot3(const V &acc, const V &src, const V &m0, const V &m1, const V &m2) {
+    return fm<L0 + 2>(dot2<L0>(acc, src, m0, m1), src, m2);
+  }
+  template <int L0> static V dot4(const V &acc, const V &src, const V &m0, const V &m1, const V &m2, const V &m3) {
+    return fm<L0 + 3>(dot3<L0>(acc, src, m0, m1, m2), src, m3);
+  }
   template <int CTRL> static V qperm(const V &x) {
     V r;
     for (int l = 0; l < 64; ++l) r.v[l] = x.v[(l & ~3) + ((CTRL >> (2 * (l & 3))) & 3)];
@@ -78,6 +86,12 @@ struct HostWave {
 #define HV_FUN(name, fn) static V name(const V &a) { V r; for (int l = 0; l < 64; ++l) r.v[l] = fn(a.v[l]); return r; }
   HV_FUN(abs_, std::fabs) HV_FUN(sqrt_, std::sqrt) HV_FUN(sin_, std::sin) HV_FUN(cos_, std::cos)
   static V atan2_(const V &a, const V &b) { V r; for (int l = 0; l < 64; ++l) r.v[l] = std::atan2(a.v[l], b.v[l]); return r; }
+  // the rarely-taken closed forms (out of line on the device)
+  static V exp_closed(const M &c, const V &x, const V &p, const M &l0, const M &l1, const M &l2, const M &l3) {
+    return qilqr::r16::exp_closed_forms<HostWave>(c, x, p, l0, l1, l2, l3);
+  }
+  static V log_closed(const M &c, const V &s2, const V &wq, const V &coeff) { return qilqr::r16::log_closed_forms<HostWave>(c, s2, wq, coeff); }
+  static V jinv_closed(const M &c, const V &th2, const V &cJ) { return qilqr::r16::jinv_closed_forms<HostWave>(c, th2, cJ); }
 };
 }  // namespace
 
@@ -175,7 +189,7 @@ void hh_rollout_tiled(const ModelConsts<double> *c, const double *traj, const do
 }
 
 // k_rollout16 on the CPU: one wavefront = four trajectories (plain [4][n][18] / [4][n][52] arrays), the operand
-// registers of every knot prepared by r16::p_load / p_compute and consumed by r16::a_control / b_knot / a_velocity
+// registers of every knot prepared by r16::p_load / p_compute and consumed by r16::b_log / a_pre / a_post / a_exp / b_compose
 // exactly as the three device wavefronts do (the LDS ring and its flags are plumbing, not arithmetic: not re-enacted).  ops_out (optional):
 // the 23 x 64 operand values of knot `ops_knot`.
 void hh_rollout16(const ModelConsts<double> *c, const double *traj, const double *gains, const double *alpha, double *out,
@@ -205,18 +219,23 @@ void hh_rollout16(const ModelConsts<double> *c, const double *traj, const double
     if (ops_out && i == ops_knot)
       for (int r = 0; r < NOPS; ++r)
         for (int l = 0; l < 64; ++l) ops_out[r * 64 + l] = op[r].v[l];
-    HV st1, st2;
-    const HV UU = a_control<HostWave>(kc, TT, QQ, VL, VW, op, st1, st2);   // wave A
+    // wave B has produced (t, q)_i and its Log against the nominal knot i; wave A takes it from there
+    HV RH, TH, VLn, VWn;
+    APre<HostWave> pre;
+    a_pre<HostWave>(kc, VL, VW, op, pre);
+    b_log<HostWave>(kc, TT, QQ, op, RH, TH);
+    const HV st = a_post<HostWave>(kc, pre, RH, TH, QQ, VL, op, i + 1 < n, VLn, VWn);  // (RH, TH) here: b_log's (TH4, TD)
     for (int l = 0; l < 64; ++l) {
       double *o = out + ((long)(l >> 4) * n + i) * 18;
       if ((l & 15) == 0) o[0] = T(l, i, 0);
-      if (st1_elem(l) >= 0) o[st1_elem(l)] = st1.v[l];
-      if (st2_elem(l) >= 0) o[st2_elem(l)] = st2.v[l];
+      if (sta_elem(l) >= 0) o[sta_elem(l)] = st.v[l];
+      if (stt_elem(l) >= 0) o[stt_elem(l)] = TT.v[l];
+      if (stq_elem(l) >= 0) o[stq_elem(l)] = QQ.v[l];
     }
     if (i + 1 < n) {  // the reference's step after the last knot is computed and discarded (ilqr.hh:168)
-      HV FL, FW, TTn, QQn, VLn, VWn;
-      b_knot<HostWave>(kc, TT, QQ, VL, VW, [&](const HV &l_, const HV &w_) { FL = l_; FW = w_; }, TTn, QQn);  // wave B
-      a_velocity<HostWave>(kc, UU, FL, FW, VLn, VWn);                                                        // wave A
+      HV TTn, QQn, DQ, PP;
+      a_exp<HostWave>(kc, VL, VW, DQ, PP);  // E_i from v_i (on the device: computed by A one knot earlier)
+      b_compose<HostWave>(kc, TT, QQ, DQ, PP, TTn, QQn);
       TT = TTn; QQ = QQn; VL = VLn; VW = VWn;
     }
   }

@@ -708,7 +708,7 @@ def test_mixed_precision_at_headline_size():
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_randomised_models_and_horizons_match_oracle(seed, restarts=False):
+def test_randomised_models_and_horizons_match_oracle(seed, restarts=False, persistent=0):
     """Random physical parameters (mass, SPD inertia, arm, rotor torque ratio, gravity), time step,
     horizon, weights (diagonal / block-diagonal dense / fully dense symmetric, by seed) and option values;
     random SE(3) starts towards a random hover pose."""
@@ -744,7 +744,7 @@ def test_randomised_models_and_horizons_match_oracle(seed, restarts=False):
         opts["ls_max_iters"] = int(r.integers(1, 4))
         reg = (float(r.choice([0.1, 1.0, 10.0])), float(r.choice([2.0, 4.0, 10.0])), float(r.choice([1e3, 1e6])))
     cfg = dict(model=model, Q=Q, R=R, dt=dt, options=opts, desired=desired, init=init)
-    s, o = capi.from_config(cfg), oracle_for(cfg)
+    s, o = capi.from_config(cfg, persistent=persistent), oracle_for(cfg)
     if reg:
         s.set_regularisation(*reg)
         o.set_regularisation(*reg)
@@ -763,3 +763,44 @@ def test_randomised_restarts_match_oracle(seed):
     """The randomised case above with one to three trials per line search and Levenberg-Marquardt restarts
     (random mu_init, factor, mu_max) on both sides: same sequence of restarts, trials and accepted steps."""
     test_randomised_models_and_horizons_match_oracle(seed, restarts=True)
+
+
+# ------------------------------------------------------------------ the persistent solve (k_solve4: one launch per batch)
+@pytest.mark.parametrize("seed,restarts", [(s, False) for s in range(12)] + [(s, True) for s in range(100, 106)])
+def test_persistent_solve_matches_oracle(seed, restarts):
+    """The randomised cases above (models, horizons 5..90, batches 1..40 -- ragged groups of four --, dense and diagonal
+    symmetric weights, few-trial line searches with Levenberg-Marquardt restarts) through k_solve4: same statuses,
+    iteration and pass counts, costs and trajectories as the oracle."""
+    test_randomised_models_and_horizons_match_oracle(seed, restarts=restarts, persistent=1)
+
+
+def test_persistent_solve_is_one_launch_and_matches_the_rounds():
+    """persistent = 1 really takes k_solve4 (one launch per batch solve, counted by the profile), in both storage precisions,
+    with per-problem desired trajectories and the cost history; against the rounds on the same inputs: exit paths equal up
+    to threshold flips (the two paths inline the same arithmetic into different kernels), costs and trajectories agree."""
+    B, n = 203, 60
+    cfg = pb.config2(B=B, N=n, seed=9)
+    r = np.random.default_rng(5)
+    desired_batch = np.repeat(cfg["desired"][None], B, axis=0)
+    desired_batch[:, :, 1:4] += r.uniform(-0.2, 0.2, (B, 1, 3))
+    for precision, tol in (("f64", 1e-6), ("f32", 2e-3)):
+        c = dict(cfg, options=dict(cfg["options"], populate_debug=True))  # (the cost history)
+        if precision == "f32":
+            c["options"] = dict(c["options"], rtol=1e-5, atol=1e-5)
+        pers = capi.from_config(c, persistent=1, profile=1, precision=precision)
+        rnds = capi.from_config(c, persistent=2, precision=precision)
+        for desired in (None, desired_batch):
+            pers.profile_reset()
+            a = pers.solve_batch(cfg["init"], desired)
+            p = pers.profile_get()
+            assert p["solve_launches"] == 1 and p["backward_launches"] == 0 and p["rollout_launches"] == 0, p
+            b = rnds.solve_batch(cfg["init"], desired)
+            assert np.isin(a["status"], [0, 1]).all()
+            if precision == "f64":
+                assert_same_exit_paths(a, b)
+            np.testing.assert_allclose(a["cost"], b["cost"], rtol=1e-6 if precision == "f64" else 1e-3)
+            np.testing.assert_allclose(a["traj"], b["traj"], atol=tol)
+        if precision == "f64":
+            ha, hb = pers.cost_history(B), rnds.cost_history(B)
+            same = (a["iters"] == b["iters"])
+            np.testing.assert_allclose(np.nan_to_num(ha[same]), np.nan_to_num(hb[same]), rtol=1e-9)
