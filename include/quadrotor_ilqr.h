@@ -205,6 +205,36 @@ int qilqr_stream_wait_event(qilqr_solver *s, void *hip_event);
 void *qilqr_host_alloc(size_t bytes);
 void qilqr_host_free(void *p);
 
+/* ---- one batch over several devices, in ONE process (BASELINE.json configs[3]: independent problems, contiguous shards,
+ * no exchange between them -- the reference has no counterpart: its ILQR object solves one problem on one core).
+ * A sharded handle owns one qilqr_solver per entry of `devices` (an ordinal may repeat: two shards then overlap on that
+ * device through two handles and two streams).  qilqr_solve_batch_sharded cuts the B problems into n_devices contiguous
+ * shards in the order of `devices` -- B / n_devices each, the first B % n_devices one more (qilqr_shard_range; the rule of
+ * quadrotorilqr_amd/sharding.py for the one-process-per-GPU deployment) -- and solves shard r on devices[r] from a host
+ * thread of its own: its input slice goes to the device, its results come back into the caller's arrays at the shard's
+ * offset (the "gather" is the copy back itself: ragged shards need no padding), the call returns when every shard has.
+ * Arguments and results are those of qilqr_solve_batch, problem by problem bit-identical to a single-device solve of the
+ * same batch.  A shard that fails makes the call return its error (the lowest failing shard's; text through
+ * qilqr_last_error, prefixed with the shard and device); the other shards still complete. */
+typedef struct qilqr_sharded qilqr_sharded;
+/* dev: as for qilqr_create, its `device` field is ignored (NULL = defaults) */
+int qilqr_sharded_create(const qilqr_model *model, const double *Q, const double *R, const double *desired,
+                         int32_t n_desired, double dt_s, const qilqr_options *options, const qilqr_device_config *dev,
+                         const int32_t *devices, int32_t n_devices, qilqr_sharded **out);
+/* the same with the devices given as a bit mask (bit d = HIP device d), lowest ordinal first */
+int qilqr_sharded_create_mask(const qilqr_model *model, const double *Q, const double *R, const double *desired,
+                              int32_t n_desired, double dt_s, const qilqr_options *options,
+                              const qilqr_device_config *dev, uint64_t device_mask, qilqr_sharded **out);
+void qilqr_sharded_destroy(qilqr_sharded *h);
+int32_t qilqr_sharded_count(const qilqr_sharded *h);
+/* the solver of shard r (to set regularisation, read profiles or cost histories shard by shard); NULL if r is out of range */
+qilqr_solver *qilqr_sharded_solver(qilqr_sharded *h, int32_t r);
+/* problems [*begin, *begin + *count) of a batch of B belong to shard r of n_shards */
+int qilqr_shard_range(int32_t B, int32_t n_shards, int32_t r, int32_t *begin, int32_t *count);
+int qilqr_solve_batch_sharded(qilqr_sharded *h, const double *init, const double *desired_batch, int32_t B, int32_t n,
+                              double *out_traj, double *out_cost, int32_t *out_status, int32_t *out_iters,
+                              int32_t *out_n_bwd, int32_t *out_n_fwd);
+
 /* ABI version of this header */
 int qilqr_abi_version(void);
 

@@ -38,6 +38,8 @@ EXPORTS = (
     "qilqr_solve_batch_device", "qilqr_cost_trajectory", "qilqr_backwards_pass", "qilqr_forward_sim",
     "qilqr_line_search", "qilqr_cost_history", "qilqr_profile_reset", "qilqr_profile_get", "qilqr_profile_mode", "qilqr_set_regularisation",
     "qilqr_device", "qilqr_stream", "qilqr_stream_wait_event", "qilqr_host_alloc", "qilqr_host_free",
+    "qilqr_sharded_create", "qilqr_sharded_create_mask", "qilqr_sharded_destroy", "qilqr_sharded_count", "qilqr_sharded_solver",
+    "qilqr_shard_range", "qilqr_solve_batch_sharded",
     "qilqr_abi_version",
 )
 
@@ -85,6 +87,10 @@ def load():
         lib.qilqr_host_alloc.restype = C.c_void_p
         lib.qilqr_host_alloc.argtypes = [C.c_size_t]
         lib.qilqr_host_free.argtypes = [C.c_void_p]
+        lib.qilqr_sharded_solver.restype = C.c_void_p
+        lib.qilqr_sharded_solver.argtypes = [C.c_void_p, C.c_int32]
+        lib.qilqr_sharded_destroy.argtypes = [C.c_void_p]
+        lib.qilqr_sharded_count.argtypes = [C.c_void_p]
         _lib = lib
     return _lib
 
@@ -116,6 +122,50 @@ def _raise(rc, ls_max_iters=None):
     raise RuntimeError(f"quadrotor_ilqr error {rc}: {msg}")
 
 
+def _create_args(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired, options, device, profile,
+                 sync_every, force_general, single_wave_rollout, precision, streams, persistent):
+    """the C structures of qilqr_create / qilqr_sharded_create; sets self.options and self.desired"""
+    m = Model()
+    m.mass_kg = mass_kg
+    I = _d(inertia)
+    if I.shape != (3, 3):
+        raise TypeError("inertia must be 3x3")
+    for i in range(9):
+        m.inertia[i] = I.reshape(9)[i]
+    m.arm_length_m = arm_length_m
+    m.torque_to_thrust_ratio_m = torque_to_thrust_ratio_m
+    m.g_mpss = g_mpss
+    Q, R = _d(Q), _d(R)
+    if Q.shape != (12, 12) or R.shape != (4, 4):
+        raise TypeError("Q must be 12x12 and R 4x4")
+    o = Options()
+    o.step_update = options["step_update"]
+    o.desired_reduction_frac = options["desired_reduction_frac"]
+    o.ls_max_iters = int(options["ls_max_iters"])
+    o.rtol = options["rtol"]
+    o.atol = options["atol"]
+    o.max_iters = float(options["max_iters"])
+    o.populate_debug = int(bool(options.get("populate_debug", False)))
+    self.options = dict(options)
+    self.desired = _d(desired).reshape(-1, KNOT)
+    dc = DeviceConfig(int(device), int(profile), int(sync_every), int(force_general),
+                      int(single_wave_rollout), {"f64": 0, "f32": 1}[precision], int(streams), int(persistent))
+    return m, Q, R, o, dc
+
+
+def _batch_outputs(init, out):
+    """result arrays of a batch solve: fresh, or the caller's (checked)"""
+    B = init.shape[0]
+    if out is None:
+        return dict(traj=np.zeros_like(init), cost=np.zeros(B), **{k: np.zeros(B, dtype=np.int32) for k in ("status", "iters", "n_bwd", "n_fwd")})
+    for k, dt, shape in (("traj", np.float64, init.shape), ("cost", np.float64, (B,)), ("status", np.int32, (B,)),
+                         ("iters", np.int32, (B,)), ("n_bwd", np.int32, (B,)), ("n_fwd", np.int32, (B,))):
+        a = out[k]
+        if a.dtype != dt or a.shape != shape or not a.flags["C_CONTIGUOUS"]:
+            raise TypeError(f"out[{k!r}] must be a C-contiguous {np.dtype(dt).name} array of shape {shape}")
+    return out
+
+
 class QuadrotorILQRBatch:
     """ILQR<QuadrotorModel> (ilqr.hh:25-41) for batches of independent problems on one MI355X."""
 
@@ -123,31 +173,8 @@ class QuadrotorILQRBatch:
                  dt_s, options, device=0, profile=0, sync_every=2, force_general=False,
                  single_wave_rollout=False, precision="f64", streams=0, persistent=0):
         lib = load()
-        m = Model()
-        m.mass_kg = mass_kg
-        I = _d(inertia)
-        if I.shape != (3, 3):
-            raise TypeError("inertia must be 3x3")
-        for i in range(9):
-            m.inertia[i] = I.reshape(9)[i]
-        m.arm_length_m = arm_length_m
-        m.torque_to_thrust_ratio_m = torque_to_thrust_ratio_m
-        m.g_mpss = g_mpss
-        Q, R = _d(Q), _d(R)
-        if Q.shape != (12, 12) or R.shape != (4, 4):
-            raise TypeError("Q must be 12x12 and R 4x4")
-        o = Options()
-        o.step_update = options["step_update"]
-        o.desired_reduction_frac = options["desired_reduction_frac"]
-        o.ls_max_iters = int(options["ls_max_iters"])
-        o.rtol = options["rtol"]
-        o.atol = options["atol"]
-        o.max_iters = float(options["max_iters"])
-        o.populate_debug = int(bool(options.get("populate_debug", False)))
-        self.options = dict(options)
-        self.desired = _d(desired).reshape(-1, KNOT)
-        dc = DeviceConfig(int(device), int(profile), int(sync_every), int(force_general),
-                          int(single_wave_rollout), {"f64": 0, "f32": 1}[precision], int(streams), int(persistent))
+        m, Q, R, o, dc = _create_args(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired, options,
+                                      device, profile, sync_every, force_general, single_wave_rollout, precision, streams, persistent)
         self._h = C.c_void_p()
         rc = lib.qilqr_create(C.byref(m), _p(Q), _p(R), _p(self.desired), C.c_int32(len(self.desired)),
                               C.c_double(dt_s), C.byref(o), C.byref(dc), C.byref(self._h))
@@ -192,14 +219,7 @@ class QuadrotorILQRBatch:
         init = _d(init)
         B, n = init.shape[0], init.shape[1]
         des = None if desired_batch is None else _d(desired_batch)
-        if out is None:
-            out = dict(traj=np.zeros_like(init), cost=np.zeros(B), **{k: np.zeros(B, dtype=np.int32) for k in ("status", "iters", "n_bwd", "n_fwd")})
-        else:
-            for k, dt, shape in (("traj", np.float64, init.shape), ("cost", np.float64, (B,)), ("status", np.int32, (B,)),
-                                 ("iters", np.int32, (B,)), ("n_bwd", np.int32, (B,)), ("n_fwd", np.int32, (B,))):
-                a = out[k]
-                if a.dtype != dt or a.shape != shape or not a.flags["C_CONTIGUOUS"]:
-                    raise TypeError(f"out[{k!r}] must be a C-contiguous {np.dtype(dt).name} array of shape {shape}")
+        out = _batch_outputs(init, out)
         rc = load().qilqr_solve_batch(self._h, _p(init), _p(des), C.c_int32(B), C.c_int32(n), _p(out["traj"]), _p(out["cost"]),
                                       _ip(out["status"]), _ip(out["iters"]), _ip(out["n_bwd"]), _ip(out["n_fwd"]))
         if rc:
@@ -335,6 +355,65 @@ class QuadrotorILQRBatch:
         if rc:
             _raise(rc)
         return {f: getattr(p, f) for f, _ in Profile._fields_}
+
+
+class QuadrotorILQRSharded:
+    """One batch over several devices from one process (qilqr_sharded_*): contiguous shards in the order of `devices`
+    (an ordinal may repeat), one solver, stream and host thread per shard, results in place -- problem by problem identical
+    to QuadrotorILQRBatch.solve_batch.  The one-process-per-GPU deployment (torch.distributed) is in sharding.py / bench.py."""
+
+    def __init__(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired, dt_s, options,
+                 devices=(0,), profile=0, sync_every=2, force_general=False, single_wave_rollout=False, precision="f64",
+                 streams=0, persistent=0):
+        lib = load()
+        m, Q, R, o, dc = _create_args(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired, options,
+                                      0, profile, sync_every, force_general, single_wave_rollout, precision, streams, persistent)
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int32 * len(self.devices))(*self.devices)
+        self._h = C.c_void_p()
+        rc = lib.qilqr_sharded_create(C.byref(m), _p(Q), _p(R), _p(self.desired), C.c_int32(len(self.desired)), C.c_double(dt_s),
+                                      C.byref(o), C.byref(dc), arr, C.c_int32(len(self.devices)), C.byref(self._h))
+        if rc:
+            self._h = None
+            _raise(rc)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().qilqr_sharded_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shard_ranges(self, B):
+        """[(begin, count)] of every shard for a batch of B (qilqr_shard_range)"""
+        out = []
+        for r in range(len(self.devices)):
+            b0, cnt = C.c_int32(), C.c_int32()
+            rc = load().qilqr_shard_range(C.c_int32(B), C.c_int32(len(self.devices)), C.c_int32(r), C.byref(b0), C.byref(cnt))
+            if rc:
+                _raise(rc)
+            out.append((b0.value, cnt.value))
+        return out
+
+    def solve_batch(self, init, desired_batch=None, out=None):
+        init = _d(init)
+        B, n = init.shape[0], init.shape[1]
+        des = None if desired_batch is None else _d(desired_batch)
+        out = _batch_outputs(init, out)
+        rc = load().qilqr_solve_batch_sharded(self._h, _p(init), _p(des), C.c_int32(B), C.c_int32(n), _p(out["traj"]), _p(out["cost"]),
+                                              _ip(out["status"]), _ip(out["iters"]), _ip(out["n_bwd"]), _ip(out["n_fwd"]))
+        if rc:
+            _raise(rc)
+        return out
+
+
+def sharded_from_config(cfg, devices=(0,), **kw):
+    return QuadrotorILQRSharded(**cfg["model"], Q=cfg["Q"], R=cfg["R"], desired=cfg["desired"], dt_s=cfg["dt"],
+                                options=cfg["options"], devices=devices, **kw)
 
 
 def host_array(shape, dtype=np.float64):

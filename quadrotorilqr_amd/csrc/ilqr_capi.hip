@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/quadrotor_ilqr.h"
@@ -698,7 +699,7 @@ int solve_batch_device_impl(qilqr_solver *s, const double *d_init, const double 
 
 extern "C" {
 
-int qilqr_abi_version(void) { return 3; }
+int qilqr_abi_version(void) { return 4; }
 
 const char *qilqr_last_error(void) { return g_last_error.c_str(); }
 
@@ -1137,6 +1138,95 @@ int qilqr_line_search(qilqr_solver *s, const double *traj, const double *cost, c
   if (out_step) HIP_TRY(hipMemcpy(out_step, s->st.alpha, sizeof(double) * B, hipMemcpyDeviceToHost));
   if (out_traj && (rc = download_tiled(s, out_traj, s->st.traj[0], s->st.traj[1], s->st.cur, 0, B, n, 18))) return rc;
   HIP_TRY(hipGetLastError());
+  return QILQR_OK;
+}
+
+// ---- one batch over several devices in one process (include/quadrotor_ilqr.h)
+struct qilqr_sharded {
+  std::vector<qilqr_solver *> solvers;
+};
+
+int qilqr_shard_range(int32_t B, int32_t n_shards, int32_t r, int32_t *begin, int32_t *count) {
+  if (B < 0 || n_shards <= 0 || r < 0 || r >= n_shards || !begin || !count) return fail(QILQR_ERR_INVALID_ARG, "bad shard arguments");
+  const int32_t q = B / n_shards, rem = B % n_shards;
+  *begin = r * q + (r < rem ? r : rem);
+  *count = q + (r < rem ? 1 : 0);
+  return QILQR_OK;
+}
+
+int qilqr_sharded_create(const qilqr_model *model, const double *Q, const double *R, const double *desired,
+                         int32_t n_desired, double dt_s, const qilqr_options *options, const qilqr_device_config *dev,
+                         const int32_t *devices, int32_t n_devices, qilqr_sharded **out) {
+  if (!out || !devices || n_devices <= 0 || n_devices > 64) return fail(QILQR_ERR_INVALID_ARG, "bad device list");
+  qilqr_sharded *h = new qilqr_sharded();
+  for (int32_t r = 0; r < n_devices; ++r) {
+    qilqr_device_config dc = {0, 0, 2, 0, 0, 0, 0, 0};
+    if (dev) dc = *dev;
+    dc.device = devices[r];
+    qilqr_solver *s = nullptr;
+    const int rc = qilqr_create(model, Q, R, desired, n_desired, dt_s, options, &dc, &s);
+    if (rc != QILQR_OK) {
+      const std::string msg = "shard " + std::to_string(r) + " (device " + std::to_string(devices[r]) + "): " + g_last_error;
+      qilqr_sharded_destroy(h);
+      return fail(rc, msg);
+    }
+    h->solvers.push_back(s);
+  }
+  *out = h;
+  return QILQR_OK;
+}
+
+int qilqr_sharded_create_mask(const qilqr_model *model, const double *Q, const double *R, const double *desired,
+                              int32_t n_desired, double dt_s, const qilqr_options *options,
+                              const qilqr_device_config *dev, uint64_t device_mask, qilqr_sharded **out) {
+  int32_t devices[64];
+  int32_t k = 0;
+  for (int32_t d = 0; d < 64; ++d)
+    if (device_mask & (1ull << d)) devices[k++] = d;
+  if (k == 0) return fail(QILQR_ERR_INVALID_ARG, "empty device mask");
+  return qilqr_sharded_create(model, Q, R, desired, n_desired, dt_s, options, dev, devices, k, out);
+}
+
+void qilqr_sharded_destroy(qilqr_sharded *h) {
+  if (!h) return;
+  for (qilqr_solver *s : h->solvers) qilqr_destroy(s);
+  delete h;
+}
+
+int32_t qilqr_sharded_count(const qilqr_sharded *h) { return h ? (int32_t)h->solvers.size() : 0; }
+
+qilqr_solver *qilqr_sharded_solver(qilqr_sharded *h, int32_t r) {
+  return (h && r >= 0 && r < (int32_t)h->solvers.size()) ? h->solvers[r] : nullptr;
+}
+
+int qilqr_solve_batch_sharded(qilqr_sharded *h, const double *init, const double *desired_batch, int32_t B, int32_t n,
+                              double *out_traj, double *out_cost, int32_t *out_status, int32_t *out_iters,
+                              int32_t *out_n_bwd, int32_t *out_n_fwd) {
+  if (!h || h->solvers.empty() || !init) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  if (B <= 0 || n <= 0) return fail(QILQR_ERR_INVALID_ARG, "B and n must be positive");
+  const int32_t k = (int32_t)h->solvers.size();
+  std::vector<int> rcs(k, QILQR_OK);
+  std::vector<std::string> msgs(k);
+  auto run = [&](int32_t r) {
+    int32_t b0 = 0, cnt = 0;
+    (void)qilqr_shard_range(B, k, r, &b0, &cnt);
+    if (cnt == 0) return;  // fewer problems than shards
+    const size_t to = (size_t)b0 * n * 18;
+    rcs[r] = qilqr_solve_batch(h->solvers[r], init + to, desired_batch ? desired_batch + to : nullptr, cnt, n,
+                               out_traj ? out_traj + to : nullptr, out_cost ? out_cost + b0 : nullptr,
+                               out_status ? out_status + b0 : nullptr, out_iters ? out_iters + b0 : nullptr,
+                               out_n_bwd ? out_n_bwd + b0 : nullptr, out_n_fwd ? out_n_fwd + b0 : nullptr);
+    if (rcs[r] != QILQR_OK) msgs[r] = g_last_error;  // (thread-local: carried back to the caller below)
+  };
+  // shard 0 on the calling thread, the others on threads of their own (HIP's current device is per thread;
+  // qilqr_solve_batch sets it)
+  std::vector<std::thread> threads;
+  for (int32_t r = 1; r < k; ++r) threads.emplace_back(run, r);
+  run(0);
+  for (std::thread &t : threads) t.join();
+  for (int32_t r = 0; r < k; ++r)
+    if (rcs[r] != QILQR_OK)
+      return fail(rcs[r], "shard " + std::to_string(r) + " (device " + std::to_string(h->solvers[r]->device) + "): " + msgs[r]);
   return QILQR_OK;
 }
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = capi.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.qilqr_abi_version() == 3
+    assert lib.qilqr_abi_version() == 4
 
 
 def test_struct_layouts_match_header():
@@ -73,6 +73,35 @@ def test_no_cpu_fallback():
     cfg = pb.config2(B=1, N=4)
     with pytest.raises(RuntimeError, match="no HIP device|no CPU path"):
         capi.from_config(cfg)
+
+
+def test_sharded_handle_refuses_without_a_device_and_names_the_shard():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cfg = pb.config2(B=1, N=4)
+    with pytest.raises(RuntimeError, match=r"shard 0 \(device 0\).*(no HIP device|no CPU path)"):
+        capi.sharded_from_config(cfg, devices=[0, 1])
+    with pytest.raises(TypeError, match="bad device list"):
+        capi.sharded_from_config(cfg, devices=[])
+
+
+def test_c_abi_shard_ranges_are_the_ones_of_the_multi_process_deployment():
+    """qilqr_shard_range (the in-process sharded solve) against sharding.shard_range (one process per GPU): the same
+    contiguous, ragged, unpadded partition of a batch -- host arithmetic, no device needed."""
+    import ctypes as C
+    from quadrotorilqr_amd import sharding
+    lib = capi.load()
+    for B in (0, 1, 3, 7, 8, 1001, 1024, 65536):
+        for world in (1, 2, 3, 6, 8):
+            for r in range(world):
+                b0, cnt = C.c_int32(), C.c_int32()
+                assert lib.qilqr_shard_range(C.c_int32(B), C.c_int32(world), C.c_int32(r), C.byref(b0), C.byref(cnt)) == 0
+                lo, hi = sharding.shard_range(B, r, world)
+                assert (b0.value, cnt.value) == (lo, hi - lo)
+    b0, cnt = C.c_int32(), C.c_int32()
+    assert lib.qilqr_shard_range(C.c_int32(8), C.c_int32(2), C.c_int32(2), C.byref(b0), C.byref(cnt)) != 0  # shard out of range
+    assert lib.qilqr_shard_range(C.c_int32(8), C.c_int32(0), C.c_int32(0), C.byref(b0), C.byref(cnt)) != 0
 
 
 def test_product_does_not_reference_the_oracle():

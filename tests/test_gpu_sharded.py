@@ -1,0 +1,72 @@
+"""qilqr_solve_batch_sharded: one batch cut into contiguous shards, one solver / stream / host thread per shard, in one
+process.  On the one-GPU test box every shard goes to device 0 (an ordinal may repeat): the code path -- ragged shard
+ranges, slices of the caller's arrays, concurrent host threads, error propagation -- is the one an 8-GPU node takes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from quadrotorilqr_amd import capi, problems as pb  # noqa: E402
+
+
+@pytest.mark.parametrize("B,shards", [(203, 3), (5, 8), (64, 2), (1, 1)])
+def test_sharded_solve_is_the_single_device_solve_problem_by_problem(B, shards):
+    cfg = pb.config2(B=B, N=40, seed=21)
+    r = np.random.default_rng(B)
+    desired_batch = np.repeat(cfg["desired"][None], B, axis=0)
+    desired_batch[:, :, 1:4] += r.uniform(-0.2, 0.2, (B, 1, 3))
+    one = capi.from_config(cfg)
+    many = capi.sharded_from_config(cfg, devices=[0] * shards)
+    ranges = many.shard_ranges(B)
+    assert ranges[0][0] == 0 and sum(c for _, c in ranges) == B and all(a[0] + a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    for desired in (None, desired_batch):
+        a = one.solve_batch(cfg["init"], desired)
+        b = many.solve_batch(cfg["init"], desired)
+        for k in ("status", "iters", "n_bwd", "n_fwd", "cost", "traj"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    # results in place in pinned arrays of the caller
+    out = dict(traj=capi.host_array(cfg["init"].shape), cost=capi.host_array((B,)),
+               **{k: capi.host_array((B,), np.int32) for k in ("status", "iters", "n_bwd", "n_fwd")})
+    c = many.solve_batch(cfg["init"], None, out=out)
+    a = one.solve_batch(cfg["init"])
+    assert c["traj"] is out["traj"]
+    np.testing.assert_array_equal(c["traj"], a["traj"])
+    np.testing.assert_array_equal(c["iters"], a["iters"])
+
+
+def test_sharded_create_by_mask_and_accessors():
+    import ctypes as C
+    cfg = pb.config2(B=9, N=12, seed=3)
+    lib = capi.load()
+    probe = capi.sharded_from_config(cfg, devices=[0, 0])
+    assert lib.qilqr_sharded_count(probe._h) == 2
+    s1 = lib.qilqr_sharded_solver(probe._h, 1)
+    assert s1 and lib.qilqr_device(C.c_void_p(s1)) == 0 and not lib.qilqr_sharded_solver(probe._h, 2)
+    # the mask form: bit 0 -> one shard on device 0; an empty mask and an absent device are errors with a text
+    m, Q, R, o, dc = capi._create_args(probe, **cfg["model"], Q=cfg["Q"], R=cfg["R"], desired=cfg["desired"], options=cfg["options"],
+                                       device=0, profile=0, sync_every=2, force_general=False, single_wave_rollout=0,
+                                       precision="f64", streams=0, persistent=0)
+    h = C.c_void_p()
+    args = (C.byref(m), capi._p(Q), capi._p(R), capi._p(probe.desired), C.c_int32(len(probe.desired)), C.c_double(cfg["dt"]),
+            C.byref(o), C.byref(dc))
+    assert lib.qilqr_sharded_create_mask(*args, C.c_uint64(1), C.byref(h)) == 0
+    assert lib.qilqr_sharded_count(h) == 1
+    lib.qilqr_sharded_destroy(h)
+    assert lib.qilqr_sharded_create_mask(*args, C.c_uint64(0), C.byref(h)) != 0
+    assert b"empty device mask" in lib.qilqr_last_error()
+    assert lib.qilqr_sharded_create_mask(*args, C.c_uint64(1 << 63), C.byref(h)) != 0
+    assert b"shard 0 (device 63)" in lib.qilqr_last_error()
+
+
+def test_a_failing_shard_reports_itself_and_the_others_complete():
+    B = 12
+    cfg = pb.config2(B=B, N=10, seed=4)
+    many = capi.sharded_from_config(cfg, devices=[0, 0, 0])
+    bad = cfg["init"].copy()
+    bad[9, 3, 4:8] *= 1.5  # problem 9 is in shard 2 (problems 8..11): not a unit quaternion
+    out = dict(traj=np.zeros_like(bad), cost=np.zeros(B), **{k: np.full(B, -1, dtype=np.int32) for k in ("status", "iters", "n_bwd", "n_fwd")})
+    with pytest.raises(ValueError, match=r"shard 2 \(device 0\)"):
+        many.solve_batch(bad, None, out=out)
+    assert (out["status"][:8] >= 0).all() and (out["status"][8:] == -1).all()  # shards 0 and 1 solved, shard 2 untouched
+    good = many.solve_batch(cfg["init"])
+    np.testing.assert_array_equal(good["status"][:8], out["status"][:8])
