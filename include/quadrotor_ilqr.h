@@ -194,6 +194,17 @@ int qilqr_profile_mode(qilqr_solver *s, int32_t mode);
  * Restarts are not iterations; they show in out_n_bwd.  Requires mu_factor > 1, mu_max >= mu_init. */
 int qilqr_set_regularisation(qilqr_solver *s, double mu_init, double mu_factor, double mu_max);
 
+/* Runge-Kutta integration of the dynamics -- an EXTENSION: the four-stage step that
+ * quadrotor_model.cc:51-63 sketches in a comment and the reference never executes,
+ *     k_0 = f(x, u), k_i = f(x (+) h_i k_{i-1}, u) with h = {0, dt/2, dt/2, dt};  x_next = x (+) dt (k_0 + 2 k_1 + 2 k_2 + k_3) / 6,
+ * in place of the explicit Euler step of quadrotor_model.cc:33-49 in every pass (forward simulation, and the Jacobians
+ * J_x, J_u of the backward pass by the chain rule through the stages).  integrator = 0 (default): the reference's step, and
+ * then every result is the reference's; 1: the extension (fp64 solvers only).  Stated in the oracle from the reference's
+ * own primitives (oracle/ilqr_oracle.c, discrete_dynamics_rk4); measured order of accuracy on SE(3): two, against Euler's
+ * one (tests/test_oracle_rk4.py explains why not four).  The extension runs on the general kernels -- a lane per
+ * trajectory rollout, the one-wavefront backward pass over dense Jacobian records -- not on the tuned Euler path. */
+int qilqr_set_integrator(qilqr_solver *s, int32_t integrator);
+
 /* device the solver is bound to, and the HIP stream it launches on (hipStream_t as void*) */
 int qilqr_device(const qilqr_solver *s);
 void *qilqr_stream(const qilqr_solver *s);

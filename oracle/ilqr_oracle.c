@@ -573,6 +573,60 @@ static void discrete_dynamics(const Model *m, const State *x, const double u[4],
   }
 }
 
+/* EXTENSION, not in the reference's executed code: the classical Runge-Kutta step that quadrotor_model.cc:51-63 sketches in a
+ * comment --
+ *     coeffs {1/6, 2/6, 2/6, 1/6}, dt table {0, dt/2, dt/2, dt};  k = 0, x_dot = 0;
+ *     for i in 0..3:  k = continuous_dynamics(euler_step(x, k, dt_table[i]), u);  x_dot += coeffs[i] k
+ * -- followed by x_next = euler_step(x, x_dot, dt) as in :39.  Every stage restarts from x (the sketch's euler_step(x, k, .)),
+ * which on SE(3) x R^6 is the Runge-Kutta-Munthe-Kaas form with the tangent taken at x.
+ * Jacobians by the chain rule through the reference's own differentials (euler_step's J_x_lhs / J_x_rhs, :266-276, and
+ * continuous_dynamics' J_x / J_u, :80-119), the way discrete_dynamics composes them at :43-45:
+ *     x_i = x (+) h_i k_{i-1}:   A_i = dx_i/dx = El_i + Er_i K_{i-1},      B_i = dx_i/du = Er_i Ku_{i-1}
+ *     k_i = f(x_i, u):           K_i = dk_i/dx = F_x(x_i) A_i,             Ku_i = F_x(x_i) B_i + F_u
+ *     x_next = x (+) dt sum c_i k_i:   J_x = El + Er sum c_i K_i,           J_u = Er sum c_i Ku_i                       */
+static void discrete_dynamics_rk4(const Model *m, const State *x, const double u[4], double dt,
+                                  State *xn, double *Jx, double *Ju) {
+  const double coeffs[4] = {1.0 / 6.0, 2.0 / 6.0, 2.0 / 6.0, 1.0 / 6.0};
+  const double dt_table[4] = {0.0, dt / 2.0, dt / 2.0, dt};
+  const int diffs = (Jx && Ju);
+  double k[12] = {0}, xdot[12] = {0};
+  double K[144] = {0}, Ku[48] = {0}, SK[144] = {0}, SKu[48] = {0};
+  for (int i = 0; i < 4; ++i) {
+    State xi;
+    double El[144], Er[144], Fx[144], Fu[48], A[144], B[48], T[144];
+    euler_step(x, k, dt_table[i], &xi, diffs ? El : 0, diffs ? Er : 0);
+    if (diffs) {
+      mat_mul(Er, K, T, 12, 12, 12);
+      for (int e = 0; e < 144; ++e) A[e] = El[e] + T[e];
+      mat_mul(Er, Ku, B, 12, 12, 4);
+    }
+    continuous_dynamics(m, &xi, u, k, diffs ? Fx : 0, diffs ? Fu : 0);
+    if (diffs) {
+      mat_mul(Fx, A, K, 12, 12, 12);
+      mat_mul(Fx, B, Ku, 12, 12, 4);
+      for (int e = 0; e < 48; ++e) Ku[e] += Fu[e];
+      for (int e = 0; e < 144; ++e) SK[e] += coeffs[i] * K[e];
+      for (int e = 0; e < 48; ++e) SKu[e] += coeffs[i] * Ku[e];
+    }
+    for (int e = 0; e < 12; ++e) xdot[e] += coeffs[i] * k[e];
+  }
+  if (diffs) {
+    double El[144], Er[144], T[144];
+    euler_step(x, xdot, dt, xn, El, Er);
+    mat_mul(Er, SK, T, 12, 12, 12);
+    for (int e = 0; e < 144; ++e) Jx[e] = El[e] + T[e];
+    mat_mul(Er, SKu, Ju, 12, 12, 4);
+  } else {
+    euler_step(x, xdot, dt, xn, 0, 0);
+  }
+}
+/* the step the solver integrates with: 0 = the reference's explicit Euler, 1 = the sketched Runge-Kutta (extension) */
+static void discrete_step(const Model *m, int integrator, const State *x, const double u[4], double dt,
+                          State *xn, double *Jx, double *Ju) {
+  if (integrator == 1) discrete_dynamics_rk4(m, x, u, dt, xn, Jx, Ju);
+  else discrete_dynamics(m, x, u, dt, xn, Jx, Ju);
+}
+
 int orc_continuous_dynamics(const orc_model_params *mp, const double x[13], const double u[4],
                             double xdot[12], double *Jx, double *Ju) {
   Model m;
@@ -585,14 +639,19 @@ int orc_continuous_dynamics(const orc_model_params *mp, const double x[13], cons
 }
 int orc_discrete_dynamics(const orc_model_params *mp, const double x[13], const double u[4],
                           double dt, double xnext[13], double *Jx, double *Ju) {
+  return orc_discrete_step(mp, 0, x, u, dt, xnext, Jx, Ju);
+}
+int orc_discrete_step(const orc_model_params *mp, int integrator, const double x[13], const double u[4],
+                      double dt, double xnext[13], double *Jx, double *Ju) {
   Model m;
   const int rc = model_init(mp, &m);
   if (rc) return rc;
+  if (integrator != 0 && integrator != 1) return ORC_ERR_INVALID;
   State s, n;
   unpack_state(x, &s);
   double jx[144], ju[48];
   const int want = (Jx || Ju);
-  discrete_dynamics(&m, &s, u, dt, &n, want ? jx : 0, want ? ju : 0);
+  discrete_step(&m, integrator, &s, u, dt, &n, want ? jx : 0, want ? ju : 0);
   if (Jx) memcpy(Jx, jx, sizeof(jx));
   if (Ju) memcpy(Ju, ju, sizeof(ju));
   pack_state(&n, xnext);
@@ -774,6 +833,8 @@ struct orc_solver {
   orc_options opt;
   /* Levenberg-Marquardt restarts: NOT in the reference (extension); all zero = off */
   double mu_init, mu_factor, mu_max;
+  /* integrator of the discrete dynamics: 0 = explicit Euler (the reference), 1 = Runge-Kutta (extension, see discrete_dynamics_rk4) */
+  int integrator;
 };
 
 int orc_solver_create(const orc_model_params *mp, const double Q[144], const double R[16],
@@ -842,6 +903,11 @@ int orc_set_regularisation(orc_solver *s, double mu_init, double mu_factor, doub
   return ORC_OK;
 }
 
+int orc_set_integrator(orc_solver *s, int integrator) {
+  if (!s || (integrator != 0 && integrator != 1)) return ORC_ERR_INVALID;
+  s->integrator = integrator;
+  return ORC_OK;
+}
 int orc_backwards_pass(const orc_solver *s, const double *traj, int n, double *gains,
                        double terms[2]) {
   return orc_backwards_pass_reg(s, traj, n, 0.0, gains, terms);
@@ -860,7 +926,7 @@ int orc_backwards_pass_reg(const orc_solver *s, const double *traj, int n, doubl
     State x, xn;
     unpack_state(pt + 1, &x);
     double Jx[144], Ju[48];
-    discrete_dynamics(&s->model, &x, pt + 14, s->dt, &xn, Jx, Ju); /* :111-113 */
+    discrete_step(&s->model, s->integrator, &x, pt + 14, s->dt, &xn, Jx, Ju); /* :111-113 */
     double Cx[12], Cu[4], Cxx[144], Cuu[16], Cxu[48];
     knot_cost(s, pt, i, Cx, Cu, Cxx, Cuu, Cxu); /* :115-116 */
 
@@ -941,7 +1007,7 @@ int orc_forward_sim(const orc_solver *s, const double *traj, int n, const double
     pack_state(&state, o + 1);
     for (int a = 0; a < 4; ++a) o[14 + a] = u[a];
     State nx;
-    discrete_dynamics(&s->model, &state, u, s->dt, &nx, 0, 0); /* :168, last one discarded */
+    discrete_step(&s->model, s->integrator, &state, u, s->dt, &nx, 0, 0); /* :168, last one discarded */
     state = nx;
   }
   return ORC_OK;

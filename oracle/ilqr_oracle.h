@@ -96,6 +96,10 @@ int orc_continuous_dynamics(const orc_model_params *mp, const double x[13],
 int orc_discrete_dynamics(const orc_model_params *mp, const double x[13],
                           const double u[4], double dt, double xnext[13],
                           double *Jx, double *Ju);
+/* EXTENSION: the same with the integrator chosen -- 0 explicit Euler (= orc_discrete_dynamics), 1 the Runge-Kutta step
+ * sketched in the comment at quadrotor_model.cc:51-63 (see discrete_dynamics_rk4 in ilqr_oracle.c) */
+int orc_discrete_step(const orc_model_params *mp, int integrator, const double x[13], const double u[4],
+                      double dt, double xnext[13], double *Jx, double *Ju);
 /* quadrotor_model.cc:174-206 */
 void orc_state_add(const double x[13], const double tangent[12], double out[13],
                    double *J_lhs, double *J_rhs);
@@ -132,6 +136,8 @@ int orc_backwards_pass(const orc_solver *s, const double *traj, int n, double *g
 int orc_backwards_pass_reg(const orc_solver *s, const double *traj, int n, double mu, double *gains,
                            double terms[2]);
 int orc_set_regularisation(orc_solver *s, double mu_init, double mu_factor, double mu_max);
+/* EXTENSION: integrator of every pass of this solver, 0 (default, the reference) or 1 */
+int orc_set_integrator(orc_solver *s, int integrator);
 
 int orc_forward_sim(const orc_solver *s, const double *traj, int n, const double *gains,
                     double alpha, double *out_traj);

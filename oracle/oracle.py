@@ -187,6 +187,18 @@ def discrete_dynamics(mp, x, u, dt, diffs=False):
     return (xn, Jx, Ju) if diffs else xn
 
 
+def discrete_step(mp, integrator, x, u, dt, diffs=False):
+    """orc_discrete_step: integrator 0 = explicit Euler (the reference), 1 = Runge-Kutta (extension)"""
+    xn = np.zeros(13)
+    Jx = np.zeros((12, 12)) if diffs else None
+    Ju = np.zeros((12, 4)) if diffs else None
+    rc = lib().orc_discrete_step(C.byref(mp), C.c_int(integrator), _p(_d(x)), _p(_d(u)), C.c_double(dt), _p(xn),
+                                 _p(Jx), _p(Ju))
+    if rc:
+        raise RuntimeError("orc_discrete_step failed (%d)" % rc)
+    return (xn, Jx, Ju) if diffs else xn
+
+
 def state_add(x, tangent, diffs=False):
     out = np.zeros(13)
     Jl = np.zeros((12, 12)) if diffs else None
@@ -297,6 +309,10 @@ class OracleSolver:
         """Extension (not in the reference): Levenberg-Marquardt restarts in solve / solve_batch."""
         self._check(lib().orc_set_regularisation(self._h, C.c_double(mu_init), C.c_double(mu_factor),
                                                  C.c_double(mu_max)))
+
+    def set_integrator(self, integrator):
+        """Extension (not in the reference's executed code): 1 = the Runge-Kutta step of quadrotor_model.cc:51-63."""
+        self._check(lib().orc_set_integrator(self._h, C.c_int(integrator)))
 
     def forward_sim(self, traj, gains, alpha=1.0):
         traj = _d(traj).reshape(-1, 18)

@@ -37,6 +37,7 @@ EXPORTS = (
     "qilqr_create", "qilqr_destroy", "qilqr_last_error", "qilqr_solve", "qilqr_solve_batch",
     "qilqr_solve_batch_device", "qilqr_cost_trajectory", "qilqr_backwards_pass", "qilqr_forward_sim",
     "qilqr_line_search", "qilqr_cost_history", "qilqr_profile_reset", "qilqr_profile_get", "qilqr_profile_mode", "qilqr_set_regularisation",
+    "qilqr_set_integrator",
     "qilqr_device", "qilqr_stream", "qilqr_stream_wait_event", "qilqr_host_alloc", "qilqr_host_free",
     "qilqr_sharded_create", "qilqr_sharded_create_mask", "qilqr_sharded_destroy", "qilqr_sharded_count", "qilqr_sharded_solver",
     "qilqr_shard_range", "qilqr_solve_batch_sharded",
@@ -346,6 +347,12 @@ class QuadrotorILQRBatch:
                                               C.c_double(mu_max))
         if rc == ERR_INVALID_ARG:
             raise ValueError(load().qilqr_last_error().decode())
+        if rc:
+            _raise(rc)
+
+    def set_integrator(self, integrator):
+        """Runge-Kutta extension (the step sketched at quadrotor_model.cc:51-63; 0 = the reference's explicit Euler)."""
+        rc = load().qilqr_set_integrator(self._h, C.c_int32(int(integrator)))
         if rc:
             _raise(rc)
 

@@ -57,6 +57,15 @@ QILQR_HD void build_ctab(const double *Bu, const double *Q, double *tab) {
   for (int i = 0; i < 48; ++i) tab[CTAB_BU + i] = Bu[i];
   for (int i = 0; i < 144; ++i) tab[CTAB_2Q + i] = 2.0 * Q[i];
 }
+// the same for a record of layout L: with the dense M of the Runge-Kutta extension (RecLayout.dense_m) every element of
+// M is an entry of the record -- J_u too, it depends on the state there
+QILQR_HD int m_source(const RecLayout &L, int row, int col, const double *Bu, double *cst) {
+  if (L.dense_m) {
+    *cst = 0.0;
+    return LIN_BLK + row * 16 + col;
+  }
+  return m_source(row, col, Bu, cst);
+}
 // like m_source, but constants are returned as an index into the table: -1 - index
 QILQR_HD int m_source_tab(int row, int col) {
   if (col >= 12) return -1 - (CTAB_BU + row * 4 + (col - 12));
@@ -64,6 +73,9 @@ QILQR_HD int m_source_tab(int row, int col) {
   const int off = m_source(row, col, nullptr, &cst);
   if (off >= 0) return off;
   return -1 - (cst == 1.0 ? CTAB_ONE : CTAB_ZERO);
+}
+QILQR_HD int m_source_tab(const RecLayout &L, int row, int col) {
+  return L.dense_m ? LIN_BLK + row * 16 + col : m_source_tab(row, col);
 }
 QILQR_HD int cxx_source_tab(const RecLayout &L, int row, int col) {
   if (!L.sym) return L.off_cxx + row * 12 + col;

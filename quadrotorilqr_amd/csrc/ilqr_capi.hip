@@ -57,6 +57,7 @@ struct qilqr_solver {
   void *d_ctab = nullptr;       // constant operand table of k_backward, storage precision
   void *d_consts = nullptr;     // the model constants in device memory (k_linearize reads them where it uses them)
   bool f32 = false;             // mixed-precision mode (qilqr_device_config.precision == 1)
+  int integrator = 0;           // 0 explicit Euler (the reference), 1 the Runge-Kutta extension (qilqr_set_integrator)
   ModelConsts<float> constsf;   // the model constants for the fp32 lane-local kernels
   // workspace
   long cap_B = 0, cap_n = 0;
@@ -309,7 +310,17 @@ int download_tiled(qilqr_solver *s, double *h_plain, void *t0, void *t1, const i
 int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag, int round = -1) {
   const dim3 grid(cdiv(2 * ((B + 63) / 64) * 64 * n, 128));  // dynamics half + cost half
 #define QILQR_LAUNCH_LIN(S, LK, CONSTS, DCONSTS) \
-  launch(s, K_LINEARIZE, k_linearize<S, LK>, grid, dim3(128), CONSTS, DCONSTS, s->st, (int)B, (int)n, which, need_flag, round)
+  launch(s, K_LINEARIZE, (k_linearize<S, LK, 0>), grid, dim3(128), CONSTS, DCONSTS, s->st, (int)B, (int)n, which, need_flag, round)
+#define QILQR_LAUNCH_LIN_RK4(LK) \
+  launch(s, K_LINEARIZE, (k_linearize<double, LK, 1>), grid, dim3(128), s->consts, (const ModelConsts<double> *)s->d_consts, s->st, (int)B, (int)n, which, need_flag, round)
+  if (s->integrator == 1) {  // the Runge-Kutta extension: dense M at the head of the record, fp64 only
+    switch (layout_kind(s->layout)) {
+      case 0: QILQR_LAUNCH_LIN_RK4(0); break;
+      case 1: QILQR_LAUNCH_LIN_RK4(1); break;
+      default: QILQR_LAUNCH_LIN_RK4(2); break;
+    }
+    return QILQR_OK;
+  }
   switch (layout_kind(s->layout) + (s->f32 ? 3 : 0)) {
     case 0: QILQR_LAUNCH_LIN(double, 0, s->consts, (const ModelConsts<double> *)s->d_consts); break;
     case 1: QILQR_LAUNCH_LIN(double, 1, s->consts, (const ModelConsts<double> *)s->d_consts); break;
@@ -319,6 +330,7 @@ int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag, 
     default: QILQR_LAUNCH_LIN(float, 2, s->constsf, (const ModelConsts<float> *)s->d_consts); break;
   }
 #undef QILQR_LAUNCH_LIN
+#undef QILQR_LAUNCH_LIN_RK4
   return QILQR_OK;
 }
 int launch_backward(qilqr_solver *s, long B, long n, int force) {
@@ -333,7 +345,12 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
   //               against 357k at 8192; equal at 512)
   //   beyond: one wavefront per trajectory (the matrix pipe is the bound)
   const bool want4 = s->dev.force_general == 4 || (s->dev.force_general == 0 && load_B > 640 && load_B <= 8192);
-  if (s->symmetric && want4 && load_B <= 8192) {
+  if (s->integrator == 1) {
+    // the Runge-Kutta extension: every element of M comes from the record (RecLayout.dense_m), which only the one-wavefront
+    // kernel's per-lane operand pointers address (the other kernels stage 128-entry records through LDS)
+    if (s->symmetric) QILQR_LAUNCH_BWD(true, double);
+    else QILQR_LAUNCH_BWD(false, double);
+  } else if (s->symmetric && want4 && load_B <= 8192) {
     // four matrix wavefronts + one gradient wavefront + one loader wavefront per four trajectories
     if (s->f32)
       launch(s, K_BACKWARD, k_backward4<float>, dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
@@ -367,11 +384,13 @@ int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
   //   k_rollout    a lane per trajectory, one wavefront: the highest throughput, above 16384 trajectories
   const long load_B = std::max(B, s->total_B);
   const int choice = s->dev.single_wave_rollout;
-  if (choice == 1 || (choice != 3 && load_B > 16384)) {
+  if (s->integrator == 1) {  // the Runge-Kutta extension: the lane-per-trajectory kernel only
+    launch(s, K_ROLLOUT, (k_rollout<double, 1>), dim3(cdiv(B, 64)), dim3(64), s->consts, s->st, (int)B, (int)n, need_flag);
+  } else if (choice == 1 || (choice != 3 && load_B > 16384)) {
     if (s->f32)
-      launch(s, K_ROLLOUT, k_rollout<float>, dim3(cdiv(B, 64)), dim3(64), s->constsf, s->st, (int)B, (int)n, need_flag);
+      launch(s, K_ROLLOUT, (k_rollout<float, 0>), dim3(cdiv(B, 64)), dim3(64), s->constsf, s->st, (int)B, (int)n, need_flag);
     else
-      launch(s, K_ROLLOUT, k_rollout<double>, dim3(cdiv(B, 64)), dim3(64), s->consts, s->st, (int)B, (int)n, need_flag);
+      launch(s, K_ROLLOUT, (k_rollout<double, 0>), dim3(cdiv(B, 64)), dim3(64), s->consts, s->st, (int)B, (int)n, need_flag);
   } else if (choice == 3 || (choice == 0 && load_B <= R16_MAX_B)) {
     if (s->f32)
       launch(s, K_ROLLOUT, k_rollout16<float>, dim3(cdiv(B, 4)), dim3(192), s->consts, s->st, (int)B, (int)n, need_flag);
@@ -649,7 +668,7 @@ int check_quaternions(const double *traj, long count, const char *what) {
 // So 0 selects the rounds; the persistent solve stays selectable and tested.
 bool use_persistent(const qilqr_solver *s, long B) {
   (void)B;
-  return s->symmetric && s->dev.persistent == 1;
+  return s->symmetric && s->dev.persistent == 1 && s->integrator == 0;
 }
 int launch_solve4(qilqr_solver *s, long B, long n) {
   const unsigned groups = cdiv(B, 4);
@@ -889,6 +908,20 @@ int qilqr_set_regularisation(qilqr_solver *s, double mu_init, double mu_factor, 
   s->params.mu_init = mu_init;
   s->params.mu_factor = mu_factor;
   s->params.mu_max = mu_max;
+  return QILQR_OK;
+}
+
+int qilqr_set_integrator(qilqr_solver *s, int32_t integrator) {
+  if (!s) return fail(QILQR_ERR_INVALID_ARG, "null solver");
+  if (integrator != 0 && integrator != 1) return fail(QILQR_ERR_INVALID_ARG, "integrator must be 0 (explicit Euler) or 1 (Runge-Kutta)");
+  if (integrator == 1 && s->f32) return fail(QILQR_ERR_INVALID_ARG, "the Runge-Kutta extension needs precision 0 (fp64)");
+  if (integrator == s->integrator) return QILQR_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  // the knot records change shape (dense M instead of the Euler step's six blocks): the workspace is rebuilt on the next call
+  free_workspace(s);
+  s->integrator = integrator;
+  s->layout = make_layout(s->layout.sym != 0, s->layout.ur_zero != 0, integrator == 1);
   return QILQR_OK;
 }
 

@@ -123,7 +123,7 @@ __device__ __forceinline__ double cost_reduction(double QuTk, double kTQuuk, dou
 #ifndef QILQR_LIN_WAVES
 #define QILQR_LIN_WAVES 4  // register budget of k_linearize in waves per SIMD (3 avoids its few spills but the next k_backward then runs 3% slower)
 #endif
-template <typename S, int LK>
+template <typename S, int LK, int INTEG>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(QILQR_LIN_WAVES, QILQR_LIN_WAVES))) void
 k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState st, int B, int n, int which,
             int need_flag, int round) {
@@ -183,14 +183,17 @@ k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState 
   if (need_flag && !(fl & need_flag)) return;
   S pt[18];
   load_knot<true>((const S *)st.traj[buf] + knot_base<true>(b, n, 18), i, 18, pt);
-  const PlainRecWriter<S> w{(S *)st.lin[buf] + rec_base(b, n, st.layout.stride) + rec_elem(i, 0, st.layout.stride)};
+  S *rec = (S *)st.lin[buf] + rec_base(b, n, st.layout.stride) + rec_elem(i, 0, st.layout.stride);
   if (!cost_half) {
-    linearize_dynamics(c, pt, w);
+    const PlainRecWriter<S> wd{rec};
+    if (INTEG == 1) linearize_dynamics_rk4(c, pt, wd);  // the dense M of the Runge-Kutta extension
+    else linearize_dynamics(c, pt, wd);
 #ifdef QILQR_STAMPS
     lin_stamp(0, (double)pt[0]);
 #endif
     return;
   }
+  const PlainRecWriter<S> w{rec + (INTEG == 1 ? LIN_M_DENSE - LIN_M_BLOCKS : 0)};  // the cost entries follow M wherever it ends
   S pd[18];
   if (st.desired_tiled) load_knot<true>((const S *)st.desired + knot_base<true>(b, n, 18), i, 18, pd);
   else load_knot<false>((const S *)st.desired, i, 18, pd);
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
       int src;
-      if (k < 3) src = m_source_tab(4 * k + kk, j);
+      if (k < 3) src = m_source_tab(L, 4 * k + kk, j);
       else if (k < 6) src = (j < 12) ? cxx_source_tab(L, 4 * (k - 3) + kk, j) : -1 - CTAB_ZERO;
       else src = L.off_g + j;
       op[k] = (typename GA<S>::cptr)((src >= 0) ? lin + rec_elem(n - 1, src, L.stride) : (const S *)st.ctab + (-1 - src));
@@ -1530,14 +1533,14 @@ __global__ __launch_bounds__(384) void k_backward4(ModelConsts<double> c, SolveP
 // ---------------------------------------------------------------------------------------------
 // k_rollout: thread b.  traj[cur] + gains + alpha -> traj[cur ^ 1]
 // ---------------------------------------------------------------------------------------------
-template <typename S>
+template <typename S, int INTEG>
 __global__ __launch_bounds__(64) void k_rollout(ModelConsts<S> c, BatchState st, int B, int n,
                                                 int need_flag) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   if (need_flag && !(st.flags[b] & need_flag)) return;
   const int cur = st.cur[b];
-  rollout_problem<true>(c, (const S *)st.traj[cur] + knot_base<true>(b, n, 18),
+  rollout_problem<true, S, INTEG>(c, (const S *)st.traj[cur] + knot_base<true>(b, n, 18),
                         (const S *)st.gains + knot_base<true>(b, n, 52), (S)st.alpha[b],
                         (S *)st.traj[cur ^ 1] + knot_base<true>(b, n, 18), n);
 }

@@ -481,18 +481,22 @@ QILQR_HD void se3_fillQ_fast(const T rho[3], const T th[3], T Qm[9]) {
 //   [off_g ..+15] C_x (12), C_u (4)         cost.hh:51,54
 //   [off_cost]    knot cost                 cost.hh:47-48
 constexpr int LIN_BLK = 0;
-constexpr int LIN_MAX_STRIDE = 216;
+constexpr int LIN_MAX_STRIDE = 354;  // dense M (192) + general C_xx (144) + g (16) + cost, even
 
 struct RecLayout {
   int sym;      // Q == Q^T exactly
   int ur_zero;  // sym and Q[0:6, 6:12] == 0
   int off_cxx, off_g, off_cost, stride;
+  int dense_m;  // the record starts with the whole M = [J_x | J_u] (12 x 16, row-major) instead of the six Jacobian
+                // blocks of the explicit-Euler step: the Runge-Kutta extension, whose Jacobians have no such structure
 };
-QILQR_HD constexpr RecLayout make_layout(bool sym, bool ur_zero) {
+constexpr int LIN_M_DENSE = 192, LIN_M_BLOCKS = 54;
+QILQR_HD constexpr RecLayout make_layout(bool sym, bool ur_zero, bool dense_m = false) {
   RecLayout L{};
   L.sym = sym ? 1 : 0;
   L.ur_zero = (sym && ur_zero) ? 1 : 0;
-  L.off_cxx = 54;
+  L.dense_m = dense_m ? 1 : 0;
+  L.off_cxx = dense_m ? LIN_M_DENSE : LIN_M_BLOCKS;
   const int ncxx = !sym ? 144 : (L.ur_zero ? 21 : 57);
   L.off_g = L.off_cxx + ncxx;
   L.off_cost = L.off_g + 16;
@@ -575,6 +579,162 @@ QILQR_HD T knot_cost(const T *Q, const T *R, const T *pt, const T *pd, T dx[12],
   return cx + cu;
 }
 
+// ----------------------------------------------------------------- the Runge-Kutta extension
+// The step sketched in the comment at quadrotor_model.cc:51-63 (never executed by the reference; default off here):
+//     k_0 = f(x, u);  k_i = f(x (+) h_i k_{i-1}, u), h = {0, dt/2, dt/2, dt};  x_next = x (+) dt (k_0 + 2 k_1 + 2 k_2 + k_3) / 6
+// with (+) = euler_step (quadrotor_model.cc:266-276) from x in every stage.  The oracle states it from the reference's
+// primitives (oracle/ilqr_oracle.c, discrete_dynamics_rk4) and measures its order on SE(3): two (tests/test_oracle_rk4.py).
+// Jacobians by the chain rule, with the sparsity of the primitives written out: for a tangent step tau = h k[0:6],
+//     d(x (+) h k)/dx = [[Ad(Exp(-tau)), 0],[0, 1]],   d(x (+) h k)/dk = h [[Jr(tau), 0],[0, 1]],
+//     F_x = df/dx = [[0, 1],[G, D]] with G = -g hat(R^T e_z) in the rotation columns of the linear rows (quadrotor_model.cc:88-96)
+//     and D = -I^-1 (hat(w) I - hat(I w)) in the angular block (:99-111),   F_u = J_u / dt (rows 8..11).
+// MU (12 x 16) carries [d./dx | d./du] through the stages.
+template <typename T>
+struct ExpBlocks {  // for tau: Ad(Exp(-tau)) = [[Rc, SR],[0, Rc]],  Jr(tau) = [[Jr, Qm],[0, Jr]]
+  T Rc[9], SR[9], Jr[9], Qm[9];
+};
+template <typename T>
+QILQR_HD void exp_blocks(const T tau[6], ExpBlocks<T> &e) {
+  T Jl[9], p[3], qe[4];
+  so3_ljac_fast(tau + 3, Jl);
+  mat3_vec(Jl, tau, p);
+  so3_exp(tau + 3, qe);
+  const T qc[4] = {-qe[0], -qe[1], -qe[2], qe[3]};
+  T r[3], ti[3], S[9];
+  quat_to_R(qc, e.Rc);
+  mat3_vec(e.Rc, p, r);
+  ti[0] = -r[0]; ti[1] = -r[1]; ti[2] = -r[2];
+  skew3(ti, S);
+  mat3_mul(S, e.Rc, e.SR);
+  const T nrho[3] = {-tau[0], -tau[1], -tau[2]}, nth[3] = {-tau[3], -tau[4], -tau[5]};
+  se3_fillQ_fast(nrho, nth, e.Qm);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) e.Jr[3 * i + j] = Jl[3 * j + i];
+}
+// G and D of F_x at (q, v)
+template <typename T>
+QILQR_HD void continuous_blocks(const ModelConsts<T> &c, const T q[4], const T v[6], T G[9], T D[9]) {
+  T R[9];
+  quat_to_R(q, R);
+  const T rz[3] = {R[6], R[7], R[8]};
+  T H[9];
+  skew3(rz, H);
+  for (int i = 0; i < 9; ++i) G[i] = -c.g * H[i];
+  const T *om = v + 3;
+  T Wh[9], WI[9], Iw[3], IwH[9], Jd[9], S[9];
+  skew3(om, Wh);
+  mat3_mul(Wh, c.inertia, WI);
+  mat3_vec(c.inertia, om, Iw);
+  skew3(Iw, IwH);
+  for (int i = 0; i < 9; ++i) Jd[i] = WI[i] - IwH[i];
+  mat3_mul(c.inertia_inv, Jd, S);
+  for (int i = 0; i < 9; ++i) D[i] = -S[i];
+}
+// out (6 x 16) = [[A, B],[0, A]] in (6 x 6, blocks 3 x 3) times rows r0..r0+5 of X (12 x 16)
+template <typename T>
+QILQR_HD void blk6_mul(const T A[9], const T B[9], const T *X, T *out) {
+  for (int i = 0; i < 3; ++i)
+    for (int col = 0; col < 16; ++col) {
+      T top = T(0), bot = T(0);
+      for (int k = 0; k < 3; ++k) {
+        top += A[3 * i + k] * X[k * 16 + col] + B[3 * i + k] * X[(3 + k) * 16 + col];
+        bot += A[3 * i + k] * X[(3 + k) * 16 + col];
+      }
+      out[i * 16 + col] = top;
+      out[(3 + i) * 16 + col] = bot;
+    }
+}
+// One step from (t, q, v) under u; MU != nullptr: also M = [J_x | J_u] (12 x 16, row-major).
+template <typename T>
+QILQR_HD void rk4_step(const ModelConsts<T> &c, T t[3], T q[4], T v[6], const T u[4], T *MU) {
+  const T coeffs[4] = {T(1.0 / 6.0), T(2.0 / 6.0), T(2.0 / 6.0), T(1.0 / 6.0)};
+  const T hs[4] = {T(0), c.dt / T(2), c.dt / T(2), c.dt};
+  T k[12], xdot[12];
+  T K[192], SK[192];  // [dk/dx | dk/du] of the last stage, and its weighted sum
+  for (int e = 0; e < 12; ++e) { k[e] = T(0); xdot[e] = T(0); }
+  if (MU)
+    for (int e = 0; e < 192; ++e) { K[e] = T(0); SK[e] = T(0); }
+  for (int i = 0; i < 4; ++i) {
+    // x_i = x (+) h k
+    T tau[6], ti[3], qi[4], vi[6];
+    for (int a = 0; a < 6; ++a) tau[a] = hs[i] * k[a];
+    se3_rplus(t, q, tau, ti, qi);
+    for (int a = 0; a < 6; ++a) vi[a] = v[a] + hs[i] * k[6 + a];
+    T A[192];  // [dx_i/dx | dx_i/du]
+    if (MU) {
+      ExpBlocks<T> eb;
+      exp_blocks(tau, eb);
+      T JK[96];
+      blk6_mul(eb.Jr, eb.Qm, K, JK);  // Jr(tau) (dk/d.)[pose rows]
+      for (int r = 0; r < 6; ++r)
+        for (int col = 0; col < 16; ++col) {
+          T ad = T(0);  // Ad(Exp(-tau))[r][col], col < 6
+          if (col < 6) {
+            const int br = r / 3, bc = col / 3, rr = r % 3, cc = col % 3;
+            ad = (br == bc) ? eb.Rc[3 * rr + cc] : (br == 0 ? eb.SR[3 * rr + cc] : T(0));
+          }
+          A[r * 16 + col] = ad + hs[i] * JK[r * 16 + col];
+          A[(6 + r) * 16 + col] = ((col == 6 + r) ? T(1) : T(0)) + hs[i] * K[(6 + r) * 16 + col];
+        }
+    }
+    // k = f(x_i, u)
+    T acc[6];
+    body_acceleration(c, qi, vi, u, acc);
+    for (int a = 0; a < 6; ++a) { k[a] = vi[a]; k[6 + a] = acc[a]; }
+    if (MU) {
+      T G[9], D[9];
+      continuous_blocks(c, qi, vi, G, D);
+      for (int col = 0; col < 16; ++col) {
+        for (int r = 0; r < 6; ++r) K[r * 16 + col] = A[(6 + r) * 16 + col];
+        for (int r = 0; r < 3; ++r) {
+          T gl = T(0), dw = T(0);
+          for (int m = 0; m < 3; ++m) {
+            gl += G[3 * r + m] * A[(3 + m) * 16 + col];
+            dw += D[3 * r + m] * A[(9 + m) * 16 + col];
+          }
+          const T fu_l = (col >= 12) ? c.Bu[(6 + r) * 4 + (col - 12)] / c.dt : T(0);
+          const T fu_w = (col >= 12) ? c.Bu[(9 + r) * 4 + (col - 12)] / c.dt : T(0);
+          K[(6 + r) * 16 + col] = gl + fu_l;
+          K[(9 + r) * 16 + col] = dw + fu_w;
+        }
+      }
+      for (int e = 0; e < 192; ++e) SK[e] += coeffs[i] * K[e];
+    }
+    for (int e = 0; e < 12; ++e) xdot[e] += coeffs[i] * k[e];
+  }
+  // x_next = x (+) dt xdot
+  T tau[6], tn[3], qn[4];
+  for (int a = 0; a < 6; ++a) tau[a] = c.dt * xdot[a];
+  se3_rplus(t, q, tau, tn, qn);
+  if (MU) {
+    ExpBlocks<T> eb;
+    exp_blocks(tau, eb);
+    T JK[96];
+    blk6_mul(eb.Jr, eb.Qm, SK, JK);
+    for (int r = 0; r < 6; ++r)
+      for (int col = 0; col < 16; ++col) {
+        T ad = T(0);
+        if (col < 6) {
+          const int br = r / 3, bc = col / 3, rr = r % 3, cc = col % 3;
+          ad = (br == bc) ? eb.Rc[3 * rr + cc] : (br == 0 ? eb.SR[3 * rr + cc] : T(0));
+        }
+        MU[r * 16 + col] = ad + c.dt * JK[r * 16 + col];
+        MU[(6 + r) * 16 + col] = ((col == 6 + r) ? T(1) : T(0)) + c.dt * SK[(6 + r) * 16 + col];
+      }
+  }
+  for (int i = 0; i < 3; ++i) t[i] = tn[i];
+  for (int i = 0; i < 4; ++i) q[i] = qn[i];
+  for (int a = 0; a < 6; ++a) v[a] = v[a] + c.dt * xdot[6 + a];
+}
+// dynamics half of the linearisation for the Runge-Kutta step: the dense M at the head of the record (RecLayout.dense_m)
+template <typename T, typename W>
+QILQR_HD void linearize_dynamics_rk4(const ModelConsts<T> &c, const T *pt, W &w) {
+  T t[3] = {pt[1], pt[2], pt[3]}, q[4] = {pt[5], pt[6], pt[7], pt[4]}, v[6];
+  for (int i = 0; i < 6; ++i) v[i] = pt[8 + i];
+  T MU[192];
+  rk4_step(c, t, q, v, pt + 14, MU);
+  for (int e = 0; e < 192; ++e) w.put(LIN_BLK + e, MU[e]);
+}
 // Linearisation of one knot in two independent halves (k_linearize runs them in different lanes).
 // Dynamics: the six Jacobian blocks of quadrotor_model.cc:33-49, 84-119, 174-200, 266-276.
 template <typename T, typename W>
@@ -762,8 +922,10 @@ QILQR_HD T linearize_cost(const T *Q, const T *R, const T *pt, const T *pd, W &w
 }
 template <typename T>
 QILQR_HD void linearize_knot(const ModelConsts<T> &c, const RecLayout &L, const T *pt, const T *pd, T *rec) {
-  PlainRecWriter<T> w{rec};
-  linearize_dynamics(c, pt, w);
+  PlainRecWriter<T> wd{rec};
+  if (L.dense_m) linearize_dynamics_rk4(c, pt, wd);
+  else linearize_dynamics(c, pt, wd);
+  PlainRecWriter<T> w{rec + (L.dense_m ? LIN_M_DENSE - LIN_M_BLOCKS : 0)};  // the cost entries follow M wherever it ends
   switch (layout_kind(L)) {
     case 0: linearize_cost<0>(c.Q, c.R, pt, pd, w); break;
     case 1: linearize_cost<1>(c.Q, c.R, pt, pd, w); break;
@@ -1018,7 +1180,7 @@ QILQR_HD void control_law(const T *pt, const T *g, T alpha, const T dx[12], T u[
 
 // closed-loop rollout of one problem (ilqr.hh:149-172).  traj/gains/out point at this problem's
 // first element (knot_base) in the TILED or plain layout.
-template <bool TILED, typename T>
+template <bool TILED, typename T, int INTEG = 0>
 QILQR_HD void rollout_problem(const ModelConsts<T> &c, const T *traj, const T *gains, T alpha,
                               T *out, int n) {
   T pt[18], g[52];
@@ -1045,7 +1207,9 @@ QILQR_HD void rollout_problem(const ModelConsts<T> &c, const T *traj, const T *g
                      u[0], u[1], u[2], u[3]};
 #pragma unroll
     for (int e = 0; e < 18; ++e) out[knot_elem<TILED>(i, e, 18)] = o[e];
-    if (i + 1 < n) {  // the reference's step after the last knot is computed and discarded
+    if (INTEG == 1) {
+      if (i + 1 < n) rk4_step(c, t, q, v, u, (T *)nullptr);
+    } else if (i + 1 < n) {  // the reference's step after the last knot is computed and discarded
       T acc[6], tau[6];
       body_acceleration_fast(c, q, v, u, acc);
 #pragma unroll

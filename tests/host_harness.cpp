@@ -117,7 +117,27 @@ void hh_layout(const ModelConsts<double> *c, int force_general, int *out) {
 static RecLayout layout_from(const int *v) {
   RecLayout L;
   L.sym = v[0]; L.ur_zero = v[1]; L.off_cxx = v[2]; L.off_g = v[3]; L.off_cost = v[4]; L.stride = v[5];
+  L.dense_m = (v[2] == LIN_M_DENSE) ? 1 : 0;  // (the six-int wire form of the tests: the dense layouts are the ones whose C_xx starts behind a dense M)
   return L;
+}
+// the Runge-Kutta extension's layout for the same weights: out as hh_layout
+void hh_layout_rk4(const ModelConsts<double> *c, int force_general, int *out) {
+  int e[6];
+  hh_layout(c, force_general, e);
+  const RecLayout L = make_layout(e[0] != 0, e[1] != 0, true);
+  out[0] = L.sym; out[1] = L.ur_zero; out[2] = L.off_cxx; out[3] = L.off_g; out[4] = L.off_cost; out[5] = L.stride;
+}
+// one Runge-Kutta step of the device code (se3_math.h, rk4_step): x = [t(3), q(w,x,y,z), v(6)] -> xn, M = [J_x | J_u] (12 x 16)
+void hh_rk4_step(const ModelConsts<double> *c, const double *x, const double *u, double *xn, double *MU) {
+  double t[3] = {x[0], x[1], x[2]}, q[4] = {x[4], x[5], x[6], x[3]}, v[6];
+  for (int i = 0; i < 6; ++i) v[i] = x[7 + i];
+  rk4_step(*c, t, q, v, u, MU);
+  xn[0] = t[0]; xn[1] = t[1]; xn[2] = t[2];
+  xn[3] = q[3]; xn[4] = q[0]; xn[5] = q[1]; xn[6] = q[2];
+  for (int i = 0; i < 6; ++i) xn[7 + i] = v[i];
+}
+void hh_rollout_rk4(const ModelConsts<double> *c, const double *traj, const double *gains, double alpha, double *out, int n) {
+  rollout_problem<false, double, 1>(*c, traj, gains, alpha, out, n);
 }
 // the table-indexed operand sources of k_backward against the value-returning ones; returns mismatches
 int hh_check_operand_tables(const ModelConsts<double> *c, const int *lay) {
@@ -249,6 +269,20 @@ void hh_dense_jacobians(const ModelConsts<double> *c, const double *rec, double 
       const double v = off >= 0 ? rec[off] : cst;
       if (col < 12) Jx[r * 12 + col] = v;
       else Ju[r * 4 + (col - 12)] = v;
+    }
+}
+
+// the same for a record of layout `lay` (the Runge-Kutta extension's dense M included)
+void hh_dense_jacobians_lay(const ModelConsts<double> *c, const int *lay, const double *rec, double *Jx, double *Ju) {
+  const RecLayout L = layout_from(lay);
+  for (int r = 0; r < 12; ++r)
+    for (int col = 0; col < 16; ++col) {
+      double cst;
+      const int off = m_source(L, r, col, c->Bu, &cst);
+      const double v = off >= 0 ? rec[off] : cst;
+      if (col < 12) Jx[r * 12 + col] = v;
+      else Ju[r * 4 + (col - 12)] = v;
+      if ((off >= 0 ? off : -1) != (m_source_tab(L, r, col) >= 0 ? m_source_tab(L, r, col) : -1)) Jx[0] = 0.0 / 0.0;  // the two forms must agree
     }
 }
 

@@ -418,3 +418,62 @@ def test_rollout16_branches(hh):
         for b in range(4):
             _pose_close(out[b], s1.forward_sim(traj, g, al[b]), atol=1e-9)
         traj = s1.forward_sim(traj, g, 1.0)
+
+
+# ------------------------------------------------------------------ the Runge-Kutta extension (se3_math.h: rk4_step)
+@pytest.mark.parametrize("seed,dense", [(21, False), (22, True), (23, "sym")])
+def test_rk4_step_and_dense_records_match_oracle(hh, seed, dense):
+    """The device code's Runge-Kutta step -- next state and M = [J_x | J_u] by the chain rule with the primitives' sparsity
+    written out -- against the oracle's statement of it from the reference's dense primitives (orc_discrete_step, 1); then
+    the knot records of the dense layout: M at the head, the cost entries of the block layouts behind it."""
+    model, Q, R, traj, desired = random_problem(seed, dense=dense)
+    dt = 0.1
+    c = consts(hh, model, Q, R, dt)
+    mp = orc.model_params(**model)
+    n = len(traj)
+    for i in range(n):
+        xn, Jx, Ju = orc.discrete_step(mp, 1, traj[i, 1:14], traj[i, 14:18], dt, diffs=True)
+        got, MU = np.zeros(13), np.zeros((12, 16))
+        hh.hh_rk4_step(P(c), P(traj[i, 1:14].copy()), P(traj[i, 14:18].copy()), P(got), P(MU))
+        np.testing.assert_allclose(got, xn, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(MU[:, :12], Jx, rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(MU[:, 12:], Ju, rtol=1e-11, atol=1e-13)
+    lay0, lay = layout(hh, c), np.zeros(6, dtype=np.int32)
+    hh.hh_layout_rk4(P(c), C.c_int(0), lay.ctypes.data_as(C.POINTER(C.c_int)))
+    assert lay[2] == 192 and lay[5] == lay0[5] + 138 and list(lay[:2]) == list(lay0[:2])
+    lin0, lin = np.zeros((n, lay0[5])), np.zeros((n, lay[5]))
+    hh.hh_linearize(P(c), IP(lay0), P(traj), P(desired), C.c_int(n), P(lin0))
+    hh.hh_linearize(P(c), IP(lay), P(traj), P(desired), C.c_int(n), P(lin))
+    np.testing.assert_array_equal(lin[:, 192:lay[4] + 1], lin0[:, 54:lay0[4] + 1])   # the cost half is the Euler layout's, moved
+    for i in range(n):
+        _, Jx, Ju = orc.discrete_step(mp, 1, traj[i, 1:14], traj[i, 14:18], dt, diffs=True)
+        jx, ju = np.zeros((12, 12)), np.zeros((12, 4))
+        hh.hh_dense_jacobians_lay(P(c), IP(lay), P(lin[i]), P(jx), P(ju))
+        np.testing.assert_allclose(jx, Jx, rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(ju, Ju, rtol=1e-11, atol=1e-13)
+        cxx0, cxx = np.zeros((12, 12)), np.zeros((12, 12))
+        hh.hh_dense_cxx(P(c), IP(lay0), P(lin0[i]), P(cxx0))
+        hh.hh_dense_cxx(P(c), IP(lay), P(lin[i]), P(cxx))
+        np.testing.assert_array_equal(cxx, cxx0)
+    # the Euler layouts through the layout-aware accessor are what they were
+    jx0, ju0, jx1, ju1 = np.zeros((12, 12)), np.zeros((12, 4)), np.zeros((12, 12)), np.zeros((12, 4))
+    hh.hh_dense_jacobians(P(c), P(lin0[0]), P(jx0), P(ju0))
+    hh.hh_dense_jacobians_lay(P(c), IP(lay0), P(lin0[0]), P(jx1), P(ju1))
+    np.testing.assert_array_equal(jx0, jx1)
+    np.testing.assert_array_equal(ju0, ju1)
+
+
+def test_rk4_rollout_matches_oracle(hh):
+    model, Q, R = pb.MODEL_D, pb.Q_DEMO, pb.R_DEMO
+    cfg = pb.config2(B=3, N=30, seed=8)
+    c = consts(hh, cfg["model"], cfg["Q"], cfg["R"], cfg["dt"])
+    o = orc.OracleSolver(orc.model_params(**cfg["model"]), cfg["Q"], cfg["R"], cfg["desired"], cfg["dt"], orc.options(**cfg["options"]))
+    o.set_integrator(1)
+    for b in range(3):
+        tr = cfg["init"][b]
+        gains, _ = o.backwards_pass(tr)
+        for alpha in (1.0, 0.25):
+            ref = o.forward_sim(tr, gains, alpha)
+            out = np.zeros_like(tr)
+            hh.hh_rollout_rk4(P(c), P(tr.copy()), P(gains.copy()), C.c_double(alpha), P(out), C.c_int(len(tr)))
+            np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10)
