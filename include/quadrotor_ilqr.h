@@ -200,7 +200,7 @@ int qilqr_set_regularisation(qilqr_solver *s, double mu_init, double mu_factor, 
  * in place of the explicit Euler step of quadrotor_model.cc:33-49 in every pass (forward simulation, and the Jacobians
  * J_x, J_u of the backward pass by the chain rule through the stages).  integrator = 0 (default): the reference's step, and
  * then every result is the reference's; 1: the extension (fp64 solvers only).  Stated in the oracle from the reference's
- * own primitives (oracle/ilqr_oracle.c, discrete_dynamics_rk4); measured order of accuracy on SE(3): two, against Euler's
+ * own primitives; measured order of accuracy on SE(3): two, against Euler's
  * one (tests/test_oracle_rk4.py explains why not four).  The extension runs on the general kernels -- a lane per
  * trajectory rollout, the one-wavefront backward pass over dense Jacobian records -- not on the tuned Euler path. */
 int qilqr_set_integrator(qilqr_solver *s, int32_t integrator);

@@ -583,7 +583,7 @@ QILQR_HD T knot_cost(const T *Q, const T *R, const T *pt, const T *pd, T dx[12],
 // The step sketched in the comment at quadrotor_model.cc:51-63 (never executed by the reference; default off here):
 //     k_0 = f(x, u);  k_i = f(x (+) h_i k_{i-1}, u), h = {0, dt/2, dt/2, dt};  x_next = x (+) dt (k_0 + 2 k_1 + 2 k_2 + k_3) / 6
 // with (+) = euler_step (quadrotor_model.cc:266-276) from x in every stage.  The oracle states it from the reference's
-// primitives (oracle/ilqr_oracle.c, discrete_dynamics_rk4) and measures its order on SE(3): two (tests/test_oracle_rk4.py).
+// primitives and measures its order on SE(3): two (tests/test_oracle_rk4.py).
 // Jacobians by the chain rule, with the sparsity of the primitives written out: for a tangent step tau = h k[0:6],
 //     d(x (+) h k)/dx = [[Ad(Exp(-tau)), 0],[0, 1]],   d(x (+) h k)/dk = h [[Jr(tau), 0],[0, 1]],
 //     F_x = df/dx = [[0, 1],[G, D]] with G = -g hat(R^T e_z) in the rotation columns of the linear rows (quadrotor_model.cc:88-96)
