@@ -5,7 +5,10 @@
 #      and WRITE_SIZE do not fit one pass; no trace domains besides --kernel-trace with --pmc)
 # Usage: profiles/run_rocprof.sh <tag> [bench args...]
 set -u
+# The three runs profile configs[1] alone: bench.py's extra legs (several batches in flight, host buffers, B = 8192) lie
+# outside its timed region, run other batch sizes through other kernel variants, and would blur every per-kernel row.
 TAG=${1:-r01}; shift || true
+set -- --no-serving --no-host-to-host --no-large-batch "$@"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

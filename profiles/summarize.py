@@ -7,6 +7,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -16,10 +17,18 @@ def find(root, suffix):
 
 
 def short(name):
-    for k in ("k_backward", "k_rollout", "k_linearize", "k_accept", "k_init", "k_gather", "k_seed_search"):
+    """kernel class: the variants of one pass (k_backward / k_backward2 / k_backward4, k_rollout / k_rollout3 / k_rollout16) share a
+    row -- one run uses one variant of each (run_rocprof.sh switches off bench.py's legs at other batch sizes); the
+    variants seen are listed beside the row"""
+    for k in ("k_solve4", "k_backward", "k_rollout", "k_linearize", "k_accept", "k_init", "k_gather", "k_retile", "k_begin", "k_seed_search"):
         if k in name:
             return k
     return name[:60]
+
+
+def exact(name):
+    m = re.search(r"qilqr::(k_[a-z0-9_]+)", name)
+    return m.group(1) if m else name[:40]
 
 
 def main():
@@ -30,15 +39,17 @@ def main():
     for f in find(os.path.join(out, "trace"), "kernel_trace.csv"):
         rows += list(csv.DictReader(open(f)))
     stat = defaultdict(list)
+    seen = defaultdict(set)
     for r in rows:
         stat[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        seen[short(r["Kernel_Name"])].add(exact(r["Kernel_Name"]))
     total = sum(sum(v) for v in stat.values()) or 1.0
     ks = {}
     lines = ["kernel                 calls   total_us    avg_us    min_us    max_us   pct"]
     for k, v in sorted(stat.items(), key=lambda kv: -sum(kv[1])):
         ks[k] = dict(calls=len(v), total_us=sum(v), avg_us=sum(v) / len(v), min_us=min(v), max_us=max(v),
-                     pct=100 * sum(v) / total)
-        lines.append(f"{k:20s} {len(v):7d} {sum(v):10.1f} {sum(v)/len(v):9.2f} {min(v):9.2f} {max(v):9.2f} {100*sum(v)/total:5.1f}")
+                     pct=100 * sum(v) / total, kernels=sorted(seen[k]))
+        lines.append(f"{k:20s} {len(v):7d} {sum(v):10.1f} {sum(v)/len(v):9.2f} {min(v):9.2f} {max(v):9.2f} {100*sum(v)/total:5.1f}   {' '.join(sorted(seen[k]))}")
     summary["kernel_stats"] = ks
     # ---- PMC passes
     for name, sub, mult in (("FETCH_SIZE", "pmc_fetch", 2.0), ("WRITE_SIZE", "pmc_write", 1.0)):

@@ -102,6 +102,16 @@ struct GA {  // global address space views of storage type S
 #define QKEEP(x) do { } while (0)
 #endif
 
+// Workgroups go to the eight XCDs round-robin by blockIdx, and every XCD has an L2 of its own.  In the kernels that give a
+// block to FOUR trajectories (k_rollout16, k_backward4) the sixteen blocks of a tile of 64 trajectories touch the SAME
+// 128-byte lines of the tiled arrays (32 bytes each: nominal knots and gains read, gains and candidates written), so they
+// are given to one XCD: XCD x takes the contiguous range of logical blocks that its hardware blocks x, x + 8, ...
+// enumerate.  (Counters, B = 1024: FETCH_SIZE per launch 53 MB with the identity map.)
+__device__ __forceinline__ int xcd_local_block(unsigned hw_block, unsigned nblocks) {
+  constexpr unsigned XCDS = 8;
+  const unsigned x = hw_block % XCDS, k = hw_block / XCDS, per = nblocks / XCDS, rem = nblocks % XCDS;
+  return (int)(x * per + (x < rem ? x : rem) + k);
+}
 __device__ __forceinline__ bool is_converged(const SolveParams &p, double cost, double new_cost) {
   // ilqr.hh:196-205 (cost == 0 gives NaN < rtol == false and falls through to atol)
   if (fabs(cost - new_cost) / fabs(cost) < p.rtol) return true;
@@ -1335,7 +1345,7 @@ __global__ __launch_bounds__(384) void k_backward4(ModelConsts<double> c, SolveP
                                                    int force) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0..3: matrix wave of trajectory b0 + w; 4: G; 5: L
-  const int b0 = blockIdx.x * 4;
+  const int b0 = xcd_local_block(blockIdx.x, gridDim.x) * 4;
   __shared__ int s_run[4], s_cur[4], s_iters[4], s_act[4];
   __shared__ double s_cost[4];
   // four slots per trajectory: in interval i the matrix wave reads slot (i-1) & 3 and writes slot (i-2) & 3
@@ -2236,11 +2246,12 @@ __global__ __launch_bounds__(192) void k_rollout16(ModelConsts<double> c, BatchS
   const int lane = threadIdx.x & 63;
   const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: A, 1: B, 2: P
   const int row = lane >> 4;
-  const int b = blockIdx.x * 4 + row;
+  const int blk = xcd_local_block(blockIdx.x, gridDim.x);
+  const int b = blk * 4 + row;
   const bool live = (b < B) && (!need_flag || (st.flags[b < B ? b : 0] & need_flag));
   const unsigned long long livemask = __ballot(live);
   if (livemask == 0ull) return;  // identical in the three waves: block-uniform
-  const int bs = live ? b : blockIdx.x * 4 + ((__ffsll((long long)livemask) - 1) >> 4);  // dead rows alias the first live one
+  const int bs = live ? b : blk * 4 + ((__ffsll((long long)livemask) - 1) >> 4);  // dead rows alias the first live one
   const int cur = st.cur[bs];
   const S *traj = (const S *)st.traj[cur] + knot_base<true>(bs, n, 18);
   const S *gains = (const S *)st.gains + knot_base<true>(bs, n, 52);
@@ -2248,7 +2259,7 @@ __global__ __launch_bounds__(192) void k_rollout16(ModelConsts<double> c, BatchS
   __shared__ R16Lds sh;
   if (threadIdx.x < R16_NFLAGS) sh.flags[threadIdx.x] = 0;
   __syncthreads();
-  unsigned long long *stamps = st.stamps ? st.stamps + ((long)blockIdx.x * 3 + role) * 8 : nullptr;
+  unsigned long long *stamps = st.stamps ? st.stamps + ((long)blk * 3 + role) * 8 : nullptr;
   if (role == 2) {
     r16_wave_P<S>(sh, traj, gains, out, st.alpha[bs], live, n, lane, stamps);
     return;
