@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity soak: the randomised GPU test of tests/test_gpu_parity.py over many more seeds, with every
-backward kernel (automatic, k_backward2, k_backward4, one wavefront, general) and rollout kernel forced in turn, and with Levenberg-Marquardt restarts on (few trials per line search).
+backward kernel (automatic, k_backward2, k_backward4, one wavefront, general) and rollout kernel forced in turn, the one-launch solve, and with Levenberg-Marquardt restarts on (few trials per line search).
 usage: python profiles/microbench/soak.py [first_seed [n_seeds]]"""
 import sys
 
@@ -15,7 +15,9 @@ orig = capi.from_config
 bad = 0
 for label, kw in [("automatic", {}), ("k_backward2", dict(force_general=3)), ("k_backward4", dict(force_general=4)), 
                   ("one wavefront", dict(force_general=2)), ("general", dict(force_general=1)),
-                  ("k_rollout", dict(single_wave_rollout=1)), 
+                  ("k_rollout", dict(single_wave_rollout=1)), ("k_rollout3", dict(single_wave_rollout=2)), ("k_rollout16", dict(single_wave_rollout=3)),
+                  ("k_solve4", dict(persistent=1)), ("restarts, k_solve4", dict(persistent=1)),
+
                   ("three streams", dict(streams=3)), ("restarts", dict()), ("restarts, k_backward2", dict(force_general=3)),
                   ("restarts, one wavefront", dict(force_general=2)), ("restarts, general", dict(force_general=1))]:
     capi.from_config = lambda cfg, _kw=kw, **k: orig(cfg, **{**_kw, **k})

@@ -112,13 +112,13 @@ __device__ __attribute__((noinline)) void s4_follow(const ModelConsts<S> *cp, co
     if (live && i < n) solve4_linearize_lane<S, LK>(*cp, qr, st, b, i, n, buf, half);
   }
 }
-// first linearisation of the four trajectories of a group (ilqr.hh:56 needs their cost; the first backward pass their
-// records): every lane of the block takes (trajectory, knot) pairs, dynamics halves first, then cost halves
 constexpr int S4_WAVES = 8, S4_THREADS = 64 * S4_WAVES;
 // forward-phase roles by wave (waves w and w + 4 share SIMD w % 4): the control wave A and the pose wave B have a SIMD each;
 // the operand wave P shares its SIMD with one follower, the other two followers share the fourth
 constexpr int S4_W_A = 0, S4_W_B = 1, S4_W_P = 2;
 __device__ __forceinline__ bool s4_is_follower(int w) { return w == 3 || w == 7 || w == 6; }
+// first linearisation of the four trajectories of a group (ilqr.hh:56 needs their cost; the first backward pass their
+// records): every lane of the block takes (trajectory, knot) pairs, dynamics halves first, then cost halves
 template <typename S, int LK>
 __device__ __attribute__((noinline)) void s4_first(const ModelConsts<S> *cp, const S *qr, const BatchState &st, int b0, int B, int n) {
   const int per = 4 * n;
