@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Diagnostic: average launch time of the backward kernel through qilqr_backwards_pass (profile = 2, all 1024
 trajectories running), for one or more builds of the library.  usage: backward_time.py lib1.so [lib2.so ...]
-(run from a directory three levels below the repository root, e.g. quadrotorilqr_amd/lib/variants)"""
+(run from the repository root)"""
 import os, sys, numpy as np
-sys.path.insert(0, os.getcwd() + "/../../..")
+sys.path.insert(0, os.getcwd())
 from quadrotorilqr_amd import capi, problems as pb
 for lib in sys.argv[1:]:
     capi.LIB_PATH = os.path.abspath(lib); capi._lib = None
