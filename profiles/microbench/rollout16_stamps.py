@@ -24,12 +24,12 @@ print("stamps build: k_rollout16 %.2f us per launch" % (1e3 * p["rollout_ms"] / 
 out = np.zeros((B, 8), dtype=np.uint64)
 capi.load().qilqr_debug_stamps(s._h, out.ctypes.data_as(C.c_void_p), C.c_int32(B))
 blocks = B // 4
+blocks = B // 4
 st = out.reshape(-1)[: blocks * 24].reshape(blocks, 3, 8).astype(np.float64)
-names = {0: ["operand reads, velocity terms", "wait for the Log of knot i", "control, velocity", "Exp, hand-off", "store"],
-         1: ["Log, hand-off", "requests, stores", "wait for E_i", "compose"],
-         2: ["requests", "wait for loads + operand registers", "wait for a free slot", "LDS writes, flag, time store"]}
+xn = ["operand reads, requests, pose stores", "Log", "wait for v_i", "control, velocity, hand-off, store", "Exp", "wait for T_{i+1}", "compose, hand-off"]
+names = {0: xn, 1: xn, 2: ["requests", "wait for loads + operand registers", "wait for a free slot", "LDS writes, flag, time store"]}
 for role in (0, 1, 2):
-    med = np.median(st[:, role, :], axis=0) / N
-    print("wave", ["A (control)", "B (pose)", "P (operands)"][role], " total %.0f cycles/knot" % med.sum())
+    med = np.median(st[:, role, :], axis=0) / (N / 2 if role < 2 else N)
+    print("wave", ["X_0 (even knots)", "X_1 (odd knots)", "P (operands)"][role], " total %.0f cycles per %s" % (med.sum(), "own knot" if role < 2 else "knot"))
     for n_, m in zip(names[role], med):
         print(f"   {n_:42s} {m:8.0f}  {100 * m / med.sum():5.1f} %")

@@ -1942,13 +1942,13 @@ struct DevWave {
 constexpr int R16_RING = 4;
 constexpr int R16_SPIN_MAX = 1 << 22;
 constexpr int R16_CHUNK = 16;  // knots per "stored and visible" announcement of wave A (k_solve4's linearisation follows it)
-enum { R16_F_PROD = 0, R16_F_CONS_A, R16_F_CONS_B, R16_F_E, R16_F_L, R16_F_KA, R16_F_KB, R16_F_ABORT, R16_NFLAGS };
-enum { X_L = 0, X_E = 1 };
+enum { R16_F_PROD = 0, R16_F_CONS0, R16_F_CONS1, R16_F_V, R16_F_T, R16_F_K0, R16_F_K1, R16_F_ABORT, R16_NFLAGS };
+enum { X_V = 0, X_T = 1 };
 // LDS of the three rollout roles
 struct R16Lds {
   double ops[R16_RING][r16::NOPS][64];  // operand registers of R16_RING knots, [register][lane]
-  double xch[2][2][3][64];             // hand-off slots [X_L (theta | c, td, q) of knot k | X_E (dq, p) of Exp(dt v_k)][parity of k][register][lane]
-  int flags[R16_NFLAGS];               // knots produced by P / used by A, by B; E_k ready (A); Log_k ready (B); knots stored (A, B); abort
+  double xch[2][4][2][64];             // hand-off slots [X_V (v_lin, omega) of knot k | X_T (t, q) of knot k][k & 3][register][lane]
+  int flags[R16_NFLAGS];               // knots produced by P / even, odd knots whose operands are used; v_k ready; T_k ready; even, odd knots stored; abort
 };
 // The LDS executes the operations of one wavefront in the order they were issued, so a flag written after the data (or
 // after the reads of a slot) is seen after them: no s_waitcnt, and no workgroup fence -- a release fence would wait for the
@@ -2024,18 +2024,16 @@ __device__ __forceinline__ bool r16_handoff_finish(R16Lds &sh, int which, int ta
   if (__builtin_expect(f >= target, 1)) return true;
   return r16_read_handoff<NV>(sh, which, target, kind, par, a, lane);
 }
-// "knots [0, k) are stored and visible to the block": a wavefront whose only vector-memory operations are its knot stores
-// (PER per knot) announces, every R16_CHUNK / 2 knots, the knots whose stores are older than its PER * R16_CHUNK / 2 youngest
+// "my knots up to i are stored and visible to the block": a step wave's only vector-memory operations are its knot stores
+// (three per knot of its parity); every fourth knot of its own it announces the knots older than its twelve youngest stores
 // (s_waitcnt vmcnt(N) waits for all but the N youngest: nearly free), and everything after its last knot (vmcnt(0), once)
-template <int PER>
-__device__ __forceinline__ void r16_publish_stores(R16Lds &sh, int which, int i, int n, int lane) {
-  constexpr int LAG = R16_CHUNK / 2;
-  if (i + 1 == n) {
+__device__ __forceinline__ void r16_publish_stores(R16Lds &sh, int which, int i, int last, int lane) {
+  if (i == last) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    r16_flag_post(sh, which, n, lane);
-  } else if (((i + 1) % LAG) == 0 && i + 1 > LAG) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * LAG) : "memory");
-    r16_flag_post(sh, which, i + 1 - LAG, lane);
+    r16_flag_post(sh, which, i + 1, lane);
+  } else if (((i >> 1) & 3) == 3 && i >= 16) {
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // the stores of this wave's knots i, i - 2, i - 4, i - 6 may be in flight
+    r16_flag_post(sh, which, i - 8 + 1, lane);
   }
 }
 
@@ -2072,9 +2070,8 @@ __device__ __forceinline__ void r16_wave_P(R16Lds &sh, const S *traj, const S *g
     p_compute<DevWave>(pc, rc, alpha, op);
     QKEEP(op[0]); QKEEP(op[22]); QKEEP(op[10]);
     QSTAMP(1);  // P: wait for the loads, operand registers
-    // slot k % R16_RING is free once A and B have used knot k - R16_RING
-    if (k >= R16_RING && !(r16_flag_wait(sh, R16_F_CONS_A, k - R16_RING + 1, -1, lane) && r16_flag_wait(sh, R16_F_CONS_B, k - R16_RING + 1, -1, lane)))
-      ok = false;
+    // slot k % R16_RING is free once the wave of knot k - R16_RING (the same parity: the ring is even) has used it
+    if (k >= R16_RING && !r16_flag_wait(sh, R16_F_CONS0 + (k & 1), k - R16_RING + 1, -1, lane)) ok = false;
     QSTAMP(2);  // P: wait for a free slot
 #pragma unroll
     for (int r = 0; r < NOPS; ++r) sh.ops[k % R16_RING][r][lane] = op[r];
@@ -2093,146 +2090,91 @@ __device__ __forceinline__ void r16_wave_P(R16Lds &sh, const S *traj, const S *g
 #endif
 }
 
-// B: pose.  T_{i+1} = T_i E_i (E_i = Exp(dt v_i) from A), then tau_{i+1} = Log(T_nom^-1 T_{i+1}) for A; stores the pose of every
-// knot.  (TT, QQ): the pose of knot 0.  PUBLISH: announce the stored knots (k_solve4's linearisation follows them).
+// X_p: the steps of the knots of parity p.  Step i, from T_i (this wave's own, out of its step i - 2):
+//     tau_i = Log(T_nom^-1 T_i);  u_i;  v_{i+1} = v_i + dt a(q_i, v_i, u_i)  -> handed to the other wave;
+//     E_{i+1} = Exp(dt v_{i+1});  T_{i+2} = T_{i+1} E_{i+1}                   -> handed to the other wave, and kept
+// with v_i and T_{i+1} from the other wave's step i - 1.  The recurrence spans two knots, so two such waves, one knot apart,
+// never wait for each other in the steady state: v_i is posted about half a step before step i needs it, T_{i+1} likewise --
+// the hand-offs' LDS latency (~450 cycles from post to use through a progress word, which bounded every partition of a
+// knot into roles: 74 us) is off the chain.  (TT, QQ, VL, VW): the state of knot 0.  PUBLISH: announce the stored knots.
 template <typename S, bool PUBLISH>
-__device__ __forceinline__ void r16_wave_B(R16Lds &sh, const ModelConsts<double> &c, double TT, double QQ, S *out, bool live, int n,
-                                           int lane, unsigned long long *stamps_out) {
+__device__ __forceinline__ void r16_wave_X(R16Lds &sh, const ModelConsts<double> &c, int p, double TT, double QQ, double VL, double VW, S *out,
+                                           bool live, int n, int lane, unsigned long long *stamps_out) {
   using namespace r16;
-  RConsts<DevWave> kc;  // (built here: what the pose wave does not use is never computed, nor kept in registers)
+  RConsts<DevWave> kc;
   make_rconsts(c, kc);
-  const int et = stt_elem(lane), eq = stq_elem(lane);
-  const bool wt = live && et >= 0, wq = live && eq >= 0;
-  const int ot = DevWave::iuni(et >= 0 ? et : 0), oq = DevWave::iuni(eq >= 0 ? eq : 0);
+  const int ea = sta_elem(lane), et = stt_elem(lane), eq = stq_elem(lane);
+  const bool wa = live && ea >= 0, wt = live && et >= 0, wq = live && eq >= 0;
+  const int oa = DevWave::iuni(ea >= 0 ? ea : 0), ot = DevWave::iuni(et >= 0 ? et : 0), oq = DevWave::iuni(eq >= 0 ? eq : 0);
+  const int last = (n - 1) - (((n - 1) & 1) ^ p);  // this wave's last knot (< 0: none)
 #ifdef QILQR_STAMPS
   unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
-  if (!r16_flag_wait(sh, R16_F_PROD, 1, -1, lane)) return;
-  double op[OP_K];  // R_n^T (3), t_n, the conj(q_n) matrix (4): registers 0..7 of the knot's slot
+  if (p == 1 && n > 1) {  // "step -1": T_1 = T_0 Exp(dt v_0), this wave's first pose and the even wave's first compose
+    double DQ, PP, TTn, QQn;
+    a_exp<DevWave>(kc, VL, VW, DQ, PP);
+    b_compose<DevWave>(kc, TT, QQ, DQ, PP, TTn, QQn);
+    TT = TTn;
+    QQ = QQn;
+    sh.xch[X_T][1][0][lane] = TT;
+    sh.xch[X_T][1][1][lane] = QQ;
+    r16_flag_post(sh, R16_F_T, 1, lane);
+  }
+  int seen = -1;  // P's progress as last read
+  for (int i = p; i < n; i += 2) {
+    if (__builtin_expect(!r16_flag_wait(sh, R16_F_PROD, i + 1, seen, lane), 0)) return;
+    double op[NOPS];
 #pragma unroll
-  for (int r = 0; r < OP_K; ++r) op[r] = sh.ops[0][r][lane];
-  int seen = r16_flag_read(sh, R16_F_PROD);  // P's progress as last read
-  // Log_i and its hand-off; then the pose stores (after the hand-off: the control wave is waiting for it)
-  auto log_knot = [&](int i, double TT, double QQ, const double *op) {
-    double TH4, TD;
-    b_log<DevWave>(kc, TT, QQ, op, TH4, TD);
-    sh.xch[X_L][i & 1][0][lane] = TH4;
-    sh.xch[X_L][i & 1][1][lane] = TD;
-    sh.xch[X_L][i & 1][2][lane] = QQ;
-    r16_flag_post(sh, R16_F_L, i + 1, lane);
-    r16_flag_post(sh, R16_F_CONS_B, i + 1, lane);
-  };
-  auto store_knot = [&](int i, double TT, double QQ) {
+    for (int r = 0; r < NOPS; ++r) op[r] = sh.ops[i % R16_RING][r][lane];
+    seen = r16_flag_read(sh, R16_F_PROD);
+    int fv = 0;
+    double v[2] = {VL, VW};
+    if (i > 0) r16_handoff_request<2>(sh, R16_F_V, X_V, i & 3, fv, v, lane);  // v_i: posted about half a step ago
     S *ok_ = out + (long)i * (9 * 128);
     if (wt) ok_[ot] = (S)TT;
     if (wq) ok_[oq] = (S)QQ;
-    if (PUBLISH) r16_publish_stores<2>(sh, R16_F_KB, i, n, lane);
-  };
-  for (int i = 0; i + 1 < n; ++i) {  // iteration i: the pose of knot i is in (TT, QQ), its operands in op
-    log_knot(i, TT, QQ, op);
-    QSTAMP(0);  // B: Log, hand-off
-    // E_i and the operands of knot i + 1 are requested now and used after the stores, which cover the LDS round trip (A posted
-    // E_i while this wave was in Log_i, P is normally several knots ahead)
-    if (__builtin_expect(!r16_flag_wait(sh, R16_F_PROD, i + 2, seen, lane), 0)) return;
-    double opn[OP_K];
-#pragma unroll
-    for (int r = 0; r < OP_K; ++r) opn[r] = sh.ops[(i + 1) % R16_RING][r][lane];
-    seen = r16_flag_read(sh, R16_F_PROD);
-    int fe;
-    double e[2];
-    r16_handoff_request<2>(sh, R16_F_E, X_E, i & 1, fe, e, lane);
-    store_knot(i, TT, QQ);
-    QSTAMP(1);  // B: requests, stores
-    if (__builtin_expect(!r16_handoff_finish<2>(sh, R16_F_E, i + 1, X_E, i & 1, fe, e, lane), 0)) return;
-    QSTAMP(2);  // B: wait for E_i
-    double TTn, QQn;
-    b_compose<DevWave>(kc, TT, QQ, e[0], e[1], TTn, QQn);
-    TT = TTn;
-    QQ = QQn;
-#pragma unroll
-    for (int r = 0; r < OP_K; ++r) op[r] = opn[r];
-    QSTAMP(3);  // B: compose
-  }
-  log_knot(n - 1, TT, QQ, op);  // the last knot: the reference's step after it is computed and discarded (ilqr.hh:168)
-  store_knot(n - 1, TT, QQ);
-#ifdef QILQR_STAMPS
-  if (lane == 0 && stamps_out)
-    for (int k = 0; k < 8; ++k) stamps_out[k] = stamp_sum[k];
-#endif
-}
-
-// A: control, velocity, Exp; stores v_i, u_i.  (VL, VW): the velocity of knot 0.
-template <typename S, bool PUBLISH>
-__device__ __forceinline__ void r16_wave_A(R16Lds &sh, const ModelConsts<double> &c, double VL, double VW, S *out, bool live, int n,
-                                           int lane, unsigned long long *stamps_out) {
-  using namespace r16;
-  RConsts<DevWave> kc;  // (built here: what the control wave does not use is never computed, nor kept in registers)
-  make_rconsts(c, kc);
-  const int ea = sta_elem(lane);
-  const bool wa = live && ea >= 0;
-  const int oa = DevWave::iuni(ea >= 0 ? ea : 0);
-#ifdef QILQR_STAMPS
-  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
-#endif
-  if (n > 1) {  // E_0 = Exp(dt v_0): the pose wave's first compose
-    double DQ, PP;
-    a_exp<DevWave>(kc, VL, VW, DQ, PP);
-    sh.xch[X_E][0][0][lane] = DQ;
-    sh.xch[X_E][0][1][lane] = PP;
-    r16_flag_post(sh, R16_F_E, 1, lane);
-  }
-  int seen = -1;  // P's progress as last read
-  for (int i = 0; i + 1 < n; ++i) {
-    if (__builtin_expect(!r16_flag_wait(sh, R16_F_PROD, i + 1, seen, lane), 0)) return;
-    double op[NOPS];  // the gain columns, u_nom + alpha k, v_nom: registers 8..22 of the knot's slot
-#pragma unroll
-    for (int r = OP_K; r < NOPS; ++r) op[r] = sh.ops[i % R16_RING][r][lane];
-    seen = r16_flag_read(sh, R16_F_PROD);  // for the next knot: P is normally several knots ahead, and this read's latency is covered by the knot
-    int fl;
-    double l[3];
-    r16_handoff_request<3>(sh, R16_F_L, X_L, i & 1, fl, l, lane);  // (if the pose wave is ahead: no second round trip)
+    QSTAMP(0);  // X: operand reads, requests, pose stores
+    double TH4, TD;
+    b_log<DevWave>(kc, TT, QQ, op, TH4, TD);
+    const double RH = a_rho<DevWave>(TH4, TD);
+    QSTAMP(1);  // X: Log
+    if (i > 0) {
+      if (__builtin_expect(!r16_handoff_finish<2>(sh, R16_F_V, i, X_V, i & 3, fv, v, lane), 0)) return;
+    }
+    QSTAMP(2);  // X: wait for v_i
+    const bool advance = i + 1 < n;  // the reference's step after the last knot is computed and discarded (ilqr.hh:168)
     APre<DevWave> pre;
-    a_pre<DevWave>(kc, VL, VW, op, pre);  // what needs only v_i: runs while the pose wave is still in Log_i
-    QSTAMP(0);  // A: operand reads, velocity terms
-    if (__builtin_expect(!r16_handoff_finish<3>(sh, R16_F_L, i + 1, X_L, i & 1, fl, l, lane), 0)) return;
-    QSTAMP(1);  // A: wait for the Log of knot i
-    double VLn, VWn;
-    const double st = a_post<DevWave>(kc, pre, l[0], l[1], l[2], VL, op, true, VLn, VWn);
-    r16_flag_post(sh, R16_F_CONS_A, i + 1, lane);  // the slot's values have been used
-    QSTAMP(2);  // A: control, velocity
-    if (__builtin_expect(i + 2 < n, 1)) {  // E_{i+1} for the pose of knot i + 2
+    a_pre<DevWave>(kc, v[0], v[1], op, pre);
+    double VLn = 0.0, VWn = 0.0;
+    const double st = a_post<DevWave, true>(kc, pre, TH4, RH, QQ, v[0], op, advance, VLn, VWn);
+    r16_flag_post(sh, R16_F_CONS0 + p, i + 1, lane);  // the slot's values have been used
+    if (__builtin_expect(advance, 1)) {
+      sh.xch[X_V][(i + 1) & 3][0][lane] = VLn;
+      sh.xch[X_V][(i + 1) & 3][1][lane] = VWn;
+      r16_flag_post(sh, R16_F_V, i + 1, lane);
+    }
+    if (wa) ok_[oa] = (S)st;
+    if (PUBLISH) r16_publish_stores(sh, R16_F_K0 + p, i, last, lane);
+    QSTAMP(3);  // X: control, velocity, hand-off, store
+    if (i + 2 < n) {
+      int ft;
+      double t[2];
+      r16_handoff_request<2>(sh, R16_F_T, X_T, (i + 1) & 3, ft, t, lane);  // T_{i+1}: posted at the end of the other wave's step i - 1
       double DQ, PP;
       a_exp<DevWave>(kc, VLn, VWn, DQ, PP);
-      sh.xch[X_E][(i + 1) & 1][0][lane] = DQ;
-      sh.xch[X_E][(i + 1) & 1][1][lane] = PP;
-      r16_flag_post(sh, R16_F_E, i + 2, lane);
+      QSTAMP(4);  // X: Exp
+      if (__builtin_expect(!r16_handoff_finish<2>(sh, R16_F_T, i + 1, X_T, (i + 1) & 3, ft, t, lane), 0)) return;
+      QSTAMP(5);  // X: wait for T_{i+1}
+      double TTn, QQn;
+      b_compose<DevWave>(kc, t[0], t[1], DQ, PP, TTn, QQn);
+      TT = TTn;
+      QQ = QQn;
+      sh.xch[X_T][(i + 2) & 3][0][lane] = TT;
+      sh.xch[X_T][(i + 2) & 3][1][lane] = QQ;
+      r16_flag_post(sh, R16_F_T, i + 2, lane);
+      QSTAMP(6);  // X: compose, hand-off
     }
-    QSTAMP(3);  // A: Exp, hand-off
-    S *ok_ = out + (long)i * (9 * 128);
-    if (wa) ok_[oa] = (S)st;
-    if (PUBLISH) r16_publish_stores<1>(sh, R16_F_KA, i, n, lane);
-    VL = VLn;
-    VW = VWn;
-    QSTAMP(4);  // A: store
-  }
-  {  // the last knot: its control only -- the reference's step after it is computed and discarded (ilqr.hh:168)
-    const int i = n - 1;
-    if (!r16_flag_wait(sh, R16_F_PROD, i + 1, seen, lane)) return;
-    double op[NOPS];
-#pragma unroll
-    for (int r = OP_K; r < NOPS; ++r) op[r] = sh.ops[i % R16_RING][r][lane];
-    APre<DevWave> pre;
-    a_pre<DevWave>(kc, VL, VW, op, pre);
-    double l[3];
-    if (!r16_read_handoff<3>(sh, R16_F_L, i + 1, X_L, i & 1, l, lane)) return;
-    double VLn, VWn;
-    const double st = a_post<DevWave>(kc, pre, l[0], l[1], l[2], VL, op, false, VLn, VWn);
-    r16_flag_post(sh, R16_F_CONS_A, i + 1, lane);
-    S *ok_ = out + (long)i * (9 * 128);
-    if (wa) ok_[oa] = (S)st;
-    if (PUBLISH) r16_publish_stores<1>(sh, R16_F_KA, i, n, lane);
   }
 #ifdef QILQR_STAMPS
   if (lane == 0 && stamps_out)
@@ -2244,7 +2186,7 @@ template <typename S>
 __global__ __launch_bounds__(192) void k_rollout16(ModelConsts<double> c, BatchState st, int B, int n, int need_flag) {
   using namespace r16;
   const int lane = threadIdx.x & 63;
-  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: A, 1: B, 2: P
+  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: X_0 (even knots), 1: X_1 (odd knots), 2: P
   const int row = lane >> 4;
   const int blk = xcd_local_block(blockIdx.x, gridDim.x);
   const int b = blk * 4 + row;
@@ -2265,10 +2207,9 @@ __global__ __launch_bounds__(192) void k_rollout16(ModelConsts<double> c, BatchS
     return;
   }
   auto ld0 = [&](int e) -> double { return e >= 0 ? (double)traj[knot_elem<true>(0, e, 18)] : 0.0; };
-  const double s0 = ld0(role == 1 ? tt_elem(lane) : vl_elem(lane)), s1 = ld0(role == 1 ? qq_elem(lane) : vw_elem(lane));
+  const double TT = ld0(tt_elem(lane)), QQ = ld0(qq_elem(lane)), VL = ld0(vl_elem(lane)), VW = ld0(vw_elem(lane));
   R16_LOADS_DONE();
-  if (role == 1) r16_wave_B<S, false>(sh, c, s0, s1, out, live, n, lane, stamps);
-  else r16_wave_A<S, false>(sh, c, s0, s1, out, live, n, lane, stamps);
+  r16_wave_X<S, false>(sh, c, role, TT, QQ, VL, VW, out, live, n, lane, stamps);
 }
 
 // ---------------------------------------------------------------------------------------------

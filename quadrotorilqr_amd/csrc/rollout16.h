@@ -328,11 +328,12 @@ QILQR_HD void a_pre(const RConsts<W> &k, typename W::V VL, typename W::V VW, con
 }
 // control wave, with (theta | c, td) of tau_i and q_i from the pose wave: u_i (ilqr.hh:158-161; rows in Q3), v_{i+1} = v_i + dt a(q_i,
 // v_i, u_i) (quadrotor_model.cc:65-78), and what the wave stores for knot i: st = [v_lin | 0 | omega | u]
-template <class W>
+// (RHO_DONE: TD is rho already -- a_rho was applied by the wave that computed the Log)
+template <class W, bool RHO_DONE = false>
 QILQR_HD typename W::V a_post(const RConsts<W> &k, const APre<W> &r, typename W::V TH, typename W::V TD, typename W::V QQ,
                               typename W::V VL, const typename W::V *op, bool advance, typename W::V &VLn, typename W::V &VWn) {
   typedef typename W::V V;
-  const V RH = a_rho<W>(TH, TD);  // (lane j = 3 of TH holds the Jacobian coefficient: the control law broadcasts lanes 0..2 only)
+  const V RH = RHO_DONE ? TD : a_rho<W>(TH, TD);  // (lane j = 3 of TH holds the Jacobian coefficient: the control law broadcasts lanes 0..2 only)
   const V u1 = W::template dot3<0>(V(0.0), TH, op[OP_K + 3], op[OP_K + 4], op[OP_K + 5]);
   const V u0 = W::template dot3<0>(op[OP_U0], RH, op[OP_K + 0], op[OP_K + 1], op[OP_K + 2]);
   const V UU = (u0 + u1) + (r.u2 + r.u3);

@@ -57,20 +57,12 @@ __device__ __attribute__((noinline)) void s4_operands(const S *traj, const S *ga
   r16_wave_P<S>(s4_r16, traj, gains, out, alpha, live, n, lane, nullptr);
 }
 template <typename S>
-__device__ __attribute__((noinline)) void s4_pose(const ModelConsts<double> &c, const S *traj, S *out, bool live, int n, int lane) {
+__device__ __attribute__((noinline)) void s4_steps(const ModelConsts<double> &c, int parity, const S *traj, S *out, bool live, int n, int lane) {
   using namespace r16;
   auto ld0 = [&](int e) -> double { return e >= 0 ? (double)traj[knot_elem<true>(0, e, 18)] : 0.0; };
-  const double TT = ld0(tt_elem(lane)), QQ = ld0(qq_elem(lane));
+  const double TT = ld0(tt_elem(lane)), QQ = ld0(qq_elem(lane)), VL = ld0(vl_elem(lane)), VW = ld0(vw_elem(lane));
   R16_LOADS_DONE();
-  r16_wave_B<S, true>(s4_r16, c, TT, QQ, out, live, n, lane, nullptr);
-}
-template <typename S>
-__device__ __attribute__((noinline)) void s4_control(const ModelConsts<double> &c, const S *traj, S *out, bool live, int n, int lane) {
-  using namespace r16;
-  auto ld0 = [&](int e) -> double { return e >= 0 ? (double)traj[knot_elem<true>(0, e, 18)] : 0.0; };
-  const double VL = ld0(vl_elem(lane)), VW = ld0(vw_elem(lane));
-  R16_LOADS_DONE();
-  r16_wave_A<S, true>(s4_r16, c, VL, VW, out, live, n, lane, nullptr);
+  r16_wave_X<S, true>(s4_r16, c, parity, TT, QQ, VL, VW, out, live, n, lane, nullptr);
 }
 
 // one lane's share of a linearisation: the dynamics blocks (half = 0) or the cost differentials and the knot cost (half = 1)
@@ -107,7 +99,9 @@ __device__ __attribute__((noinline)) void s4_follow(const ModelConsts<S> *cp, co
     if (t >= ntasks) break;
     const int k0 = (t >> 1) * R16_CHUNK, half = t & 1;
     const int need = (k0 + R16_CHUNK < n) ? k0 + R16_CHUNK : n;
-    if (!(r16_flag_wait_relaxed(s4_r16, R16_F_KA, need, lane) && r16_flag_wait_relaxed(s4_r16, R16_F_KB, need, lane))) break;
+    // knots [0, need) are stored when each step wave has announced its last knot below `need`
+    const int m0 = (need - 1) - ((need - 1) & 1), m1 = (need - 1) - (((need - 1) & 1) ^ 1);
+    if (!(r16_flag_wait_relaxed(s4_r16, R16_F_K0, m0 + 1, lane) && (m1 < 0 || r16_flag_wait_relaxed(s4_r16, R16_F_K1, m1 + 1, lane)))) break;
     const int i = k0 + (lane & 15);
     if (live && i < n) solve4_linearize_lane<S, LK>(*cp, qr, st, b, i, n, buf, half);
   }
@@ -115,7 +109,7 @@ __device__ __attribute__((noinline)) void s4_follow(const ModelConsts<S> *cp, co
 constexpr int S4_WAVES = 8, S4_THREADS = 64 * S4_WAVES;
 // forward-phase roles by wave (waves w and w + 4 share SIMD w % 4): the control wave A and the pose wave B have a SIMD each;
 // the operand wave P shares its SIMD with one follower, the other two followers share the fourth
-constexpr int S4_W_A = 0, S4_W_B = 1, S4_W_P = 2;
+constexpr int S4_W_X0 = 0, S4_W_X1 = 1, S4_W_P = 2;
 __device__ __forceinline__ bool s4_is_follower(int w) { return w == 3 || w == 7 || w == 6; }
 // first linearisation of the four trajectories of a group (ilqr.hh:56 needs their cost; the first backward pass their
 // records): every lane of the block takes (trajectory, knot) pairs, dynamics halves first, then cost halves
@@ -320,8 +314,7 @@ __global__ __launch_bounds__(S4_THREADS) void k_solve4(ModelConsts<double> c, co
         const S *gains = (const S *)st.gains + knot_base<true>(bs, n, 52);
         S *out = (S *)st.traj[cur ^ 1] + knot_base<true>(bs, n, 18);
         // a wavefront per SIMD for the three rollout roles (waves w, w + 4 share SIMD w % 4); the two linearising waves share the fourth
-        if (w == S4_W_A) s4_control<S>(c, traj, out, live, n, lane);
-        else if (w == S4_W_B) s4_pose<S>(c, traj, out, live, n, lane);
+        if (w == S4_W_X0 || w == S4_W_X1) s4_steps<S>(c, w, traj, out, live, n, lane);
         else if (w == S4_W_P) s4_operands<S>(traj, gains, out, sl[lrow].alpha, live, n, lane);
         else if (s4_is_follower(w)) s4_follow<S, LK>(cp, qr, st, sl[row].b, sl[row].cur ^ 1, live, n, lane);
         QSTAMP(3);
