@@ -1843,17 +1843,16 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
 // k_rollout16: SIXTEEN LANES PER TRAJECTORY (rollout16.h): block = 192 = control wavefront A + pose wavefront B +
 // operand wavefront P for four trajectories (b0 = 4 blockIdx.x; row r of 16 lanes <-> trajectory b0 + r).  At B = 1024
 // that is 256 blocks -- one per CU -- instead of the 16 blocks of k_rollout3, and about a third of its instructions
-// per knot, cut into the two halves that are independent inside a knot:
-//   A (r16::a_pre, a_post, a_exp): u_i = u_nom + alpha k + K [tau_i ; v_i - v_nom], v_{i+1} = v_i + dt a(q_i, v_i, u_i), and
-//      E_{i+1} = Exp(dt v_{i+1}); stores v_i, u_i
-//   B (r16::b_compose, b_log): T_{i+1} = T_i E_i, then the pose error tau_{i+1} = Log(T_nom^-1 T_{i+1}); stores the poses
-//      (the recurrence spans two knots -- Log_i -> u_i -> v_{i+1} -> E_{i+1} -> T_{i+2} -> Log_{i+2} -- so the two waves work on
-//      alternate knots at the same time, with two hand-offs per two knots and about the same instruction count each)
-//   P (r16::p_load, p_compute): for knot k (running up to R16_RING - 1 knots ahead of A): loads the nominal knot and the
+// per knot.  The recurrence spans two knots (Log_i -> u_i -> v_{i+1} -> E_{i+1} -> T_{i+2} -> Log_{i+2}), so two knots can be
+// in flight, and they are given to two IDENTICAL wavefronts one knot apart rather than to roles:
+//   X_p (r16_wave_X; p = 0, 1): the whole step of the knots of parity p -- tau_i = Log(T_nom^-1 T_i),
+//      u_i = u_nom + alpha k + K [tau_i ; v_i - v_nom], v_{i+1} = v_i + dt a(q_i, v_i, u_i), E_{i+1} = Exp(dt v_{i+1}),
+//      T_{i+2} = T_{i+1} E_{i+1} -- from its own T_i and the other wave's v_i and T_{i+1}; stores knot i
+//   P (r16::p_load, p_compute): for knot k (running up to R16_RING - 1 knots ahead): loads the nominal knot and the
 //      gains (tiled global layout, per-lane element offsets), forms the 23 operand registers and writes them to ring slot
 //      k % R16_RING as [register][lane]; copies the time column to the output trajectory.
-// The waves never meet at a barrier inside the loop.  LDS words carry progress: knots produced by P / used by A / by B,
-// "E_k ready" (A), "tau_k ready" (B); the values themselves go through double-buffered LDS slots.
+// The waves never meet at a barrier inside the loop.  LDS words carry progress: knots produced by P / even, odd knots used,
+// "v_k ready", "T_k ready"; the values themselves go through four-deep LDS slots (k & 3).
 // LDS operations of a wavefront execute in order, so a flag written after the data is seen after the data; every spin
 // is bounded, so a lost flag ends the kernel instead of hanging it.
 // Trajectories of the block that are not being rolled out this round alias the block's first live trajectory (their
@@ -2068,7 +2067,7 @@ __device__ __forceinline__ void r16_wave_P(R16Lds &sh, const S *traj, const S *g
     QSTAMP(0);  // P: requests
     double op[NOPS];
     p_compute<DevWave>(pc, rc, alpha, op);
-    QKEEP(op[0]); QKEEP(op[22]); QKEEP(op[10]);
+    QKEEP(op[0]); QKEEP(op[r16::NOPS - 1]); QKEEP(op[10]);
     QSTAMP(1);  // P: wait for the loads, operand registers
     // slot k % R16_RING is free once the wave of knot k - R16_RING (the same parity: the ring is even) has used it
     if (k >= R16_RING && !r16_flag_wait(sh, R16_F_CONS0 + (k & 1), k - R16_RING + 1, -1, lane)) ok = false;
@@ -2128,15 +2127,17 @@ __device__ __forceinline__ void r16_wave_X(R16Lds &sh, const ModelConsts<double>
 #pragma unroll
     for (int r = 0; r < NOPS; ++r) op[r] = sh.ops[i % R16_RING][r][lane];
     seen = r16_flag_read(sh, R16_F_PROD);
-    int fv = 0;
-    double v[2] = {VL, VW};
-    if (i > 0) r16_handoff_request<2>(sh, R16_F_V, X_V, i & 3, fv, v, lane);  // v_i: posted about half a step ago
     S *ok_ = out + (long)i * (9 * 128);
     if (wt) ok_[ot] = (S)TT;
     if (wq) ok_[oq] = (S)QQ;
-    QSTAMP(0);  // X: operand reads, requests, pose stores
+    QSTAMP(0);  // X: operand reads, pose stores
     double TH4, TD;
     b_log<DevWave>(kc, TT, QQ, op, TH4, TD);
+    // v_i: the other wave posts it about now (after its control section, half a step ahead of this one's): requested as late as
+    // the LDS round trip allows -- a request that comes before the post has to be repeated by polling
+    int fv = 0;
+    double v[2] = {VL, VW};
+    if (i > 0) r16_handoff_request<2>(sh, R16_F_V, X_V, i & 3, fv, v, lane);
     const double RH = a_rho<DevWave>(TH4, TD);
     QSTAMP(1);  // X: Log
     if (i > 0) {

@@ -42,15 +42,19 @@ namespace r16 {
 
 // ---------------------------------------------------------------------------------------------------------------
 // operand registers prepared by P for one knot (value per lane; rows of matrices live in the lanes that consume them)
+// Every operand is used through one quad of a row only -- as the multiplier of a broadcast-multiply-add whose result is read in
+// that quad, or as a term of a difference that is then broadcast from that quad -- so operands that live in different quads
+// SHARE a register: a step wave reads 13 registers per knot from LDS, not 23 (the reads' issue was a quarter of a step).
+// What a register holds in the quads its users do not look at is data of another operand: results there are finite and unread.
 enum {
-  OP_RT = 0,    // 3: column c of R_n^T as rows in Q0: lane (Q0, j) holds R_n[c][j]
-  OP_TN = 3,    // nominal translation in Q1 (j < 3)
-  OP_LQ = 4,    // 4: column c of the left-multiplication matrix of conj(q_n), rows (x, y, z, w) in Q0
-  OP_K = 8,     // 12: column c of the feedback gain K (4 x 12), rows in Q3
-  OP_U0 = 20,   // u_nom + alpha k in Q3
-  OP_VNL = 21,  // nominal linear velocity (j < 3 of every quad)
-  OP_VNW = 22,  // nominal angular velocity
-  NOPS = 23
+  OP_K = 0,     // 12: Q3: column c of the feedback gain K (4 x 12) as rows;
+                //     Q0 of registers 0..2: column c of R_n^T as rows (lane (Q0, j) holds R_n[c][j]) = OP_RT + c,
+                //     Q0 of registers 3..6: column c of the left-multiplication matrix of conj(q_n), rows (x, y, z, w) = OP_LQ + c
+  OP_RT = 0,
+  OP_LQ = 3,
+  OP_MISC = 12, // Q0: nominal linear velocity, Q1: nominal translation, Q2: nominal angular velocity (j < 3 each), Q3: u_nom + alpha k
+  OP_TN = OP_MISC, OP_U0 = OP_MISC, OP_VNL = OP_MISC, OP_VNW = OP_MISC,
+  NOPS = 13
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -67,7 +71,7 @@ struct RConsts {
   V GW[4];             // column a of dt I^-1 arms, rows in every quad
   V GRAVC, S1, S2;     // gravity: -g dt e_z, and the signed scales of the two quaternion permutations
   V MQ1, MQ1_3, MW;
-  V MQ0_3, MQ2_3;      // store assembly
+  V MQ0_3, MQ2_3, MQ3; // store assembly
   V M3;                // 1 in lanes j < 3
   V PC[8];             // per-lane polynomial coefficients (lane-in-row 0..5)
   M L0, L1, L2, L3;    // lane-in-row == 0..3 (patching the Exp coefficients on the closed-form path)
@@ -96,6 +100,7 @@ QILQR_HD void make_rconsts(const ModelConsts<double> &c, RConsts<W> &k) {
   k.MW = W::vconst([&](int l) { return j(l) == 3 ? 1.0 : 0.0; });
   k.MQ0_3 = W::vconst([&](int l) { return (q(l) == 0 && j(l) < 3) ? 1.0 : 0.0; });
   k.MQ2_3 = W::vconst([&](int l) { return (q(l) == 2 && j(l) < 3) ? 1.0 : 0.0; });
+  k.MQ3 = W::vconst([&](int l) { return q(l) == 3 ? 1.0 : 0.0; });
   k.M3 = W::vconst([&](int l) { return j(l) < 3 ? 1.0 : 0.0; });
   for (int e = 0; e < 8; ++e)
     k.PC[e] = W::vconst([&](int l) {
@@ -123,16 +128,15 @@ QILQR_HD typename W::V cross_rot(typename W::V ap, typename W::V app, typename W
   return W::fma(ap, bpp, -(app * bp));
 }
 
-// One knot of the rollout for four trajectories.  The recurrence has a two-knot period -- the pose of knot i + 2 needs
-// v_{i+1}, which needs u_i, which needs the pose of knot i:  Log_i -> u_i -> v_{i+1} -> Exp(dt v_{i+1}) -> T_{i+2} -> Log_{i+2}
-// -- so two wavefronts share a knot with TWO hand-offs per period and about the same number of instructions each (a lone
-// wavefront is bound by instruction issue, ~2.4 ns per VALU instruction, not by dependences):
-//   control wave A:  a_pre (what needs only v_i), then with tau_i from B:  a_post: u_i, v_{i+1};  a_exp: E_{i+1} = Exp(dt v_{i+1})
-//   pose wave B:     b_compose: T_{i+1} = T_i E_i;  b_log: tau_{i+1} = Log(T_nom^-1 T_{i+1}) less its last two cross products
-//                    (a_rho, in A: the pose wave's instructions are the dearer ones -- longer dependent DPP chains)
-// v never leaves A; the pose never leaves B except as (rho, theta, q) for the control law and gravity.
+// One step of the rollout for four trajectories, as the pieces the device code composes (ilqr_kernels.h, r16_wave_X; the
+// host harness composes them the same way).  The recurrence has a two-knot period -- the pose of knot i + 2 needs v_{i+1},
+// which needs u_i, which needs the pose of knot i:  Log_i -> u_i -> v_{i+1} -> Exp(dt v_{i+1}) -> T_{i+2} -> Log_{i+2} -- and the
+// step of knot i is
+//     b_log (+ a_rho): tau_i = Log(T_nom^-1 T_i);   a_pre, a_post: u_i, v_{i+1} = v_i + dt a(q_i, v_i, u_i);
+//     a_exp: E_{i+1} = Exp(dt v_{i+1});             b_compose: T_{i+2} = T_{i+1} E_{i+1}
+// (the a_ / b_ prefixes are those of an earlier partition of the knot into a control and a pose wavefront).
 
-// control wave, Exp(dt v) (quadrotor_model.cc:33-49, 174-200 -- the pose integrates with the OLD velocity): the quaternion
+// Exp(dt v) (quadrotor_model.cc:33-49, 174-200 -- the pose integrates with the OLD velocity): the quaternion
 // increment DQ = (sin(th/2)/th theta_e ; cos(th/2)) as (x, y, z, w) in every quad, the translation increment PP in Q1
 template <class W>
 QILQR_HD void a_exp(const RConsts<W> &k, typename W::V VL, typename W::V VW, typename W::V &DQ, typename W::V &PP) {
@@ -187,7 +191,7 @@ QILQR_HD typename W::V exp_closed_forms(typename W::M closed, typename W::V th2e
   return W::sel(W::land(closed, L3), (theta - st) / (xc * theta), P1);
 }
 
-// pose wave, first half: T <- T E with E = (DQ, PP) from a_exp:  t += R(q) p,  q <- q DQ
+// T <- T E with E = (DQ, PP) from a_exp:  t += R(q) p,  q <- q DQ
 template <class W>
 QILQR_HD void b_compose(const RConsts<W> &k, typename W::V TT, typename W::V QQ, typename W::V DQ, typename W::V PP,
                         typename W::V &TTn, typename W::V &QQn) {
@@ -318,7 +322,7 @@ QILQR_HD void a_pre(const RConsts<W> &k, typename W::V VL, typename W::V VW, con
   typedef typename W::V V;
   const V dvl = VL - op[OP_VNL], dvw = VW - op[OP_VNW];
   r.u2 = W::template dot3<0>(V(0.0), dvl, op[OP_K + 6], op[OP_K + 7], op[OP_K + 8]);
-  r.u3 = W::template dot3<0>(V(0.0), dvw, op[OP_K + 9], op[OP_K + 10], op[OP_K + 11]);
+  r.u3 = W::template dot3<8>(V(0.0), dvw, op[OP_K + 9], op[OP_K + 10], op[OP_K + 11]);  // (v_nom's angular part sits in Q2)
   r.st0 = W::fma(k.MQ2_3, VW, k.MQ0_3 * VL);
   const V IW = W::template dot3<0>(V(0.0), VW, k.IC[0], k.IC[1], k.IC[2]);  // I omega in Q2
   const V A1 = k.SA * VW;  // [0 | . | omega | 0]
@@ -336,8 +340,8 @@ QILQR_HD typename W::V a_post(const RConsts<W> &k, const APre<W> &r, typename W:
   const V RH = RHO_DONE ? TD : a_rho<W>(TH, TD);  // (lane j = 3 of TH holds the Jacobian coefficient: the control law broadcasts lanes 0..2 only)
   const V u1 = W::template dot3<0>(V(0.0), TH, op[OP_K + 3], op[OP_K + 4], op[OP_K + 5]);
   const V u0 = W::template dot3<0>(op[OP_U0], RH, op[OP_K + 0], op[OP_K + 1], op[OP_K + 2]);
-  const V UU = (u0 + u1) + (r.u2 + r.u3);
-  const V st = r.st0 + UU;
+  const V UU = (u0 + u1) + (r.u2 + r.u3);  // valid in Q3 (the shared registers leave other operands' products elsewhere)
+  const V st = W::fma(k.MQ3, UU, r.st0);
   if (!advance) return st;  // the reference's step after the last knot is computed and discarded (ilqr.hh:168)
   // gravity in the body frame: (z, w, x, .) and (w, z, y, .) of q
   const V aL = W::template dot2<0>(VL + k.GRAVC, QQ, k.S1 * W::template qperm<0xCE>(QQ), k.S2 * W::template qperm<0xDB>(QQ));
@@ -376,7 +380,7 @@ template <class W>
 struct PConsts {
   typedef typename W::V V;
   typename W::I e_uj, e_h[3], e_lq[4], e_tn, e_vl, e_vw, e_un, e_k, e_K[12];  // element indices per lane
-  V s_h[3], s_lq[4], d_c[3], mQ0_3, mQ0, mQ1_3, mQ3, m3;                      // signs / masks per lane
+  V s_h[3], s_lq[4], d_c[3], mQ0_3, mQ0, mQ1_3, mQ2_3, mQ3, m3;               // signs / masks per lane
 };
 template <class W>
 QILQR_HD void make_pconsts(PConsts<W> &p) {
@@ -411,6 +415,7 @@ QILQR_HD void make_pconsts(PConsts<W> &p) {
   p.mQ0 = W::vconst([&](int l) { return q(l) == 0 ? 1.0 : 0.0; });
   p.mQ1_3 = W::vconst([&](int l) { return (q(l) == 1 && j(l) < 3) ? 1.0 : 0.0; });
   p.mQ3 = W::vconst([&](int l) { return q(l) == 3 ? 1.0 : 0.0; });
+  p.mQ2_3 = W::vconst([&](int l) { return (q(l) == 2 && j(l) < 3) ? 1.0 : 0.0; });
   p.m3 = W::vconst([&](int l) { return j(l) < 3 ? 1.0 : 0.0; });
 }
 
@@ -442,16 +447,18 @@ QILQR_HD void p_compute(const PConsts<W> &p, const RAWT *raw, typename W::V alph
   const V dd = 1.0 - 2.0 * ((x * x + y * y) + z * z);
   const V w2 = w + w;
   const V uc[3] = {x + x, y + y, z + z};
+  V rt[3], lq[4];
   for (int c = 0; c < 3; ++c) {
     const V h = V(raw[RAW_H + c]) * p.s_h[c];
-    op[OP_RT + c] = W::fma(uc[c], uj, W::fma(w2, h, p.d_c[c] * dd));
+    rt[c] = W::fma(uc[c], uj, W::fma(w2, h, p.d_c[c] * dd));
   }
-  op[OP_TN] = V(raw[RAW_TN]) * p.mQ1_3;
-  for (int c = 0; c < 4; ++c) op[OP_LQ + c] = V(raw[RAW_LQ + c]) * p.s_lq[c];
-  for (int c = 0; c < 12; ++c) op[OP_K + c] = V(raw[RAW_K + c]) * p.mQ3;
-  op[OP_U0] = W::fma(alpha, V(raw[RAW_KFF]), V(raw[RAW_UN])) * p.mQ3;
-  op[OP_VNL] = V(raw[RAW_VL]) * p.m3;
-  op[OP_VNW] = V(raw[RAW_VW]) * p.m3;
+  for (int c = 0; c < 4; ++c) lq[c] = V(raw[RAW_LQ + c]) * p.s_lq[c];
+  for (int c = 0; c < 12; ++c) {
+    const V kq3 = V(raw[RAW_K + c]) * p.mQ3;
+    op[OP_K + c] = c < 3 ? kq3 + rt[c] : (c < 7 ? kq3 + lq[c - 3] : kq3);  // (Q0 of the first seven: R_n^T, conj(q_n))
+  }
+  op[OP_MISC] = W::fma(alpha, V(raw[RAW_KFF]), V(raw[RAW_UN])) * p.mQ3 + V(raw[RAW_TN]) * p.mQ1_3 +
+                (V(raw[RAW_VL]) * p.mQ0_3 + V(raw[RAW_VW]) * p.mQ2_3);
 }
 
 }  // namespace r16

@@ -299,7 +299,7 @@ def _rollout16(hh, c, trajs, gains, alpha, ops_knot=-1):
     """four trajectories through the CPU re-enactment of k_rollout16's two wavefronts"""
     trajs, gains, alpha = (np.ascontiguousarray(a, dtype=float) for a in (trajs, gains, alpha))
     out = np.zeros_like(trajs)
-    ops = np.zeros((23, 64))
+    ops = np.zeros((13, 64))
     hh.hh_rollout16(P(c), P(trajs), P(gains), P(alpha), P(out), C.c_int(trajs.shape[1]), C.c_int(ops_knot), P(ops))
     return out, ops
 
@@ -313,9 +313,10 @@ def _pose_close(a, b, atol):
 
 
 def test_rollout16_operand_registers(hh):
-    """what wavefront P prepares for a knot, against the definitions: R_n^T rows in Q0, the nominal translation in
-    Q1, the left-multiplication matrix of conj(q_n) in Q0, the gain columns and u_nom + alpha k in Q3, zeros in
-    every lane that owns nothing"""
+    """what wavefront P prepares for a knot, against the definitions: thirteen registers shared by quad -- the gain columns
+    in Q3 of registers 0..11, with the rows of R_n^T in Q0 of registers 0..2 and the left-multiplication matrix of conj(q_n)
+    in Q0 of registers 3..6; register 12: nominal linear velocity (Q0), nominal translation (Q1), nominal angular velocity
+    (Q2), u_nom + alpha k (Q3); zeros in every lane that owns nothing"""
     cfg, trajs = _random_cfg16(41, 5)
     c = consts(hh, cfg["model"], cfg["Q"], cfg["R"], cfg["dt"])
     r = np.random.default_rng(5)
@@ -323,27 +324,29 @@ def test_rollout16_operand_registers(hh):
     gains = r.uniform(-1, 1, (4, 5, 52))
     alpha = np.array([1.0, 0.5, 0.25, 0.125])
     _, ops = _rollout16(hh, c, tr, gains, alpha, ops_knot=2)
+    assert ops.shape[0] == 13
     for row in range(4):
         p = tr[row][2]
         w, x, y, z = p[4:8]
-        if True:
-            Rn = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
-                           [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
-                           [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        Rn = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                       [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                       [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
         L = np.array([[w, z, -y, -x], [-z, w, x, -y], [y, -x, w, -z], [x, y, z, w]])  # conj(q_n) (x) . on (x, y, z, w)
         k, K = orc.gains_to_kK(gains[row][2:3])
         for l in range(16):
             lane, q, j = 16 * row + l, l >> 2, l & 3
-            for cc in range(3):
-                np.testing.assert_allclose(ops[cc, lane], Rn[cc, j] if (q == 0 and j < 3) else 0.0, atol=1e-15)
-            np.testing.assert_allclose(ops[3, lane], p[1 + j] if (q == 1 and j < 3) else 0.0)
-            for cc in range(4):
-                np.testing.assert_allclose(ops[4 + cc, lane], L[j, cc] if q == 0 else 0.0)
             for cc in range(12):
-                np.testing.assert_allclose(ops[8 + cc, lane], K[0][j, cc] if q == 3 else 0.0)
-            np.testing.assert_allclose(ops[20, lane], p[14 + j] + alpha[row] * k[0][j] if q == 3 else 0.0, rtol=1e-15)
-            np.testing.assert_allclose(ops[21, lane], p[8 + j] if j < 3 else 0.0)
-            np.testing.assert_allclose(ops[22, lane], p[11 + j] if j < 3 else 0.0)
+                if q == 3:
+                    want = K[0][j, cc]
+                elif q == 0 and cc < 3:
+                    want = Rn[cc, j] if j < 3 else 0.0
+                elif q == 0 and cc < 7:
+                    want = L[j, cc - 3]
+                else:
+                    want = 0.0
+                np.testing.assert_allclose(ops[cc, lane], want, atol=1e-15)
+            want = [p[8 + j] if j < 3 else 0.0, p[1 + j] if j < 3 else 0.0, p[11 + j] if j < 3 else 0.0, p[14 + j] + alpha[row] * k[0][j]][q]
+            np.testing.assert_allclose(ops[12, lane], want, rtol=1e-15)
 
 
 @pytest.mark.parametrize("seed,dense", [(51, False), (52, True)])
