@@ -8,7 +8,7 @@ from quadrotorilqr_amd import capi, problems as pb
 libs = sys.argv[1:] or [capi.LIB_PATH]
 for lib in libs:
     capi.LIB_PATH = os.path.abspath(lib); capi._lib = None
-    for B in (1024, 64):
+    for B in (1024, 64, 2048, 4096):
         cfg = pb.config2(B=B, N=100)
         base = capi.from_config(cfg)
         # a rollout as it occurs inside a solve: the third iteration's (the trajectory is already near its nominal one)
