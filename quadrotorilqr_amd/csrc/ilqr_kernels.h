@@ -1851,8 +1851,8 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
 //   P (r16::p_load, p_compute): for knot k (running up to R16_RING - 1 knots ahead): loads the nominal knot and the
 //      gains (tiled global layout, per-lane element offsets), forms the 23 operand registers and writes them to ring slot
 //      k % R16_RING as [register][lane]; copies the time column to the output trajectory.
-// The waves never meet at a barrier inside the loop.  LDS words carry progress: knots produced by P / even, odd knots used,
-// "v_k ready", "T_k ready"; the values themselves go through four-deep LDS slots (k & 3).
+// The waves never meet at a barrier inside the loop.  LDS words carry progress: knots produced by P, "v_k ready" (which
+// also frees knot k - 1's operand slot), "T_k ready"; the values themselves go through four-deep LDS slots (k & 3).
 // LDS operations of a wavefront execute in order, so a flag written after the data is seen after the data; every spin
 // is bounded, so a lost flag ends the kernel instead of hanging it.
 // Trajectories of the block that are not being rolled out this round alias the block's first live trajectory (their
@@ -1941,13 +1941,13 @@ struct DevWave {
 constexpr int R16_RING = 4;
 constexpr int R16_SPIN_MAX = 1 << 22;
 constexpr int R16_CHUNK = 16;  // knots per "stored and visible" announcement of wave A (k_solve4's linearisation follows it)
-enum { R16_F_PROD = 0, R16_F_CONS0, R16_F_CONS1, R16_F_V, R16_F_T, R16_F_K0, R16_F_K1, R16_F_ABORT, R16_NFLAGS };
+enum { R16_F_PROD = 0, R16_F_V, R16_F_T, R16_F_K0, R16_F_K1, R16_F_ABORT, R16_NFLAGS };
 enum { X_V = 0, X_T = 1 };
 // LDS of the three rollout roles
 struct R16Lds {
   double ops[R16_RING][r16::NOPS][64];  // operand registers of R16_RING knots, [register][lane]
   double xch[2][4][2][64];             // hand-off slots [X_V (v_lin, omega) of knot k | X_T (t, q) of knot k][k & 3][register][lane]
-  int flags[R16_NFLAGS];               // knots produced by P / even, odd knots whose operands are used; v_k ready; T_k ready; even, odd knots stored; abort
+  int flags[R16_NFLAGS];               // knots produced by P; v_k ready (and knot k - 1's operands used); T_k ready; even, odd knots stored; abort
 };
 // The LDS executes the operations of one wavefront in the order they were issued, so a flag written after the data (or
 // after the reads of a slot) is seen after them: no s_waitcnt, and no workgroup fence -- a release fence would wait for the
@@ -2024,14 +2024,14 @@ __device__ __forceinline__ bool r16_handoff_finish(R16Lds &sh, int which, int ta
   return r16_read_handoff<NV>(sh, which, target, kind, par, a, lane);
 }
 // "my knots up to i are stored and visible to the block": a step wave's only vector-memory operations are its knot stores
-// (three per knot of its parity); every fourth knot of its own it announces the knots older than its twelve youngest stores
+// (two per knot of its parity); every fourth knot of its own it announces the knots older than its eight youngest stores
 // (s_waitcnt vmcnt(N) waits for all but the N youngest: nearly free), and everything after its last knot (vmcnt(0), once)
 __device__ __forceinline__ void r16_publish_stores(R16Lds &sh, int which, int i, int last, int lane) {
   if (i == last) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     r16_flag_post(sh, which, i + 1, lane);
   } else if (((i >> 1) & 3) == 3 && i >= 16) {
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // the stores of this wave's knots i, i - 2, i - 4, i - 6 may be in flight
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the stores of this wave's knots i, i - 2, i - 4, i - 6 may be in flight
     r16_flag_post(sh, which, i - 8 + 1, lane);
   }
 }
@@ -2069,8 +2069,9 @@ __device__ __forceinline__ void r16_wave_P(R16Lds &sh, const S *traj, const S *g
     p_compute<DevWave>(pc, rc, alpha, op);
     QKEEP(op[0]); QKEEP(op[r16::NOPS - 1]); QKEEP(op[10]);
     QSTAMP(1);  // P: wait for the loads, operand registers
-    // slot k % R16_RING is free once the wave of knot k - R16_RING (the same parity: the ring is even) has used it
-    if (k >= R16_RING && !r16_flag_wait(sh, R16_F_CONS0 + (k & 1), k - R16_RING + 1, -1, lane)) ok = false;
+    // slot k % R16_RING is free once the step of knot k - R16_RING has used its operands: that step posts v_{k - R16_RING + 1}
+    // behind their last use, and the "v ready" word only grows (a step posts after it has taken the previous step's v)
+    if (k >= R16_RING && !r16_flag_wait(sh, R16_F_V, k - R16_RING + 1, -1, lane)) ok = false;
     QSTAMP(2);  // P: wait for a free slot
 #pragma unroll
     for (int r = 0; r < NOPS; ++r) sh.ops[k % R16_RING][r][lane] = op[r];
@@ -2102,9 +2103,9 @@ __device__ __forceinline__ void r16_wave_X(R16Lds &sh, const ModelConsts<double>
   using namespace r16;
   RConsts<DevWave> kc;
   make_rconsts(c, kc);
-  const int ea = sta_elem(lane), et = stt_elem(lane), eq = stq_elem(lane);
-  const bool wa = live && ea >= 0, wt = live && et >= 0, wq = live && eq >= 0;
-  const int oa = DevWave::iuni(ea >= 0 ? ea : 0), ot = DevWave::iuni(et >= 0 ? et : 0), oq = DevWave::iuni(eq >= 0 ? eq : 0);
+  const int ea = sta_elem(lane), ep = stp_elem(lane);
+  const bool wa = live && ea >= 0, wp = live && ep >= 0;
+  const int oa = DevWave::iuni(ea >= 0 ? ea : 0), opz = DevWave::iuni(ep >= 0 ? ep : 0);
   const int last = (n - 1) - (((n - 1) & 1) ^ p);  // this wave's last knot (< 0: none)
 #ifdef QILQR_STAMPS
   unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
@@ -2128,9 +2129,8 @@ __device__ __forceinline__ void r16_wave_X(R16Lds &sh, const ModelConsts<double>
     for (int r = 0; r < NOPS; ++r) op[r] = sh.ops[i % R16_RING][r][lane];
     seen = r16_flag_read(sh, R16_F_PROD);
     S *ok_ = out + (long)i * (9 * 128);
-    if (wt) ok_[ot] = (S)TT;
-    if (wq) ok_[oq] = (S)QQ;
-    QSTAMP(0);  // X: operand reads, pose stores
+    if (wp) ok_[opz] = (S)__builtin_fma(kc.MQ0, QQ, TT);  // [q | t] in one store
+    QSTAMP(0);  // X: operand reads, pose store
     double TH4, TD;
     b_log<DevWave>(kc, TT, QQ, op, TH4, TD);
     // v_i: the other wave posts it about now (after its control section, half a step ahead of this one's): requested as late as
@@ -2149,8 +2149,7 @@ __device__ __forceinline__ void r16_wave_X(R16Lds &sh, const ModelConsts<double>
     a_pre<DevWave>(kc, v[0], v[1], op, pre);
     double VLn = 0.0, VWn = 0.0;
     const double st = a_post<DevWave, true>(kc, pre, TH4, RH, QQ, v[0], op, advance, VLn, VWn);
-    r16_flag_post(sh, R16_F_CONS0 + p, i + 1, lane);  // the slot's values have been used
-    if (__builtin_expect(advance, 1)) {
+    if (__builtin_expect(advance, 1)) {  // (the post also tells P that knot i's operand slot is free)
       sh.xch[X_V][(i + 1) & 3][0][lane] = VLn;
       sh.xch[X_V][(i + 1) & 3][1][lane] = VWn;
       r16_flag_post(sh, R16_F_V, i + 1, lane);

@@ -71,7 +71,7 @@ struct RConsts {
   V GW[4];             // column a of dt I^-1 arms, rows in every quad
   V GRAVC, S1, S2;     // gravity: -g dt e_z, and the signed scales of the two quaternion permutations
   V MQ1, MQ1_3, MW;
-  V MQ0_3, MQ2_3, MQ3; // store assembly
+  V MQ0_3, MQ2_3, MQ3, MQ0; // store assembly
   V M3;                // 1 in lanes j < 3
   V PC[8];             // per-lane polynomial coefficients (lane-in-row 0..5)
   M L0, L1, L2, L3;    // lane-in-row == 0..3 (patching the Exp coefficients on the closed-form path)
@@ -101,6 +101,7 @@ QILQR_HD void make_rconsts(const ModelConsts<double> &c, RConsts<W> &k) {
   k.MQ0_3 = W::vconst([&](int l) { return (q(l) == 0 && j(l) < 3) ? 1.0 : 0.0; });
   k.MQ2_3 = W::vconst([&](int l) { return (q(l) == 2 && j(l) < 3) ? 1.0 : 0.0; });
   k.MQ3 = W::vconst([&](int l) { return q(l) == 3 ? 1.0 : 0.0; });
+  k.MQ0 = W::vconst([&](int l) { return q(l) == 0 ? 1.0 : 0.0; });
   k.M3 = W::vconst([&](int l) { return j(l) < 3 ? 1.0 : 0.0; });
   for (int e = 0; e < 8; ++e)
     k.PC[e] = W::vconst([&](int l) {
@@ -359,6 +360,12 @@ QILQR_HD int sta_elem(int l) {
   if (q == 3) return 14 + j;
   if (j == 3 || q == 1) return -1;
   return q == 0 ? 8 + j : 11 + j;
+}
+// pose = [q (x, y, z, w) in Q0 | t in Q1] (RConsts::MQ0 q + t: the translation register is zero outside Q1) in ONE store
+QILQR_HD int stp_elem(int l) {
+  const int q = (l >> 2) & 3, j = l & 3;
+  if (q == 0) return j == 3 ? 4 : 5 + j;
+  return (q == 1 && j < 3) ? 1 + j : -1;
 }
 QILQR_HD int stt_elem(int l) { return (((l >> 2) & 3) == 1 && (l & 3) < 3) ? 1 + (l & 3) : -1; }
 QILQR_HD int stq_elem(int l) {
