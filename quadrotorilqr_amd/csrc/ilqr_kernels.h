@@ -1520,11 +1520,14 @@ __global__ __launch_bounds__(384) void k_backward4(ModelConsts<double> c, SolveP
 
   if (w == 5) {
     // ------------------------------------------------------------------ L: knot records of four trajectories
+    // a trajectory with nothing to do this round is streamed as a duplicate of the block's first running one (the wave stays
+    // branch-free and the duplicate's loads hit the lines the original just fetched: no HBM traffic for records nobody uses)
+    const int first = s_run[0] ? 0 : (s_run[1] ? 1 : (s_run[2] ? 2 : 3));
     const S *rec[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int bg = (b0 + g < B) ? b0 + g : B - 1;
-      rec[g] = (const S *)st.lin[s_cur[g]] + rec_base(bg, n, L.stride);
+      const int gs = s_run[g] ? g : first;
+      rec[g] = (const S *)st.lin[s_cur[gs]] + rec_base(b0 + gs, n, L.stride);
     }
     bw4_loader_wave<S>(ring, L, rec[0], rec[1], rec[2], rec[3], n, lane);
     return;

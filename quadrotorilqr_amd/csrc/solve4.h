@@ -279,11 +279,13 @@ __global__ __launch_bounds__(S4_THREADS) void k_solve4(ModelConsts<double> c, co
             }
           }
         } else if (w == 5) {
+          // (a trajectory that skips this backward phase is streamed as a duplicate of the first one that does not)
+          const int first = sl[0].run ? 0 : (sl[1].run ? 1 : (sl[2].run ? 2 : 3));
           const S *rec[4];
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const int bg = sl[g].b >= 0 ? sl[g].b : sl[0].b;
-            rec[g] = (const S *)st.lin[sl[g].cur] + rec_base(bg, n, L.stride);
+            const int gs = sl[g].run ? g : first;
+            rec[g] = (const S *)st.lin[sl[gs].cur] + rec_base(sl[gs].b, n, L.stride);
           }
           s4_loader<S>(L, rec[0], rec[1], rec[2], rec[3], n, lane);
         } else if (w >= 6) {
