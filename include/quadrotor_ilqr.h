@@ -94,7 +94,7 @@ typedef struct {
                       0 = automatic (2 from 4096 trajectories on, else 1: see auto_parts in ilqr_capi.hip), at most 8 */
   int32_t persistent; /* the solve as ONE launch (k_solve4: blocks of eight wavefronts own four trajectories each from the
                          first linearisation to the exit status, no rounds, no host in the loop; symmetric weights only):
-                         0 = whichever measures faster (today the rounds, at every batch size: DESIGN.md), 1 = always,
+                         0 = whichever measures faster (today the rounds: level at 1024 trajectories, ahead at most other sizes), 1 = always,
                          2 = never (rounds of three launches) */
 } qilqr_device_config;
 

@@ -661,10 +661,11 @@ int check_quaternions(const double *traj, long count, const char *what) {
 // The persistent solve (solve4.h): every trajectory from its first linearisation to its exit status in ONE launch.
 // Requirements: symmetric weights (the matrix-core recursion of k_backward4), no per-round host visibility (debug capture
 // of trajectories uses the rounds).  qilqr_device_config.persistent: 0 = by measurement, 1 = always, 2 = never.
-// By measurement (profiles/microbench/persistent_sweep.py, MI355X, N = 100, device-resident) the rounds are the faster path
-// at every batch size -- 256: 4.35 vs 4.67 ms, 1024: 5.90 vs 6.00, 2048: 8.3 vs 9.9, 8192: 22.0 vs 28.8 -- since the rollout
-// kernel of the rounds got its sixteen lanes per trajectory: both paths are bound by (iterations of the slowest trajectory) x
-// (latency of one iteration), and inside k_solve4 the forward phase ends one linearisation task (~15 us) after the rollout.
+// By measurement (profiles/microbench/persistent_sweep.py, MI355X, N = 100, device-resident, ms per batch solve) the rounds are
+// level or ahead at every batch size but one -- 256: 4.15 vs 4.45, 1024: 5.63 vs 5.74, 1536: 7.52 vs 7.21, 2048: 8.1 vs 9.5,
+// 8192: 22.0 vs 27.6: both paths are bound by (iterations of the slowest trajectory) x (latency of one iteration), and inside
+// k_solve4 the forward phase ends one linearisation task (~11 us) after the rollout while its step waves run beside three
+// linearising wavefronts.
 // So 0 selects the rounds; the persistent solve stays selectable and tested.
 bool use_persistent(const qilqr_solver *s, long B) {
   (void)B;
