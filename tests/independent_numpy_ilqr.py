@@ -124,6 +124,42 @@ class Model:
         J_rhs = dt * J_rhs                             # euler_step scales the whole block (:272)
         return (T @ E, v + dt * acc), J_lhs + J_rhs @ Jcx, J_rhs @ Jcu
 
+    # ---- the Runge-Kutta extension: the step sketched in the comment at quadrotor_model.cc:51-63, from THIS file's primitives
+    def _euler(self, T, v, k, h, diffs=False):
+        """detail::euler_step (quadrotor_model.cc:266-276) of the state (T, v) along the tangent k = [pose rate ; acceleration]"""
+        tau = h * k[:6]
+        E = se3_exp(tau)
+        out = (T @ E, v + h * k[6:])
+        if not diffs:
+            return out
+        J_lhs = np.eye(12)
+        J_lhs[:6, :6] = np.linalg.inv(Ad(E))
+        J_rhs = np.eye(12)
+        J_rhs[:6, :6] = se3_right_jacobian(tau)
+        return out, J_lhs, h * J_rhs
+
+    def step_rk4(self, T, v, u, dt, diffs=False):
+        """k = 0, x_dot = 0; for (c, h) in ((1/6, 0), (2/6, dt/2), (2/6, dt/2), (1/6, dt)): k = f(euler_step(x, k, h), u);
+        x_dot += c k; then x (+) dt x_dot.  Jacobians: the chain rule through the stages."""
+        k, xdot = np.zeros(12), np.zeros(12)
+        K, Ku, SK, SKu = np.zeros((12, 12)), np.zeros((12, 4)), np.zeros((12, 12)), np.zeros((12, 4))
+        for c, h in ((1 / 6, 0.0), (2 / 6, dt / 2), (2 / 6, dt / 2), (1 / 6, dt)):
+            if diffs:
+                (Ti, vi), El, Er = self._euler(T, v, k, h, True)
+                A, Bm = El + Er @ K, Er @ Ku
+                acc, Fx, Fu = self.continuous(Ti, vi, u, True)
+                K, Ku = Fx @ A, Fx @ Bm + Fu
+                SK, SKu = SK + c * K, SKu + c * Ku
+            else:
+                Ti, vi = self._euler(T, v, k, h)
+                acc = self.continuous(Ti, vi, u)
+            k = np.concatenate([vi, acc])
+            xdot = xdot + c * k
+        if not diffs:
+            return self._euler(T, v, xdot, dt)
+        out, El, Er = self._euler(T, v, xdot, dt, True)
+        return out, El + Er @ SK, Er @ SKu
+
 
 def cost_knot(Q, R, T, v, u, Td, vd, ud, diffs=False):
     """CostFunction::operator() (cost.hh:36-61)"""
@@ -141,8 +177,9 @@ def cost_knot(Q, R, T, v, u, Td, vd, ud, diffs=False):
 class ILQR:
     """ILQR<QuadrotorModel> (ilqr.hh:25-206) on (n, 18) knot arrays"""
 
-    def __init__(self, model, Q, R, desired, dt, options):
+    def __init__(self, model, Q, R, desired, dt, options, integrator=0):
         self.model, self.Q, self.R, self.dt, self.o = model, np.asarray(Q, float), np.asarray(R, float), dt, options
+        self.step = model.step_rk4 if integrator == 1 else model.step  # 1: the Runge-Kutta extension
         self.des = [(pose_from_knot(p), p[8:14].copy(), p[14:18].copy()) for p in np.asarray(desired)]
 
     @staticmethod
@@ -162,7 +199,7 @@ class ILQR:
         QuTk = kTQuuk = 0.0
         for i in range(n - 1, -1, -1):
             T, v, u = pts[i]
-            _, Jx, Ju = self.model.step(T, v, u, self.dt, True)
+            _, Jx, Ju = self.step(T, v, u, self.dt, True)
             _, C = cost_knot(self.Q, self.R, T, v, u, *self.des[i], diffs=True)
             Qx = C["x"] + Jx.T @ vx
             Qu = C["u"] + Ju.T @ vx
@@ -185,7 +222,7 @@ class ILQR:
             dx = np.concatenate([se3_log(np.linalg.inv(Tn) @ T), v - vn])
             u = un + alpha * ks[i] + Ks[i] @ dx
             out.append((T, v, u))
-            T, v = self.model.step(T, v, u, self.dt)
+            T, v = self.step(T, v, u, self.dt)
         return out
 
     def is_converged(self, cost, new):  # ilqr.hh:196-205

@@ -91,3 +91,42 @@ def test_config2_golden_problems_reproduce_the_oracle(b):
     np.testing.assert_allclose(out["cost"], G["cfg2_cost"][b], rtol=1e-8)
     np.testing.assert_allclose(out["cost_hist"], G["cfg2_cost_hist"][b][:out["iters"]], rtol=1e-8)
     np.testing.assert_allclose(align_quaternion_signs(out["traj"], G["cfg2_traj"][b]), G["cfg2_traj"][b], atol=1e-6)
+
+
+# ---- the Runge-Kutta extension: no reference output exists for it; here the oracle's statement of the sketch
+# (quadrotor_model.cc:51-63) meets a second statement built from other primitives
+def test_rk4_step_and_jacobians_agree_with_the_oracle():
+    r = np.random.default_rng(17)
+    A = r.uniform(-0.3, 0.3, (3, 3))
+    model = dict(mass_kg=1.7, inertia=A @ A.T + np.diag([1.0, 1.5, 2.0]), arm_length_m=0.6, torque_to_thrust_ratio_m=0.3, g_mpss=9.81)
+    mp = orc.model_params(**model)
+    m = ind.Model(**model)
+    for _ in range(6):
+        x = np.concatenate([orc.se3_exp(np.concatenate([r.uniform(-1, 1, 3), r.uniform(-1.2, 1.2, 3)])), r.uniform(-2, 2, 6)])
+        u = r.uniform(0, 6, 4)
+        dt = float(r.choice([0.05, 0.1, 0.2]))
+        xn, Jx, Ju = orc.discrete_step(mp, 1, x, u, dt, diffs=True)
+        knot = np.concatenate([[0.0], x, u])
+        (Tn, vn), jx, ju = m.step_rk4(ind.pose_from_knot(knot), x[7:13].copy(), u, dt, True)
+        got = ind.knot_from_state(0.0, Tn, vn, u)[1:14]
+        if np.dot(got[3:7], xn[3:7]) < 0:
+            got[3:7] *= -1.0
+        np.testing.assert_allclose(got, xn, atol=1e-12)
+        np.testing.assert_allclose(jx, Jx, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(ju, Ju, rtol=1e-9, atol=1e-11)
+
+
+def test_rk4_solves_reproduce_the_oracle():
+    cfg = pb.config2(B=3, N=30, seed=12)
+    cfg["options"] = dict(cfg["options"], rtol=1e-10, atol=1e-10)
+    o = orc.OracleSolver(orc.model_params(**cfg["model"]), cfg["Q"], cfg["R"], cfg["desired"], cfg["dt"], orc.options(**cfg["options"]))
+    o.set_integrator(1)
+    ref = o.solve_batch(cfg["init"])
+    s = independent_solver(cfg)
+    s.step = s.model.step_rk4
+    for b in range(3):
+        out = s.solve(cfg["init"][b])
+        assert out["iters"] == ref["iters"][b] and out["status"] == ref["status"][b]
+        assert out["n_bwd"] == ref["n_bwd"][b] and out["n_fwd"] == ref["n_fwd"][b]
+        np.testing.assert_allclose(out["cost"], ref["cost"][b], rtol=1e-8)
+        np.testing.assert_allclose(align_quaternion_signs(out["traj"], ref["traj"][b]), ref["traj"][b], atol=1e-6)
