@@ -2125,15 +2125,20 @@ __device__ __forceinline__ void r16_wave_X(R16Lds &sh, const ModelConsts<double>
     r16_flag_post(sh, R16_F_T, 1, lane);
   }
   int seen = -1;  // P's progress as last read
-  for (int i = p; i < n; i += 2) {
-    if (__builtin_expect(!r16_flag_wait(sh, R16_F_PROD, i + 1, seen, lane), 0)) return;
-    double op[NOPS];
+  // One step.  `op`: the knot's operand registers, already requested by the previous step of this wave if `have` (their LDS
+  // round trip then lies behind that step's compose); `opn` / `have_n`: the same for this wave's next knot, requested here.
+  // The loop calls it with the two register sets alternating (no copies).
+  auto step = [&](int i, double (&op)[NOPS], bool have, double (&opn)[NOPS], bool &have_n) -> bool {
+    if (!have) {
+      if (__builtin_expect(!r16_flag_wait(sh, R16_F_PROD, i + 1, seen, lane), 0)) return false;
 #pragma unroll
-    for (int r = 0; r < NOPS; ++r) op[r] = sh.ops[i % R16_RING][r][lane];
-    seen = r16_flag_read(sh, R16_F_PROD);
+      for (int r = 0; r < NOPS; ++r) op[r] = sh.ops[i % R16_RING][r][lane];
+      seen = r16_flag_read(sh, R16_F_PROD);
+    }
+    have_n = false;
     S *ok_ = out + (long)i * (9 * 128);
     if (wp) ok_[opz] = (S)__builtin_fma(kc.MQ0, QQ, TT);  // [q | t] in one store
-    QSTAMP(0);  // X: operand reads, pose store
+    QSTAMP(0);  // X: operand reads (if not requested ahead), pose store
     double TH4, TD;
     b_log<DevWave>(kc, TT, QQ, op, TH4, TD);
     // v_i: the other wave posts it about now (after its control section, half a step ahead of this one's): requested as late as
@@ -2144,7 +2149,7 @@ __device__ __forceinline__ void r16_wave_X(R16Lds &sh, const ModelConsts<double>
     const double RH = a_rho<DevWave>(TH4, TD);
     QSTAMP(1);  // X: Log
     if (i > 0) {
-      if (__builtin_expect(!r16_handoff_finish<2>(sh, R16_F_V, i, X_V, i & 3, fv, v, lane), 0)) return;
+      if (__builtin_expect(!r16_handoff_finish<2>(sh, R16_F_V, i, X_V, i & 3, fv, v, lane), 0)) return false;
     }
     QSTAMP(2);  // X: wait for v_i
     const bool advance = i + 1 < n;  // the reference's step after the last knot is computed and discarded (ilqr.hh:168)
@@ -2167,8 +2172,16 @@ __device__ __forceinline__ void r16_wave_X(R16Lds &sh, const ModelConsts<double>
       double DQ, PP;
       a_exp<DevWave>(kc, VLn, VWn, DQ, PP);
       QSTAMP(4);  // X: Exp
-      if (__builtin_expect(!r16_handoff_finish<2>(sh, R16_F_T, i + 1, X_T, (i + 1) & 3, ft, t, lane), 0)) return;
+      if (__builtin_expect(!r16_handoff_finish<2>(sh, R16_F_T, i + 1, X_T, (i + 1) & 3, ft, t, lane), 0)) return false;
       QSTAMP(5);  // X: wait for T_{i+1}
+      // the operands of this wave's next knot, if P has them (it is normally three knots ahead): requested here, used after
+      // the compose
+      if (seen >= i + 3) {
+#pragma unroll
+        for (int r = 0; r < NOPS; ++r) opn[r] = sh.ops[(i + 2) % R16_RING][r][lane];
+        seen = r16_flag_read(sh, R16_F_PROD);
+        have_n = true;
+      }
       double TTn, QQn;
       b_compose<DevWave>(kc, t[0], t[1], DQ, PP, TTn, QQn);
       TT = TTn;
@@ -2178,6 +2191,14 @@ __device__ __forceinline__ void r16_wave_X(R16Lds &sh, const ModelConsts<double>
       r16_flag_post(sh, R16_F_T, i + 2, lane);
       QSTAMP(6);  // X: compose, hand-off
     }
+    return true;
+  };
+  double opA[NOPS], opB[NOPS];
+  bool haveA = false, haveB = false;
+  for (int i = p; i < n; i += 4) {
+    if (!step(i, opA, haveA, opB, haveB)) return;
+    if (i + 2 >= n) break;
+    if (!step(i + 2, opB, haveB, opA, haveA)) return;
   }
 #ifdef QILQR_STAMPS
   if (lane == 0 && stamps_out)
