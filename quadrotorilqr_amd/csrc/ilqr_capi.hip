@@ -251,6 +251,8 @@ int from_tiled(qilqr_solver *s, double *d_plain, void *t0, void *t1, const int *
 
 // bind the desired trajectory (shared, or per problem: plain device array, re-tiled here) and reset
 // the buffer selectors
+bool use_persistent(const qilqr_solver *s, long B);
+bool records_tiled(const qilqr_solver *s, long load_B, bool persistent);
 int begin_batch(qilqr_solver *s, long B, long n, const double *d_desired_batch) {
   if (B <= 0 || n <= 0) return fail(QILQR_ERR_INVALID_ARG, "B and n must be positive");
   if (!d_desired_batch && n > s->n_desired)
@@ -268,6 +270,7 @@ int begin_batch(qilqr_solver *s, long B, long n, const double *d_desired_batch) 
     s->st.desired_tiled = 0;
   }
   s->total_B = B;
+  s->st.layout.tiled = records_tiled(s, B, use_persistent(s, B)) ? 1 : 0;
   launch(s, K_OTHER, k_begin, dim3(cdiv(B, 256)), dim3(256), s->st, (int)B);
   return QILQR_OK;
 }
@@ -309,11 +312,11 @@ int download_tiled(qilqr_solver *s, double *h_plain, void *t0, void *t1, const i
 
 int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag, int round = -1) {
   const dim3 grid(cdiv(2 * ((B + 63) / 64) * 64 * n, 128));  // dynamics half + cost half
-#define QILQR_LAUNCH_LIN(S, LK, CONSTS, DCONSTS) \
-  launch(s, K_LINEARIZE, (k_linearize<S, LK, 0>), grid, dim3(128), CONSTS, DCONSTS, s->st, (int)B, (int)n, which, need_flag, round)
+#define QILQR_LAUNCH_LIN(S, LK, TILED, CONSTS, DCONSTS) \
+  launch(s, K_LINEARIZE, (k_linearize<S, LK, 0, TILED>), grid, dim3(128), CONSTS, DCONSTS, s->st, (int)B, (int)n, which, need_flag, round)
 #define QILQR_LAUNCH_LIN_RK4(LK) \
-  launch(s, K_LINEARIZE, (k_linearize<double, LK, 1>), grid, dim3(128), s->consts, (const ModelConsts<double> *)s->d_consts, s->st, (int)B, (int)n, which, need_flag, round)
-  if (s->integrator == 1) {  // the Runge-Kutta extension: dense M at the head of the record, fp64 only
+  launch(s, K_LINEARIZE, (k_linearize<double, LK, 1, false>), grid, dim3(128), s->consts, (const ModelConsts<double> *)s->d_consts, s->st, (int)B, (int)n, which, need_flag, round)
+  if (s->integrator == 1) {  // the Runge-Kutta extension: dense M at the head of the record, fp64 only, plain placement
     switch (layout_kind(s->layout)) {
       case 0: QILQR_LAUNCH_LIN_RK4(0); break;
       case 1: QILQR_LAUNCH_LIN_RK4(1); break;
@@ -321,42 +324,62 @@ int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag, 
     }
     return QILQR_OK;
   }
-  switch (layout_kind(s->layout) + (s->f32 ? 3 : 0)) {
-    case 0: QILQR_LAUNCH_LIN(double, 0, s->consts, (const ModelConsts<double> *)s->d_consts); break;
-    case 1: QILQR_LAUNCH_LIN(double, 1, s->consts, (const ModelConsts<double> *)s->d_consts); break;
-    case 2: QILQR_LAUNCH_LIN(double, 2, s->consts, (const ModelConsts<double> *)s->d_consts); break;
-    case 3: QILQR_LAUNCH_LIN(float, 0, s->constsf, (const ModelConsts<float> *)s->d_consts); break;
-    case 4: QILQR_LAUNCH_LIN(float, 1, s->constsf, (const ModelConsts<float> *)s->d_consts); break;
-    default: QILQR_LAUNCH_LIN(float, 2, s->constsf, (const ModelConsts<float> *)s->d_consts); break;
+  // (the placement of the records, s->st.layout.tiled, was chosen with the call's backward kernel: records_tiled)
+  switch (layout_kind(s->layout) + (s->f32 ? 3 : 0) + (s->st.layout.tiled ? 6 : 0)) {
+    case 0: QILQR_LAUNCH_LIN(double, 0, false, s->consts, (const ModelConsts<double> *)s->d_consts); break;
+    case 1: QILQR_LAUNCH_LIN(double, 1, false, s->consts, (const ModelConsts<double> *)s->d_consts); break;
+    case 2: QILQR_LAUNCH_LIN(double, 2, false, s->consts, (const ModelConsts<double> *)s->d_consts); break;
+    case 3: QILQR_LAUNCH_LIN(float, 0, false, s->constsf, (const ModelConsts<float> *)s->d_consts); break;
+    case 4: QILQR_LAUNCH_LIN(float, 1, false, s->constsf, (const ModelConsts<float> *)s->d_consts); break;
+    case 5: QILQR_LAUNCH_LIN(float, 2, false, s->constsf, (const ModelConsts<float> *)s->d_consts); break;
+    case 6: QILQR_LAUNCH_LIN(double, 0, true, s->consts, (const ModelConsts<double> *)s->d_consts); break;
+    case 7: QILQR_LAUNCH_LIN(double, 1, true, s->consts, (const ModelConsts<double> *)s->d_consts); break;
+    case 8: QILQR_LAUNCH_LIN(double, 2, true, s->consts, (const ModelConsts<double> *)s->d_consts); break;
+    case 9: QILQR_LAUNCH_LIN(float, 0, true, s->constsf, (const ModelConsts<float> *)s->d_consts); break;
+    case 10: QILQR_LAUNCH_LIN(float, 1, true, s->constsf, (const ModelConsts<float> *)s->d_consts); break;
+    default: QILQR_LAUNCH_LIN(float, 2, true, s->constsf, (const ModelConsts<float> *)s->d_consts); break;
   }
 #undef QILQR_LAUNCH_LIN
 #undef QILQR_LAUNCH_LIN_RK4
   return QILQR_OK;
+}
+// Which backward kernel a call with `load_B` trajectories in flight takes (symmetric weights), by how many trajectories share
+// the chip's 1024 SIMDs:
+//   up to 640: k_backward2 (a matrix and a gradient wavefront per trajectory, each alone on its SIMD)
+//   up to 8192: k_backward4 (one gradient and one loader wavefront per four trajectories: fewer co-resident
+//               waves; whole solves: 205k against 190k solves/s at 2048, 275k against 265k at 4096, 372k
+//               against 357k at 8192; equal at 512)
+//   beyond: one wavefront per trajectory (the matrix pipe is the bound)
+// The Runge-Kutta extension and non-symmetric weights take the one-wavefront kernel at every size.
+enum BackwardKind { BW_FOUR, BW_TWO, BW_ONE };
+BackwardKind backward_kind(const qilqr_solver *s, long load_B) {
+  if (s->integrator == 1 || !s->symmetric) return BW_ONE;
+  const bool want4 = s->dev.force_general == 4 || (s->dev.force_general == 0 && load_B > 640 && load_B <= 8192);
+  if (want4 && load_B <= 8192) return BW_FOUR;
+  if (s->dev.force_general != 2 && load_B <= 8192) return BW_TWO;
+  return BW_ONE;
+}
+// The knot records are placed for their reader (se3_math.h, rec_base): tiled for the kernels that stage them through LDS
+// (k_backward4, k_backward2, k_solve4), plain for the one-wavefront kernel.  Decided once per call, with the batch size
+// the kernel choice goes by.
+bool records_tiled(const qilqr_solver *s, long load_B, bool persistent) {
+  return persistent || backward_kind(s, load_B) != BW_ONE;
 }
 int launch_backward(qilqr_solver *s, long B, long n, int force) {
 #define QILQR_LAUNCH_BWD(SYM, S)                                                                              \
   launch(s, K_BACKWARD, (k_backward<SYM, S>), dim3((unsigned)B), dim3(64), s->consts, s->params, s->st, \
                      (int)B, (int)n, force)
   const long load_B = std::max(B, s->total_B);
-  // Which backward kernel (symmetric weights), by how many trajectories share the chip's 1024 SIMDs:
-  //   up to 640: k_backward2 (a matrix and a gradient wavefront per trajectory, each alone on its SIMD)
-  //   up to 8192: k_backward4 (one gradient and one loader wavefront per four trajectories: fewer co-resident
-  //               waves; whole solves: 205k against 190k solves/s at 2048, 275k against 265k at 4096, 372k
-  //               against 357k at 8192; equal at 512)
-  //   beyond: one wavefront per trajectory (the matrix pipe is the bound)
-  const bool want4 = s->dev.force_general == 4 || (s->dev.force_general == 0 && load_B > 640 && load_B <= 8192);
-  if (s->integrator == 1) {
-    // the Runge-Kutta extension: every element of M comes from the record (RecLayout.dense_m), which only the one-wavefront
-    // kernel's per-lane operand pointers address (the other kernels stage 128-entry records through LDS)
-    if (s->symmetric) QILQR_LAUNCH_BWD(true, double);
-    else QILQR_LAUNCH_BWD(false, double);
-  } else if (s->symmetric && want4 && load_B <= 8192) {
+  // (the records were linearised in the placement this choice reads: begin_batch sets st.layout.tiled from the same function;
+  // the one-wavefront kernel addresses its operands through rec_elem and reads either)
+  const BackwardKind kind = s->st.layout.tiled ? backward_kind(s, load_B) : BW_ONE;
+  if (kind == BW_FOUR) {
     // four matrix wavefronts + one gradient wavefront + one loader wavefront per four trajectories
     if (s->f32)
       launch(s, K_BACKWARD, k_backward4<float>, dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
     else
       launch(s, K_BACKWARD, k_backward4<double>, dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
-  } else if (s->symmetric && s->dev.force_general != 2 && load_B <= 8192) {
+  } else if (kind == BW_TWO) {
     // two cooperating wavefronts per trajectory (matrix recursion / gradient recursion + operand streaming):
     // shortens one trajectory's chain; above ~8 trajectories per SIMD the chip is bound by the matrix pipe and
     // the one-wavefront kernel gives 2% more throughput
@@ -514,7 +537,7 @@ BatchState slice_state(const qilqr_solver *s, long b0, long n, int part) {
   auto adv = [&](const void *p, long elems) { return (void *)((char *)p + (size_t)elems * es); };
   for (int k = 0; k < 2; ++k) {
     v.traj[k] = adv(w.traj[k], knot_base<true>(b0, n, 18));
-    v.lin[k] = adv(w.lin[k], rec_base(b0, n, w.layout.stride));
+    v.lin[k] = adv(w.lin[k], rec_base(w.layout, b0, n));  // (b0 is a multiple of 64: the same offset in either placement)
     v.knot_cost[k] = w.knot_cost[k] + cost_index(b0, 0, n);
   }
   v.gains = adv(w.gains, knot_base<true>(b0, n, 52));

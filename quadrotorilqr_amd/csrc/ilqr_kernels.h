@@ -82,6 +82,7 @@ struct GA {  // global address space views of storage type S
   typedef const S __attribute__((address_space(1))) *cptr;
   typedef S v2 __attribute__((ext_vector_type(2)));
   typedef v2 __attribute__((address_space(1))) *ptr2;
+  typedef const v2 __attribute__((address_space(1))) *cptr2;
 };
 
 #ifdef QILQR_STAMPS
@@ -133,7 +134,7 @@ __device__ __forceinline__ double cost_reduction(double QuTk, double kTQuuk, dou
 #ifndef QILQR_LIN_WAVES
 #define QILQR_LIN_WAVES 4  // register budget of k_linearize in waves per SIMD (3 avoids its few spills but the next k_backward then runs 3% slower)
 #endif
-template <typename S, int LK, int INTEG>
+template <typename S, int LK, int INTEG, bool TILED>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(QILQR_LIN_WAVES, QILQR_LIN_WAVES))) void
 k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState st, int B, int n, int which,
             int need_flag, int round) {
@@ -193,9 +194,10 @@ k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState 
   if (need_flag && !(fl & need_flag)) return;
   S pt[18];
   load_knot<true>((const S *)st.traj[buf] + knot_base<true>(b, n, 18), i, 18, pt);
-  S *rec = (S *)st.lin[buf] + rec_base(b, n, st.layout.stride) + rec_elem(i, 0, st.layout.stride);
+  S *rec = (S *)st.lin[buf] + rec_base(st.layout, b, n) + rec_elem(st.layout, i, 0);  // (st.layout.tiled == TILED: the host launches the matching instantiation)
+  typedef typename std::conditional<TILED, TiledRecWriter<S>, PlainRecWriter<S>>::type Writer;
   if (!cost_half) {
-    const PlainRecWriter<S> wd{rec};
+    const Writer wd{rec};
     if (INTEG == 1) linearize_dynamics_rk4(c, pt, wd);  // the dense M of the Runge-Kutta extension
     else linearize_dynamics(c, pt, wd);
 #ifdef QILQR_STAMPS
@@ -203,7 +205,8 @@ k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState 
 #endif
     return;
   }
-  const PlainRecWriter<S> w{rec + (INTEG == 1 ? LIN_M_DENSE - LIN_M_BLOCKS : 0)};  // the cost entries follow M wherever it ends
+  static_assert(!(TILED && INTEG == 1), "the dense records of the Runge-Kutta extension are plain");
+  const Writer w{rec + (INTEG == 1 ? LIN_M_DENSE - LIN_M_BLOCKS : 0)};  // the cost entries follow M wherever it ends
   S pd[18];
   if (st.desired_tiled) load_knot<true>((const S *)st.desired + knot_base<true>(b, n, 18), i, 18, pd);
   else load_knot<false>((const S *)st.desired, i, 18, pd);
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   const RecLayout L = st.layout;
   // the recursion itself is always fp64 (fp64 MFMA); S is only the type of the records read and of
   // the gains written
-  const S *lin = (const S *)st.lin[cur] + rec_base(b, n, L.stride);
+  const S *lin = (const S *)st.lin[cur] + rec_base(L, b, n);  // (plain records: the host sets L.tiled = 0 when it launches this kernel)
   S *gains = (S *)st.gains + knot_base<true>(b, n, 52);
 
   constexpr int LD = 17;  // padded leading dimension: column reads of a row-major tile
@@ -466,14 +469,14 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   typename GA<S>::cptr op[7];
   long step[7];
   {
-    const long knot_step = rec_elem(1, 0, L.stride) - rec_elem(0, 0, L.stride);  // one knot back
+    const long knot_step = rec_elem(L, 1, 0) - rec_elem(L, 0, 0);  // one knot back
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
       int src;
       if (k < 3) src = m_source_tab(L, 4 * k + kk, j);
       else if (k < 6) src = (j < 12) ? cxx_source_tab(L, 4 * (k - 3) + kk, j) : -1 - CTAB_ZERO;
       else src = L.off_g + j;
-      op[k] = (typename GA<S>::cptr)((src >= 0) ? lin + rec_elem(n - 1, src, L.stride) : (const S *)st.ctab + (-1 - src));
+      op[k] = (typename GA<S>::cptr)((src >= 0) ? lin + rec_elem(L, n - 1, src) : (const S *)st.ctab + (-1 - src));
       step[k] = (src >= 0) ? knot_step : 0;
     }
   }
@@ -817,7 +820,7 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
 
   const int j = lane & 15, kk = lane >> 4;
   const RecLayout L = st.layout;
-  const S *lin = (const S *)st.lin[cur] + rec_base(b, n, L.stride);
+  const S *lin = (const S *)st.lin[cur] + rec_base(L, b, n);  // (tiled records: the host sets L.tiled = 1 when it launches this kernel)
   S *gains = (S *)st.gains + knot_base<true>(b, n, 52);
   __shared__ double ring[3][BW2_BUF];
   __shared__ double kf[2][80];  // [0..63] K, column j at [4 j ..]; [64..73] l10 l20 l30 l21 l31 l32 1/d0..1/d3
@@ -837,29 +840,26 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
     ring[1][BW2_REC + t] = v;
     ring[2][BW2_REC + t] = v;
   }
-  typedef typename GA<S>::cptr gptr;
-  const int tail = (L.stride - 65 < lane) ? L.stride - 65 : lane;  // second load: elements 64 .. stride-1, clamped
+  // a record is stride / 2 entry pairs, 128 elements apart (tiled placement): lane l fetches pair l (clamped: the lanes
+  // beyond the record fetch its last pair again and drop it into ring entries nobody reads)
+  typedef typename GA<S>::v2 rv2;
+  typedef typename GA<S>::cptr2 rptr2;
+  const int pair = (lane < L.stride / 2) ? lane : L.stride / 2 - 1;
 
   if (role == 1) {
     // ------------------------------------------------------------------ G: records + gradient
-    auto rec_ptr = [&](int i) { return (gptr)(lin + rec_elem(i, 0, L.stride)); };
-    S r0 = 0, r1 = 0;
+    auto rec_pair = [&](int i) -> rv2 { return *(rptr2)(lin + rec_elem(L, i, 2 * pair)); };
+    rv2 r = {0, 0};
     {
-      gptr q1 = rec_ptr(n - 1);
-      const S a0 = q1[lane], a1 = q1[64 + tail];
-      ring[(n - 1) % 3][lane] = (double)a0;
-      ring[(n - 1) % 3][64 + lane] = (double)a1;
+      const rv2 a = rec_pair(n - 1);
+      ring[(n - 1) % 3][2 * lane] = (double)a.x;
+      ring[(n - 1) % 3][2 * lane + 1] = (double)a.y;
       if (n >= 2) {
-        gptr q2 = rec_ptr(n - 2);
-        const S b0 = q2[lane], b1 = q2[64 + tail];
-        ring[(n - 2) % 3][lane] = (double)b0;
-        ring[(n - 2) % 3][64 + lane] = (double)b1;
+        const rv2 b2 = rec_pair(n - 2);
+        ring[(n - 2) % 3][2 * lane] = (double)b2.x;
+        ring[(n - 2) % 3][2 * lane + 1] = (double)b2.y;
       }
-      if (n >= 3) {
-        gptr q3 = rec_ptr(n - 3);
-        r0 = q3[lane];
-        r1 = q3[64 + tail];
-      }
+      if (n >= 3) r = rec_pair(n - 3);
     }
     __syncthreads();
     double vxl[3] = {0.0, 0.0, 0.0};  // V_x[4 kc + kk]
@@ -902,14 +902,10 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
     for (int i = n - 1; i >= 0; --i) {
       if (i + 1 <= n - 1) gradient_step(i + 1);
       if (i - 2 >= 0) {
-        ring[(i - 2) % 3][lane] = (double)r0;
-        ring[(i - 2) % 3][64 + lane] = (double)r1;
+        ring[(i - 2) % 3][2 * lane] = (double)r.x;
+        ring[(i - 2) % 3][2 * lane + 1] = (double)r.y;
       }
-      if (i - 3 >= 0) {
-        gptr q = rec_ptr(i - 3);
-        r0 = q[lane];
-        r1 = q[64 + tail];
-      }
+      if (i - 3 >= 0) r = rec_pair(i - 3);
       __syncthreads();
     }
     gradient_step(0);
@@ -1154,34 +1150,30 @@ __device__ __forceinline__ double bw4_gradient_wave(double (&ring)[4][4][BW2_BUF
   gradient_step(0);
   return QuTk;
 }
-// L: streams the knot records of the block's four trajectories (rec0..rec3: their record bases) into the rings
+// L: streams the knot records of the block's four trajectories (rec0..rec3: their record bases, TILED placement) into the
+// rings: a record is stride / 2 entry pairs 128 elements apart, lane l fetches pair l of each trajectory with one 16-byte
+// load (the four trajectories of the block are neighbours in their tile: the four loads hit the same lines) and writes it to
+// ring entries 2 l, 2 l + 1; lanes beyond the record fetch its last pair again into entries nobody reads
 template <typename S>
 __device__ __forceinline__ void bw4_loader_wave(double (&ring)[4][4][BW2_BUF], const RecLayout &L, const S *rec0, const S *rec1,
                                                 const S *rec2, const S *rec3, int n, int lane) {
-  const int tl = (L.stride - 65 < lane) ? L.stride - 65 : lane;  // second load: elements 64 .. stride-1, clamped
-  typename GA<S>::cptr lp[4] = {(typename GA<S>::cptr)rec0, (typename GA<S>::cptr)rec1, (typename GA<S>::cptr)rec2,
-                               (typename GA<S>::cptr)rec3};
-  S q0[4] = {0, 0, 0, 0}, q1[4] = {0, 0, 0, 0};
+  typedef typename GA<S>::v2 rv2;
+  typedef typename GA<S>::cptr2 rptr2;
+  const int pair = (lane < L.stride / 2) ? lane : L.stride / 2 - 1;
+  const S *lp[4] = {rec0, rec1, rec2, rec3};
+  auto rec_pair = [&](int g, int i) -> rv2 { return *(rptr2)(lp[g] + rec_elem(L, i, 2 * pair)); };
+  rv2 q[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #pragma unroll
   for (int g = 0; g < 4; ++g) {  // (trajectories with nothing to do are streamed too: no branches in this wave)
-    typename GA<S>::cptr a = lp[g] + rec_elem(n - 1, 0, L.stride);
-    const S a0 = a[lane], a1 = a[64 + tl];
-    S b0_ = 0, b1_ = 0;
+    const rv2 a = rec_pair(g, n - 1);
+    rv2 b_ = {0, 0};
+    if (n >= 2) b_ = rec_pair(g, n - 2);
+    if (n >= 3) q[g] = rec_pair(g, n - 3);
+    ring[g][(n - 1) & 3][2 * lane] = (double)a.x;
+    ring[g][(n - 1) & 3][2 * lane + 1] = (double)a.y;
     if (n >= 2) {
-      typename GA<S>::cptr b2 = lp[g] + rec_elem(n - 2, 0, L.stride);
-      b0_ = b2[lane];
-      b1_ = b2[64 + tl];
-    }
-    if (n >= 3) {
-      typename GA<S>::cptr c3 = lp[g] + rec_elem(n - 3, 0, L.stride);
-      q0[g] = c3[lane];
-      q1[g] = c3[64 + tl];
-    }
-    ring[g][(n - 1) & 3][lane] = (double)a0;
-    ring[g][(n - 1) & 3][64 + lane] = (double)a1;
-    if (n >= 2) {
-      ring[g][(n - 2) & 3][lane] = (double)b0_;
-      ring[g][(n - 2) & 3][64 + lane] = (double)b1_;
+      ring[g][(n - 2) & 3][2 * lane] = (double)b_.x;
+      ring[g][(n - 2) & 3][2 * lane + 1] = (double)b_.y;
     }
   }
   __syncthreads();  // rings and constant tables are filled
@@ -1191,17 +1183,13 @@ __device__ __forceinline__ void bw4_loader_wave(double (&ring)[4][4][BW2_BUF], c
     if (i - 2 >= 0) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        ring[g][(i - 2) & 3][lane] = (double)q0[g];
-        ring[g][(i - 2) & 3][64 + lane] = (double)q1[g];
+        ring[g][(i - 2) & 3][2 * lane] = (double)q[g].x;
+        ring[g][(i - 2) & 3][2 * lane + 1] = (double)q[g].y;
       }
     }
     if (i - 3 >= 0) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        typename GA<S>::cptr a = lp[g] + rec_elem(i - 3, 0, L.stride);
-        q0[g] = a[lane];
-        q1[g] = a[64 + tl];
-      }
+      for (int g = 0; g < 4; ++g) q[g] = rec_pair(g, i - 3);
     }
     __syncthreads();
   }
@@ -1527,7 +1515,7 @@ __global__ __launch_bounds__(384) void k_backward4(ModelConsts<double> c, SolveP
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int gs = s_run[g] ? g : first;
-      rec[g] = (const S *)st.lin[s_cur[gs]] + rec_base(b0 + gs, n, L.stride);
+      rec[g] = (const S *)st.lin[s_cur[gs]] + rec_base(L, b0 + gs, n);
     }
     bw4_loader_wave<S>(ring, L, rec[0], rec[1], rec[2], rec[3], n, lane);
     return;

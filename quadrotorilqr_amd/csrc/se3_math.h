@@ -489,6 +489,8 @@ struct RecLayout {
   int off_cxx, off_g, off_cost, stride;
   int dense_m;  // the record starts with the whole M = [J_x | J_u] (12 x 16, row-major) instead of the six Jacobian
                 // blocks of the explicit-Euler step: the Runge-Kutta extension, whose Jacobians have no such structure
+  int tiled;    // placement of the records in memory (not of the entries in a record): see rec_base / rec_elem.  Set per
+                // call by the host to what the call's backward kernel reads
 };
 constexpr int LIN_M_DENSE = 192, LIN_M_BLOCKS = 54;
 QILQR_HD constexpr RecLayout make_layout(bool sym, bool ur_zero, bool dense_m = false) {
@@ -503,19 +505,35 @@ QILQR_HD constexpr RecLayout make_layout(bool sym, bool ur_zero, bool dense_m = 
   L.stride = (L.off_cost + 1 + 1) & ~1;  // even: records stay 16-byte aligned
   return L;
 }
-// Device layout of the knot records: [b][knot i][stride], one contiguous record per knot.
-// (A layout with the 64 trajectories of a tile interleaved in 128-byte chunks, written out coalesced
-// through LDS, was measured: k_linearize is bound by the bytes it writes, not by how they are
-// addressed, and the padding such a layout needs made both it and k_backward slower.  Placing the 64
-// records of a wavefront next to each other ([tile][knot][lane][stride]) changes nothing either.)
-QILQR_HD long rec_base(long b, long n, int stride) { return b * n * stride; }
-QILQR_HD long rec_elem(long i, int k, int stride) { return i * stride + k; }
-QILQR_HD long rec_count(long B, long n, int stride) { return B * n * stride; }
+// Device layout of the knot records, two forms.
+// PLAIN  [b][knot][stride]: one contiguous record per knot.  What the one-wavefront backward kernel reads (seven entries per
+//   lane and knot through per-lane pointers: a trajectory's knot is six cache lines).
+// TILED  [tile of 64 trajectories][knot][entry pair][trajectory in tile][2]: the layout of the trajectories and gains.  What
+//   k_linearize writes best -- its 64 lanes hold one knot of 64 consecutive trajectories, so a store instruction covers one
+//   contiguous kilobyte instead of 64 pieces of 64 different lines (the kernel was bound by the L2's request rate, not by
+//   bytes: 36 -> 23 us per launch at B = 1024 with every trajectory live, 325 -> 175 at B = 8192) -- and what the kernels
+//   that stage records through LDS read (k_backward4, k_backward2, k_solve4: one 16-byte load per lane and record).
+// (Measured and dropped earlier: contiguous records written out through an LDS transpose -- padding, slower -- and the 64
+// records of a wavefront next to each other, [tile][knot][lane][stride], which changes nothing: each lane's stores still
+// go to a line of their own.)
+QILQR_HD long rec_base(const RecLayout &L, long b, long n) {
+  return L.tiled ? (b >> 6) * n * L.stride * 64 + (b & 63) * 2 : b * n * L.stride;
+}
+QILQR_HD long rec_elem(const RecLayout &L, long i, int k) {
+  return L.tiled ? (i * (L.stride / 2) + (k >> 1)) * 128 + (k & 1) : i * L.stride + k;
+}
+QILQR_HD long rec_count(long B, long n, int stride) { return ((B + 63) / 64) * 64 * n * stride; }  // (room for either form)
 // The linearisation hands its entries to a writer: put(k, v) stores entry k of the record.
 template <typename T>
 struct PlainRecWriter {
   T *rec;
   QILQR_HD void put(int k, T v) const { rec[k] = v; }  // (non-temporal stores here are 6x slower: the L2 must merge them)
+};
+// the same for the tiled placement: rec points at entry 0 of the knot; entry pairs are 128 elements apart
+template <typename T>
+struct TiledRecWriter {
+  T *rec;
+  QILQR_HD void put(int k, T v) const { rec[(k >> 1) * 128 + (k & 1)] = v; }
 };
 // symmetric layouts, rows i < 6 of C_xx in order of production: row i holds its part of the upper triangle
 // of the pose block (columns i..5) and, when the pose x velocity block is stored, its six entries of that

@@ -72,7 +72,7 @@ __device__ __forceinline__ void solve4_linearize_lane(const ModelConsts<S> &cl, 
                                                       int buf, int half) {
   S pt[18];
   load_knot<true>((const S *)st.traj[buf] + knot_base<true>(b, n, 18), i, 18, pt);
-  const PlainRecWriter<S> w{(S *)st.lin[buf] + rec_base(b, n, st.layout.stride) + rec_elem(i, 0, st.layout.stride)};
+  const TiledRecWriter<S> w{(S *)st.lin[buf] + rec_base(st.layout, b, n) + rec_elem(st.layout, i, 0)};  // (tiled records: what bw4_loader_wave reads)
   if (half == 0) {
     linearize_dynamics(cl, pt, w);
     return;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(S4_THREADS) void k_solve4(ModelConsts<double> c, co
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int gs = sl[g].run ? g : first;
-            rec[g] = (const S *)st.lin[sl[gs].cur] + rec_base(sl[gs].b, n, L.stride);
+            rec[g] = (const S *)st.lin[sl[gs].cur] + rec_base(L, sl[gs].b, n);
           }
           s4_loader<S>(L, rec[0], rec[1], rec[2], rec[3], n, lane);
         } else if (w >= 6) {

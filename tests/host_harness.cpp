@@ -117,6 +117,7 @@ void hh_layout(const ModelConsts<double> *c, int force_general, int *out) {
 static RecLayout layout_from(const int *v) {
   RecLayout L;
   L.sym = v[0]; L.ur_zero = v[1]; L.off_cxx = v[2]; L.off_g = v[3]; L.off_cost = v[4]; L.stride = v[5];
+  L.tiled = 0;  // (the host harness keeps records contiguous: placement in memory is the device's business)
   L.dense_m = (v[2] == LIN_M_DENSE) ? 1 : 0;  // (the six-int wire form of the tests: the dense layouts are the ones whose C_xx starts behind a dense M)
   return L;
 }
