@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Diagnostic: two builds of the library on the same box, alternately, on large batches (boards differ by a few
 per cent on the bandwidth-bound configurations, so an A/B across gpurun calls is not one).
-usage (from the repository root): PYTHONPATH=. python3 profiles/microbench/ab_big.py libA.so libB.so [B ...]"""
+usage (from the repository root): PYTHONPATH=. python3 profiles/microbench/ab_big.py libA.so libB.so [libC.so ...] [B ...]"""
 import sys, time
 import torch
 from quadrotorilqr_amd import capi, problems as pb
-libs = sys.argv[1:3]
-sizes = [int(x) for x in sys.argv[3:]] or [65536]
+libs = [a for a in sys.argv[1:] if a.endswith('.so')]
+sizes = [int(a) for a in sys.argv[1:] if not a.endswith('.so')] or [65536]
 dev = torch.device("cuda:0")
 for B in sizes:
     cfg = pb.config2(B=B, N=100, seed=4)

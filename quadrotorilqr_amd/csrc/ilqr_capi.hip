@@ -354,9 +354,8 @@ int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag, 
 enum BackwardKind { BW_FOUR, BW_TWO, BW_ONE };
 BackwardKind backward_kind(const qilqr_solver *s, long load_B) {
   if (s->integrator == 1 || !s->symmetric) return BW_ONE;
-  const bool want4 = s->dev.force_general == 4 || (s->dev.force_general == 0 && load_B > 640 && load_B <= 8192);
-  if (want4 && load_B <= 8192) return BW_FOUR;
-  if (s->dev.force_general != 2 && load_B <= 8192) return BW_TWO;
+  if (s->dev.force_general == 4 || (s->dev.force_general == 0 && load_B > 640 && load_B <= 8192)) return BW_FOUR;
+  if (s->dev.force_general == 3 || (s->dev.force_general != 2 && load_B <= 8192)) return BW_TWO;
   return BW_ONE;
 }
 // The knot records are placed for their reader (se3_math.h, rec_base): tiled for the kernels that stage them through LDS

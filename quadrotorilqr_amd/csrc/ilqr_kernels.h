@@ -45,11 +45,11 @@ struct SolveParams {
 struct BatchState {
   // Buffers whose element type S is the solver's storage precision (double, or float in the
   // mixed-precision mode): kernels are instantiated on S and cast.
-  void *traj[2];         // TILED (se3_math.h) [tile][n][9][64][2]: current / candidate trajectories
+  void *traj[2];         // TILED (se3_math.h) [tile][n][9][TILE][2]: current / candidate trajectories
   void *lin[2];          // [B][n][layout.stride] knot records of traj[k] (se3_math.h, rec_base / rec_elem)
   RecLayout layout;
-  double *knot_cost[2];  // [tile][n][64]
-  void *gains;           // TILED [tile][n][26][64][2]
+  double *knot_cost[2];  // [tile][n][TILE]
+  void *gains;           // TILED [tile][n][26][TILE][2]
   const void *desired;   // shared: plain [n_desired][18]; per problem: TILED like traj
   int desired_tiled;     // 0 shared, 1 per problem
   int *cur;              // which of traj[] / lin[] is current
@@ -103,11 +103,12 @@ struct GA {  // global address space views of storage type S
 #define QKEEP(x) do { } while (0)
 #endif
 
-// Workgroups go to the eight XCDs round-robin by blockIdx, and every XCD has an L2 of its own.  In the kernels that give a
-// block to FOUR trajectories (k_rollout16, k_backward4) the sixteen blocks of a tile of 64 trajectories touch the SAME
-// 128-byte lines of the tiled arrays (32 bytes each: nominal knots and gains read, gains and candidates written), so they
-// are given to one XCD: XCD x takes the contiguous range of logical blocks that its hardware blocks x, x + 8, ...
-// enumerate.  (Counters, B = 1024: FETCH_SIZE per launch 53 MB with the identity map.)
+// Workgroups go to the eight XCDs round-robin by blockIdx, and every XCD has an L2 of its own.  The kernels that give a
+// block to FOUR trajectories (k_rollout16, k_backward4) hand XCD x the contiguous range of logical blocks that its hardware
+// blocks x, x + 8, ... enumerate, so that a block of k_rollout16 finds the gains in the L2 its k_backward4 block wrote
+// them through, and the candidate it writes is where the next k_backward4 block looks for it.  (Introduced when tiles were
+// 64 trajectories wide and sixteen blocks shared every line -- counters, B = 1024: FETCH_SIZE per launch 53 MB with the
+// identity map, 31 with this one; with tiles of four it keeps producer and consumer of a tile on one XCD.)
 __device__ __forceinline__ int xcd_local_block(unsigned hw_block, unsigned nblocks) {
   constexpr unsigned XCDS = 8;
   const unsigned x = hw_block % XCDS, k = hw_block / XCDS, per = nblocks / XCDS, rem = nblocks % XCDS;
@@ -200,6 +201,7 @@ k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState 
     const Writer wd{rec};
     if (INTEG == 1) linearize_dynamics_rk4(c, pt, wd);  // the dense M of the Runge-Kutta extension
     else linearize_dynamics(c, pt, wd);
+    wd.flush();
 #ifdef QILQR_STAMPS
     lin_stamp(0, (double)pt[0]);
 #endif
@@ -211,6 +213,7 @@ k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState 
   if (st.desired_tiled) load_knot<true>((const S *)st.desired + knot_base<true>(b, n, 18), i, 18, pd);
   else load_knot<false>((const S *)st.desired, i, 18, pd);
   const S cost = linearize_cost<LK>(qr, qr + 144, pt, pd, w);
+  w.flush();
   st.knot_cost[buf][cost_index(b, i, n)] = (double)cost;  // summed in fp64 (k_init / k_backward)
 #ifdef QILQR_STAMPS
   lin_stamp(1, (double)cost);
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
     ring[1][BW2_REC + t] = v;
     ring[2][BW2_REC + t] = v;
   }
-  // a record is stride / 2 entry pairs, 128 elements apart (tiled placement): lane l fetches pair l (clamped: the lanes
+  // a record is stride / 2 entry pairs, TILE2 elements apart (tiled placement): lane l fetches pair l (clamped: the lanes
   // beyond the record fetch its last pair again and drop it into ring entries nobody reads)
   typedef typename GA<S>::v2 rv2;
   typedef typename GA<S>::cptr2 rptr2;
@@ -869,7 +872,7 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
     gptr2 kdst = (gptr2)(gains + knot_elem<true>(n - 1, 0, 52));  // k of knot n-1; lanes other than 0 use the dump slot
     const long kstep = (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2;
     gptr2 kdst0 = (lane == 0) ? kdst : (gptr2)((S *)st.dump + 4 * (long)b);
-    gptr2 kdst1 = (lane == 0) ? kdst + 64 : (gptr2)((S *)st.dump + 4 * (long)b + 2);
+    gptr2 kdst1 = (lane == 0) ? kdst + TILE : (gptr2)((S *)st.dump + 4 * (long)b + 2);
     const long kst = (lane == 0) ? kstep : 0;
     auto gradient_step = [&](int q) {
       const double *buf = ring[q % 3];
@@ -1151,45 +1154,56 @@ __device__ __forceinline__ double bw4_gradient_wave(double (&ring)[4][4][BW2_BUF
   return QuTk;
 }
 // L: streams the knot records of the block's four trajectories (rec0..rec3: their record bases, TILED placement) into the
-// rings: a record is stride / 2 entry pairs 128 elements apart, lane l fetches pair l of each trajectory with one 16-byte
-// load (the four trajectories of the block are neighbours in their tile: the four loads hit the same lines) and writes it to
-// ring entries 2 l, 2 l + 1; lanes beyond the record fetch its last pair again into entries nobody reads
+// rings.  A record is stride / 2 entry pairs TILE2 elements apart, and with tiles of four the block's trajectories are the
+// four slots of one tile: lane l takes trajectory g = l & 3 and entry pairs l / 4 + 16 j (j = 0..3), so that one load
+// instruction covers sixteen pairs of all four trajectories -- a contiguous kilobyte when they use the same record buffer
+// (each trajectory has its own current buffer, hence a base per lane) -- and the lane writes its sixteen bytes to ring
+// entries 2 pair, 2 pair + 1 of ring g.  Pairs beyond the record are clamped to its last pair and land in entries nobody
+// reads.
 template <typename S>
 __device__ __forceinline__ void bw4_loader_wave(double (&ring)[4][4][BW2_BUF], const RecLayout &L, const S *rec0, const S *rec1,
                                                 const S *rec2, const S *rec3, int n, int lane) {
+  static_assert(BW2_BUF % 2 == 0 && BW2_REC == 128, "ring entries are written in aligned pairs, 64 of them per record slot");
   typedef typename GA<S>::v2 rv2;
   typedef typename GA<S>::cptr2 rptr2;
-  const int pair = (lane < L.stride / 2) ? lane : L.stride / 2 - 1;
-  const S *lp[4] = {rec0, rec1, rec2, rec3};
-  auto rec_pair = [&](int g, int i) -> rv2 { return *(rptr2)(lp[g] + rec_elem(L, i, 2 * pair)); };
+  typedef double dv2 __attribute__((ext_vector_type(2)));
+  const int g = lane & 3, npairs = L.stride / 2;
+  const S *lp = (g & 2) ? ((g & 1) ? rec3 : rec2) : ((g & 1) ? rec1 : rec0);
+  int poff[4];   // element offset of the lane's j-th pair inside a knot
+  double *dst[4];  // its ring entries in slot 0
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int pu = (lane >> 2) + 16 * j, pc = pu < npairs ? pu : npairs - 1;
+    poff[j] = (int)rec_elem(L, 0, 2 * pc);
+    dst[j] = &ring[g][0][2 * pu];
+  }
+  const long knot_step = rec_elem(L, 1, 0);
+  auto rec_pair = [&](int j, int i) -> rv2 { return *(rptr2)(lp + (long)i * knot_step + poff[j]); };
+  auto put = [&](int j, int i, rv2 v) {
+    const dv2 d = {(double)v.x, (double)v.y};
+    *reinterpret_cast<dv2 *>(dst[j] + (i & 3) * BW2_BUF) = d;
+  };
   rv2 q[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {  // (trajectories with nothing to do are streamed too: no branches in this wave)
-    const rv2 a = rec_pair(g, n - 1);
+  for (int j = 0; j < 4; ++j) {  // (trajectories with nothing to do are streamed too: no branches in this wave)
+    const rv2 a = rec_pair(j, n - 1);
     rv2 b_ = {0, 0};
-    if (n >= 2) b_ = rec_pair(g, n - 2);
-    if (n >= 3) q[g] = rec_pair(g, n - 3);
-    ring[g][(n - 1) & 3][2 * lane] = (double)a.x;
-    ring[g][(n - 1) & 3][2 * lane + 1] = (double)a.y;
-    if (n >= 2) {
-      ring[g][(n - 2) & 3][2 * lane] = (double)b_.x;
-      ring[g][(n - 2) & 3][2 * lane + 1] = (double)b_.y;
-    }
+    if (n >= 2) b_ = rec_pair(j, n - 2);
+    if (n >= 3) q[j] = rec_pair(j, n - 3);
+    put(j, n - 1, a);
+    if (n >= 2) put(j, n - 2, b_);
   }
   __syncthreads();  // rings and constant tables are filled
   for (int i = n - 1; i >= 0; --i) {
-    // first the four records requested one interval ago, then the next four requests: the wait in front of
+    // first the four pieces requested one interval ago, then the next four requests: the wait in front of
     // the LDS writes is for loads that are all older than anything in flight
     if (i - 2 >= 0) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        ring[g][(i - 2) & 3][2 * lane] = (double)q[g].x;
-        ring[g][(i - 2) & 3][2 * lane + 1] = (double)q[g].y;
-      }
+      for (int j = 0; j < 4; ++j) put(j, i - 2, q[j]);
     }
     if (i - 3 >= 0) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) q[g] = rec_pair(g, i - 3);
+      for (int j = 0; j < 4; ++j) q[j] = rec_pair(j, i - 3);
     }
     __syncthreads();
   }
@@ -1338,7 +1352,7 @@ __global__ __launch_bounds__(384) void k_backward4(ModelConsts<double> c, SolveP
   __shared__ double s_cost[4];
   // four slots per trajectory: in interval i the matrix wave reads slot (i-1) & 3 and writes slot (i-2) & 3
   // while G reads slot (i+1) & 3
-  __shared__ double ring[4][4][BW2_BUF];
+  __shared__ __attribute__((aligned(16))) double ring[4][4][BW2_BUF];
   __shared__ double kf[4][2][80];
   const RecLayout L = st.layout;
 
@@ -1596,8 +1610,8 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
   // all three execute exactly 1 + n barriers.
   if (role == 2) {
     // ------------------------------------------------------------------ L: loader
-    const sv2 *tp = reinterpret_cast<const sv2 *>(traj);   // pair k of knot i: tp[(i * 9 + k) * 64]
-    const sv2 *gp = reinterpret_cast<const sv2 *>(gains);  //                   gp[(i * 26 + k) * 64]
+    const sv2 *tp = reinterpret_cast<const sv2 *>(traj);   // pair k of knot i: tp[(i * 9 + k) * TILE]
+    const sv2 *gp = reinterpret_cast<const sv2 *>(gains);  //                   gp[(i * 26 + k) * TILE]
     sv2 ra[35], rb[35], pa[4], pb[4];
     // Lanes whose trajectory is not being rolled out this round request nothing after the first knots (in the
     // late rounds a tile holds a handful of live trajectories and 16-byte sectors of the others would be most
@@ -1606,15 +1620,15 @@ __global__ __launch_bounds__(192) void k_rollout3(ModelConsts<S> c, BatchState s
     auto load_ops = [&](int k, sv2 (&r)[35], bool every_lane) {
       if (k < n && (every_lane || live)) {
 #pragma unroll
-        for (int e = 0; e < 9; ++e) r[e] = tp[((long)k * 9 + e) * 64];
+        for (int e = 0; e < 9; ++e) r[e] = tp[((long)k * 9 + e) * TILE];
 #pragma unroll
-        for (int e = 0; e < 26; ++e) r[9 + e] = gp[((long)k * 26 + e) * 64];
+        for (int e = 0; e < 26; ++e) r[9 + e] = gp[((long)k * 26 + e) * TILE];
       }
     };
     auto load_pose = [&](int k, sv2 (&r)[4], bool every_lane) {
       if (k < n && (every_lane || live)) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = tp[((long)k * 9 + e) * 64];
+        for (int e = 0; e < 4; ++e) r[e] = tp[((long)k * 9 + e) * TILE];
       }
     };
     load_ops(0, ra, true);
@@ -1856,9 +1870,9 @@ struct DevWave {
   typedef int I;
   template <class F> static __device__ __forceinline__ V vconst(F f) { return f((int)(threadIdx.x & 63)); }
   template <class F> static __device__ __forceinline__ M mconst(F f) { return f((int)(threadIdx.x & 63)); }
-  // element indices of a knot become offsets into the tiled layout, (e / 2) * 128 + e % 2 (se3_math.h, knot_elem): the
+  // element indices of a knot become offsets into the tiled layout, (e / 2) * TILE2 + e % 2 (se3_math.h, knot_elem): the
   // loads of wavefront P are then a wave-uniform knot pointer plus a 32-bit lane offset, no address arithmetic per knot
-  static __device__ __forceinline__ I iuni(int e) { return (e >> 1) * 128 + (e & 1); }
+  static __device__ __forceinline__ I iuni(int e) { return (e >> 1) * TILE2 + (e & 1); }
   template <class F> static __device__ __forceinline__ I iconst(F f) { return iuni(f((int)(threadIdx.x & 63))); }
   // value of lane L of the caller's row of 16 (v_mov_b64_dpp row_newbcast)
   template <int L> static __device__ __forceinline__ V bc(V x) { return __builtin_amdgcn_mov_dpp(x, 0x150 + L, 0xf, 0xf, false); }
@@ -2042,7 +2056,7 @@ __device__ __forceinline__ void r16_wave_P(R16Lds &sh, const S *traj, const S *g
   S rawA[NRAW], rawB[NRAW], tmA, tmB;
   auto request = [&](int k, S (&raw)[NRAW], S &tm) {
     const int kk = k < n ? k : n - 1;
-    const S *tk = traj + (long)kk * (9 * 128), *gk = gains + (long)kk * (26 * 128);
+    const S *tk = traj + (long)kk * (9 * TILE2), *gk = gains + (long)kk * (26 * TILE2);
     tm = tk[0];  // time_s: the oldest request of the knot
     auto ld = [&](int off) -> S { return tk[off]; };
     auto lg = [&](int off) -> S { return gk[off]; };
@@ -2124,7 +2138,7 @@ __device__ __forceinline__ void r16_wave_X(R16Lds &sh, const ModelConsts<double>
       seen = r16_flag_read(sh, R16_F_PROD);
     }
     have_n = false;
-    S *ok_ = out + (long)i * (9 * 128);
+    S *ok_ = out + (long)i * (9 * TILE2);
     if (wp) ok_[opz] = (S)__builtin_fma(kc.MQ0, QQ, TT);  // [q | t] in one store
     QSTAMP(0);  // X: operand reads (if not requested ahead), pose store
     double TH4, TD;

@@ -49,20 +49,33 @@ struct Eps<float> {
 };
 
 // ----------------------------------------------------------------- batch layouts
-// Per-knot arrays that the lane-per-trajectory kernels touch (trajectories W = 18, gains W = 52,
-// knot costs W = 1) are stored "tiled": trajectories are grouped 64 at a time and, inside a tile,
-// the trajectory index is the fastest dimension in units of 16 bytes:
-//     [tile = b / 64][knot i][pair e / 2][lane = b % 64][e % 2]
-// so that the 64 lanes of a wavefront, each reading element pair (e, e+1) of ITS trajectory, touch
-// 1 KiB of consecutive memory (global_load_dwordx4, fully coalesced) instead of 64 separate cache
-// lines.  TILED = false is the plain [b][i][W] layout of the C ABI (and of the CPU harness).
+// Per-knot arrays (trajectories W = 18, gains W = 52, knot costs W = 1, knot records) are stored "tiled": trajectories are
+// grouped TILE at a time and, inside a tile, the trajectory index is the fastest dimension in units of 16 bytes:
+//     [tile = b / TILE][knot i][pair e / 2][slot = b % TILE][e % 2]
+// TILE = 4 is the ownership of the kernels that carry a solve: k_backward4, k_rollout16 and k_solve4 give a workgroup to
+// four consecutive trajectories, so a knot of a tile (gains: 1664 bytes, records: 2944, trajectories: 576) is one
+// contiguous piece of memory that exactly one workgroup reads or writes, whole cache lines at a time.  The
+// lane-per-trajectory kernels (k_linearize, k_rollout, k_rollout3, the format conversions) see 64-byte pieces, sixteen per
+// instruction.
+// (TILE = 64, the first design, gave those kernels one contiguous kilobyte per instruction, but the sixteen workgroups
+// of a tile then shared every line, 32 bytes each, and so did the 64 one-wavefront workgroups of the largest batches.
+// Same box, whole solves, TILE 64 -> 4: B = 1024 +1 %, 8192 +4 %, 65536 +11 %; k_backward4 fetches 38.8 MB per launch
+// instead of 44.4 and k_rollout16 26.6 instead of 30.5, while k_linearize takes 189 us instead of 166 at B = 8192.
+// TILE = 8 measures like 64.  Build with -DQILQR_TILE=64 to compare: make variant NAME=t64 DEFS=-DQILQR_TILE=64.)
+// TILED = false is the plain [b][i][W] layout of the C ABI (and of the CPU harness).
+#ifndef QILQR_TILE
+#define QILQR_TILE 4
+#endif
+constexpr int TILE = QILQR_TILE, TILE2 = 2 * TILE;  // (TILE2: elements between consecutive entry pairs of a trajectory)
+constexpr int TILE_LOG = TILE == 64 ? 6 : TILE == 32 ? 5 : TILE == 16 ? 4 : TILE == 8 ? 3 : TILE == 4 ? 2 : -1;
+static_assert(TILE_LOG > 0 && (1 << TILE_LOG) == TILE, "TILE is 4, 8, 16, 32 or 64 (sub-batches start at multiples of 64)");
 template <bool TILED>
 QILQR_HD long knot_base(long b, long n, int W) {
-  return TILED ? (b >> 6) * n * (W >> 1) * 128 + ((b & 63) << 1) : b * n * W;
+  return TILED ? (b >> TILE_LOG) * n * (W >> 1) * TILE2 + ((b & (TILE - 1)) << 1) : b * n * W;
 }
 template <bool TILED>
 QILQR_HD long knot_elem(long i, int e, int W) {
-  return TILED ? (i * (W >> 1) + (e >> 1)) * 128 + (e & 1) : i * W + e;
+  return TILED ? (i * (W >> 1) + (e >> 1)) * TILE2 + (e & 1) : i * W + e;
 }
 template <bool TILED, typename T>
 QILQR_HD void load_knot(const T *base, long i, int W, T *dst) {
@@ -71,8 +84,8 @@ QILQR_HD void load_knot(const T *base, long i, int W, T *dst) {
     if (e < W) dst[e] = base[knot_elem<TILED>(i, e, W)];
 }
 QILQR_HD long tiled_count(long B, long n, int W) { return ((B + 63) >> 6) * 64 * n * W; }
-// knot costs: [tile][i][lane]
-QILQR_HD long cost_index(long b, long i, long n) { return ((b >> 6) * n + i) * 64 + (b & 63); }
+// knot costs: [tile][i][slot]
+QILQR_HD long cost_index(long b, long i, long n) { return ((b >> TILE_LOG) * n + i) * TILE + (b & (TILE - 1)); }
 
 // ----------------------------------------------------------------- 3-vectors / 3x3 (row-major)
 template <typename T>
@@ -508,32 +521,61 @@ QILQR_HD constexpr RecLayout make_layout(bool sym, bool ur_zero, bool dense_m = 
 // Device layout of the knot records, two forms.
 // PLAIN  [b][knot][stride]: one contiguous record per knot.  What the one-wavefront backward kernel reads (seven entries per
 //   lane and knot through per-lane pointers: a trajectory's knot is six cache lines).
-// TILED  [tile of 64 trajectories][knot][entry pair][trajectory in tile][2]: the layout of the trajectories and gains.  What
-//   k_linearize writes best -- its 64 lanes hold one knot of 64 consecutive trajectories, so a store instruction covers one
-//   contiguous kilobyte instead of 64 pieces of 64 different lines (the kernel was bound by the L2's request rate, not by
-//   bytes: 36 -> 23 us per launch at B = 1024 with every trajectory live, 325 -> 175 at B = 8192) -- and what the kernels
-//   that stage records through LDS read (k_backward4, k_backward2, k_solve4: one 16-byte load per lane and record).
+// TILED  [tile of TILE trajectories][knot][entry pair][slot][2]: the layout of the trajectories and gains.  What k_linearize
+//   writes best -- its 64 lanes hold one knot of 64 consecutive trajectories, so a 16-byte store per lane fills sixteen
+//   64-byte pieces instead of touching 64 different lines (the kernel was bound by the L2's request rate, not by bytes:
+//   36 -> 24 us per launch at B = 1024 with every trajectory live, 325 -> 189 at B = 8192) -- and what the kernels that
+//   stage records through LDS read (k_backward4, k_backward2, k_solve4: one 16-byte load per lane and record; a knot of
+//   k_backward4's four trajectories is 23 consecutive lines).
 // (Measured and dropped earlier: contiguous records written out through an LDS transpose -- padding, slower -- and the 64
 // records of a wavefront next to each other, [tile][knot][lane][stride], which changes nothing: each lane's stores still
 // go to a line of their own.)
 QILQR_HD long rec_base(const RecLayout &L, long b, long n) {
-  return L.tiled ? (b >> 6) * n * L.stride * 64 + (b & 63) * 2 : b * n * L.stride;
+  return L.tiled ? (b >> TILE_LOG) * n * L.stride * TILE + (b & (TILE - 1)) * 2 : b * n * L.stride;
 }
 QILQR_HD long rec_elem(const RecLayout &L, long i, int k) {
-  return L.tiled ? (i * (L.stride / 2) + (k >> 1)) * 128 + (k & 1) : i * L.stride + k;
+  return L.tiled ? (i * (L.stride / 2) + (k >> 1)) * TILE2 + (k & 1) : i * L.stride + k;
 }
 QILQR_HD long rec_count(long B, long n, int stride) { return ((B + 63) / 64) * 64 * n * stride; }  // (room for either form)
-// The linearisation hands its entries to a writer: put(k, v) stores entry k of the record.
+// The linearisation hands its entries to a writer: put(k, v) stores entry k of the record; flush() ends the record.
 template <typename T>
 struct PlainRecWriter {
   T *rec;
   QILQR_HD void put(int k, T v) const { rec[k] = v; }  // (non-temporal stores here are 6x slower: the L2 must merge them)
+  QILQR_HD void flush() const {}
 };
-// the same for the tiled placement: rec points at entry 0 of the knot; entry pairs are 128 elements apart
+// the same for the tiled placement: rec points at entry 0 of the knot; entry pairs are TILE2 elements apart.  The entries
+// arrive almost always in ascending order (the loops that produce them are unrolled, k is a constant at every call): an even
+// entry waits in a register for its odd neighbour and the two leave as one 16-byte store -- half the store instructions,
+// and each writes whole 64-byte pieces of the tiles' lines instead of every other eight bytes of them.
 template <typename T>
 struct TiledRecWriter {
   T *rec;
-  QILQR_HD void put(int k, T v) const { rec[(k >> 1) * 128 + (k & 1)] = v; }
+  mutable T pend = T(0);
+  mutable int pend_k = -1;  // the even entry that is waiting, or -1
+  QILQR_HD void put(int k, T v) const {
+    if ((k & 1) == 0) {
+      flush();
+      pend = v;
+      pend_k = k;
+    } else if (pend_k == k - 1) {
+#ifdef __HIPCC__
+      typedef T pair_t __attribute__((ext_vector_type(2)));
+      const pair_t pr = {pend, v};
+      *reinterpret_cast<pair_t *>(rec + (k >> 1) * TILE2) = pr;
+#else
+      rec[(k >> 1) * TILE2] = pend;
+      rec[(k >> 1) * TILE2 + 1] = v;
+#endif
+      pend_k = -1;
+    } else {
+      rec[(k >> 1) * TILE2 + 1] = v;
+    }
+  }
+  QILQR_HD void flush() const {
+    if (pend_k >= 0) rec[(pend_k >> 1) * TILE2] = pend;
+    pend_k = -1;
+  }
 };
 // symmetric layouts, rows i < 6 of C_xx in order of production: row i holds its part of the upper triangle
 // of the pose block (columns i..5) and, when the pose x velocity block is stored, its six entries of that

@@ -34,7 +34,7 @@ struct Solve4Slot {  // state of one trajectory of the block (LDS)
 // LDS of the block, at namespace scope so that the role wrappers below -- separate functions, each with its own register
 // allocation -- address it as LDS (a pointer handed to a non-inlined function would be generic: flat loads).  Inlined into
 // one kernel body the seven roles fight for 256 registers and the rollout's control wave spills 23 values per knot.
-__shared__ double s4_ring[4][4][BW2_BUF];
+__shared__ __attribute__((aligned(16))) double s4_ring[4][4][BW2_BUF];
 __shared__ double s4_kf[4][2][80];
 __shared__ R16Lds s4_r16;
 __shared__ Solve4Slot s4_slot[4];
@@ -75,12 +75,14 @@ __device__ __forceinline__ void solve4_linearize_lane(const ModelConsts<S> &cl, 
   const TiledRecWriter<S> w{(S *)st.lin[buf] + rec_base(st.layout, b, n) + rec_elem(st.layout, i, 0)};  // (tiled records: what bw4_loader_wave reads)
   if (half == 0) {
     linearize_dynamics(cl, pt, w);
+    w.flush();
     return;
   }
   S pd[18];
   if (st.desired_tiled) load_knot<true>((const S *)st.desired + knot_base<true>(b, n, 18), i, 18, pd);
   else load_knot<false>((const S *)st.desired, i, 18, pd);
   const S cost = linearize_cost<LK>(qr, qr + 144, pt, pd, w);
+  w.flush();
   st.knot_cost[buf][cost_index(b, i, n)] = (double)cost;  // summed in fp64 (settle)
 }
 

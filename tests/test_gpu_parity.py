@@ -237,12 +237,14 @@ def test_two_wave_backward_matches_single_wave():
         trajs = two.forward_sim(cfg["init"], np.zeros((B, n, 52)), 1.0)
         g2, t2 = two.backwards_pass(trajs)
         g1, t1 = one.backwards_pass(trajs)
-        # (the two kernels read records in different placements, written by two instantiations of k_linearize: in the mixed
-        # mode, where the records are computed in fp32, those may round differently)
-        rt = 1e-12 if prec == "f64" else 1e-6
+        # (the two kernels read records in different placements, written by two instantiations of k_linearize, which the
+        # compiler contracts into fused multiply-adds differently: the records agree to rounding, not bit for bit, and the
+        # recursion carries that to about 1e-11 of the largest gain -- each is as far from the oracle as from the other;
+        # in the mixed mode the records are computed in fp32)
+        rt = 1e-10 if prec == "f64" else 1e-6
         np.testing.assert_allclose(t2, t1, rtol=rt, atol=1e-300)
-        np.testing.assert_allclose(g2, g1, rtol=1e-11 if prec == "f64" else 1e-3,
-                                   atol=(1e-13 if prec == "f64" else 1e-4) * max(np.abs(g1).max(), 1e-300))
+        np.testing.assert_allclose(g2, g1, rtol=1e-9 if prec == "f64" else 1e-3,
+                                   atol=(5e-11 if prec == "f64" else 1e-4) * max(np.abs(g1).max(), 1e-300))
         # whole solves.  In the mixed mode the default tolerances (1e-12) are below what fp32 records can resolve, so the two
         # placements' rounding decides where a solve stops: there the kernels that share a placement (k_backward2, k_backward4)
         # are held to each other, and to the one-wavefront kernel by the final cost only
