@@ -1296,4 +1296,46 @@ int qilqr_debug_stamps(qilqr_solver *s, unsigned long long *out, int32_t B) {
 }
 #endif
 
+#ifdef QILQR_DIAG
+// diagnostic build only (make variant NAME=diag DEFS=-DQILQR_DIAG; profiles/microbench/beside.py): the rollout kernel of the
+// state a qilqr_forward_sim call left behind, `reps` times on the solver's stream, alone (beside = 0) or while a second
+// stream runs k_linearize launches back to back (beside = 1).  us[0]: microseconds per rollout launch; us[1]: per
+// linearisation launch.  Timing only: the linearisation reads the candidate while it is being written.
+int qilqr_debug_rollout_beside_linearize(qilqr_solver *s, int32_t B, int32_t n, int32_t reps, int32_t beside, float *us) {
+  HIP_TRY(hipSetDevice(s->device));
+  int rc;
+  if ((rc = ensure_parts(s, 1))) return rc;
+  hipEvent_t e[4];
+  for (auto &x : e) HIP_TRY(hipEventCreate(&x));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  hipStream_t main_stream = s->stream, side = s->part_stream[0];
+  const int nlin = 4 * reps;
+  if (beside) {
+    s->stream = side;
+    HIP_TRY(hipEventRecord(e[2], side));
+    for (int k = 0; k < nlin; ++k)
+      if ((rc = launch_linearize(s, B, n, 1, 0, -1))) break;
+    HIP_TRY(hipEventRecord(e[3], side));
+    s->stream = main_stream;
+    if (rc) return rc;
+  }
+  HIP_TRY(hipEventRecord(e[0], main_stream));
+  for (int k = 0; k < reps; ++k)
+    if ((rc = launch_rollout(s, B, n, 0))) return rc;
+  HIP_TRY(hipEventRecord(e[1], main_stream));
+  HIP_TRY(hipStreamSynchronize(main_stream));
+  HIP_TRY(hipStreamSynchronize(side));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e[0], e[1]));
+  us[0] = 1e3f * ms / reps;
+  us[1] = 0.f;
+  if (beside) {
+    HIP_TRY(hipEventElapsedTime(&ms, e[2], e[3]));
+    us[1] = 1e3f * ms / nlin;
+  }
+  for (auto &x : e) HIP_TRY(hipEventDestroy(x));
+  return QILQR_OK;
+}
+#endif
+
 }  // extern "C"
