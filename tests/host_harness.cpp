@@ -176,6 +176,33 @@ void hh_linearize(const ModelConsts<double> *c, const int *lay, const double *tr
   const RecLayout L = layout_from(lay);
   for (int i = 0; i < n; ++i) linearize_knot(*c, L, traj + i * 18, desired + i * 18, lin + (long)i * L.stride);
 }
+// the tiled placement of the records (se3_math.h: rec_base / rec_elem, TiledRecWriter's paired stores): B trajectories of n knots
+// are linearised through the tiled writer into `tiled` (rec_count(B, n, stride) doubles, pre-filled by the caller) and read
+// back entry by entry into the plain [B][n][stride] array `lin`; returns TILE
+int hh_linearize_tiled(const ModelConsts<double> *c, const int *lay, const double *traj, const double *desired, int B, int n,
+                       double *tiled, double *lin) {
+  RecLayout L = layout_from(lay);
+  L.tiled = 1;
+  for (int b = 0; b < B; ++b)
+    for (int i = 0; i < n; ++i) {
+      const double *pt = traj + ((long)b * n + i) * 18, *pd = desired + (long)i * 18;
+      const TiledRecWriter<double> w{tiled + rec_base(L, b, n) + rec_elem(L, i, 0)};
+      linearize_dynamics(*c, pt, w);
+      w.flush();
+      switch (layout_kind(L)) {
+        case 0: linearize_cost<0>(c->Q, c->R, pt, pd, w); break;
+        case 1: linearize_cost<1>(c->Q, c->R, pt, pd, w); break;
+        default: linearize_cost<2>(c->Q, c->R, pt, pd, w); break;
+      }
+      w.flush();
+    }
+  for (int b = 0; b < B; ++b)
+    for (int i = 0; i < n; ++i)
+      for (int k = 0; k < L.stride; ++k)
+        lin[((long)b * n + i) * L.stride + k] = tiled[rec_base(L, b, n) + rec_elem(L, i, k)];
+  return TILE;
+}
+long hh_rec_count(int B, int n, int stride) { return rec_count(B, n, stride); }
 void hh_rollout(const ModelConsts<double> *c, const double *traj, const double *gains, double alpha, double *out,
                 int n) {
   rollout_problem<false>(*c, traj, gains, alpha, out, n);

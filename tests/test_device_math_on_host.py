@@ -108,6 +108,30 @@ def test_knot_records_match_oracle(hh, seed, dense):
         np.testing.assert_allclose(lin[i, lay[3] + 12:lay[3] + 16], D["u"], rtol=1e-12, atol=1e-13)
 
 
+@pytest.mark.parametrize("seed,dense", [(4, False), (5, True), (6, "sym")])
+def test_tiled_placement_of_the_records_is_a_permutation_of_the_plain_one(hh, seed, dense):
+    """rec_base / rec_elem and the paired stores of TiledRecWriter (what k_linearize writes for k_backward4, k_backward2
+    and k_solve4): the same entries as the plain records, bit for bit, each in a place of its own (nothing else of the
+    buffer is touched), for batches that do not fill their last tile"""
+    model, Q, R, _, desired = random_problem(seed, n=5, dense=dense)
+    c = consts(hh, model, Q, R, 0.1)
+    lay = layout(hh, c)
+    B, n, stride = 7, 5, int(lay[5])
+    trajs = np.stack([random_problem(100 * seed + b, n=n, dense=dense)[3] for b in range(B)])
+    plain = np.zeros((B, n, stride))
+    for b in range(B):
+        hh.hh_linearize(P(c), IP(lay), P(trajs[b]), P(desired), C.c_int(n), P(plain[b]))
+    hh.hh_rec_count.restype = C.c_long
+    count = hh.hh_rec_count(C.c_int(B), C.c_int(n), C.c_int(stride))
+    tiled = np.full(count, np.nan)
+    back = np.zeros((B, n, stride))
+    tile = hh.hh_linearize_tiled(P(c), IP(lay), P(trajs), P(desired), C.c_int(B), C.c_int(n), P(tiled), P(back))
+    assert tile in (4, 8, 16, 32, 64)
+    used = lay[4] + 1  # entries a record holds (the stride is rounded up to an even number)
+    np.testing.assert_array_equal(back[..., :used], plain[..., :used])
+    assert np.isfinite(tiled).sum() == B * n * used  # every entry written once, to a place of its own
+
+
 def test_knot_records_across_series_branches(hh):
     # the linearisation's Jacobian coefficients switch between manif's small-angle constants
     # (theta^2 <= 1e-10), power series (theta^2 <= 0.25 / 0.26) and the closed forms: sweep the step
