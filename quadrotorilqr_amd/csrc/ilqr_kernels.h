@@ -133,7 +133,7 @@ __device__ __forceinline__ double cost_reduction(double QuTk, double kTQuuk, dou
 // LK: layout kind of the records (se3_math.h, layout_kind).
 // ---------------------------------------------------------------------------------------------
 #ifndef QILQR_LIN_WAVES
-#define QILQR_LIN_WAVES 4  // register budget of k_linearize in waves per SIMD (3 avoids its few spills but the next k_backward then runs 3% slower)
+#define QILQR_LIN_WAVES 3  // register budget of k_linearize in waves per SIMD: no spills (with 4, and the records' paired stores, 200-300 bytes of scratch per lane: 23.9 against 21.6 us per launch with every trajectory live, -1.7 % of a solve at B = 1024)
 #endif
 template <typename S, int LK, int INTEG, bool TILED>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(QILQR_LIN_WAVES, QILQR_LIN_WAVES))) void
