@@ -311,11 +311,11 @@ int download_tiled(qilqr_solver *s, double *h_plain, void *t0, void *t1, const i
 }
 
 int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag, int round = -1) {
-  const dim3 grid(cdiv(2 * ((B + 63) / 64) * 64 * n, 128));  // dynamics half + cost half
+  const dim3 grid(cdiv(2 * ((B + 63) / 64) * 64 * n, QILQR_LIN_BLOCK));  // dynamics half + cost half
 #define QILQR_LAUNCH_LIN(S, LK, TILED, CONSTS, DCONSTS) \
-  launch(s, K_LINEARIZE, (k_linearize<S, LK, 0, TILED>), grid, dim3(128), CONSTS, DCONSTS, s->st, (int)B, (int)n, which, need_flag, round)
+  launch(s, K_LINEARIZE, (k_linearize<S, LK, 0, TILED>), grid, dim3(QILQR_LIN_BLOCK), CONSTS, DCONSTS, s->st, (int)B, (int)n, which, need_flag, round)
 #define QILQR_LAUNCH_LIN_RK4(LK) \
-  launch(s, K_LINEARIZE, (k_linearize<double, LK, 1, false>), grid, dim3(128), s->consts, (const ModelConsts<double> *)s->d_consts, s->st, (int)B, (int)n, which, need_flag, round)
+  launch(s, K_LINEARIZE, (k_linearize<double, LK, 1, false>), grid, dim3(QILQR_LIN_BLOCK), s->consts, (const ModelConsts<double> *)s->d_consts, s->st, (int)B, (int)n, which, need_flag, round)
   if (s->integrator == 1) {  // the Runge-Kutta extension: dense M at the head of the record, fp64 only, plain placement
     switch (layout_kind(s->layout)) {
       case 0: QILQR_LAUNCH_LIN_RK4(0); break;

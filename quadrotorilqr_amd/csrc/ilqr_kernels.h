@@ -132,11 +132,14 @@ __device__ __forceinline__ double cost_reduction(double QuTk, double kTQuuk, dou
 // need_flag: only problems whose flags contain it (0 = all).  round >= 0: publish the active count.
 // LK: layout kind of the records (se3_math.h, layout_kind).
 // ---------------------------------------------------------------------------------------------
+#ifndef QILQR_LIN_BLOCK
+#define QILQR_LIN_BLOCK 128
+#endif
 #ifndef QILQR_LIN_WAVES
 #define QILQR_LIN_WAVES 3  // register budget of k_linearize in waves per SIMD: no spills (with 4, and the records' paired stores, 200-300 bytes of scratch per lane: 23.9 against 21.6 us per launch with every trajectory live, -1.7 % of a solve at B = 1024)
 #endif
 template <typename S, int LK, int INTEG, bool TILED>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(QILQR_LIN_WAVES, QILQR_LIN_WAVES))) void
+__global__ __launch_bounds__(QILQR_LIN_BLOCK) __attribute__((amdgpu_waves_per_eu(QILQR_LIN_WAVES, QILQR_LIN_WAVES))) void
 k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState st, int B, int n, int which,
             int need_flag, int round) {
   // The weights Q (144) and R (16) are more constants than a wave has scalar registers: the block keeps
@@ -144,7 +147,7 @@ k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState 
   // them; everything else comes from the by-value copy c.
   // (one copy per wavefront, filled by the wavefronts of the cost half only and without a block barrier: the
   // dynamics half does not wait for weights it never reads)
-  __shared__ S qr_all[2][160];
+  __shared__ S qr_all[QILQR_LIN_BLOCK / 64][160];
   S *qr = qr_all[threadIdx.x >> 6];
   // thread -> (half, tile, knot, lane): the 64 lanes of a wavefront hold one knot of 64 consecutive trajectories
   long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -176,8 +179,11 @@ k_linearize(ModelConsts<S> c, const ModelConsts<S> *__restrict__ cp, BatchState 
                          __HIP_MEMORY_SCOPE_SYSTEM);
   }
   const long per_half = (long)((B + 63) / 64) * n * 64;
-  const bool cost_half = id >= per_half;
-  if (cost_half) id -= per_half;
+  // the cost half, the longer of the two (lone-wave time 8.6 against 4.6 us), takes the first half of the grid: at 3 200
+  // wavefronts for 3 072 places (B = 1024, three per SIMD) the ones that wait for a place are then short ones
+  // (21.8 -> 19.2 us per launch with every trajectory live)
+  const bool cost_half = id < per_half;
+  if (!cost_half) id -= per_half;
   if (id >= per_half) return;  // grid padding (whole wavefronts)
   const int lane = (int)(id & 63);
   const long rest = id >> 6;
