@@ -77,7 +77,7 @@ typedef struct {
                          configuration is given): it reads the count k rounds late, i.e. keeps the stream k rounds
                          ahead of the device (k <= 6).  The results do not depend on it. */
   int32_t force_general; /* backward kernel.  0: by the weights and the batch (symmetric Q, R: k_backward2 -- a matrix
-                            and a gradient wavefront per trajectory -- up to 640 trajectories, k_backward4 -- one
+                            and a gradient wavefront per trajectory -- below 512 trajectories, k_backward4 -- one
                             gradient and one loader wavefront per four trajectories -- up to 8192, one wavefront
                             per trajectory beyond); 1: the general kernel even when Q, R are symmetric; 2: the
                             one-wavefront kernel for symmetric weights (k_backward<true>); 3: k_backward2;

@@ -345,16 +345,17 @@ int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag, 
 }
 // Which backward kernel a call with `load_B` trajectories in flight takes (symmetric weights), by how many trajectories share
 // the chip's 1024 SIMDs:
-//   up to 640: k_backward2 (a matrix and a gradient wavefront per trajectory, each alone on its SIMD)
+//   below 512: k_backward2 (a matrix and a gradient wavefront per trajectory, each alone on its SIMD)
 //   up to 8192: k_backward4 (one gradient and one loader wavefront per four trajectories: fewer co-resident
 //               waves; whole solves: 205k against 190k solves/s at 2048, 275k against 265k at 4096, 372k
-//               against 357k at 8192; equal at 512)
+//               against 357k at 8192; with tiles of four 86.3k against 85.3k at 512, 106.9k against 104.5k at 640,
+//               61.1k against 62.3k at 256)
 //   beyond: one wavefront per trajectory (the matrix pipe is the bound)
 // The Runge-Kutta extension and non-symmetric weights take the one-wavefront kernel at every size.
 enum BackwardKind { BW_FOUR, BW_TWO, BW_ONE };
 BackwardKind backward_kind(const qilqr_solver *s, long load_B) {
   if (s->integrator == 1 || !s->symmetric) return BW_ONE;
-  if (s->dev.force_general == 4 || (s->dev.force_general == 0 && load_B > 640 && load_B <= 8192)) return BW_FOUR;
+  if (s->dev.force_general == 4 || (s->dev.force_general == 0 && load_B >= 512 && load_B <= 8192)) return BW_FOUR;
   if (s->dev.force_general == 3 || (s->dev.force_general != 2 && load_B <= 8192)) return BW_TWO;
   return BW_ONE;
 }

@@ -611,7 +611,7 @@ def test_config2_full_size_properties():
     np.testing.assert_array_equal(out_p["traj"], out["traj"][perm])
     np.testing.assert_array_equal(out_p["iters"], out["iters"][perm])
     # A batch of one gives the same result as the same problem inside the batch.  Not the same bits: the
-    # backward kernel is chosen by batch size (k_backward2 below 640 trajectories, k_backward4 above) and the
+    # backward kernel is chosen by batch size (k_backward2 below 512 trajectories, k_backward4 from there) and the
     # two sum the twelve terms of M^T V_x in different orders; measured difference 2e-15.
     one = s.solve_batch(cfg["init"][17:18])
     assert one["iters"][0] == out["iters"][17] and one["status"][0] == out["status"][17]
