@@ -49,13 +49,17 @@ QILQR_HD int m_source(int row, int col, const double *Bu, double *cst) {
 // Constant operand table (device memory, built once per solver): entries that do not change from
 // knot to knot are read through the same unconditional loads as the record entries, so that the
 // loads of knot i-1 can be issued before the chain of knot i and nothing selects on their result.
-//   [0] = 0, [1] = 1, [2..49] = J_u (12x4), [50..193] = 2 Q (12x12)
-constexpr int CTAB_ZERO = 0, CTAB_ONE = 1, CTAB_BU = 2, CTAB_2Q = 50, CTAB_SIZE = 194;
+//   [0] = 0, [1] = 1, [2..49] = J_u (12x4), [50..85] = 2 Q[6:12, 6:12] (the velocity block of C_xx, the only constant part
+//   of it that a symmetric layout reads from the table: cxx_source_tab).  86 entries: the kernels that stage records
+//   through LDS keep a copy behind every ring slot, and at 194 entries (all of 2 Q, round 1) k_backward4's 46 KB of LDS
+//   allowed three blocks per CU where 33 KB allow four
+constexpr int CTAB_ZERO = 0, CTAB_ONE = 1, CTAB_BU = 2, CTAB_2Q = 50, CTAB_SIZE = 86;
 QILQR_HD void build_ctab(const double *Bu, const double *Q, double *tab) {
   tab[CTAB_ZERO] = 0.0;
   tab[CTAB_ONE] = 1.0;
   for (int i = 0; i < 48; ++i) tab[CTAB_BU + i] = Bu[i];
-  for (int i = 0; i < 144; ++i) tab[CTAB_2Q + i] = 2.0 * Q[i];
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) tab[CTAB_2Q + r * 6 + c] = 2.0 * Q[(6 + r) * 12 + 6 + c];
 }
 // the same for a record of layout L: with the dense M of the Runge-Kutta extension (RecLayout.dense_m) every element of
 // M is an entry of the record -- J_u too, it depends on the state there
@@ -82,7 +86,7 @@ QILQR_HD int cxx_source_tab(const RecLayout &L, int row, int col) {
   const int i = row < col ? row : col, j = row < col ? col : row;
   if (j < 6) return L.off_cxx + symrow_index(!L.ur_zero, i, j);
   if (i < 6) return L.ur_zero ? -1 - CTAB_ZERO : L.off_cxx + symrow_index(true, i, j);
-  return -1 - (CTAB_2Q + row * 12 + col);
+  return -1 - (CTAB_2Q + (row - 6) * 6 + (col - 6));  // (i >= 6 here: both indices are in the velocity block)
 }
 
 }  // namespace qilqr

@@ -375,10 +375,16 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
   const BackwardKind kind = s->st.layout.tiled ? backward_kind(s, load_B) : BW_ONE;
   if (kind == BW_FOUR) {
     // four matrix wavefronts + one gradient wavefront + one loader wavefront per four trajectories
-    if (s->f32)
-      launch(s, K_BACKWARD, k_backward4<float>, dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
+    // (register budget by how many blocks the chip has to hold: see k_backward4)
+    const bool many = load_B > 4096;
+    if (s->f32 && many)
+      launch(s, K_BACKWARD, (k_backward4<float, 6>), dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
+    else if (s->f32)
+      launch(s, K_BACKWARD, (k_backward4<float, 5>), dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
+    else if (many)
+      launch(s, K_BACKWARD, (k_backward4<double, 6>), dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
     else
-      launch(s, K_BACKWARD, k_backward4<double>, dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
+      launch(s, K_BACKWARD, (k_backward4<double, 5>), dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
   } else if (kind == BW_TWO) {
     // two cooperating wavefronts per trajectory (matrix recursion / gradient recursion + operand streaming):
     // shortens one trajectory's chain; above ~8 trajectories per SIMD the chip is bound by the matrix pipe and

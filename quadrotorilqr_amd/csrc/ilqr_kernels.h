@@ -1351,8 +1351,12 @@ __device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], d
 #endif
 }
 
-template <typename S>
-__global__ __launch_bounds__(384) void k_backward4(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n,
+// WAVES: register budget in waves per SIMD.  5 (90 registers, nothing spilled): three blocks per CU, the fastest single
+// block; 6 (80 registers, four of them spilled outside the knot loop): four blocks per CU -- with 33 KB of LDS per block the
+// registers are what decides -- for the launches that have more than three blocks per CU to run (B = 8192 in two parts:
+// 404 000 -> 412 000 solves/s; nothing at 4096, -0.5 % at 1024)
+template <typename S, int WAVES>
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_backward4(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n,
                                                    int force) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0..3: matrix wave of trajectory b0 + w; 4: G; 5: L
