@@ -231,20 +231,20 @@ inline double max_restarts(const SolveParams &p) {
 // (zero_word: an int the same launch sets to zero -- the group queue of a persistent solve that follows)
 int to_tiled(qilqr_solver *s, const double *d_plain, void *tiled, long B, long n, int W, int *zero_word = nullptr) {
   if (s->f32)
-    launch(s, K_OTHER, k_retile<float>, dim3(cdiv(B * n * W, 256)), dim3(256), d_plain, (double *)nullptr,
+    launch(s, K_OTHER, k_retile<float>, dim3((unsigned)cdiv(B, TILE), (unsigned)cdiv(n * (W / 2) * TILE, 256)), dim3(256), d_plain, (double *)nullptr,
                        (float *)tiled, (float *)tiled, (const int *)nullptr, 0, (int)B, (int)n, W, 1, zero_word);
   else
-    launch(s, K_OTHER, k_retile<double>, dim3(cdiv(B * n * W, 256)), dim3(256), d_plain,
+    launch(s, K_OTHER, k_retile<double>, dim3((unsigned)cdiv(B, TILE), (unsigned)cdiv(n * (W / 2) * TILE, 256)), dim3(256), d_plain,
                        (double *)nullptr, (double *)tiled, (double *)tiled, (const int *)nullptr, 0, (int)B, (int)n, W, 1, zero_word);
   return QILQR_OK;
 }
 // tiled -> plain [B][n][W] fp64 (device); sel/flip choose between t0 and t1 per trajectory
 int from_tiled(qilqr_solver *s, double *d_plain, void *t0, void *t1, const int *sel, int flip, long B, long n, int W) {
   if (s->f32)
-    launch(s, K_OTHER, k_retile<float>, dim3(cdiv(B * n * W, 256)), dim3(256), (const double *)nullptr,
+    launch(s, K_OTHER, k_retile<float>, dim3((unsigned)cdiv(B, TILE), (unsigned)cdiv(n * (W / 2) * TILE, 256)), dim3(256), (const double *)nullptr,
                        d_plain, (float *)t0, (float *)t1, sel, flip, (int)B, (int)n, W, 0, (int *)nullptr);
   else
-    launch(s, K_OTHER, k_retile<double>, dim3(cdiv(B * n * W, 256)), dim3(256), (const double *)nullptr,
+    launch(s, K_OTHER, k_retile<double>, dim3((unsigned)cdiv(B, TILE), (unsigned)cdiv(n * (W / 2) * TILE, 256)), dim3(256), (const double *)nullptr,
                        d_plain, (double *)t0, (double *)t1, sel, flip, (int)B, (int)n, W, 0, (int *)nullptr);
   return QILQR_OK;
 }
@@ -668,10 +668,10 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
 int gather(qilqr_solver *s, long B, long n, double *d_traj, double *d_cost, int *d_status, int *d_iters,
            int *d_bwd, int *d_fwd) {
   if (s->f32)
-    launch(s, K_OTHER, k_gather<float>, dim3(cdiv(B * n * 18, 256)), dim3(256), s->st, (int)B, (int)n,
+    launch(s, K_OTHER, k_gather<float>, dim3((unsigned)cdiv(B, TILE), (unsigned)cdiv(n * 9 * TILE, 256)), dim3(256), s->st, (int)B, (int)n,
                        d_traj, d_cost, d_status, d_iters, d_bwd, d_fwd);
   else
-    launch(s, K_OTHER, k_gather<double>, dim3(cdiv(B * n * 18, 256)), dim3(256), s->st, (int)B, (int)n,
+    launch(s, K_OTHER, k_gather<double>, dim3((unsigned)cdiv(B, TILE), (unsigned)cdiv(n * 9 * TILE, 256)), dim3(256), s->st, (int)B, (int)n,
                        d_traj, d_cost, d_status, d_iters, d_bwd, d_fwd);
   return QILQR_OK;
 }
