@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--shards", choices=("same", "distinct"), default="same",
+                    help="config 1 with N > 1: 'same' = every rank solves the configs[1] batch itself (the problems of the N = 1 line: per-GPU work exactly fixed); "
+                         "'distinct' = rank r solves shard (r + step) mod N of N x 1024 distinct problems")
     ap.add_argument("--config", type=int, default=1, choices=(1, 3),
                     help="BASELINE.json configs[k]: 1 = B 1024 per GPU (weak scaling, default); 3 = one batch of 65536 sharded over the GPUs (strong scaling)")
     ap.add_argument("--batch", type=int, default=0, help="config 1: problems per GPU (default 1024); config 3: problems in total (default 65536)")
@@ -143,23 +146,33 @@ def main():
         cfg = pb.config2(B=B, N=N, seed=seed, b0=lo)  # counter-based generator: keyed by the global problem index
         shard_at = lambda step: list(range(world))
     else:
-        # configs[1]: 1024 problems per GPU; the global batch of a step is the N shards of 1024 distinct problems
-        # (shard k = problems k*B .. (k+1)*B of the generator); rank r solves shard (r + step) mod N.  How long a shard
-        # takes is set by its slowest problem (31 to 45 rollouts over the first eight shards), so a fixed assignment
-        # would make every step wait for the same unlucky rank; rotating it evens the ranks' totals over the steps
-        # without any exchange (sharding.shard_of_step).
+        # configs[1]: 1024 problems per GPU, weak scaling.  How long a batch takes is set by its slowest problem, and the
+        # 1024-problem shards of one seeded sequence differ in that (the first eight: 30 to 45 rollouts, 4.96 to 6.81 ms,
+        # shard 0 -- the N = 1 line -- 6 % faster than their mean: profiles/microbench/shard_times.py), so with distinct
+        # shards value_N / (N value_1) measures which shards N brings in, not the machine.
+        #   --shards same (default): every rank solves the configs[1] batch itself -- the per-GPU work is exactly that of
+        #     the N = 1 line, and the gather still moves every rank's trajectories to rank 0;
+        #   --shards distinct: the global batch of a step is N shards of 1024 distinct problems (shard k = problems
+        #     k*B .. (k+1)*B of the generator) and rank r solves shard (r + step) mod N: a fixed assignment would make
+        #     every step wait for the same unlucky rank, rotating it evens the ranks' totals over the steps without any
+        #     exchange (sharding.shard_of_step).
+        # (One batch of distinct problems cut over the GPUs is --config 3.)
         B, seed = args.batch or 1024, 2
         B_total = B * world
         sizes = [B] * world
-        cfg = pb.config2(B=B, N=N, seed=seed, b0=rank * B)
-        shard_at = lambda step: [sharding.shard_of_step(r, step, world) for r in range(world)]
+        same = args.shards == "same"
+        cfg = pb.config2(B=B, N=N, seed=seed, b0=0 if same else rank * B)
+        if same:
+            shard_at = lambda step: list(range(world))
+        else:
+            shard_at = lambda step: [sharding.shard_of_step(r, step, world) for r in range(world)]
     solver = capi.from_config(cfg, device=dev.index, profile=(0 if args.no_profile else (2 if args.profile_all else 1)), sync_every=args.sync_every,
                               force_general=args.backward, streams=args.streams, persistent=args.persistent,
                               **({} if args.rollout < 0 else dict(single_wave_rollout=args.rollout)))
 
     init = torch.from_numpy(cfg["init"]).to(dev)
     inits = {rank: init}  # by shard index
-    if not strong:
+    if not strong and not same:
         for sh in range(world):
             if sh not in inits:
                 inits[sh] = torch.from_numpy(pb.config2(B=B, N=N, seed=seed, b0=sh * B)["init"]).to(dev)
@@ -426,6 +439,7 @@ def main():
             conf = {"workload": workload, "batch_per_gpu": B, "knots": N,
                     "parallelism": f"batch-shard x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
                     "shard_assignment": ("one shard" if world == 1 else
+                                         f"every rank solves the {B} problems of the N = 1 line (--shards same)" if same else
                                          f"{world} shards of {B} distinct problems per step; rank r solves shard (r + step) mod {world}")}
         line = {
             "metric": "iLQR solves/sec (batch, 100-knot SE(3) quadrotor)", "value": value, "unit": "solves/s",

@@ -49,10 +49,12 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
 
 
 @pytest.mark.gpu
-def test_two_rank_code_path_on_one_gpu():
+@pytest.mark.parametrize("shards", ["same", "distinct"])
+def test_two_rank_code_path_on_one_gpu(shards):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with the test
-    hook that puts both ranks on GPU 0 over gloo: rotating shard assignment, the gather to rank 0 inside the
-    timed region, max-over-ranks timing, one JSON line from rank 0 only."""
+    hook that puts both ranks on GPU 0 over gloo: the default weak-scaling workload (every rank solves the N = 1 line's
+    problems) and the rotating assignment of distinct shards, the gather to rank 0 inside the timed region,
+    max-over-ranks timing, one JSON line from rank 0 only."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -61,7 +63,7 @@ def test_two_rank_code_path_on_one_gpu():
     env = dict(os.environ, QILQR_BENCH_ONE_DEVICE_TEST="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                          "--gpus", "2", "--steps", "4", "--warmup", "1"] + ([] if shards == "same" else ["--shards", "distinct"]),
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -70,7 +72,11 @@ def test_two_rank_code_path_on_one_gpu():
     assert j["n_gpus"] == 2 and j["steps"] == 4 and j["scaling"] == "weak"
     assert j["cpu_baseline"] is None  # rank 0 at N = 1 only
     assert abs(j["value"] - 2 * 1024 * 1e3 / j["ms_per_step"]) / j["value"] < 1e-6
-    assert "shard (r + step) mod 2" in j["config"]["shard_assignment"]
+    if shards == "same":
+        assert "problems of the N = 1 line" in j["config"]["shard_assignment"]
+        assert j["iters_max"] == 32  # configs[1]'s slowest problem (BENCH line of N = 1), on every rank
+    else:
+        assert "shard (r + step) mod 2" in j["config"]["shard_assignment"]
     assert j["status_counts"][2] == 0 and j["status_counts"][3] == 0  # every problem of the last shard converged
     assert j["gather_ms"] > 0 and j["host_to_host"] is None and j["large_batch"] is None
 
