@@ -3,9 +3,10 @@
 
 Default (what the driver runs): BASELINE.json configs[1] -- B = 1024 random SE(3) starts per GPU, 100 knots, fp64,
 model A.  One "step" = one batched solve of the whole per-GPU batch, inputs already resident
-in HBM.  N > 1: launched by torch.distributed.run, one rank per GPU; each rank solves its own shard of 1024 problems
-(weak scaling, no data-path collective) and the converged trajectories are gathered on rank 0 over RCCL inside the
-timed region.
+in HBM.  N > 1: launched by torch.distributed.run, one rank per GPU; each rank solves 1024 problems per step -- by
+default the configs[1] batch itself, so that the per-GPU work is exactly the N = 1 line's (--shards distinct: its own
+shard of N x 1024 distinct problems) -- weak scaling, no data-path collective, and the converged trajectories are
+gathered on rank 0 over RCCL inside the timed region.
 
 --config 3: BASELINE.json configs[3] as specified -- ONE batch of 65536 problems (seed 4) cut into contiguous shards
 over the N ranks (8192 per GPU at N = 8; strong scaling: the same total batch at every N), RCCL gather of the
