@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: average k_linearize launch time through qilqr_cost_trajectory (profile = 2).
-usage: linearize_time.py [lib.so ...]"""
+usage: [BLIST=16,1024] linearize_time.py [lib.so ...]   (B = 16: the lone-wave time of the longer half plus launch)"""
 import os
 import sys
 
@@ -14,7 +14,7 @@ libs = sys.argv[1:] or [capi.LIB_PATH]
 for lib in libs:
     capi.LIB_PATH = os.path.abspath(lib)
     capi._lib = None
-    for B in (1024, 8192):
+    for B in [int(x) for x in os.environ.get("BLIST", "1024,8192").split(",")]:
         cfg = pb.config2(B=B, N=100)
         s = capi.from_config(cfg, profile=2)
         traj = s.forward_sim(cfg["init"], np.zeros((B, 100, 52)), 1.0)
