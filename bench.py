@@ -3,10 +3,12 @@
 
 Default (what the driver runs): BASELINE.json configs[1] -- B = 1024 random SE(3) starts per GPU, 100 knots, fp64,
 model A.  One "step" = one batched solve of the whole per-GPU batch, inputs already resident
-in HBM.  N > 1: launched by torch.distributed.run, one rank per GPU; each rank solves 1024 problems per step -- by
-default the configs[1] batch itself, so that the per-GPU work is exactly the N = 1 line's (--shards distinct: its own
-shard of N x 1024 distinct problems) -- weak scaling, no data-path collective, and the converged trajectories are
-gathered on rank 0 over RCCL inside the timed region.
+in HBM.  N > 1: launched by torch.distributed.run, one rank per GPU; a step solves N x 1024 DISTINCT problems (shard k =
+problems k*1024 .. (k+1)*1024 of the configs[1] generator; rank r solves shard (r + step) mod N) -- weak scaling, no
+data-path collective, and the converged trajectories are gathered on rank 0 over RCCL inside the timed region.  The
+line also carries `shard_rounds` (the rollouts of every shard's slowest problem: the straggler that sets a shard's
+time) and, from a short leg after the timed region in which every rank solves shard 0 (--shards same as a
+diagnostic), `same_shard.machine_efficiency`: the machine's own scaling with the per-GPU work exactly fixed.
 
 --config 3: BASELINE.json configs[3] as specified -- ONE batch of 65536 problems (seed 4) cut into contiguous shards
 over the N ranks (8192 per GPU at N = 8; strong scaling: the same total batch at every N), RCCL gather of the
@@ -92,9 +94,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--shards", choices=("same", "distinct"), default="same",
-                    help="config 1 with N > 1: 'same' = every rank solves the configs[1] batch itself (the problems of the N = 1 line: per-GPU work exactly fixed); "
-                         "'distinct' = rank r solves shard (r + step) mod N of N x 1024 distinct problems")
+    ap.add_argument("--shards", choices=("same", "distinct"), default="distinct",
+                    help="config 1 with N > 1: 'distinct' (default) = a step is N x 1024 distinct problems, rank r solves shard (r + step) mod N; "
+                         "'same' = diagnostic: every rank solves shard 0 (the problems of the N = 1 line: per-GPU work exactly fixed)")
     ap.add_argument("--config", type=int, default=1, choices=(1, 3),
                     help="BASELINE.json configs[k]: 1 = B 1024 per GPU (weak scaling, default); 3 = one batch of 65536 sharded over the GPUs (strong scaling)")
     ap.add_argument("--batch", type=int, default=0, help="config 1: problems per GPU (default 1024); config 3: problems in total (default 65536)")
@@ -102,7 +104,8 @@ def main():
     ap.add_argument("--sync-every", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="HIP events around every kernel, not only the two candidates for dominant kernel")
-    ap.add_argument("--rollout", type=int, default=-1, help="rollout kernel: 0 pose + control + loader waves, 1 single wave (default: library default)")
+    ap.add_argument("--rollout", type=int, default=-1, help="rollout kernel (qilqr_device_config.single_wave_rollout): 0 by the batch (k_rollout16 up to 4096 trajectories, k_rollout3 up to 16384, k_rollout beyond), "
+                                                             "1 k_rollout, 2 k_rollout3, 3 k_rollout16 (default: library default)")
     ap.add_argument("--backward", type=int, default=0, help="diagnostic: backward kernel (qilqr_device_config.force_general: 0 automatic, 1 general, 2 one wavefront per trajectory)")
     ap.add_argument("--persistent", type=int, default=0, help="qilqr_device_config.persistent: 0 by the batch, 1 the solve as one launch (k_solve4), 2 rounds of three launches")
     ap.add_argument("--streams", type=int, default=0, help="sub-batches on their own streams (qilqr_device_config.streams; 0 automatic)")
@@ -149,14 +152,14 @@ def main():
     else:
         # configs[1]: 1024 problems per GPU, weak scaling.  How long a batch takes is set by its slowest problem, and the
         # 1024-problem shards of one seeded sequence differ in that (the first eight: 30 to 45 rollouts, 4.96 to 6.81 ms,
-        # shard 0 -- the N = 1 line -- 6 % faster than their mean: profiles/microbench/shard_times.py), so with distinct
-        # shards value_N / (N value_1) measures which shards N brings in, not the machine.
-        #   --shards same (default): every rank solves the configs[1] batch itself -- the per-GPU work is exactly that of
-        #     the N = 1 line, and the gather still moves every rank's trajectories to rank 0;
-        #   --shards distinct: the global batch of a step is N shards of 1024 distinct problems (shard k = problems
-        #     k*B .. (k+1)*B of the generator) and rank r solves shard (r + step) mod N: a fixed assignment would make
-        #     every step wait for the same unlucky rank, rotating it evens the ranks' totals over the steps without any
-        #     exchange (sharding.shard_of_step).
+        # shard 0 -- the N = 1 line -- 6 % faster than their mean: profiles/microbench/shard_times.py).  That spread IS
+        # the workload ("random SE(3) starts per GPU"), so it is measured, and shown in `shard_rounds`:
+        #   --shards distinct (default): the global batch of a step is N shards of 1024 distinct problems (shard k =
+        #     problems k*B .. (k+1)*B of the generator) and rank r solves shard (r + step) mod N: a fixed assignment would
+        #     make every step wait for the same unlucky rank, rotating it evens the ranks' totals over the steps without
+        #     any exchange (sharding.shard_of_step);
+        #   --shards same (diagnostic): every rank solves shard 0 -- the per-GPU work is exactly that of the N = 1 line.
+        #     The default run measures this too, in a short leg after the timed region (`same_shard`).
         # (One batch of distinct problems cut over the GPUs is --config 3.)
         B, seed = args.batch or 1024, 2
         B_total = B * world
@@ -173,6 +176,8 @@ def main():
 
     init = torch.from_numpy(cfg["init"]).to(dev)
     inits = {rank: init}  # by shard index
+    if not strong and same:
+        inits = {sh: init for sh in range(world)}  # every "shard" is shard 0
     if not strong and not same:
         for sh in range(world):
             if sh not in inits:
@@ -192,6 +197,8 @@ def main():
     step_no = [0]
     gathered = [None, None]  # per output buffer set: event after its last gather (N > 1)
     pass_knots = torch.zeros(2, dtype=torch.float64, device=dev)  # sum over the timed steps of n_bwd, n_fwd (this rank)
+    # per shard: the rollouts of its slowest problem (= the rounds its batch solve takes), as seen in the timed steps
+    shard_rounds = torch.zeros(world, dtype=torch.int32, device=dev)
     count_passes = [False]
 
     def gather(k, step):
@@ -209,6 +216,7 @@ def main():
                                   wait_current_stream=False)
         if count_passes[0] and world > 1:  # rotating shards: the pass counts differ from step to step
             pass_knots.add_(torch.stack([out_i[2].sum(), out_i[3].sum()]).to(torch.float64))
+            shard_rounds[sh] = torch.maximum(shard_rounds[sh], out_i[3].max())
         if world > 1:  # the one exchange of the path: converged trajectories to rank 0
             gather(k, step_no[0])
             gathered[k] = torch.cuda.Event()
@@ -261,7 +269,51 @@ def main():
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         gather_ms = float(tg.item()) * 1e3
 
+    # ---- diagnostic leg (N > 1, configs[1], after the timed region, never `value`): the machine's own scaling.  Every rank
+    # solves shard 0 -- exactly the N = 1 line's work -- with the gather, all ranks together; then rank 0 solves it alone.
+    same_shard = None
+    if world > 1 and not strong:
+        ks = max(2, min(args.steps, 10))
+        sor0 = list(range(world))
+
+        def same_step(k):
+            solver.solve_batch_device(inits[0], out_traj[k], out_cost[k], out_i[0], out_i[1], out_i[2], out_i[3],
+                                      wait_current_stream=False)
+            sharding.gather_to_root(to_wire(out_traj[k]), sizes, out=g_traj, shard_of_rank=sor0)
+            sharding.gather_to_root(to_wire(out_cost[k]), sizes, out=g_cost, shard_of_rank=sor0)
+
+        same_step(0)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(ks):
+            same_step(i & 1)
+        fence()
+        ts = to_wire(torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev))
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        alone = None
+        if rank == 0:  # (the other ranks wait at the barrier of the fence below, their GPUs idle)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(ks):
+                solver.solve_batch_device(inits[0], out_traj[0], out_cost[0], out_i[0], out_i[1], out_i[2], out_i[3],
+                                          wait_current_stream=False)
+            torch.cuda.synchronize()
+            alone = time.perf_counter() - t1
+        fence()
+        if rank == 0:
+            v_same, v_alone = B * world * ks / float(ts.item()), B * ks / alone
+            same_shard = {"what": f"every rank solves shard 0 (the N = 1 line's problems) + gather to rank 0, {ks} steps; then rank 0 alone, {ks} steps",
+                          "value": v_same, "ms_per_step": float(ts.item()) / ks * 1e3, "one_rank_alone_value": v_alone,
+                          "machine_efficiency": v_same / (world * v_alone)}
+        # (the last solve of this leg overwrote out_i with shard 0's counts: the line's iters/status are shard 0's)
+
     status, iters, n_bwd, n_fwd = (t.cpu().numpy() for t in out_i)
+    if world > 1:
+        sr = to_wire(shard_rounds.clone())
+        dist.all_reduce(sr, op=dist.ReduceOp.MAX)
+        shard_rounds_list = [int(v) for v in sr.cpu().numpy()]
+    else:
+        shard_rounds_list = [int(n_fwd.max())]
     total = B_total * args.steps
     value = total / dt
     if world > 1:
@@ -440,8 +492,8 @@ def main():
             conf = {"workload": workload, "batch_per_gpu": B, "knots": N,
                     "parallelism": f"batch-shard x{world}" + (" + RCCL gather to rank 0" if world > 1 else ""),
                     "shard_assignment": ("one shard" if world == 1 else
-                                         f"every rank solves the {B} problems of the N = 1 line (--shards same)" if same else
-                                         f"{world} shards of {B} distinct problems per step; rank r solves shard (r + step) mod {world}")}
+                                         f"every rank solves the {B} problems of the N = 1 line (--shards same, diagnostic)" if same else
+                                         f"distinct: {world} shards of {B} distinct problems per step; rank r solves shard (r + step) mod {world}")}
         line = {
             "metric": "iLQR solves/sec (batch, 100-knot SE(3) quadrotor)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -451,6 +503,8 @@ def main():
             "status_counts": np.bincount(status, minlength=4).tolist(),
             "knot_steps_per_s": knot_steps / dt,
             "gather_ms": gather_ms,
+            "shard_rounds": shard_rounds_list,  # per shard: rollouts of its slowest problem (the straggler sets a shard's time)
+            "same_shard": same_shard,
             "roofline": roofline, "cpu_baseline": cpu, "host_to_host": h2h, "large_batch": large, "serving": serving,
         }
         print(json.dumps(line))

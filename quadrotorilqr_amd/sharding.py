@@ -31,8 +31,23 @@ def shard_of_step(rank, step, world):
     return (rank + step) % world
 
 
+_warmed_groups = set()
+
+
+def _first_call_rendezvous(t, group):
+    """Once per process group: one tiny all-reduce that every rank enters.  The NCCL (RCCL) communicator of a group is
+    created lazily by the first operation on it and every rank must take part in that creation; a ragged gather in
+    which some shard is empty (B < world) is entered by the root and the non-empty ranks only, so without this the
+    first such call could wait for ranks that never come."""
+    key = id(group) if group is not None else None
+    if key in _warmed_groups:
+        return
+    dist.all_reduce(torch.zeros(1, dtype=torch.float32, device=t.device), group=group)
+    _warmed_groups.add(key)
+
+
 def gather_to_root(t, sizes, dst=0, group=None, out=None, shard_of_rank=None):
-    """Gather per-rank tensors on rank `dst` in SHARD order.
+    """Gather per-rank tensors on rank `dst` (a rank of `group`) in SHARD order.
 
     t              this rank's shard: first dimension = the size of the shard it holds
     sizes          size of every shard, in shard order
@@ -57,9 +72,12 @@ def gather_to_root(t, sizes, dst=0, group=None, out=None, shard_of_rank=None):
     if t.shape[0] != sizes[mine]:
         raise ValueError(f"rank {rank} holds shard {mine} of {sizes[mine]} rows but passed {t.shape[0]}")
     t = t.contiguous()
+    _first_call_rendezvous(t, group)
+    # ranks are ranks of `group` throughout; the point-to-point operations address their peers by global rank
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     if rank != dst:
         if t.shape[0] > 0:
-            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, dst, group)]):
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, peer(dst), group)]):
                 w.wait()
         return None
     if out is None:
@@ -71,7 +89,7 @@ def gather_to_root(t, sizes, dst=0, group=None, out=None, shard_of_rank=None):
         k = shard_of_rank[r]
         if r == dst or sizes[k] == 0:
             continue
-        ops.append(dist.P2POp(dist.irecv, out[offs[k]:offs[k + 1]], r, group))  # a contiguous row range: received in place
+        ops.append(dist.P2POp(dist.irecv, out[offs[k]:offs[k + 1]], peer(r), group))  # a contiguous row range: received in place
     works = dist.batch_isend_irecv(ops) if ops else []
     out[offs[mine]:offs[mine + 1]].copy_(t)
     for w in works:

@@ -52,9 +52,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
 @pytest.mark.parametrize("shards", ["same", "distinct"])
 def test_two_rank_code_path_on_one_gpu(shards):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with the test
-    hook that puts both ranks on GPU 0 over gloo: the default weak-scaling workload (every rank solves the N = 1 line's
-    problems) and the rotating assignment of distinct shards, the gather to rank 0 inside the timed region,
-    max-over-ranks timing, one JSON line from rank 0 only."""
+    hook that puts both ranks on GPU 0 over gloo: the default weak-scaling workload (N x 1024 distinct problems per step,
+    rotating assignment) and the diagnostic in which every rank solves the N = 1 line's problems, the gather to rank 0
+    inside the timed region, max-over-ranks timing, one JSON line from rank 0 only."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -63,7 +63,7 @@ def test_two_rank_code_path_on_one_gpu(shards):
     env = dict(os.environ, QILQR_BENCH_ONE_DEVICE_TEST="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--steps", "4", "--warmup", "1"] + ([] if shards == "same" else ["--shards", "distinct"]),
+                          "--gpus", "2", "--steps", "4", "--warmup", "1"] + ([] if shards == "distinct" else ["--shards", "same"]),
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -74,9 +74,14 @@ def test_two_rank_code_path_on_one_gpu(shards):
     assert abs(j["value"] - 2 * 1024 * 1e3 / j["ms_per_step"]) / j["value"] < 1e-6
     if shards == "same":
         assert "problems of the N = 1 line" in j["config"]["shard_assignment"]
-        assert j["iters_max"] == 32  # configs[1]'s slowest problem (BENCH line of N = 1), on every rank
-    else:
-        assert "shard (r + step) mod 2" in j["config"]["shard_assignment"]
+        assert j["shard_rounds"][0] == j["shard_rounds"][1]  # the same problems on every rank
+    else:  # the default
+        assert j["config"]["shard_assignment"].startswith("distinct") and "shard (r + step) mod 2" in j["config"]["shard_assignment"]
+        assert j["shard_rounds"][0] != j["shard_rounds"][1]  # shards 0 and 1 of the generator: 33 and 31 rollouts for their slowest problems
+    assert len(j["shard_rounds"]) == 2 and min(j["shard_rounds"]) > 10
+    assert j["iters_max"] == 32  # the last solve of the run is the same-shard leg's: configs[1]'s slowest problem (BENCH line of N = 1)
+    ss = j["same_shard"]
+    assert ss["value"] > 0 and ss["one_rank_alone_value"] > 0 and 0 < ss["machine_efficiency"] < 1.5
     assert j["status_counts"][2] == 0 and j["status_counts"][3] == 0  # every problem of the last shard converged
     assert j["gather_ms"] > 0 and j["host_to_host"] is None and j["large_batch"] is None
 

@@ -86,3 +86,40 @@ def test_gather_reassembles_the_batch_in_global_order(B, world, step):
     whole = pb.config2(B=B, N=6, seed=4)["init"]
     np.testing.assert_array_equal(traj, whole * 2.0 + 1.0)
     np.testing.assert_array_equal(cost, whole[:, :, 1:4].sum(axis=(1, 2)))
+
+
+def _subgroup_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    members = [1, 2]  # a group that does not contain global rank 0: group rank g is global rank g + 1
+    group = dist.new_group(members)
+    if rank in members:
+        g = members.index(rank)
+        sizes = sharding.shard_sizes(5, 2)
+        lo, hi = sharding.shard_range(5, g, 2)
+        mine = torch.arange(lo, hi, dtype=torch.float64).reshape(-1, 1) * 10.0
+        got = sharding.gather_to_root(mine, sizes, dst=0, group=group)  # the root is GROUP rank 0 = global rank 1
+        if g == 0:
+            q.put(got.numpy())
+        else:
+            assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_inside_a_subgroup_addresses_peers_by_global_rank():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(got, np.arange(5, dtype=np.float64).reshape(-1, 1) * 10.0)
