@@ -79,9 +79,21 @@ typedef struct {
   int32_t force_general; /* backward kernel.  0: by the weights and the batch (symmetric Q, R: k_backward2 -- a matrix
                             and a gradient wavefront per trajectory -- below 512 trajectories, k_backward4 -- one
                             gradient and one loader wavefront per four trajectories -- up to 8192, one wavefront
-                            per trajectory beyond); 1: the general kernel even when Q, R are symmetric; 2: the
-                            one-wavefront kernel for symmetric weights (k_backward<true>); 3: k_backward2;
-                            4: k_backward4 */
+                            per trajectory beyond; non-symmetric Q or R: the general kernel); 1: the general kernel even
+                            when Q, R are symmetric; 2: the one-wavefront kernel for symmetric weights
+                            (k_backward<true>); 3: k_backward2; 4: k_backward4.
+                            WHICH ARITHMETIC A CALLER GETS.  The general kernel evaluates ilqr.hh:118-140 in the
+                            reference's own forms: Q_uu factored by Eigen's diagonally pivoted LDL^T (largest |d_ii| of
+                            the trailing block, first on ties), V_x = Q_x - K^T Q_uu k, V_xx = Q_xx - K^T Q_uu K, not
+                            symmetrised -- force_general = 1 REPRODUCES THE REFERENCE, including its loss of accuracy
+                            beyond about 150 knots (the unsymmetrised recursion amplifies rounding asymmetry until the
+                            gains are noise: DESIGN.md section 4).  The symmetric-weight kernels (selected silently
+                            whenever Q == Q^T and R == R^T exactly, i.e. for every weight the reference's demo and tests
+                            use) DELIBERATELY DIFFER: unpivoted LDL^T (same result in exact arithmetic for positive
+                            definite Q_uu; loses eps / p for an indefinite Q_uu with a tiny leading entry p) and the
+                            equivalent forms V_x = Q_x + K^T Q_u, V_xx = Q_xx + Q_xu K on a symmetric accumulator, which
+                            agree with the reference to rounding up to about 150 knots and stay bounded and convergent
+                            beyond, where the reference's results are rounding noise. */
   int32_t single_wave_rollout; /* rollout kernel: 0 (default) = by the batch: sixteen lanes per trajectory, four
                                   trajectories per block (k_rollout16) up to 4096 trajectories, a lane per trajectory
                                   in three cooperating wavefronts (k_rollout3) up to 16384, in one wavefront (k_rollout)
@@ -94,8 +106,9 @@ typedef struct {
                       0 = automatic (2 from 4096 trajectories on, else 1: see auto_parts in ilqr_capi.hip), at most 8 */
   int32_t persistent; /* the solve as ONE launch (k_solve4: blocks of eight wavefronts own four trajectories each from the
                          first linearisation to the exit status, no rounds, no host in the loop; symmetric weights only):
-                         0 = whichever measures faster (today the rounds: level at 1024 trajectories, ahead at most other sizes), 1 = always,
-                         2 = never (rounds of three launches) */
+                         0 = the rounds of three launches at every batch size (by measurement they are level or ahead at every size
+                         but one, DESIGN.md section 4: the library never selects the one-launch solve by itself), 1 = always k_solve4,
+                         2 = never (the same as 0 today) */
 } qilqr_device_config;
 
 /* A handle owns its device workspace and stream: use it from one thread at a time (different handles are

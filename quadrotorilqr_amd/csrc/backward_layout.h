@@ -89,4 +89,95 @@ QILQR_HD int cxx_source_tab(const RecLayout &L, int row, int col) {
   return -1 - (CTAB_2Q + (row - 6) * 6 + (col - 6));  // (i >= 6 here: both indices are in the velocity block)
 }
 
+// Eigen 3.4.0 LDLT<Matrix4d, Lower> as the reference uses it (ilqr.hh:126-128: Q_uu.ldlt().solve(rhs)): in place on the
+// lower triangle, DIAGONAL PIVOTING (the largest |d_ii| of the trailing block, the first one on ties), x = P^T L^-T D^-1
+// L^-1 P b with IEEE divisions.  Every index is a compile-time constant (the pivot position is dispatched over its three
+// possible values), so the 4x4 stays in registers.  Used by the general kernel (k_backward<false>: non-symmetric weights,
+// or force_general = 1), where faithfulness to the reference is the point; the symmetric-weight kernels factor without
+// pivoting (identical in exact arithmetic when Q_uu is positive definite).
+template <int K, int BIG>
+QILQR_HD void ldlt4_swap(double (&m)[16], double (&y)[4]) {
+  // symmetric exchange of rows / columns K and BIG restricted to the lower triangle, and of the right-hand side's entries
+#pragma unroll
+  for (int jj = 0; jj < K; ++jj) { const double t = m[K * 4 + jj]; m[K * 4 + jj] = m[BIG * 4 + jj]; m[BIG * 4 + jj] = t; }
+#pragma unroll
+  for (int ii = BIG + 1; ii < 4; ++ii) { const double t = m[ii * 4 + K]; m[ii * 4 + K] = m[ii * 4 + BIG]; m[ii * 4 + BIG] = t; }
+  { const double t = m[K * 4 + K]; m[K * 4 + K] = m[BIG * 4 + BIG]; m[BIG * 4 + BIG] = t; }
+#pragma unroll
+  for (int ii = K + 1; ii < BIG; ++ii) { const double t = m[ii * 4 + K]; m[ii * 4 + K] = m[BIG * 4 + ii]; m[BIG * 4 + ii] = t; }
+  { const double t = y[K]; y[K] = y[BIG]; y[BIG] = t; }
+}
+template <int K>
+QILQR_HD int ldlt4_pivot_step(double (&m)[16], double (&y)[4]) {
+  int big = K;
+  double best = fabs(m[K * 4 + K]);
+#pragma unroll
+  for (int ii = K + 1; ii < 4; ++ii)
+    if (fabs(m[ii * 4 + ii]) > best) { best = fabs(m[ii * 4 + ii]); big = ii; }
+  if constexpr (K < 1) { if (big == 1) ldlt4_swap<K, 1>(m, y); }
+  if constexpr (K < 2) { if (big == 2) ldlt4_swap<K, 2>(m, y); }
+  if constexpr (K < 3) { if (big == 3) ldlt4_swap<K, 3>(m, y); }
+  if constexpr (K > 0) {
+    double temp[K > 0 ? K : 1];
+#pragma unroll
+    for (int jj = 0; jj < K; ++jj) temp[jj] = m[jj * 4 + jj] * m[K * 4 + jj];
+    double sacc = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < K; ++jj) sacc += m[K * 4 + jj] * temp[jj];
+    m[K * 4 + K] -= sacc;
+#pragma unroll
+    for (int ii = K + 1; ii < 4; ++ii) {
+      double r = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < K; ++jj) r += m[ii * 4 + jj] * temp[jj];
+      m[ii * 4 + K] -= r;
+    }
+  }
+  const double akk = m[K * 4 + K];
+  if (fabs(akk) > 0.0) {
+#pragma unroll
+    for (int ii = K + 1; ii < 4; ++ii) m[ii * 4 + K] /= akk;
+  }
+  return big;
+}
+// x = Q_uu^-1 rhs.  (The permutation is applied to the right-hand side as the factorisation finds it: the same
+// transpositions, in the same order, that Eigen applies to b before the triangular solves.)
+QILQR_HD void ldlt4_pivoted_solve(const double (&Quu)[16], const double (&rhs)[4], double (&x)[4]) {
+  double m[16], y[4];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) m[e] = Quu[e];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) y[e] = rhs[e];
+  const int t0 = ldlt4_pivot_step<0>(m, y);
+  const int t1 = ldlt4_pivot_step<1>(m, y);
+  const int t2 = ldlt4_pivot_step<2>(m, y);
+  (void)ldlt4_pivot_step<3>(m, y);
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < ii; ++jj) y[ii] -= m[ii * 4 + jj] * y[jj];
+  const double tol = 2.2250738585072014e-308;  // numeric_limits<double>::min(), Eigen's threshold for a zero pivot
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) y[ii] = (fabs(m[ii * 4 + ii]) > tol) ? y[ii] / m[ii * 4 + ii] : 0.0;
+#pragma unroll
+  for (int ii = 3; ii >= 0; --ii)
+#pragma unroll
+    for (int jj = ii + 1; jj < 4; ++jj) y[ii] -= m[jj * 4 + ii] * y[jj];
+  // P^T: the transpositions in reverse order
+  auto unswap = [&](int k, int big) {
+    double a = y[k];
+    const double b = (big == 1) ? y[1] : ((big == 2) ? y[2] : y[3]);
+    if (big != k) {
+      y[k] = b;
+      if (big == 1) y[1] = a; else if (big == 2) y[2] = a; else y[3] = a;
+    }
+  };
+  unswap(2, t2);
+  unswap(1, t1);
+  unswap(0, t0);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) x[e] = y[e];
+}
+
+
 }  // namespace qilqr

@@ -415,7 +415,7 @@ int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
   const int choice = s->dev.single_wave_rollout;
   if (s->integrator == 1) {  // the Runge-Kutta extension: the lane-per-trajectory kernel only
     launch(s, K_ROLLOUT, (k_rollout<double, 1>), dim3(cdiv(B, 64)), dim3(64), s->consts, s->st, (int)B, (int)n, need_flag);
-  } else if (choice == 1 || (choice != 3 && load_B > 16384)) {
+  } else if (choice == 1 || (choice == 0 && load_B > 16384)) {  // (a forced choice is honoured at every batch size)
     if (s->f32)
       launch(s, K_ROLLOUT, (k_rollout<float, 0>), dim3(cdiv(B, 64)), dim3(64), s->constsf, s->st, (int)B, (int)n, need_flag);
     else

@@ -581,29 +581,35 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
     }
     QKEEP(Quu[15]); QKEEP(Quu[0]); QKEEP(Qu[3]); QKEEP(rhs[3]); QKEEP(rhs[0]);
     QSTAMP(4);  // broadcast of Q_uu, Q_u, right-hand sides
-    // LDL^T of the lower triangle of Q_uu (the reference: Eigen LDLT, ilqr.hh:126; no pivoting here)
-    const double i0 = rcp_nr(Quu[0]);
-    const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
-    const double d1 = Quu[5] - l10 * Quu[4];
-    const double i1 = rcp_nr(d1);
-    const double c21 = Quu[9] - l20 * Quu[4], c31 = Quu[13] - l30 * Quu[4];
-    const double l21 = c21 * i1, l31 = c31 * i1;
-    const double d2 = Quu[10] - l20 * Quu[8] - l21 * c21;
-    const double i2 = rcp_nr(d2);
-    const double c32 = Quu[14] - l30 * Quu[8] - l31 * c21;
-    const double l32 = c32 * i2;
-    const double d3 = Quu[15] - l30 * Quu[12] - l31 * c31 - l32 * c32;
-    const double i3 = rcp_nr(d3);
-    QKEEP(i3); QKEEP(l32); QKEEP(l31);
+    // one right-hand side per lane: K[:, j] = -Quu^-1 Q_xu[j, :]^T in lanes j < 12 and k = -Quu^-1 Q_u in lane 12
+    // (ilqr.hh:127-128); k is then broadcast
     double kcol[4];
-    {
-      // one right-hand side per lane: K[:, j] = -Quu^-1 Q_xu[j, :]^T in lanes j < 12 and
-      // k = -Quu^-1 Q_u in lane 12   (ilqr.hh:127-128); k is then broadcast
+    if constexpr (SYM) {
+      // LDL^T of the lower triangle of Q_uu without pivoting (Q_uu = 2 R + J_u^T V_xx J_u is positive definite for the
+      // weights this kernel is launched for; the reference's Eigen LDLT pivots on the diagonal: same result in exact arithmetic)
+      const double i0 = rcp_nr(Quu[0]);
+      const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
+      const double d1 = Quu[5] - l10 * Quu[4];
+      const double i1 = rcp_nr(d1);
+      const double c21 = Quu[9] - l20 * Quu[4], c31 = Quu[13] - l30 * Quu[4];
+      const double l21 = c21 * i1, l31 = c31 * i1;
+      const double d2 = Quu[10] - l20 * Quu[8] - l21 * c21;
+      const double i2 = rcp_nr(d2);
+      const double c32 = Quu[14] - l30 * Quu[8] - l31 * c21;
+      const double l32 = c32 * i2;
+      const double d3 = Quu[15] - l30 * Quu[12] - l31 * c31 - l32 * c32;
+      const double i3 = rcp_nr(d3);
+      QKEEP(i3); QKEEP(l32); QKEEP(l31);
       const double y0 = rhs[0], y1 = rhs[1] - l10 * y0, y2 = rhs[2] - l20 * y0 - l21 * y1,
                    y3 = rhs[3] - l30 * y0 - l31 * y1 - l32 * y2;
       const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
                    x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
       kcol[0] = -x0; kcol[1] = -x1; kcol[2] = -x2; kcol[3] = -x3;
+    } else {
+      // the reference's factorisation: Eigen's diagonally pivoted LDL^T (ilqr.hh:126), restated in ldlt4_pivoted_solve
+      double xs[4];
+      ldlt4_pivoted_solve(Quu, rhs, xs);
+      kcol[0] = -xs[0]; kcol[1] = -xs[1]; kcol[2] = -xs[2]; kcol[3] = -xs[3];
     }
     QKEEP(kcol[0]); QKEEP(kcol[3]);
     QSTAMP(5);  // factorisation + solve
@@ -2041,16 +2047,19 @@ __device__ __forceinline__ bool r16_handoff_finish(R16Lds &sh, int which, int ta
   if (__builtin_expect(f >= target, 1)) return true;
   return r16_read_handoff<NV>(sh, which, target, kind, par, a, lane);
 }
-// "my knots up to i are stored and visible to the block": a step wave's only vector-memory operations are its knot stores
-// (two per knot of its parity); every fourth knot of its own it announces the knots older than its eight youngest stores
-// (s_waitcnt vmcnt(N) waits for all but the N youngest: nearly free), and everything after its last knot (vmcnt(0), once)
+// "my knots up to i are stored and visible to the block": every fourth knot of its own a step wave waits for ALL its
+// outstanding vector-memory operations (s_waitcnt vmcnt(0)) and announces the knots it has stored so far.  (Round 2 waited
+// for all but the eight youngest operations -- vmcnt(8), "the stores of knots i .. i - 6 may be in flight" -- which is only
+// right while a step issues exactly two stores and nothing else that counts: a spill inside the loop would have made the
+// announcement early and the followers read knots not yet written, silently.  The full wait costs one store latency per
+// eight knots on a path that only k_solve4 takes.)
 __device__ __forceinline__ void r16_publish_stores(R16Lds &sh, int which, int i, int last, int lane) {
   if (i == last) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     r16_flag_post(sh, which, i + 1, lane);
   } else if (((i >> 1) & 3) == 3 && i >= 16) {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the stores of this wave's knots i, i - 2, i - 4, i - 6 may be in flight
-    r16_flag_post(sh, which, i - 8 + 1, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    r16_flag_post(sh, which, i + 1, lane);
   }
 }
 

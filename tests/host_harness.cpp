@@ -314,6 +314,15 @@ void hh_dense_jacobians_lay(const ModelConsts<double> *c, const int *lay, const 
     }
 }
 
+// the general kernel's factorisation of Q_uu on its own: x = A^-1 b by the device code's restatement of Eigen's pivoted LDL^T
+void hh_ldlt4_pivoted_solve(const double *A, const double *b, double *x) {
+  double Am[16], bv[4], xv[4];
+  for (int e = 0; e < 16; ++e) Am[e] = A[e];
+  for (int e = 0; e < 4; ++e) bv[e] = b[e];
+  ldlt4_pivoted_solve(Am, bv, xv);
+  for (int e = 0; e < 4; ++e) x[e] = xv[e];
+}
+
 // k_backward re-enacted lane by lane (same statements, loops over the 64 lanes between the
 // points where the kernel exchanges data).  sym = 1: the SYM = true instantiation (accumulator tile
 // reused as A operand, V_x / V_xx / k^T Quu k in their Q_xu forms), sym = 0: the general one.
@@ -394,6 +403,11 @@ void hh_backward_emulated(const ModelConsts<double> *cp, const int *lay, const d
       const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
                    x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
       kcol_all[l][0] = -x0; kcol_all[l][1] = -x1; kcol_all[l][2] = -x2; kcol_all[l][3] = -x3;
+      if (!sym) {  // the general kernel factors as the reference does: Eigen's diagonally pivoted LDL^T (backward_layout.h)
+        double xs[4];
+        ldlt4_pivoted_solve(Quu, rhs, xs);
+        for (int aa = 0; aa < 4; ++aa) kcol_all[l][aa] = -xs[aa];
+      }
       for (int bb = 0; bb < 4; ++bb)
         mc_all[l][bb] = kcol_all[l][0] * Quu[bb] + kcol_all[l][1] * Quu[4 + bb] + kcol_all[l][2] * Quu[8 + bb] +
                         kcol_all[l][3] * Quu[12 + bb];

@@ -504,3 +504,45 @@ def test_rk4_rollout_matches_oracle(hh):
             out = np.zeros_like(tr)
             hh.hh_rollout_rk4(P(c), P(tr.copy()), P(gains.copy()), C.c_double(alpha), P(out), C.c_int(len(tr)))
             np.testing.assert_allclose(out, ref, rtol=0, atol=1e-10)
+
+
+def test_pivoted_ldlt_of_the_general_kernel_is_eigens(hh):
+    """ldlt4_pivoted_solve (backward_layout.h: the factorisation of Q_uu in k_backward<false>, i.e. non-symmetric weights or
+    force_general = 1) against the oracle's restatement of Eigen 3.4.0 LDLT<Matrix4d, Lower> (ilqr.hh:126-128): the same
+    pivots, hence the same solution to rounding, on SPD, indefinite, tiny-leading-pivot, tied-diagonal and singular inputs;
+    only the lower triangle is read."""
+    from oracle import oracle as orc
+    r = np.random.default_rng(11)
+    cases = []
+    for _ in range(40):
+        A = r.uniform(-1, 1, (4, 4))
+        cases.append(A @ A.T + 0.1 * np.eye(4))                      # SPD
+        S = r.uniform(-1, 1, (4, 4))
+        cases.append((S + S.T) / 2)                                    # symmetric indefinite, random pivot order
+    for p in (1e-4, 1e-8, 1e-12, 0.0):
+        R = np.eye(4)
+        R[0, 0] = p
+        R[0, 1] = R[1, 0] = 1.0
+        cases.append(R)                                                 # tiny (or zero) leading entry: the pivot moves
+    T = np.full((4, 4), 0.25) + np.diag([2.0, 2.0, 2.0, 2.0])
+    cases.append(T)                                                     # ties on the diagonal: the first one wins
+    cases.append(np.diag([0.0, 3.0, 0.0, 1.0]))                         # zero pivots: Eigen's solve puts 0 there
+    U = r.uniform(-1, 1, (4, 4))
+    U[np.triu_indices(4, 1)] = 777.0                                    # garbage above the diagonal is never read
+    cases.append(U + np.diag([3.0, 3.0, 3.0, 3.0]))
+    for A in cases:
+        A = np.ascontiguousarray(A, dtype=float)
+        b = r.uniform(-1, 1, 4)
+        x = np.zeros(4)
+        hh.hh_ldlt4_pivoted_solve(P(A), P(b), P(x))
+        ref = orc.ldlt4_solve(A, b)
+        np.testing.assert_allclose(x, np.asarray(ref).reshape(4), rtol=1e-13, atol=1e-13 * max(1.0, np.abs(ref).max()))
+    # the documented case (tests/test_gpu_robustness.py): k = -du to rounding whatever the leading entry
+    for p in (1e-4, 1e-8, 1e-12):
+        R = np.eye(4)
+        R[0, 0] = p
+        R[0, 1] = R[1, 0] = 1.0
+        du = r.uniform(-1, 1, 4)
+        x = np.zeros(4)
+        hh.hh_ldlt4_pivoted_solve(P(np.ascontiguousarray(2 * R)), P(np.ascontiguousarray(2 * R @ du)), P(x))
+        assert np.abs(x - du).max() < 1e-13

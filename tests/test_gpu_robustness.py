@@ -1,5 +1,6 @@
-"""Where the device path deliberately leaves the reference's arithmetic, pinned by tests: the factorisation of Q_uu
-(unpivoted LDL^T in registers against Eigen's diagonally pivoted ldlt(), ilqr.hh:126) and fractional max_iters."""
+"""Where the device path deliberately leaves the reference's arithmetic, pinned by tests: the factorisation of Q_uu in the
+symmetric-weight kernels (unpivoted LDL^T in registers against Eigen's diagonally pivoted ldlt(), ilqr.hh:126; the general
+kernel -- non-symmetric weights, or force_general = 1 -- pivots as Eigen does) and fractional max_iters."""
 import numpy as np
 import pytest
 
@@ -63,6 +64,9 @@ def test_indefinite_quu_with_well_conditioned_minors_matches_pivoted_ldlt():
         np.testing.assert_allclose(g[b], g_ref, rtol=1e-11, atol=1e-13)
         np.testing.assert_allclose(terms[b], t_ref, rtol=1e-11)
     assert _k_error(g, init, cfg["desired"]) < 1e-13
+    gg, tg = capi.from_config(cfg, force_general=1).backwards_pass(init)  # the pivoting kernel: other pivot order, same answer
+    np.testing.assert_allclose(gg, g, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(tg, terms, rtol=1e-11)
     # and over a horizon (Q_uu = 2 R + J_u^T V_xx J_u stays indefinite near the end of the trajectory)
     cfg8 = dict(pb.config2(B=4, N=8, seed=3), R=R)
     g8, t8 = capi.from_config(cfg8).backwards_pass(cfg8["init"])
@@ -92,6 +96,15 @@ def test_tiny_leading_pivot_is_where_unpivoted_ldlt_leaves_eigen(pivot):
     assert np.isfinite(g).all() and e_gpu < 100 * np.finfo(float).eps / pivot
     if pivot <= 1e-8:
         assert e_gpu > 10 * e_ref   # this is where the two factorisations part ways
+    # force_general = 1 selects the kernel that keeps the reference's forms, Eigen's diagonal pivoting included
+    # (backward_layout.h, ldlt4_pivoted_solve): it starts with R[1][1] as Eigen does and stays at rounding level
+    g1, t1 = capi.from_config(cfg, force_general=1).backwards_pass(init)
+    e_gen = _k_error(g1, init, cfg["desired"])
+    assert e_gen <= max(10 * e_ref, 1e-15)
+    for b in range(len(init)):
+        g_ref, t_ref = ref.backwards_pass(init[b])
+        np.testing.assert_allclose(g1[b], g_ref, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(t1[b], t_ref, rtol=1e-11)
 
 
 def test_fractional_max_iters_counts_like_the_reference_loop():
