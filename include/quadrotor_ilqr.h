@@ -259,6 +259,30 @@ int qilqr_solve_batch_sharded(qilqr_sharded *h, const double *init, const double
                               double *out_traj, double *out_cost, int32_t *out_status, int32_t *out_iters,
                               int32_t *out_n_bwd, int32_t *out_n_fwd);
 
+/* The same batch solve with the results gathered in ONE device's memory (BASELINE.json configs[3]: "sharded ... with RCCL
+ * gather over xGMI"; the C counterpart of quadrotorilqr_amd/sharding.gather_to_root for a host that drives every GPU from
+ * one process).  Inputs are host arrays as for qilqr_solve_batch_sharded; d_out_* are device arrays on the device of shard
+ * `root` (devices[root]), B x n x 18 doubles / B doubles / B int32, any of them may be NULL.  Every shard's rows travel from
+ * its solver's staging buffers straight into their place in the root's arrays -- ragged shards, no padding, no second
+ * copy -- as soon as that shard has finished, by the handle's transport:
+ *   QILQR_TRANSPORT_RCCL       ncclSend on the shard's device / ncclRecv on the root's, one group per call, over one
+ *                              communicator per distinct device (ncclCommInitAll: all in this process); librccl.so.1 is
+ *                              loaded when the first communicator is needed
+ *   QILQR_TRANSPORT_PEER_COPY  hipMemcpyPeerAsync
+ *   QILQR_TRANSPORT_AUTO       (default) RCCL when the shards sit on more than one device, device copies when they all share
+ *                              one; falls back to peer copies if RCCL cannot be loaded or initialised
+ * qilqr_sharded_transport says in words which one a handle uses (and why, after a fallback); forcing _RCCL fails instead of
+ * falling back.  gather_ms (may be NULL): the exposed part of the gather -- from the moment the slowest shard's solve has
+ * finished to the moment the root holds every row.  Results are, problem by problem, those of qilqr_solve_batch. */
+#define QILQR_TRANSPORT_AUTO 0
+#define QILQR_TRANSPORT_RCCL 1
+#define QILQR_TRANSPORT_PEER_COPY 2
+int qilqr_sharded_set_transport(qilqr_sharded *h, int32_t transport);
+const char *qilqr_sharded_transport(qilqr_sharded *h);
+int qilqr_solve_batch_sharded_device(qilqr_sharded *h, const double *init, const double *desired_batch, int32_t B, int32_t n,
+                                     int32_t root, double *d_out_traj, double *d_out_cost, int32_t *d_out_status,
+                                     int32_t *d_out_iters, int32_t *d_out_n_bwd, int32_t *d_out_n_fwd, double *gather_ms);
+
 /* ABI version of this header */
 int qilqr_abi_version(void);
 

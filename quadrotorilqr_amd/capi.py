@@ -41,6 +41,7 @@ EXPORTS = (
     "qilqr_device", "qilqr_stream", "qilqr_stream_wait_event", "qilqr_host_alloc", "qilqr_host_free",
     "qilqr_sharded_create", "qilqr_sharded_create_mask", "qilqr_sharded_destroy", "qilqr_sharded_count", "qilqr_sharded_solver",
     "qilqr_shard_range", "qilqr_solve_batch_sharded",
+    "qilqr_sharded_set_transport", "qilqr_sharded_transport", "qilqr_solve_batch_sharded_device",
     "qilqr_abi_version",
 )
 
@@ -92,6 +93,9 @@ def load():
         lib.qilqr_sharded_solver.argtypes = [C.c_void_p, C.c_int32]
         lib.qilqr_sharded_destroy.argtypes = [C.c_void_p]
         lib.qilqr_sharded_count.argtypes = [C.c_void_p]
+        lib.qilqr_sharded_set_transport.argtypes = [C.c_void_p, C.c_int32]
+        lib.qilqr_sharded_transport.argtypes = [C.c_void_p]
+        lib.qilqr_sharded_transport.restype = C.c_char_p
         _lib = lib
     return _lib
 
@@ -416,6 +420,45 @@ class QuadrotorILQRSharded:
         if rc:
             _raise(rc)
         return out
+
+
+    TRANSPORTS = {"auto": 0, "rccl": 1, "peer_copy": 2}
+
+    def set_transport(self, transport):
+        """how qilqr_solve_batch_sharded_device moves the shards' rows to the root: 'auto', 'rccl' (ncclSend / ncclRecv), 'peer_copy'"""
+        rc = load().qilqr_sharded_set_transport(self._h, C.c_int32(self.TRANSPORTS[transport]))
+        if rc:
+            _raise(rc)
+        return self.transport()
+
+    def transport(self):
+        return load().qilqr_sharded_transport(self._h).decode()
+
+    def solve_batch_gathered(self, init, out_traj, out_cost, out_status, out_iters, out_n_bwd, out_n_fwd, desired_batch=None, root=0):
+        """qilqr_solve_batch_sharded_device: host inputs, results gathered into device arrays (torch tensors, contiguous, on the
+        device of shard `root`): traj (B, n, 18) float64, cost (B,) float64, the rest (B,) int32; any may be None.
+        Returns the exposed gather time in ms."""
+        init = _d(init)
+        B, n = init.shape[0], init.shape[1]
+        des = None if desired_batch is None else _d(desired_batch)
+        import torch
+
+        def ptr(t, dtype, shape):
+            if t is None:
+                return None
+            if t.dtype != dtype or tuple(t.shape) != shape or not t.is_contiguous() or t.device.index != self.devices[root]:
+                raise ValueError(f"output tensor must be contiguous {dtype} {shape} on device {self.devices[root]}")
+            return C.c_void_p(t.data_ptr())
+
+        torch.cuda.synchronize(self.devices[root])  # nothing of the caller's is still writing the outputs
+        ms = C.c_double(0.0)
+        rc = load().qilqr_solve_batch_sharded_device(
+            self._h, _p(init), _p(des), C.c_int32(B), C.c_int32(n), C.c_int32(root), ptr(out_traj, torch.float64, (B, n, 18)),
+            ptr(out_cost, torch.float64, (B,)), ptr(out_status, torch.int32, (B,)), ptr(out_iters, torch.int32, (B,)),
+            ptr(out_n_bwd, torch.int32, (B,)), ptr(out_n_fwd, torch.int32, (B,)), C.byref(ms))
+        if rc:
+            _raise(rc)
+        return ms.value
 
 
 def sharded_from_config(cfg, devices=(0,), **kw):

@@ -4,10 +4,16 @@
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -744,11 +750,60 @@ int solve_batch_device_impl(qilqr_solver *s, const double *d_init, const double 
   return QILQR_OK;
 }
 
+// The host-buffer batch solve up to, but not including, the copies back: checks, staging buffers (kept between calls, no
+// hipMalloc / hipFree per call), H2D, the solve, the gather into s->stage_traj / stage_cost / stage_int -- everything
+// enqueued on the solver's stream, nothing waited for.  The copies are plain hipMemcpyAsync: direct DMA when the caller's
+// buffers are pinned (qilqr_host_alloc, or any hipHostMalloc / hipHostRegister'ed memory), HIP's own chunked staging when
+// they are pageable.
+int solve_batch_staged(qilqr_solver *s, const double *init, const double *desired_batch, int32_t B, int32_t n) {
+  if (!s || !init) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  if (B <= 0 || n <= 0) return fail(QILQR_ERR_INVALID_ARG, "B and n must be positive");
+  if (!desired_batch && n > s->n_desired)
+    return fail(QILQR_ERR_LENGTH_MISMATCH, "trajectory longer than desired trajectory");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t cnt = 18 * (size_t)B * n, tb = sizeof(double) * cnt;
+  auto grow = [&](auto **p, size_t *cap, size_t want, size_t elem) -> hipError_t {
+    if (want <= *cap) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc((void **)p, want * elem);
+    if (e == hipSuccess) *cap = want;
+    return e;
+  };
+  hipError_t e = grow(&s->stage_traj, &s->stage_traj_cap, cnt, sizeof(double));
+  if (e == hipSuccess && desired_batch) e = grow(&s->stage_des, &s->stage_des_cap, cnt, sizeof(double));
+  if (e == hipSuccess && (size_t)B > s->stage_B_cap) {
+    if (s->stage_cost) (void)hipFree(s->stage_cost);
+    if (s->stage_int) (void)hipFree(s->stage_int);
+    s->stage_cost = nullptr;
+    s->stage_int = nullptr;
+    s->stage_B_cap = 0;
+    e = hipMalloc((void **)&s->stage_cost, sizeof(double) * B);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->stage_int, sizeof(int) * 4 * B);
+    if (e == hipSuccess) s->stage_B_cap = B;
+  }
+  // The uploads are enqueued first and the quaternion checks (manif's constructor check, SURVEY.md 8b: 0.1-0.2 ms of host
+  // time for 1024 x 100 knots) run while the copy engine works; nothing that computes is enqueued before they have passed.
+  if (e == hipSuccess) e = hipMemcpyAsync(s->stage_traj, init, tb, hipMemcpyHostToDevice, s->stream);
+  if (e == hipSuccess && desired_batch) e = hipMemcpyAsync(s->stage_des, desired_batch, tb, hipMemcpyHostToDevice, s->stream);
+  if (e != hipSuccess) return fail(QILQR_ERR_HIP, std::string("staging: ") + hipGetErrorString(e));
+  int rc;
+  if ((rc = check_quaternions(init, (long)B * n, "initial trajectory")) ||
+      (desired_batch && (rc = check_quaternions(desired_batch, (long)B * n, "desired trajectory")))) {
+    (void)hipStreamSynchronize(s->stream);  // the uploads read the caller's buffers: finished before the error returns
+    return rc;
+  }
+  int *d_int = s->stage_int;
+  return solve_batch_device_impl(s, s->stage_traj, desired_batch ? s->stage_des : nullptr, B, n, s->stage_traj, s->stage_cost, d_int,
+                                 d_int + B, d_int + 2 * B, d_int + 3 * B, /*drain=*/false);
+}
+
 }  // namespace
 
 extern "C" {
 
-int qilqr_abi_version(void) { return 4; }
+int qilqr_abi_version(void) { return 5; }
 
 const char *qilqr_last_error(void) { return g_last_error.c_str(); }
 
@@ -994,51 +1049,16 @@ int qilqr_stream_wait_event(qilqr_solver *s, void *hip_event) {
   return QILQR_OK;
 }
 
-// host-buffer wrapper: stage through device buffers the solver keeps between calls (no hipMalloc / hipFree per
-// call).  The copies are plain hipMemcpy: direct DMA when the caller's buffers are pinned (qilqr_host_alloc, or any
-// hipHostMalloc / hipHostRegister'ed memory), HIP's own chunked staging when they are pageable.
+// host-buffer wrapper: solve_batch_staged, then the copies back behind the gather on the solver's stream; one wait at the end
 int qilqr_solve_batch(qilqr_solver *s, const double *init, const double *desired_batch, int32_t B, int32_t n,
                       double *out_traj, double *out_cost, int32_t *out_status, int32_t *out_iters,
                       int32_t *out_n_bwd, int32_t *out_n_fwd) {
-  if (!s || !init) return fail(QILQR_ERR_INVALID_ARG, "null argument");
-  if (B <= 0 || n <= 0) return fail(QILQR_ERR_INVALID_ARG, "B and n must be positive");
-  if (!desired_batch && n > s->n_desired)
-    return fail(QILQR_ERR_LENGTH_MISMATCH, "trajectory longer than desired trajectory");
-  int rc;
-  if ((rc = check_quaternions(init, (long)B * n, "initial trajectory"))) return rc;
-  if (desired_batch && (rc = check_quaternions(desired_batch, (long)B * n, "desired trajectory"))) return rc;
-  HIP_TRY(hipSetDevice(s->device));
-  const size_t cnt = 18 * (size_t)B * n, tb = sizeof(double) * cnt;
-  auto grow = [&](auto **p, size_t *cap, size_t want, size_t elem) -> hipError_t {
-    if (want <= *cap) return hipSuccess;
-    if (*p) (void)hipFree(*p);
-    *p = nullptr;
-    *cap = 0;
-    hipError_t e = hipMalloc((void **)p, want * elem);
-    if (e == hipSuccess) *cap = want;
-    return e;
-  };
-  hipError_t e = grow(&s->stage_traj, &s->stage_traj_cap, cnt, sizeof(double));
-  if (e == hipSuccess && desired_batch) e = grow(&s->stage_des, &s->stage_des_cap, cnt, sizeof(double));
-  if (e == hipSuccess && (size_t)B > s->stage_B_cap) {
-    if (s->stage_cost) (void)hipFree(s->stage_cost);
-    if (s->stage_int) (void)hipFree(s->stage_int);
-    s->stage_cost = nullptr;
-    s->stage_int = nullptr;
-    s->stage_B_cap = 0;
-    e = hipMalloc((void **)&s->stage_cost, sizeof(double) * B);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->stage_int, sizeof(int) * 4 * B);
-    if (e == hipSuccess) s->stage_B_cap = B;
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(s->stage_traj, init, tb, hipMemcpyHostToDevice, s->stream);
-  if (e == hipSuccess && desired_batch) e = hipMemcpyAsync(s->stage_des, desired_batch, tb, hipMemcpyHostToDevice, s->stream);
-  if (e != hipSuccess) return fail(QILQR_ERR_HIP, std::string("staging: ") + hipGetErrorString(e));
-  double *d_cost = s->stage_cost;
-  int *d_int = s->stage_int;
-  rc = solve_batch_device_impl(s, s->stage_traj, desired_batch ? s->stage_des : nullptr, B, n, s->stage_traj, d_cost, d_int,
-                               d_int + B, d_int + 2 * B, d_int + 3 * B, /*drain=*/false);
+  int rc = solve_batch_staged(s, init, desired_batch, B, n);
   if (rc != QILQR_OK) return rc;
-  // the copies back follow the gather on the solver's stream; one wait at the end
+  const size_t tb = sizeof(double) * 18 * (size_t)B * n;
+  const double *d_cost = s->stage_cost;
+  const int *d_int = s->stage_int;
+  hipError_t e = hipSuccess;
   if (out_traj) e = hipMemcpyAsync(out_traj, s->stage_traj, tb, hipMemcpyDeviceToHost, s->stream);
   if (e == hipSuccess && out_cost) e = hipMemcpyAsync(out_cost, d_cost, sizeof(double) * B, hipMemcpyDeviceToHost, s->stream);
   if (e == hipSuccess && out_status) e = hipMemcpyAsync(out_status, d_int, sizeof(int) * B, hipMemcpyDeviceToHost, s->stream);
@@ -1205,9 +1225,191 @@ int qilqr_line_search(qilqr_solver *s, const double *traj, const double *cost, c
 }
 
 // ---- one batch over several devices in one process (include/quadrotor_ilqr.h)
+// RCCL is bound at run time (dlopen of librccl.so.1 when a sharded handle first needs a communicator), not as a link-time
+// dependency: the library is 570 MB of code objects that a single-device caller never uses, and a host process that has
+// PyTorch loaded already holds one under the same soname, which is then the one that is used.
+extern "C++" {
+namespace {
+struct Rccl {
+  void *lib = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string error;
+  bool ok = false;
+};
+Rccl &rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) {
+      const char *err = dlerror();
+      r.error = std::string("librccl.so.1 cannot be loaded: ") + (err ? err : "?");
+      return;
+    }
+#define QILQR_RCCL_SYM(field, sym)                                    \
+  r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, #sym)); \
+  if (!r.field) {                                                     \
+    r.error = "librccl has no " #sym;                                 \
+    return;                                                           \
+  }
+    QILQR_RCCL_SYM(GetVersion, ncclGetVersion)
+    QILQR_RCCL_SYM(CommInitAll, ncclCommInitAll)
+    QILQR_RCCL_SYM(CommDestroy, ncclCommDestroy)
+    QILQR_RCCL_SYM(GroupStart, ncclGroupStart)
+    QILQR_RCCL_SYM(GroupEnd, ncclGroupEnd)
+    QILQR_RCCL_SYM(Send, ncclSend)
+    QILQR_RCCL_SYM(Recv, ncclRecv)
+    QILQR_RCCL_SYM(GetErrorString, ncclGetErrorString)
+#undef QILQR_RCCL_SYM
+    r.ok = true;
+  });
+  return r;
+}
+// the caller's current HIP device is put back on every return path (a torch host process has one)
+struct DeviceGuard {
+  int dev = -1;
+  DeviceGuard() {
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+  }
+  ~DeviceGuard() {
+    if (dev >= 0) (void)hipSetDevice(dev);
+  }
+};
+}  // namespace
+}  // extern "C++"
+
 struct qilqr_sharded {
   std::vector<qilqr_solver *> solvers;
+  std::vector<int> device;     // per shard: its HIP device
+  std::vector<int> uniq;       // the distinct devices, in order of first appearance: rank k of the communicator is uniq[k]
+  std::vector<int> rank_of;    // per shard: index of its device in uniq
+  int transport = QILQR_TRANSPORT_AUTO;  // as requested
+  int resolved = 0;                      // QILQR_TRANSPORT_RCCL or QILQR_TRANSPORT_PEER_COPY once the gather path exists
+  std::vector<ncclComm_t> comms;         // per distinct device (RCCL transport)
+  std::vector<hipStream_t> gstream;      // per distinct device: the stream the gather of that device's shards runs on
+  std::vector<hipEvent_t> done;          // per shard: its solve (and gather kernel) have finished
+  std::string info;
 };
+
+extern "C++" {
+namespace {
+void sharded_drop_gather_path(qilqr_sharded *h) {
+  for (size_t k = 0; k < h->comms.size(); ++k)
+    if (h->comms[k]) (void)rccl().CommDestroy(h->comms[k]);
+  h->comms.clear();
+  h->resolved = 0;
+}
+// communicators (RCCL) or nothing (peer copies), streams and events: built when the first gathered solve needs them
+int sharded_ensure_gather_path(qilqr_sharded *h) {
+  if (h->resolved) return QILQR_OK;
+  const int nuniq = (int)h->uniq.size();
+  if (h->gstream.empty()) {
+    h->gstream.assign(nuniq, nullptr);
+    for (int k = 0; k < nuniq; ++k) {
+      HIP_TRY(hipSetDevice(h->uniq[k]));
+      HIP_TRY(hipStreamCreateWithFlags(&h->gstream[k], hipStreamNonBlocking));
+    }
+    h->done.assign(h->solvers.size(), nullptr);
+    for (size_t r = 0; r < h->solvers.size(); ++r) {
+      HIP_TRY(hipSetDevice(h->device[r]));
+      HIP_TRY(hipEventCreateWithFlags(&h->done[r], hipEventDisableTiming));
+    }
+  }
+  // automatic: RCCL when the shards sit on more than one device (point-to-point over xGMI into the root's rows), plain device
+  // copies when they all share one (nothing to communicate)
+  int want = h->transport;
+  if (want == QILQR_TRANSPORT_AUTO) want = nuniq > 1 ? QILQR_TRANSPORT_RCCL : QILQR_TRANSPORT_PEER_COPY;
+  if (want == QILQR_TRANSPORT_RCCL) {
+    Rccl &R = rccl();
+    if (!R.ok) {
+      if (h->transport == QILQR_TRANSPORT_RCCL) return fail(QILQR_ERR_HIP, "RCCL transport requested: " + R.error);
+      want = QILQR_TRANSPORT_PEER_COPY;
+      h->info = "peer copies (hipMemcpyPeerAsync): " + R.error;
+    } else {
+      h->comms.assign(nuniq, nullptr);
+      const ncclResult_t st = R.CommInitAll(h->comms.data(), nuniq, h->uniq.data());
+      if (st != ncclSuccess) {
+        h->comms.clear();
+        const std::string why = std::string("ncclCommInitAll: ") + R.GetErrorString(st);
+        if (h->transport == QILQR_TRANSPORT_RCCL) return fail(QILQR_ERR_HIP, "RCCL transport requested: " + why);
+        want = QILQR_TRANSPORT_PEER_COPY;
+        h->info = "peer copies (hipMemcpyPeerAsync): " + why;
+      } else {
+        int ver = 0;
+        (void)R.GetVersion(&ver);
+        h->info = "rccl: ncclSend / ncclRecv, " + std::to_string(nuniq) + " rank" + (nuniq > 1 ? "s" : "") + " in one process (version code " +
+                  std::to_string(ver) + ")";
+      }
+    }
+  }
+  if (want == QILQR_TRANSPORT_PEER_COPY && h->info.rfind("peer copies", 0) != 0) h->info = "peer copies (hipMemcpyPeerAsync)";
+  h->resolved = want;
+  return QILQR_OK;
+}
+
+// One shard's solve on the calling thread.  host_out: copy back into the caller's host arrays (qilqr_solve_batch); otherwise
+// leave the results in the solver's staging buffers and record done[r] behind them (qilqr_solve_batch_sharded_device).
+struct ShardCall {
+  const double *init, *desired;
+  int32_t B, n;
+  double *out_traj, *out_cost;
+  int32_t *out_status, *out_iters, *out_n_bwd, *out_n_fwd;
+  bool host_out;
+};
+void run_shard(qilqr_sharded *h, const ShardCall &c, int32_t r, int *rc_out, std::string *msg_out) {
+  const int32_t k = (int32_t)h->solvers.size();
+  int32_t b0 = 0, cnt = 0;
+  (void)qilqr_shard_range(c.B, k, r, &b0, &cnt);
+  if (cnt == 0) return;  // fewer problems than shards
+  const size_t to = (size_t)b0 * c.n * 18;
+  int rc;
+  if (c.host_out) {
+    rc = qilqr_solve_batch(h->solvers[r], c.init + to, c.desired ? c.desired + to : nullptr, cnt, c.n,
+                           c.out_traj ? c.out_traj + to : nullptr, c.out_cost ? c.out_cost + b0 : nullptr,
+                           c.out_status ? c.out_status + b0 : nullptr, c.out_iters ? c.out_iters + b0 : nullptr,
+                           c.out_n_bwd ? c.out_n_bwd + b0 : nullptr, c.out_n_fwd ? c.out_n_fwd + b0 : nullptr);
+  } else {
+    rc = solve_batch_staged(h->solvers[r], c.init + to, c.desired ? c.desired + to : nullptr, cnt, c.n);
+    if (rc == QILQR_OK && hipEventRecord(h->done[r], h->solvers[r]->stream) != hipSuccess) rc = fail(QILQR_ERR_HIP, "hipEventRecord");
+  }
+  *rc_out = rc;
+  if (rc != QILQR_OK) *msg_out = g_last_error;  // (thread-local: carried back to the caller)
+}
+// every shard on a host thread of its own (HIP's current device is per thread), shard 0 on the caller's
+int run_all_shards(qilqr_sharded *h, const ShardCall &c) {
+  const int32_t k = (int32_t)h->solvers.size();
+  std::vector<int> rcs(k, QILQR_OK);
+  std::vector<std::string> msgs(k);
+  std::vector<std::thread> threads;
+  bool spawn_failed = false;
+  try {
+    threads.reserve(k);
+    for (int32_t r = 1; r < k; ++r) threads.emplace_back(run_shard, h, std::cref(c), r, &rcs[r], &msgs[r]);
+  } catch (...) {
+    spawn_failed = true;  // (std::system_error: no thread could be started; the shards that have one still run)
+  }
+  const int32_t started = 1 + (int32_t)threads.size();
+  run_shard(h, c, 0, &rcs[0], &msgs[0]);
+  for (std::thread &t : threads) t.join();
+  if (spawn_failed)  // the shards without a thread run here, one after the other
+    for (int32_t r = started; r < k; ++r) run_shard(h, c, r, &rcs[r], &msgs[r]);
+  for (int32_t r = 0; r < k; ++r)
+    if (rcs[r] != QILQR_OK)
+      return fail(rcs[r], "shard " + std::to_string(r) + " (device " + std::to_string(h->device[r]) + "): " + msgs[r]);
+  return QILQR_OK;
+}
+}  // namespace
+}  // extern "C++"
 
 int qilqr_shard_range(int32_t B, int32_t n_shards, int32_t r, int32_t *begin, int32_t *count) {
   if (B < 0 || n_shards <= 0 || r < 0 || r >= n_shards || !begin || !count) return fail(QILQR_ERR_INVALID_ARG, "bad shard arguments");
@@ -1221,19 +1423,35 @@ int qilqr_sharded_create(const qilqr_model *model, const double *Q, const double
                          int32_t n_desired, double dt_s, const qilqr_options *options, const qilqr_device_config *dev,
                          const int32_t *devices, int32_t n_devices, qilqr_sharded **out) {
   if (!out || !devices || n_devices <= 0 || n_devices > 64) return fail(QILQR_ERR_INVALID_ARG, "bad device list");
-  qilqr_sharded *h = new qilqr_sharded();
-  for (int32_t r = 0; r < n_devices; ++r) {
-    qilqr_device_config dc = {0, 0, 2, 0, 0, 0, 0, 0};
-    if (dev) dc = *dev;
-    dc.device = devices[r];
-    qilqr_solver *s = nullptr;
-    const int rc = qilqr_create(model, Q, R, desired, n_desired, dt_s, options, &dc, &s);
-    if (rc != QILQR_OK) {
-      const std::string msg = "shard " + std::to_string(r) + " (device " + std::to_string(devices[r]) + "): " + g_last_error;
-      qilqr_sharded_destroy(h);
-      return fail(rc, msg);
+  DeviceGuard guard;
+  qilqr_sharded *h = nullptr;
+  try {
+    h = new qilqr_sharded();
+    for (int32_t r = 0; r < n_devices; ++r) {
+      qilqr_device_config dc = {0, 0, 2, 0, 0, 0, 0, 0};
+      if (dev) dc = *dev;
+      dc.device = devices[r];
+      qilqr_solver *s = nullptr;
+      const int rc = qilqr_create(model, Q, R, desired, n_desired, dt_s, options, &dc, &s);
+      if (rc != QILQR_OK) {
+        const std::string msg = "shard " + std::to_string(r) + " (device " + std::to_string(devices[r]) + "): " + g_last_error;
+        qilqr_sharded_destroy(h);
+        return fail(rc, msg);
+      }
+      h->solvers.push_back(s);
+      h->device.push_back(devices[r]);
+      int idx = -1;
+      for (size_t u = 0; u < h->uniq.size(); ++u)
+        if (h->uniq[u] == devices[r]) idx = (int)u;
+      if (idx < 0) {
+        idx = (int)h->uniq.size();
+        h->uniq.push_back(devices[r]);
+      }
+      h->rank_of.push_back(idx);
     }
-    h->solvers.push_back(s);
+  } catch (...) {  // std::bad_alloc and friends do not cross the C ABI
+    if (h) qilqr_sharded_destroy(h);
+    return fail(QILQR_ERR_INVALID_ARG, "qilqr_sharded_create: out of host memory");
   }
   *out = h;
   return QILQR_OK;
@@ -1252,7 +1470,19 @@ int qilqr_sharded_create_mask(const qilqr_model *model, const double *Q, const d
 
 void qilqr_sharded_destroy(qilqr_sharded *h) {
   if (!h) return;
+  DeviceGuard guard;
   for (qilqr_solver *s : h->solvers) qilqr_destroy(s);
+  sharded_drop_gather_path(h);
+  for (size_t k = 0; k < h->gstream.size(); ++k)
+    if (h->gstream[k]) {
+      (void)hipSetDevice(h->uniq[k]);
+      (void)hipStreamDestroy(h->gstream[k]);
+    }
+  for (size_t r = 0; r < h->done.size(); ++r)
+    if (h->done[r]) {
+      (void)hipSetDevice(h->device[r]);
+      (void)hipEventDestroy(h->done[r]);
+    }
   delete h;
 }
 
@@ -1267,30 +1497,115 @@ int qilqr_solve_batch_sharded(qilqr_sharded *h, const double *init, const double
                               int32_t *out_n_bwd, int32_t *out_n_fwd) {
   if (!h || h->solvers.empty() || !init) return fail(QILQR_ERR_INVALID_ARG, "null argument");
   if (B <= 0 || n <= 0) return fail(QILQR_ERR_INVALID_ARG, "B and n must be positive");
+  DeviceGuard guard;
+  try {
+    const ShardCall c{init, desired_batch, B, n, out_traj, out_cost, out_status, out_iters, out_n_bwd, out_n_fwd, true};
+    return run_all_shards(h, c);
+  } catch (...) {
+    return fail(QILQR_ERR_INVALID_ARG, "qilqr_solve_batch_sharded: out of host memory");
+  }
+}
+
+int qilqr_sharded_set_transport(qilqr_sharded *h, int32_t transport) {
+  if (!h) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  if (transport != QILQR_TRANSPORT_AUTO && transport != QILQR_TRANSPORT_RCCL && transport != QILQR_TRANSPORT_PEER_COPY)
+    return fail(QILQR_ERR_INVALID_ARG, "transport must be QILQR_TRANSPORT_AUTO, _RCCL or _PEER_COPY");
+  DeviceGuard guard;
+  if (transport != h->transport) sharded_drop_gather_path(h);
+  h->transport = transport;
+  h->info.clear();
+  return sharded_ensure_gather_path(h);
+}
+
+const char *qilqr_sharded_transport(qilqr_sharded *h) {
+  if (!h) return "";
+  DeviceGuard guard;
+  if (!h->resolved && sharded_ensure_gather_path(h) != QILQR_OK) return "";
+  return h->info.c_str();
+}
+
+// The C counterpart of quadrotorilqr_amd/sharding.gather_to_root: every shard's results go from the staging buffers of its
+// solver straight into ITS rows of the root device's arrays -- ragged (shards differ by one problem when the count does not
+// divide B), no padding, nothing concatenated afterwards.  RCCL transport: one ncclSend on the shard's device and one
+// ncclRecv on the root's per array, all inside one group (a single host thread drives every communicator of the process);
+// a shard on the root's own device is a send and a receive on the same communicator.  Peer-copy transport:
+// hipMemcpyPeerAsync.  Either way the transfer of a shard starts when that shard's solve has finished (stream-ordered
+// behind its `done` event), not when the slowest has.
+int qilqr_solve_batch_sharded_device(qilqr_sharded *h, const double *init, const double *desired_batch, int32_t B, int32_t n,
+                                     int32_t root, double *d_out_traj, double *d_out_cost, int32_t *d_out_status,
+                                     int32_t *d_out_iters, int32_t *d_out_n_bwd, int32_t *d_out_n_fwd, double *gather_ms) {
+  if (!h || h->solvers.empty() || !init) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  if (B <= 0 || n <= 0) return fail(QILQR_ERR_INVALID_ARG, "B and n must be positive");
   const int32_t k = (int32_t)h->solvers.size();
-  std::vector<int> rcs(k, QILQR_OK);
-  std::vector<std::string> msgs(k);
-  auto run = [&](int32_t r) {
-    int32_t b0 = 0, cnt = 0;
-    (void)qilqr_shard_range(B, k, r, &b0, &cnt);
-    if (cnt == 0) return;  // fewer problems than shards
-    const size_t to = (size_t)b0 * n * 18;
-    rcs[r] = qilqr_solve_batch(h->solvers[r], init + to, desired_batch ? desired_batch + to : nullptr, cnt, n,
-                               out_traj ? out_traj + to : nullptr, out_cost ? out_cost + b0 : nullptr,
-                               out_status ? out_status + b0 : nullptr, out_iters ? out_iters + b0 : nullptr,
-                               out_n_bwd ? out_n_bwd + b0 : nullptr, out_n_fwd ? out_n_fwd + b0 : nullptr);
-    if (rcs[r] != QILQR_OK) msgs[r] = g_last_error;  // (thread-local: carried back to the caller below)
-  };
-  // shard 0 on the calling thread, the others on threads of their own (HIP's current device is per thread;
-  // qilqr_solve_batch sets it)
-  std::vector<std::thread> threads;
-  for (int32_t r = 1; r < k; ++r) threads.emplace_back(run, r);
-  run(0);
-  for (std::thread &t : threads) t.join();
-  for (int32_t r = 0; r < k; ++r)
-    if (rcs[r] != QILQR_OK)
-      return fail(rcs[r], "shard " + std::to_string(r) + " (device " + std::to_string(h->solvers[r]->device) + "): " + msgs[r]);
-  return QILQR_OK;
+  if (root < 0 || root >= k) return fail(QILQR_ERR_INVALID_ARG, "root must be a shard index");
+  DeviceGuard guard;
+  try {
+    int rc = sharded_ensure_gather_path(h);
+    if (rc) return rc;
+    const ShardCall c{init, desired_batch, B, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false};
+    if ((rc = run_all_shards(h, c))) {
+      for (qilqr_solver *s : h->solvers) {  // nothing of a failed call stays in flight
+        (void)hipSetDevice(s->device);
+        (void)hipStreamSynchronize(s->stream);
+      }
+      return rc;
+    }
+    const int rr = h->rank_of[root], root_dev = h->device[root];
+    hipStream_t rs = h->gstream[rr];
+    // the pieces: (source on the shard's device, destination on the root's, bytes), six arrays per shard
+    struct Piece { const void *src; void *dst; size_t count; ncclDataType_t type; size_t bytes; };
+    std::vector<std::vector<Piece>> pieces(k);
+    for (int32_t r = 0; r < k; ++r) {
+      int32_t b0 = 0, cnt = 0;
+      (void)qilqr_shard_range(B, k, r, &b0, &cnt);
+      if (cnt == 0) continue;
+      qilqr_solver *s = h->solvers[r];
+      HIP_TRY(hipSetDevice(h->device[r]));
+      HIP_TRY(hipStreamWaitEvent(h->gstream[h->rank_of[r]], h->done[r], 0));
+      const size_t row = (size_t)n * 18;
+      if (d_out_traj) pieces[r].push_back({s->stage_traj, d_out_traj + (size_t)b0 * row, (size_t)cnt * row, ncclDouble, sizeof(double) * cnt * row});
+      if (d_out_cost) pieces[r].push_back({s->stage_cost, d_out_cost + b0, (size_t)cnt, ncclDouble, sizeof(double) * cnt});
+      int32_t *outs[4] = {d_out_status, d_out_iters, d_out_n_bwd, d_out_n_fwd};
+      for (int q = 0; q < 4; ++q)
+        if (outs[q]) pieces[r].push_back({s->stage_int + (size_t)q * cnt, outs[q] + b0, (size_t)cnt, ncclInt32, sizeof(int32_t) * cnt});
+    }
+    if (h->resolved == QILQR_TRANSPORT_RCCL) {
+      Rccl &R = rccl();
+      ncclResult_t st = R.GroupStart();
+      for (int32_t r = 0; r < k && st == ncclSuccess; ++r)
+        for (const Piece &pc : pieces[r]) {
+          st = R.Send(pc.src, pc.count, pc.type, rr, h->comms[h->rank_of[r]], h->gstream[h->rank_of[r]]);
+          if (st == ncclSuccess) st = R.Recv(pc.dst, pc.count, pc.type, h->rank_of[r], h->comms[rr], rs);
+          if (st != ncclSuccess) break;
+        }
+      const ncclResult_t st_end = R.GroupEnd();
+      if (st == ncclSuccess) st = st_end;
+      if (st != ncclSuccess) return fail(QILQR_ERR_HIP, std::string("RCCL gather: ") + R.GetErrorString(st));
+    } else {
+      for (int32_t r = 0; r < k; ++r) {
+        HIP_TRY(hipSetDevice(h->device[r]));
+        for (const Piece &pc : pieces[r])
+          HIP_TRY(hipMemcpyPeerAsync(pc.dst, root_dev, pc.src, h->device[r], pc.bytes, h->gstream[h->rank_of[r]]));
+      }
+    }
+    // exposed gather time: from the moment the last solve has finished to the moment the root holds every row
+    for (int32_t r = 0; r < k; ++r)
+      if (!pieces[r].empty()) {
+        HIP_TRY(hipSetDevice(h->device[r]));
+        HIP_TRY(hipEventSynchronize(h->done[r]));
+      }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t u = 0; u < h->uniq.size(); ++u) {
+      HIP_TRY(hipSetDevice(h->uniq[u]));
+      HIP_TRY(hipStreamSynchronize(h->gstream[u]));
+    }
+    if (gather_ms) *gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (qilqr_solver *s : h->solvers)
+      if (s->dev.profile) drain_events(s);
+    return QILQR_OK;
+  } catch (...) {
+    return fail(QILQR_ERR_INVALID_ARG, "qilqr_solve_batch_sharded_device: out of host memory");
+  }
 }
 
 #ifdef QILQR_STAMPS

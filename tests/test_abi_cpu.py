@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = capi.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.qilqr_abi_version() == 4
+    assert lib.qilqr_abi_version() == 5
 
 
 def test_struct_layouts_match_header():

@@ -70,3 +70,46 @@ def test_a_failing_shard_reports_itself_and_the_others_complete():
     assert (out["status"][:8] >= 0).all() and (out["status"][8:] == -1).all()  # shards 0 and 1 solved, shard 2 untouched
     good = many.solve_batch(cfg["init"])
     np.testing.assert_array_equal(good["status"][:8], out["status"][:8])
+
+
+@pytest.mark.parametrize("transport", ["rccl", "peer_copy", "auto"])
+@pytest.mark.parametrize("B,shards,root", [(203, 3, 0), (5, 8, 2), (64, 2, 1)])
+def test_results_gathered_into_one_devices_memory(transport, B, shards, root):
+    """qilqr_solve_batch_sharded_device: every shard's rows go from its solver's staging buffers straight to their place in
+    the root device's arrays -- ragged shards, more shards than problems -- over RCCL (ncclSend / ncclRecv inside one group;
+    on this one-GPU box every shard sits on device 0, so the communicator has ONE rank and every transfer is a send and a
+    receive on it: the calls, the grouping, the stream ordering behind each shard's `done` event and the offsets are those
+    of an 8-GPU node, the wire is not) or by peer copies; bit-identical to the single-device solve either way."""
+    import torch
+    cfg = pb.config2(B=B, N=40, seed=21)
+    one = capi.from_config(cfg)
+    a = one.solve_batch(cfg["init"])
+    many = capi.sharded_from_config(cfg, devices=[0] * shards)
+    said = many.set_transport(transport)
+    if transport == "rccl":
+        assert said.startswith("rccl: ncclSend / ncclRecv, 1 rank")
+    else:
+        assert said.startswith("peer copies")   # 'auto' with every shard on one device: nothing to communicate
+    dev = torch.device("cuda", 0)
+    out = dict(traj=torch.full((B, 40, 18), float("nan"), dtype=torch.float64, device=dev),
+               cost=torch.full((B,), float("nan"), dtype=torch.float64, device=dev),
+               **{k: torch.full((B,), -7, dtype=torch.int32, device=dev) for k in ("status", "iters", "n_bwd", "n_fwd")})
+    for rep in range(2):  # the second call reuses communicators, streams and events
+        ms = many.solve_batch_gathered(cfg["init"], out["traj"], out["cost"], out["status"], out["iters"], out["n_bwd"], out["n_fwd"],
+                                       root=root)
+        assert 0.0 <= ms < 1e3
+        for k in ("status", "iters", "n_bwd", "n_fwd", "cost", "traj"):
+            np.testing.assert_array_equal(out[k].cpu().numpy(), a[k], err_msg=k)
+    # any output may be absent; a bad root is refused
+    many.solve_batch_gathered(cfg["init"], None, out["cost"], None, None, None, None, root=root)
+    np.testing.assert_array_equal(out["cost"].cpu().numpy(), a["cost"])
+    with pytest.raises(Exception):
+        many.solve_batch_gathered(cfg["init"], None, out["cost"], None, None, None, None, root=shards)
+    # a failing shard names itself, nothing stays in flight, and the handle still works afterwards
+    bad = cfg["init"].copy()
+    bad[B - 1, 3, 4:8] *= 1.5
+    with pytest.raises(Exception) as ei:
+        many.solve_batch_gathered(bad, out["traj"], out["cost"], out["status"], out["iters"], out["n_bwd"], out["n_fwd"], root=root)
+    assert "shard" in str(ei.value) and "quaternion" in str(ei.value)
+    many.solve_batch_gathered(cfg["init"], out["traj"], None, None, None, None, None, root=root)
+    np.testing.assert_array_equal(out["traj"].cpu().numpy(), a["traj"])
