@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Runs the non-headline BASELINE.json configurations at full size on the GPU box and prints one
 JSON line per configuration (wall time of qilqr_solve_batch_device with inputs resident in HBM,
-status histogram, pass counts).  Usage: python profiles/run_configs.py [config4shard] [config5] [config5reg] [big]"""
+status histogram, pass counts).  Usage: python profiles/run_configs.py [config3] [config3f64] [config4shard] [config5] [config5reg] [big]
+(config3 = BASELINE.json configs[2]: B = 8192, N = 200, mixed fp32 / fp64 mode)"""
 import json
 import os
 import sys
@@ -14,10 +15,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quadrotorilqr_amd import capi, problems as pb  # noqa: E402
 
 
-def run(name, cfg, reps=2, reg=None):
+def run(name, cfg, reps=2, reg=None, **solver_kw):
     dev = torch.device("cuda", 0)
     B, N = cfg["init"].shape[:2]
-    s = capi.from_config(cfg, sync_every=2)
+    s = capi.from_config(cfg, sync_every=2, **solver_kw)
     if reg:
         s.set_regularisation(*reg)  # Levenberg-Marquardt restarts (extension)
     init = torch.from_numpy(cfg["init"]).to(dev)
@@ -32,7 +33,7 @@ def run(name, cfg, reps=2, reg=None):
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t)
     st, it, nb, nf = (x.cpu().numpy() for x in ints)
-    print(json.dumps({"config": name, "B": B, "N": N, "seconds": best, "solves_per_s": B / best,
+    print(json.dumps({"config": name, "B": B, "N": N, **{k: str(v) for k, v in solver_kw.items()}, "seconds": best, "solves_per_s": B / best,
                       "knot_steps_per_s": float((nb.sum() + nf.sum()) * N / best),
                       "status_counts": np.bincount(st, minlength=4).tolist(), "iters_mean": float(it.mean()),
                       "iters_max": int(it.max()), "n_bwd_mean": float(nb.mean()), "n_fwd_mean": float(nf.mean())}))
@@ -40,6 +41,10 @@ def run(name, cfg, reps=2, reg=None):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["config4shard", "config5"]
+    if "config3" in which:  # BASELINE.json configs[2]: fp32 storage / lane-local arithmetic, fp64 recursion and decisions
+        run("configs[2] (B=8192, N=200, seed 3), precision f32 (mixed)", pb.config3(), precision="f32")
+    if "config3f64" in which:  # the same problems and tolerances in the fp64 mode, for comparison
+        run("configs[2] problems (B=8192, N=200, seed 3), precision f64", pb.config3(), precision="f64")
     if "config4shard" in which:  # one rank's shard of configs[3]: 8192 problems, 100 knots, seed 4
         run("configs[3] shard of one GPU (B=8192, N=100, seed 4)", pb.config2(B=8192, N=100, seed=4))
     if "config5" in which:

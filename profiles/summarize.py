@@ -68,6 +68,19 @@ def main():
         for k, d in sorted(summary[name].items()):
             lines.append(f"  {k:20s} launches {d['launches']:6d}  raw KiB/launch {d['kib_per_launch_raw']:12.1f}  "
                          f"corrected MB/launch {d['bytes_per_launch_corrected']/1e6:10.3f}")
+    # ---- per-kernel HBM rate: (fetched + written bytes per launch, from the two PMC passes) / average launch duration of the trace
+    if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
+        lines.append("")
+        lines.append("HBM rate per kernel = (FETCH x 2 + WRITE bytes per launch) / avg launch duration of the kernel trace; peak 8000 GB/s")
+        summary["hbm_rate"] = {}
+        for k, d in ks.items():
+            f_, w_ = summary["FETCH_SIZE"].get(k), summary["WRITE_SIZE"].get(k)
+            if not f_ or not w_ or d["avg_us"] <= 0:
+                continue
+            byts = f_["bytes_per_launch_corrected"] + w_["bytes_per_launch_corrected"]
+            gbs = byts / (d["avg_us"] * 1e-6) / 1e9
+            summary["hbm_rate"][k] = dict(bytes_per_launch=byts, gb_per_s=gbs, frac_of_8tb=gbs / 8000.0)
+            lines.append(f"  {k:20s} {byts/1e6:10.3f} MB/launch  {d['avg_us']:9.2f} us  {gbs:9.1f} GB/s  {100*gbs/8000.0:5.1f} % of peak")
     for f in ("bench_trace.log",):
         p = os.path.join(out, f)
         if os.path.exists(p):

@@ -1240,16 +1240,36 @@ struct Rccl {
   decltype(&ncclSend) Send = nullptr;
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
-  std::string error;
+  std::string error, path;
   bool ok = false;
 };
 Rccl &rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (r.lib) break;
+    // Which librccl: the one that ships BESIDE the HIP runtime this process runs on (found from the address of a HIP entry
+    // point).  A process can hold two ROCm installations -- PyTorch bundles its own libamdhip64 and librccl, this library is
+    // linked against /opt/rocm's, and whichever libamdhip64 was loaded first serves both -- and an RCCL built for the other
+    // runtime fails in ncclCommInitAll ("unhandled cuda error": measured, torch's librccl 7.0 on the 7.2 runtime).  Loaded
+    // RTLD_LOCAL: a second copy beside one the host process already uses keeps its own state and exports nothing.
+    std::vector<std::string> names;
+    Dl_info where;
+    if (dladdr((const void *)&hipGetDeviceCount, &where) && where.dli_fname) {
+      const std::string path(where.dli_fname);
+      const size_t slash = path.rfind('/');
+      if (slash != std::string::npos) {
+        names.push_back(path.substr(0, slash + 1) + "librccl.so.1");
+        names.push_back(path.substr(0, slash + 1) + "librccl.so");
+      }
+    }
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    for (const std::string &name : names) {
+      r.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) {
+        r.path = name;
+        break;
+      }
     }
     if (!r.lib) {
       const char *err = dlerror();
@@ -1348,7 +1368,7 @@ int sharded_ensure_gather_path(qilqr_sharded *h) {
         int ver = 0;
         (void)R.GetVersion(&ver);
         h->info = "rccl: ncclSend / ncclRecv, " + std::to_string(nuniq) + " rank" + (nuniq > 1 ? "s" : "") + " in one process (version code " +
-                  std::to_string(ver) + ")";
+                  std::to_string(ver) + ", " + R.path + ")";
       }
     }
   }

@@ -20,6 +20,25 @@ def test_demo_through_the_binding_matches_golden():
     np.testing.assert_array_equal(out["iters"][-1], out["optimized"])  # solve returns the last accepted rollout
 
 
+def test_config1_demo_at_its_own_100_knots_through_the_binding():
+    """BASELINE.json configs[0] as it is specified -- the demo with horizon_s = 10.0, i.e. 100 knots, default ILQROptions
+    (quadrotor_ilqr.py:257-306 with the horizon of SURVEY.md section 8b) -- through the reference's Python surface: messages
+    in, QuadrotorILQR(...) positional, solve(desired), messages out.  The problem is chaotic in the reference algorithm itself
+    (tests/test_oracle_golden.py::test_demo100_is_chaotic: the desired roll sits on the Log branch cut), so it is held to the
+    bar of tests/test_gpu_parity.py::test_demo100_config1: the same exit path and iteration count as the oracle, one
+    ILQRIterDebug per iteration, the cost history within 1e-3."""
+    from src.demo import main
+    out = main(10.0)
+    status, iters = (int(v) for v in G["demo100_meta"][:2])  # max_iters, 100
+    assert status == 2 and len(out["costs"]) == len(out["iters"]) == iters == 100
+    np.testing.assert_allclose(out["costs"], G["demo100_cost_hist"], rtol=1e-3)
+    assert out["costs"][-1] < out["costs"][0] / 50
+    assert out["optimized"].shape == (100, 18) and out["desired"].shape == (100, 18)
+    np.testing.assert_array_equal(out["optimized"][:, 0], out["desired"][:, 0])          # time_s passes through (ilqr.hh:164)
+    np.testing.assert_array_equal(out["optimized"][0, 1:14], out["desired"][0, 1:14])    # knot 0 state is the input's (:156)
+    np.testing.assert_array_equal(out["iters"][-1], out["optimized"])                    # the last accepted rollout is returned
+
+
 def test_binding_types_and_debug_switch():
     import src.ilqr_debug_pb2 as dbg
     import src.trajectory_pb2 as traj
