@@ -435,27 +435,28 @@ class QuadrotorILQRSharded:
         return load().qilqr_sharded_transport(self._h).decode()
 
     def solve_batch_gathered(self, init, out_traj, out_cost, out_status, out_iters, out_n_bwd, out_n_fwd, desired_batch=None, root=0):
-        """qilqr_solve_batch_sharded_device: host inputs, results gathered into device arrays (torch tensors, contiguous, on the
-        device of shard `root`): traj (B, n, 18) float64, cost (B,) float64, the rest (B,) int32; any may be None.
+        """qilqr_solve_batch_sharded_device: host inputs, results gathered into device arrays on the device of shard `root`:
+        traj (B, n, 18) float64, cost (B,) float64, the rest (B,) int32; any may be None.  An output is a raw device address
+        (int: the caller vouches for its size) or a contiguous torch tensor of that dtype and shape on that device.
         Returns the exposed gather time in ms."""
         init = _d(init)
         B, n = init.shape[0], init.shape[1]
         des = None if desired_batch is None else _d(desired_batch)
-        import torch
 
         def ptr(t, dtype, shape):
             if t is None:
                 return None
-            if t.dtype != dtype or tuple(t.shape) != shape or not t.is_contiguous() or t.device.index != self.devices[root]:
+            if isinstance(t, int):
+                return C.c_void_p(t)
+            if str(t.dtype) != dtype or tuple(t.shape) != shape or not t.is_contiguous() or t.device.index != self.devices[root]:
                 raise ValueError(f"output tensor must be contiguous {dtype} {shape} on device {self.devices[root]}")
             return C.c_void_p(t.data_ptr())
 
-        torch.cuda.synchronize(self.devices[root])  # nothing of the caller's is still writing the outputs
         ms = C.c_double(0.0)
         rc = load().qilqr_solve_batch_sharded_device(
-            self._h, _p(init), _p(des), C.c_int32(B), C.c_int32(n), C.c_int32(root), ptr(out_traj, torch.float64, (B, n, 18)),
-            ptr(out_cost, torch.float64, (B,)), ptr(out_status, torch.int32, (B,)), ptr(out_iters, torch.int32, (B,)),
-            ptr(out_n_bwd, torch.int32, (B,)), ptr(out_n_fwd, torch.int32, (B,)), C.byref(ms))
+            self._h, _p(init), _p(des), C.c_int32(B), C.c_int32(n), C.c_int32(root), ptr(out_traj, "torch.float64", (B, n, 18)),
+            ptr(out_cost, "torch.float64", (B,)), ptr(out_status, "torch.int32", (B,)), ptr(out_iters, "torch.int32", (B,)),
+            ptr(out_n_bwd, "torch.int32", (B,)), ptr(out_n_fwd, "torch.int32", (B,)), C.byref(ms))
         if rc:
             _raise(rc)
         return ms.value

@@ -72,6 +72,35 @@ def test_a_failing_shard_reports_itself_and_the_others_complete():
     np.testing.assert_array_equal(good["status"][:8], out["status"][:8])
 
 
+class _Hip:
+    """device buffers without torch: the HIP runtime this process already runs on, through ctypes (loading PyTorch's second
+    ROCm runtime into a process that has already initialised /opt/rocm's is what these tests must not depend on)"""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.lib = C.CDLL("libamdhip64.so.7")
+        self.ptrs = []
+
+    def alloc(self, nbytes, fill=0xFF):
+        p = self.C.c_void_p()
+        assert self.lib.hipMalloc(self.C.byref(p), self.C.c_size_t(nbytes)) == 0
+        assert self.lib.hipMemset(p, self.C.c_int(fill), self.C.c_size_t(nbytes)) == 0
+        assert self.lib.hipDeviceSynchronize() == 0
+        self.ptrs.append(p)
+        return p.value
+
+    def download(self, ptr, shape, dtype):
+        a = np.empty(shape, dtype=dtype)
+        assert self.lib.hipMemcpy(a.ctypes.data_as(self.C.c_void_p), self.C.c_void_p(ptr), self.C.c_size_t(a.nbytes), self.C.c_int(2)) == 0
+        return a
+
+    def close(self):
+        for p in self.ptrs:
+            self.lib.hipFree(p)
+        self.ptrs = []
+
+
 @pytest.mark.parametrize("transport", ["rccl", "peer_copy", "auto"])
 @pytest.mark.parametrize("B,shards,root", [(203, 3, 0), (5, 8, 2), (64, 2, 1)])
 def test_results_gathered_into_one_devices_memory(transport, B, shards, root):
@@ -80,7 +109,6 @@ def test_results_gathered_into_one_devices_memory(transport, B, shards, root):
     on this one-GPU box every shard sits on device 0, so the communicator has ONE rank and every transfer is a send and a
     receive on it: the calls, the grouping, the stream ordering behind each shard's `done` event and the offsets are those
     of an 8-GPU node, the wire is not) or by peer copies; bit-identical to the single-device solve either way."""
-    import torch
     cfg = pb.config2(B=B, N=40, seed=21)
     one = capi.from_config(cfg)
     a = one.solve_batch(cfg["init"])
@@ -90,26 +118,58 @@ def test_results_gathered_into_one_devices_memory(transport, B, shards, root):
         assert said.startswith("rccl: ncclSend / ncclRecv, 1 rank")
     else:
         assert said.startswith("peer copies")   # 'auto' with every shard on one device: nothing to communicate
-    dev = torch.device("cuda", 0)
-    out = dict(traj=torch.full((B, 40, 18), float("nan"), dtype=torch.float64, device=dev),
-               cost=torch.full((B,), float("nan"), dtype=torch.float64, device=dev),
-               **{k: torch.full((B,), -7, dtype=torch.int32, device=dev) for k in ("status", "iters", "n_bwd", "n_fwd")})
-    for rep in range(2):  # the second call reuses communicators, streams and events
-        ms = many.solve_batch_gathered(cfg["init"], out["traj"], out["cost"], out["status"], out["iters"], out["n_bwd"], out["n_fwd"],
-                                       root=root)
-        assert 0.0 <= ms < 1e3
-        for k in ("status", "iters", "n_bwd", "n_fwd", "cost", "traj"):
-            np.testing.assert_array_equal(out[k].cpu().numpy(), a[k], err_msg=k)
-    # any output may be absent; a bad root is refused
-    many.solve_batch_gathered(cfg["init"], None, out["cost"], None, None, None, None, root=root)
-    np.testing.assert_array_equal(out["cost"].cpu().numpy(), a["cost"])
-    with pytest.raises(Exception):
-        many.solve_batch_gathered(cfg["init"], None, out["cost"], None, None, None, None, root=shards)
-    # a failing shard names itself, nothing stays in flight, and the handle still works afterwards
-    bad = cfg["init"].copy()
-    bad[B - 1, 3, 4:8] *= 1.5
-    with pytest.raises(Exception) as ei:
-        many.solve_batch_gathered(bad, out["traj"], out["cost"], out["status"], out["iters"], out["n_bwd"], out["n_fwd"], root=root)
-    assert "shard" in str(ei.value) and "quaternion" in str(ei.value)
-    many.solve_batch_gathered(cfg["init"], out["traj"], None, None, None, None, None, root=root)
-    np.testing.assert_array_equal(out["traj"].cpu().numpy(), a["traj"])
+    hip = _Hip()
+    shapes = dict(traj=((B, 40, 18), np.float64), cost=((B,), np.float64),
+                  **{k: ((B,), np.int32) for k in ("status", "iters", "n_bwd", "n_fwd")})
+    out = {k: hip.alloc(int(np.prod(sh)) * np.dtype(dt).itemsize) for k, (sh, dt) in shapes.items()}
+    get = lambda k: hip.download(out[k], *shapes[k])
+    try:
+        for rep in range(2):  # the second call reuses communicators, streams and events
+            ms = many.solve_batch_gathered(cfg["init"], out["traj"], out["cost"], out["status"], out["iters"], out["n_bwd"], out["n_fwd"],
+                                           root=root)
+            assert 0.0 <= ms < 1e3
+            for k in ("status", "iters", "n_bwd", "n_fwd", "cost", "traj"):
+                np.testing.assert_array_equal(get(k), a[k], err_msg=k)
+        # any output may be absent; a bad root is refused
+        many.solve_batch_gathered(cfg["init"], None, out["cost"], None, None, None, None, root=root)
+        np.testing.assert_array_equal(get("cost"), a["cost"])
+        with pytest.raises(Exception):
+            many.solve_batch_gathered(cfg["init"], None, out["cost"], None, None, None, None, root=shards)
+        # a failing shard names itself, nothing stays in flight, and the handle still works afterwards
+        bad = cfg["init"].copy()
+        bad[B - 1, 3, 4:8] *= 1.5
+        with pytest.raises(Exception) as ei:
+            many.solve_batch_gathered(bad, out["traj"], out["cost"], out["status"], out["iters"], out["n_bwd"], out["n_fwd"], root=root)
+        assert "shard" in str(ei.value) and "quaternion" in str(ei.value)
+        many.solve_batch_gathered(cfg["init"], out["traj"], None, None, None, None, None, root=root)
+        np.testing.assert_array_equal(get("traj"), a["traj"])
+    finally:
+        many.close()
+        hip.close()
+
+
+def test_plain_c_host_gathers_over_rccl():
+    """tests/c/sharded_gather_harness.c: a C program with include/quadrotor_ilqr.h, the HIP runtime and nothing else in the
+    process solves a batch sharded three ways, gathers it into the root's memory over RCCL and over peer copies, compares
+    with the single-device solve bit for bit and reports the exposed gather time."""
+    import json
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    exe = os.path.join(here, "c", "sharded_gather_harness")
+    src = exe + ".c"
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-std=c99", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+                               src, "-L" + os.path.join(root, "quadrotorilqr_amd", "lib"), "-lquadrotor_ilqr", "-L/opt/rocm/lib",
+                               "-lamdhip64", "-lm", "-Wl,-rpath," + os.path.join(root, "quadrotorilqr_amd", "lib"),
+                               "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    for transport, said in ((1, "rccl: ncclSend / ncclRecv"), (2, "peer copies")):
+        # (1536 problems: shards of 512 take the same backward kernel as the whole batch -- which kernel a batch size selects
+        # shows in the last bits of a trajectory, tests/test_gpu_parity.py::test_config2_full_size_properties)
+        r = subprocess.run([exe, str(transport), "1536", "100", "1", "0", "0", "0"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert j["bit_identical"] is True and j["transport"].startswith(said) and j["shards"] == 3 and j["converged"] == 1536
+        assert 0 <= j["gather_ms_best_of_3"] < 100
+        print(j)
