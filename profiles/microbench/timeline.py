@@ -17,7 +17,7 @@ for p in paths:
             n = r["Kernel_Name"]
             if "qilqr" not in n:
                 continue
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n.split("<")[0].split("::")[-1].split("(")[0]))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n.split("(")[0].split("<")[0].split("::")[-1]))
 rows.sort()
 solves, cur = [], []
 for r in rows:
