@@ -88,6 +88,14 @@ struct qilqr_solver {
   double *stage_traj = nullptr, *stage_des = nullptr, *stage_cost = nullptr;
   int *stage_int = nullptr;
   size_t stage_traj_cap = 0, stage_des_cap = 0, stage_B_cap = 0;
+  // copy-back of the finished trajectories under the tail rounds of a host-buffer batch solve (EarlyOut below)
+  void *early_out = nullptr;              // EarlyOut *, set by qilqr_solve_batch for the duration of its solve
+  hipStream_t early_stream = nullptr;
+  hipEvent_t early_evt = nullptr;
+  int *d_early = nullptr;                 // [2 B]: early[B] | late_slot[B]
+  size_t early_cap = 0;                   // B it was allocated for
+  char *d_late = nullptr, *h_late = nullptr;  // compact rows of the trajectories that finished late: device block, pinned host block
+  size_t late_bytes = 0;
   // profiling
   std::vector<EventPair> events;
   size_t events_used = 0;
@@ -455,12 +463,94 @@ int read_active(qilqr_solver *s, int *n_active) {
   return QILQR_OK;
 }
 
+// ---- host-buffer batch solve: the copy-back under the tail of the solve.
+// A batch takes as long as its slowest problem (configs[1]: 33 rounds for a mean of 12.5 iterations), and for the last third of
+// the rounds nine trajectories in ten already have their exit status while the copy engines sit idle.  When the host sees
+// the count of running trajectories fall to B / 8, it marks the finished ones between two rounds (k_mark_final, on the
+// solver's stream), and a second stream gathers exactly those and copies the result arrays to the caller's (pinned) host
+// buffers while the rounds of the others go on.  After the last round the late finishers -- at most B / 8 -- are gathered into
+// a small compact block, copied, and put into their rows by the host.  The caller's arrays end up bit-identical to the
+// one-piece copy.
+struct EarlyOut {
+  double *h_traj, *h_cost;
+  int32_t *h_status, *h_iters, *h_bwd, *h_fwd;
+  unsigned threshold = 0;  // fire when the active count is at or below this (and not zero)
+  bool fired = false;
+  int late_cap = 0;        // rows of the compact block: the active count seen when firing (the count only falls)
+  struct LateLayout *layout = nullptr;
+};
+struct LateLayout {  // one block, device and host alike: [traj rows][cost][status | iters | n_bwd | n_fwd][idx][count]
+  size_t traj, cost, ints, idx, count, bytes;
+};
+inline LateLayout late_layout(long rows, long n) {
+  LateLayout L;
+  L.traj = 0;
+  L.cost = sizeof(double) * (size_t)rows * n * 18;
+  L.ints = L.cost + sizeof(double) * rows;
+  L.idx = L.ints + sizeof(int) * 4 * rows;
+  L.count = L.idx + sizeof(int) * rows;
+  L.bytes = L.count + sizeof(int) * 2;
+  return L;
+}
+int ensure_early_buffers(qilqr_solver *s, long B, long n, long rows) {
+  if (!s->early_stream) HIP_TRY(hipStreamCreateWithFlags(&s->early_stream, hipStreamNonBlocking));
+  if (!s->early_evt) HIP_TRY(hipEventCreateWithFlags(&s->early_evt, hipEventDisableTiming));
+  if ((size_t)B > s->early_cap) {
+    if (s->d_early) (void)hipFree(s->d_early);
+    s->d_early = nullptr;
+    s->early_cap = 0;
+    HIP_TRY(hipMalloc((void **)&s->d_early, sizeof(int) * 2 * (size_t)B));
+    s->early_cap = (size_t)B;
+  }
+  const size_t want = late_layout(rows, n).bytes;
+  if (want > s->late_bytes) {
+    if (s->d_late) (void)hipFree(s->d_late);
+    if (s->h_late) (void)hipHostFree(s->h_late);
+    s->d_late = s->h_late = nullptr;
+    s->late_bytes = 0;
+    HIP_TRY(hipMalloc((void **)&s->d_late, want));
+    HIP_TRY(hipHostMalloc((void **)&s->h_late, want, hipHostMallocDefault));
+    s->late_bytes = want;
+  }
+  return QILQR_OK;
+}
+int gather(qilqr_solver *s, long B, long n, double *d_traj, double *d_cost, int *d_status, int *d_iters, int *d_bwd, int *d_fwd,
+           const int *mask, int want, const int *row_of);
+// called from the polling loop of run_solve when the count has fallen to the threshold
+int fire_early_out(qilqr_solver *s, long B, long n, EarlyOut *eo, unsigned active) {
+  eo->fired = true;
+  eo->late_cap = (int)active;
+  *eo->layout = late_layout((long)active, n);
+  int *early = s->d_early, *late_count = (int *)(s->d_late + eo->layout->count);
+  launch(s, K_OTHER, k_mark_final, dim3(cdiv(B, 256)), dim3(256), s->st, (int)B, early, late_count);
+  HIP_TRY(hipEventRecord(s->early_evt, s->stream));
+  HIP_TRY(hipStreamWaitEvent(s->early_stream, s->early_evt, 0));
+  hipStream_t main_stream = s->stream;
+  s->stream = s->early_stream;  // (launch() goes to s->stream)
+  int *d_int = s->stage_int;
+  const int rc = gather(s, B, n, eo->h_traj ? s->stage_traj : nullptr, eo->h_cost ? s->stage_cost : nullptr, eo->h_status ? d_int : nullptr,
+                        eo->h_iters ? d_int + B : nullptr, eo->h_bwd ? d_int + 2 * B : nullptr, eo->h_fwd ? d_int + 3 * B : nullptr, early, 1,
+                        nullptr);
+  s->stream = main_stream;
+  if (rc) return rc;
+  hipStream_t es = s->early_stream;
+  if (eo->h_traj) HIP_TRY(hipMemcpyAsync(eo->h_traj, s->stage_traj, sizeof(double) * 18 * (size_t)B * n, hipMemcpyDeviceToHost, es));
+  if (eo->h_cost) HIP_TRY(hipMemcpyAsync(eo->h_cost, s->stage_cost, sizeof(double) * B, hipMemcpyDeviceToHost, es));
+  if (eo->h_status) HIP_TRY(hipMemcpyAsync(eo->h_status, d_int, sizeof(int) * B, hipMemcpyDeviceToHost, es));
+  if (eo->h_iters) HIP_TRY(hipMemcpyAsync(eo->h_iters, d_int + B, sizeof(int) * B, hipMemcpyDeviceToHost, es));
+  if (eo->h_bwd) HIP_TRY(hipMemcpyAsync(eo->h_bwd, d_int + 2 * B, sizeof(int) * B, hipMemcpyDeviceToHost, es));
+  if (eo->h_fwd) HIP_TRY(hipMemcpyAsync(eo->h_fwd, d_int + 3 * B, sizeof(int) * B, hipMemcpyDeviceToHost, es));
+  return QILQR_OK;
+}
+
 // The outer loop of ILQR::solve (ilqr.hh:53-87) for trajectories already in st.traj[0].
 // on_round (optional) is called after every synchronised round (debug capture).
 // drain = false: return as soon as the host knows that no trajectory is active; the caller enqueues
 // its own work behind the rounds still in flight and waits for the stream itself.
+// on_count (optional): called with the count of running trajectories each time the free-running loop learns one.
 template <typename F>
-int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool drain = true) {
+int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool drain = true,
+              const std::function<int(unsigned)> *on_count = nullptr) {
   int rc;
   if ((rc = launch_linearize(s, B, n, 0, 0))) return rc;
   {
@@ -517,6 +607,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
           __builtin_ia32_pause();
         }
         if ((unsigned)v == 0) break;
+        if (on_count && (rc = (*on_count)((unsigned)v))) return rc;
       }
     }
   }
@@ -672,13 +763,13 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
 }
 
 int gather(qilqr_solver *s, long B, long n, double *d_traj, double *d_cost, int *d_status, int *d_iters,
-           int *d_bwd, int *d_fwd) {
+           int *d_bwd, int *d_fwd, const int *mask = nullptr, int want = 0, const int *row_of = nullptr) {
   if (s->f32)
     launch(s, K_OTHER, k_gather<float>, dim3((unsigned)cdiv(B, TILE), (unsigned)cdiv(n * 9 * TILE, 256)), dim3(256), s->st, (int)B, (int)n,
-                       d_traj, d_cost, d_status, d_iters, d_bwd, d_fwd);
+                       d_traj, d_cost, d_status, d_iters, d_bwd, d_fwd, mask, want, row_of);
   else
     launch(s, K_OTHER, k_gather<double>, dim3((unsigned)cdiv(B, TILE), (unsigned)cdiv(n * 9 * TILE, 256)), dim3(256), s->st, (int)B, (int)n,
-                       d_traj, d_cost, d_status, d_iters, d_bwd, d_fwd);
+                       d_traj, d_cost, d_status, d_iters, d_bwd, d_fwd, mask, want, row_of);
   return QILQR_OK;
 }
 
@@ -738,8 +829,27 @@ int solve_batch_device_impl(qilqr_solver *s, const double *d_init, const double 
     if ((rc = launch_solve4(s, B, n))) return rc;
   } else if (nparts > 1) {
     if ((rc = run_solve_parts(s, B, n, nparts))) return rc;
-  } else if ((rc = run_solve(s, B, n, s->dev.sync_every, [] { return QILQR_OK; }, false))) {
-    return rc;
+  } else {
+    EarlyOut *eo = static_cast<EarlyOut *>(s->early_out);
+    const std::function<int(unsigned)> hook = [&](unsigned active) -> int {
+      if (eo->fired || active > eo->threshold) return QILQR_OK;
+      return fire_early_out(s, B, n, eo, active);
+    };
+    if ((rc = run_solve(s, B, n, s->dev.sync_every, [] { return QILQR_OK; }, false, eo ? &hook : nullptr))) return rc;
+    if (eo && eo->fired) {
+      // the late finishers into the compact block, one copy to the pinned host block; qilqr_solve_batch puts them in place
+      const LateLayout L = *eo->layout;
+      int *early = s->d_early, *late_slot = early + s->early_cap, *late_idx = (int *)(s->d_late + L.idx), *late_count = (int *)(s->d_late + L.count);
+      launch(s, K_OTHER, k_late_slots, dim3(cdiv(B, 256)), dim3(256), (int)B, (const int *)early, late_count, late_idx, late_slot, eo->late_cap);
+      int *li = (int *)(s->d_late + L.ints);
+      const long R = eo->late_cap;
+      if ((rc = gather(s, B, n, eo->h_traj ? (double *)(s->d_late + L.traj) : nullptr, eo->h_cost ? (double *)(s->d_late + L.cost) : nullptr,
+                       eo->h_status ? li : nullptr, eo->h_iters ? li + R : nullptr, eo->h_bwd ? li + 2 * R : nullptr,
+                       eo->h_fwd ? li + 3 * R : nullptr, early, 0, late_slot)))
+        return rc;
+      HIP_TRY(hipMemcpyAsync(s->h_late, s->d_late, L.bytes, hipMemcpyDeviceToHost, s->stream));
+      return QILQR_OK;  // (drain is false on this path: the caller waits for both streams)
+    }
   }
   if ((rc = gather(s, B, n, d_out_traj, d_out_cost, d_out_status, d_out_iters, d_out_n_bwd, d_out_n_fwd)))
     return rc;
@@ -914,6 +1024,11 @@ void qilqr_destroy(qilqr_solver *s) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
+  if (s->early_stream) (void)hipStreamDestroy(s->early_stream);
+  if (s->early_evt) (void)hipEventDestroy(s->early_evt);
+  if (s->d_early) (void)hipFree(s->d_early);
+  if (s->d_late) (void)hipFree(s->d_late);
+  if (s->h_late) (void)hipHostFree(s->h_late);
   if (s->stage_traj) (void)hipFree(s->stage_traj);
   if (s->stage_des) (void)hipFree(s->stage_des);
   if (s->stage_cost) (void)hipFree(s->stage_cost);
@@ -1049,24 +1164,82 @@ int qilqr_stream_wait_event(qilqr_solver *s, void *hip_event) {
   return QILQR_OK;
 }
 
-// host-buffer wrapper: solve_batch_staged, then the copies back behind the gather on the solver's stream; one wait at the end
+// host-buffer wrapper: solve_batch_staged, then the copies back -- behind the gather on the solver's stream, or, for a batch
+// whose outputs are pinned, in two parts with the first under the tail rounds of the solve (EarlyOut)
+namespace {
+bool pinned_or_null(const void *p) {
+  if (!p) return true;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // (an ordinary malloc'ed pointer is reported as an error by some runtimes: not pinned, and not sticky)
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+}  // namespace
 int qilqr_solve_batch(qilqr_solver *s, const double *init, const double *desired_batch, int32_t B, int32_t n,
                       double *out_traj, double *out_cost, int32_t *out_status, int32_t *out_iters,
                       int32_t *out_n_bwd, int32_t *out_n_fwd) {
+  if (!s) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  // the two-part copy-back pays when the trajectories are megabytes and the rounds run free on one stream; it needs pinned
+  // outputs (a copy to pageable memory would hold this thread, which has rounds to enqueue)
+  EarlyOut eo{out_traj, out_cost, out_status, out_iters, out_n_bwd, out_n_fwd};
+  LateLayout late{};
+  eo.layout = &late;
+  const bool early = out_traj && B >= 256 && (size_t)B * n * 144 >= ((size_t)2 << 20) && s->dev.sync_every > 1 && auto_parts(s, B) == 1 &&
+                     !use_persistent(s, B) && 0.0 < s->params.max_iters && pinned_or_null(out_traj) && pinned_or_null(out_cost) &&
+                     pinned_or_null(out_status) && pinned_or_null(out_iters) && pinned_or_null(out_n_bwd) && pinned_or_null(out_n_fwd);
+  if (early) {
+    eo.threshold = (unsigned)(B / 8);
+    HIP_TRY(hipSetDevice(s->device));
+    int rc0 = ensure_early_buffers(s, B, n, eo.threshold);
+    if (rc0) return rc0;
+    s->early_out = &eo;
+  }
   int rc = solve_batch_staged(s, init, desired_batch, B, n);
-  if (rc != QILQR_OK) return rc;
+  s->early_out = nullptr;
+  if (rc != QILQR_OK) {
+    if (eo.fired) {  // nothing of a failed call keeps writing the caller's arrays
+      (void)hipStreamSynchronize(s->early_stream);
+      (void)hipStreamSynchronize(s->stream);
+    }
+    return rc;
+  }
   const size_t tb = sizeof(double) * 18 * (size_t)B * n;
   const double *d_cost = s->stage_cost;
   const int *d_int = s->stage_int;
   hipError_t e = hipSuccess;
-  if (out_traj) e = hipMemcpyAsync(out_traj, s->stage_traj, tb, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess && out_cost) e = hipMemcpyAsync(out_cost, d_cost, sizeof(double) * B, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess && out_status) e = hipMemcpyAsync(out_status, d_int, sizeof(int) * B, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess && out_iters) e = hipMemcpyAsync(out_iters, d_int + B, sizeof(int) * B, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess && out_n_bwd) e = hipMemcpyAsync(out_n_bwd, d_int + 2 * B, sizeof(int) * B, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess && out_n_fwd) e = hipMemcpyAsync(out_n_fwd, d_int + 3 * B, sizeof(int) * B, hipMemcpyDeviceToHost, s->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-  if (e == hipSuccess) e = hipGetLastError();
+  if (eo.fired) {
+    e = hipStreamSynchronize(s->early_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) {
+      const int count = *(const int *)(s->h_late + late.count);
+      if (count < 0 || count > eo.late_cap) return fail(QILQR_ERR_HIP, "copy back: more late trajectories than were running");
+      const int *idx = (const int *)(s->h_late + late.idx);
+      const double *lt = (const double *)(s->h_late + late.traj), *lc = (const double *)(s->h_late + late.cost);
+      const int *li = (const int *)(s->h_late + late.ints);
+      const size_t row = (size_t)n * 18;
+      for (int k = 0; k < count; ++k) {
+        const int b = idx[k];
+        std::memcpy(out_traj + (size_t)b * row, lt + (size_t)k * row, sizeof(double) * row);
+        if (out_cost) out_cost[b] = lc[k];
+        if (out_status) out_status[b] = li[k];
+        if (out_iters) out_iters[b] = li[eo.late_cap + k];
+        if (out_n_bwd) out_n_bwd[b] = li[2 * eo.late_cap + k];
+        if (out_n_fwd) out_n_fwd[b] = li[3 * eo.late_cap + k];
+      }
+    }
+  } else {
+    if (out_traj) e = hipMemcpyAsync(out_traj, s->stage_traj, tb, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess && out_cost) e = hipMemcpyAsync(out_cost, d_cost, sizeof(double) * B, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess && out_status) e = hipMemcpyAsync(out_status, d_int, sizeof(int) * B, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess && out_iters) e = hipMemcpyAsync(out_iters, d_int + B, sizeof(int) * B, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess && out_n_bwd) e = hipMemcpyAsync(out_n_bwd, d_int + 2 * B, sizeof(int) * B, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess && out_n_fwd) e = hipMemcpyAsync(out_n_fwd, d_int + 3 * B, sizeof(int) * B, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+  }
   if (s->dev.profile) drain_events(s);
   if (e != hipSuccess) return fail(QILQR_ERR_HIP, std::string("copy back: ") + hipGetErrorString(e));
   return QILQR_OK;

@@ -2328,29 +2328,49 @@ __global__ void k_accept(SolveParams p, BatchState st, int B, int n, int ls_only
 // Block (b, chunk): trajectory b = blockIdx.x, thread = one 16-byte entry pair of it (no 64-bit division per element:
 // with one thread per element and three of them this kernel and k_retile took 13 and 16 us for 14.7 MB each)
 // ---------------------------------------------------------------------------------------------
+// mask (optional): only the trajectories with mask[b] == want take part.  row_of (optional): trajectory b goes to row row_of[b]
+// of the output arrays instead of row b (the compact copy of the trajectories that finished late, k_late_slots).
 template <typename S>
 __global__ void k_gather(BatchState st, int B, int n, double *out_traj, double *out_cost, int *out_status,
-                         int *out_iters, int *out_n_bwd, int *out_n_fwd) {
+                         int *out_iters, int *out_n_bwd, int *out_n_fwd, const int *mask, int want, const int *row_of) {
   // thread = one 16-byte piece of tile blockIdx.x in the order the tile is stored: (knot, pair) q >> TILE_LOG of trajectory
   // slot q & (TILE - 1) -- the tiled side is one contiguous run per wavefront, the plain side TILE runs
   const int q = blockIdx.y * blockDim.x + threadIdx.x;
   const int b = blockIdx.x * TILE + (q & (TILE - 1)), kp = q >> TILE_LOG;
   if (kp >= n * 9 || b >= B) return;
+  if (mask && mask[b] != want) return;
+  const long row = row_of ? row_of[b] : b;
   if (out_traj) {
     typedef typename GA<S>::v2 sv2;
     const int i = kp / 9, pr = kp - 9 * i;
     const sv2 v = *reinterpret_cast<const sv2 *>((const S *)st.traj[st.cur[b]] + knot_base<true>(b, n, 18) + knot_elem<true>(i, 2 * pr, 18));
-    double *o = out_traj + ((long)b * n * 9 + kp) * 2;
+    double *o = out_traj + (row * n * 9 + kp) * 2;
     o[0] = (double)v.x;
     o[1] = (double)v.y;
   }
   if (kp == 0) {
-    if (out_cost) out_cost[b] = st.cost[b];
-    if (out_status) out_status[b] = st.status[b];
-    if (out_iters) out_iters[b] = st.iters[b];
-    if (out_n_bwd) out_n_bwd[b] = st.n_bwd[b];
-    if (out_n_fwd) out_n_fwd[b] = st.n_fwd[b];
+    if (out_cost) out_cost[row] = st.cost[b];
+    if (out_status) out_status[row] = st.status[b];
+    if (out_iters) out_iters[row] = st.iters[b];
+    if (out_n_bwd) out_n_bwd[row] = st.n_bwd[b];
+    if (out_n_fwd) out_n_fwd[row] = st.n_fwd[b];
   }
+}
+// The copy-back of a host-buffer batch solve in two parts (qilqr_solve_batch): k_mark_final, on the solver's stream between two
+// rounds, notes which trajectories have reached their exit status (nothing of theirs changes any more); those are gathered
+// and copied to the host on a second stream while the rounds of the others go on.  k_late_slots, after the last round, gives
+// each of the others a row of a small compact buffer.
+__global__ void k_mark_final(BatchState st, int B, int *early, int *late_count) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0) *late_count = 0;
+  if (b < B) early[b] = (st.flags[b] == 0) ? 1 : 0;
+}
+__global__ void k_late_slots(int B, const int *early, int *late_count, int *late_idx, int *late_slot, int cap) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B || early[b]) return;
+  const int slot = atomicAdd(late_count, 1);
+  late_slot[b] = slot < cap ? slot : cap - 1;  // (never more than cap: the count of running trajectories only falls)
+  if (slot < cap) late_idx[slot] = b;
 }
 
 // plain [B][n][W] <-> tiled, W = 18 or 52 (even).  to_tiled = 1: plain -> tiled.  sel (optional): per-trajectory choice of
