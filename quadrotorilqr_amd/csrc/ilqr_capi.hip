@@ -153,6 +153,17 @@ void drain_events(qilqr_solver *s) {
   s->events_used = 0;
 }
 
+// After a stream has drained: did a kernel give up (BatchState::host_error)?  k_rollout16 ends a block whose wavefronts lost
+// a hand-off instead of spinning for ever; the trajectories of that block are then not what the solve should have produced.
+int device_error(qilqr_solver *s) {
+  unsigned long long *w = s->h_active + 8 * (1 + qilqr_solver::MAX_PARTS);
+  const unsigned long long v = __atomic_load_n(w, __ATOMIC_ACQUIRE);
+  if (!v) return QILQR_OK;
+  __atomic_store_n(w, 0ull, __ATOMIC_RELEASE);
+  return fail(QILQR_ERR_HIP, "k_rollout16: a hand-off between the wavefronts of block " + std::to_string((unsigned)v) +
+                                 " never arrived (bounded spin ran out); its rollout was abandoned and the results of this call are invalid");
+}
+
 void free_workspace(qilqr_solver *s) {
   for (void *p : s->allocs) (void)hipFree(p);
   s->allocs.clear();
@@ -359,18 +370,19 @@ int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag, 
 }
 // Which backward kernel a call with `load_B` trajectories in flight takes (symmetric weights), by how many trajectories share
 // the chip's 1024 SIMDs:
-//   below 512: k_backward2 (a matrix and a gradient wavefront per trajectory, each alone on its SIMD)
-//   up to 8192: k_backward4 (one gradient and one loader wavefront per four trajectories: fewer co-resident
-//               waves; whole solves: 205k against 190k solves/s at 2048, 275k against 265k at 4096, 372k
-//               against 357k at 8192; with tiles of four 86.3k against 85.3k at 512, 106.9k against 104.5k at 640,
-//               61.1k against 62.3k at 256)
+//   up to 8192: k_backward4 (four matrix wavefronts, one gradient and one loader wavefront per four trajectories)
 //   beyond: one wavefront per trajectory (the matrix pipe is the bound)
+// k_backward2 (a matrix and a gradient wavefront per trajectory) was the choice below 512 trajectories in rounds 1 and 2; it
+// wins nowhere by more than 2 % (whole solves, tiles of four: 62.3k against 61.1k solves/s at 256, 85.3k against 86.3k at 512,
+// 104.5k against 106.9k at 640) and lives in the diagnostics build now (force_general = 3 there).
 // The Runge-Kutta extension and non-symmetric weights take the one-wavefront kernel at every size.
 enum BackwardKind { BW_FOUR, BW_TWO, BW_ONE };
 BackwardKind backward_kind(const qilqr_solver *s, long load_B) {
   if (s->integrator == 1 || !s->symmetric) return BW_ONE;
-  if (s->dev.force_general == 4 || (s->dev.force_general == 0 && load_B >= 512 && load_B <= 8192)) return BW_FOUR;
-  if (s->dev.force_general == 3 || (s->dev.force_general != 2 && load_B <= 8192)) return BW_TWO;
+#ifdef QILQR_WITH_BACKWARD2
+  if (s->dev.force_general == 3) return BW_TWO;
+#endif
+  if (s->dev.force_general == 4 || (s->dev.force_general != 2 && load_B <= 8192)) return BW_FOUR;
   return BW_ONE;
 }
 // The knot records are placed for their reader (se3_math.h, rec_base): tiled for the kernels that stage them through LDS
@@ -399,16 +411,16 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
       launch(s, K_BACKWARD, (k_backward4<double, 6>), dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
     else
       launch(s, K_BACKWARD, (k_backward4<double, 5>), dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
+#ifdef QILQR_WITH_BACKWARD2
   } else if (kind == BW_TWO) {
-    // two cooperating wavefronts per trajectory (matrix recursion / gradient recursion + operand streaming):
-    // shortens one trajectory's chain; above ~8 trajectories per SIMD the chip is bound by the matrix pipe and
-    // the one-wavefront kernel gives 2% more throughput
+    // two cooperating wavefronts per trajectory (matrix recursion / gradient recursion + operand streaming)
     if (s->f32)
       launch(s, K_BACKWARD, k_backward2<float>, dim3((unsigned)B), dim3(128), s->consts, s->params, s->st, (int)B, (int)n,
              force);
     else
       launch(s, K_BACKWARD, k_backward2<double>, dim3((unsigned)B), dim3(128), s->consts, s->params, s->st, (int)B,
              (int)n, force);
+#endif
   } else if (s->symmetric) {
     if (s->f32) QILQR_LAUNCH_BWD(true, float);
     else QILQR_LAUNCH_BWD(true, double);
@@ -614,6 +626,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
   if (drain) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipGetLastError());
+    return device_error(s);
   }
   return QILQR_OK;
 }
@@ -795,8 +808,14 @@ int check_quaternions(const double *traj, long count, const char *what) {
 // So 0 selects the rounds; the persistent solve stays selectable and tested.
 bool use_persistent(const qilqr_solver *s, long B) {
   (void)B;
+#ifdef QILQR_WITH_SOLVE4
   return s->symmetric && s->dev.persistent == 1 && s->integrator == 0;
+#else
+  (void)s;
+  return false;  // k_solve4 is in the diagnostics build (qilqr_create refuses persistent = 1 here)
+#endif
 }
+#ifdef QILQR_WITH_SOLVE4
 int launch_solve4(qilqr_solver *s, long B, long n) {
   const unsigned groups = cdiv(B, 4);
   const unsigned grid = std::min<unsigned>(groups, (unsigned)s->num_cus);  // one block per CU (256 VGPRs, 105 KB of LDS); the rest queue
@@ -813,6 +832,9 @@ int launch_solve4(qilqr_solver *s, long B, long n) {
 #undef QILQR_LAUNCH_S4
   return QILQR_OK;
 }
+#else
+int launch_solve4(qilqr_solver *, long, long) { return fail(QILQR_ERR_INVALID_ARG, "k_solve4 is in the diagnostics build"); }
+#endif
 
 // The batch solve on device-resident buffers.  drain = false: return with the gather enqueued, the caller puts
 // its own copies behind it and waits for the stream itself.
@@ -857,7 +879,7 @@ int solve_batch_device_impl(qilqr_solver *s, const double *d_init, const double 
   HIP_TRY(hipStreamSynchronize(s->stream));
   HIP_TRY(hipGetLastError());
   if (s->dev.profile) drain_events(s);
-  return QILQR_OK;
+  return device_error(s);
 }
 
 // The host-buffer batch solve up to, but not including, the copies back: checks, staging buffers (kept between calls, no
@@ -938,6 +960,14 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   if (dev) dc = *dev;
   if (dc.device < 0 || dc.device >= ndev) return fail(QILQR_ERR_INVALID_ARG, "bad device ordinal");
   if (dc.sync_every < 1) dc.sync_every = 1;
+#ifndef QILQR_WITH_SOLVE4
+  if (dc.persistent == 1)
+    return fail(QILQR_ERR_INVALID_ARG, "persistent = 1 (k_solve4, the one-launch solve) is in the diagnostics build: make -C quadrotorilqr_amd/csrc diag");
+#endif
+#ifndef QILQR_WITH_BACKWARD2
+  if (dc.force_general == 3)
+    return fail(QILQR_ERR_INVALID_ARG, "force_general = 3 (k_backward2) is in the diagnostics build: make -C quadrotorilqr_amd/csrc diag");
+#endif
 
   qilqr_solver *s = new qilqr_solver();
   s->device = dc.device;
@@ -984,12 +1014,13 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   }
   if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_counters, sizeof(int) * COUNT_WORDS, hipHostMallocDefault);
   if (e == hipSuccess)
-    e = hipHostMalloc((void **)&s->h_active, sizeof(unsigned long long) * 8 * (1 + qilqr_solver::MAX_PARTS),
-                      hipHostMallocMapped | hipHostMallocCoherent);
+    e = hipHostMalloc((void **)&s->h_active, sizeof(unsigned long long) * (8 * (1 + qilqr_solver::MAX_PARTS) + 1),
+                      hipHostMallocMapped | hipHostMallocCoherent);  // (+ 1: the error word, BatchState::host_error)
   if (e == hipSuccess) {
-    for (int k = 0; k < 8 * (1 + qilqr_solver::MAX_PARTS); ++k) s->h_active[k] = 0;
+    for (int k = 0; k < 8 * (1 + qilqr_solver::MAX_PARTS) + 1; ++k) s->h_active[k] = 0;
     e = hipHostGetDevicePointer((void **)&s->d_active, s->h_active, 0);
     s->st.host_active = s->d_active;
+    s->st.host_error = s->d_active + 8 * (1 + qilqr_solver::MAX_PARTS);
   }
   if (e == hipSuccess) e = hipMalloc((void **)&s->d_part_counters, sizeof(int) * COUNT_WORDS * qilqr_solver::MAX_PARTS);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->main_ready, hipEventDisableTiming);
@@ -1242,7 +1273,7 @@ int qilqr_solve_batch(qilqr_solver *s, const double *init, const double *desired
   }
   if (s->dev.profile) drain_events(s);
   if (e != hipSuccess) return fail(QILQR_ERR_HIP, std::string("copy back: ") + hipGetErrorString(e));
-  return QILQR_OK;
+  return device_error(s);
 }
 
 // pinned host memory for callers of the host-buffer entry points (direct DMA instead of HIP's pageable staging)
@@ -1345,7 +1376,7 @@ int qilqr_forward_sim(qilqr_solver *s, const double *traj, const double *gains, 
   if ((rc = download_tiled(s, out_traj, s->st.traj[1], s->st.traj[1], nullptr, 0, B, n, 18))) return rc;
   HIP_TRY(hipStreamSynchronize(s->stream));
   HIP_TRY(hipGetLastError());
-  return QILQR_OK;
+  return device_error(s);
 }
 
 int qilqr_line_search(qilqr_solver *s, const double *traj, const double *cost, const double *gains,
@@ -1394,7 +1425,7 @@ int qilqr_line_search(qilqr_solver *s, const double *traj, const double *cost, c
   if (out_step) HIP_TRY(hipMemcpy(out_step, s->st.alpha, sizeof(double) * B, hipMemcpyDeviceToHost));
   if (out_traj && (rc = download_tiled(s, out_traj, s->st.traj[0], s->st.traj[1], s->st.cur, 0, B, n, 18))) return rc;
   HIP_TRY(hipGetLastError());
-  return QILQR_OK;
+  return device_error(s);
 }
 
 // ---- one batch over several devices in one process (include/quadrotor_ilqr.h)
@@ -1795,6 +1826,8 @@ int qilqr_solve_batch_sharded_device(qilqr_sharded *h, const double *init, const
     if (gather_ms) *gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (qilqr_solver *s : h->solvers)
       if (s->dev.profile) drain_events(s);
+    for (int32_t r = 0; r < k; ++r)
+      if ((rc = device_error(h->solvers[r]))) return fail(rc, "shard " + std::to_string(r) + " (device " + std::to_string(h->device[r]) + "): " + g_last_error);
     return QILQR_OK;
   } catch (...) {
     return fail(QILQR_ERR_INVALID_ARG, "qilqr_solve_batch_sharded_device: out of host memory");
@@ -1812,7 +1845,15 @@ int qilqr_debug_stamps(qilqr_solver *s, unsigned long long *out, int32_t B) {
 #endif
 
 #ifdef QILQR_DIAG
-// diagnostic build only (make variant NAME=diag DEFS=-DQILQR_DIAG; profiles/microbench/beside.py): the rollout kernel of the
+// diagnostics build only: from now on the step wavefronts of k_rollout16 withhold the velocity hand-off of knot `knot` (-1: none
+// again), on the device the solver is bound to -- the other wavefront's bounded spin then runs out and the block is abandoned
+int qilqr_debug_set_rollout_stall(qilqr_solver *s, int32_t knot) {
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_r16_stall_knot), &knot, sizeof(int)));
+  return QILQR_OK;
+}
+// diagnostic build only (make diag; profiles/microbench/beside.py): the rollout kernel of the
 // state a qilqr_forward_sim call left behind, `reps` times on the solver's stream, alone (beside = 0) or while a second
 // stream runs k_linearize launches back to back (beside = 1).  us[0]: microseconds per rollout launch; us[1]: per
 // linearisation launch.  Timing only: the linearisation reads the candidate while it is being written.

@@ -1,10 +1,12 @@
 // ilqr_kernels.h -- device kernels of the batched iLQR solver (gfx950 only).
 //
 // One outer "round" of the solver is three launches, back to back on one stream:
-//   k_backward2 / k_backward   settles the previous candidate (cost sum, Armijo test, convergence tests:
+//   k_backward4 / k_backward   settles the previous candidate (cost sum, Armijo test, convergence tests:
 //                ilqr.hh:61-84, 174-194), then the Riccati recursion on the fp64 matrix core
-//                (ilqr.hh:97-147): a matrix wavefront and a gradient wavefront per trajectory
-//                (k_backward2), or one wavefront per trajectory (k_backward)
+//                (ilqr.hh:97-147): four matrix wavefronts, a gradient and a loader wavefront per four trajectories
+//                (k_backward4), or one wavefront per trajectory (k_backward)
+//                (k_backward2 -- a matrix and a gradient wavefront per trajectory -- and the one-launch k_solve4 are in the
+//                diagnostics build: -DQILQR_DIAG, `make diag`)
 //   k_rollout3 / k_rollout     closed-loop forward simulation (ilqr.hh:149-172): pose wave + control
 //                wave + loader wave per 64 trajectories, or one lane per trajectory in one wavefront
 //   k_linearize  two lanes per knot: dynamics Jacobian blocks / cost differentials + knot cost of the
@@ -17,6 +19,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#ifdef QILQR_DIAG  // the diagnostics build carries the kernels that measured behind the product's, and fault injection
+#define QILQR_WITH_SOLVE4 1
+#define QILQR_WITH_BACKWARD2 1
+#endif
 
 #include <type_traits>
 
@@ -63,6 +70,8 @@ struct BatchState {
   int *status, *iters, *n_bwd, *n_fwd;
   int *counters;         // [COUNT_BASE + stripe]: trajectories still active, counted by k_backward (active_counter)
   unsigned long long *host_active;  // pinned host memory, 8 words: (round + 1) << 32 | active count (k_linearize)
+  unsigned long long *host_error;   // pinned host memory, one word, zero unless a kernel gave up: 1 << 32 | block (k_rollout16: a
+                                    // hand-off between its wavefronts never arrived); the host turns it into QILQR_ERR_HIP
   double *cost_hist;     // [B][hist_cap] or null
   int hist_cap;
   const void *ctab;      // constant operand table (backward_layout.h)
@@ -359,6 +368,54 @@ __device__ __forceinline__ void bcast_quu_row(const double col[4], double ghat, 
   Qu[A] = row_bcast<12 + A>(ghat);
 }
 
+// ---- the per-knot pieces every backward kernel shares (stated once; each kernel inlines them) ----------------------------
+// T = V M: three fp64 MFMAs over the contraction index 4 kc + kk (A = V_xx in A layout, B = M = [J_x | J_u])
+__device__ __forceinline__ d4 bw_tile_T(const double (&va)[3], const double (&m)[3]) {
+  d4 T = {0.0, 0.0, 0.0, 0.0};
+  T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0], m[0], T, 0, 0, 0);
+  T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1], m[1], T, 0, 0, 0);
+  T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2], m[2], T, 0, 0, 0);
+  return T;
+}
+// H = blkdiag(C_xx, C_uu) + M^T T  (ilqr.hh:118-124 in one accumulator tile): M^T in A layout is the same three registers
+// as M in B layout, and T's result registers are the B operand
+__device__ __forceinline__ d4 bw_tile_H(const double (&m)[3], const d4 &T, const double (&cx)[3], double cuu) {
+  d4 H = {cx[0], cx[1], cx[2], cuu};
+  H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
+  H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
+  H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
+  return H;
+}
+// LDL^T of the lower triangle of Q_uu WITHOUT pivoting (the symmetric-weight kernels: Q_uu = 2 R + J_u^T V_xx J_u is positive
+// definite there; Eigen's LDLT, ilqr.hh:126, pivots on the diagonal -- the same factors in exact arithmetic; the general kernel
+// pivots, backward_layout.h).  Reciprocals of the pivots by rcp_nr.
+struct Ldlt4 {
+  double l10, l20, l30, l21, l31, l32, i0, i1, i2, i3;
+};
+__device__ __forceinline__ Ldlt4 ldlt4_factor(const double (&Quu)[16]) {
+  Ldlt4 f;
+  f.i0 = rcp_nr(Quu[0]);
+  f.l10 = Quu[4] * f.i0; f.l20 = Quu[8] * f.i0; f.l30 = Quu[12] * f.i0;
+  const double d1 = Quu[5] - f.l10 * Quu[4];
+  f.i1 = rcp_nr(d1);
+  const double c21 = Quu[9] - f.l20 * Quu[4], c31 = Quu[13] - f.l30 * Quu[4];
+  f.l21 = c21 * f.i1; f.l31 = c31 * f.i1;
+  const double d2 = Quu[10] - f.l20 * Quu[8] - f.l21 * c21;
+  f.i2 = rcp_nr(d2);
+  const double c32 = Quu[14] - f.l30 * Quu[8] - f.l31 * c21;
+  f.l32 = c32 * f.i2;
+  const double d3 = Quu[15] - f.l30 * Quu[12] - f.l31 * c31 - f.l32 * c32;
+  f.i3 = rcp_nr(d3);
+  return f;
+}
+// x = -Q_uu^-1 rhs with those factors: a column of K (ilqr.hh:127) or the feed-forward k (:128)
+__device__ __forceinline__ void ldlt4_solve_neg(const Ldlt4 &f, double r0, double r1, double r2, double r3, double (&x)[4]) {
+  const double y0 = r0, y1 = r1 - f.l10 * y0, y2 = r2 - f.l20 * y0 - f.l21 * y1, y3 = r3 - f.l30 * y0 - f.l31 * y1 - f.l32 * y2;
+  const double x3 = y3 * f.i3, x2 = y2 * f.i2 - f.l32 * x3, x1 = y1 * f.i1 - f.l21 * x2 - f.l31 * x3,
+               x0 = y0 * f.i0 - f.l10 * x1 - f.l20 * x2 - f.l30 * x3;
+  x[0] = -x0; x[1] = -x1; x[2] = -x2; x[3] = -x3;
+}
+
 // SYM = true: Q and R are exactly symmetric, so V_xx and H are symmetric to rounding and the
 // accumulator tile can be reused as the next knot's A operand without a transpose; no LDS and no
 // barrier remain in the loop (Q_uu/Q_u are broadcast with DPP row broadcasts, the right-hand sides with
@@ -524,18 +581,10 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
     // on the load at the top of the loop)
     const S m_s0 = *op[0], m_s1 = *op[1], m_s2 = *op[2], cx_s0 = *op[3], cx_s1 = *op[4], cx_s2 = *op[5], g_s = *op[6];
     QSTAMP(0);  // prefetch issue
-    // T = V M
-    d4 T = {0.0, 0.0, 0.0, 0.0};
-    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0], m[0], T, 0, 0, 0);
-    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1], m[1], T, 0, 0, 0);
-    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2], m[2], T, 0, 0, 0);
+    const d4 T = bw_tile_T(va, m);
     QKEEP(T[0]); QKEEP(T[3]);
     QSTAMP(1);  // T = V M (3 MFMA) complete
-    // H = blkdiag(C_xx, C_uu) + M^T T   (ilqr.hh:118-124 in one tile)
-    d4 H = {cx[0], cx[1], cx[2], cuu};
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
+    d4 H = bw_tile_H(m, T, cx, cuu);
     QKEEP(H[0]); QKEEP(H[3]);
     QSTAMP(2);  // H (3 MFMA) complete
     // [Q_x ; Q_u] = [C_x ; C_u] + M^T V_x
@@ -587,24 +636,9 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
     if constexpr (SYM) {
       // LDL^T of the lower triangle of Q_uu without pivoting (Q_uu = 2 R + J_u^T V_xx J_u is positive definite for the
       // weights this kernel is launched for; the reference's Eigen LDLT pivots on the diagonal: same result in exact arithmetic)
-      const double i0 = rcp_nr(Quu[0]);
-      const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
-      const double d1 = Quu[5] - l10 * Quu[4];
-      const double i1 = rcp_nr(d1);
-      const double c21 = Quu[9] - l20 * Quu[4], c31 = Quu[13] - l30 * Quu[4];
-      const double l21 = c21 * i1, l31 = c31 * i1;
-      const double d2 = Quu[10] - l20 * Quu[8] - l21 * c21;
-      const double i2 = rcp_nr(d2);
-      const double c32 = Quu[14] - l30 * Quu[8] - l31 * c21;
-      const double l32 = c32 * i2;
-      const double d3 = Quu[15] - l30 * Quu[12] - l31 * c31 - l32 * c32;
-      const double i3 = rcp_nr(d3);
-      QKEEP(i3); QKEEP(l32); QKEEP(l31);
-      const double y0 = rhs[0], y1 = rhs[1] - l10 * y0, y2 = rhs[2] - l20 * y0 - l21 * y1,
-                   y3 = rhs[3] - l30 * y0 - l31 * y1 - l32 * y2;
-      const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
-                   x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
-      kcol[0] = -x0; kcol[1] = -x1; kcol[2] = -x2; kcol[3] = -x3;
+      const Ldlt4 f = ldlt4_factor(Quu);
+      QKEEP(f.i3); QKEEP(f.l32); QKEEP(f.l31);
+      ldlt4_solve_neg(f, rhs[0], rhs[1], rhs[2], rhs[3], kcol);
     } else {
       // the reference's factorisation: Eigen's diagonally pivoted LDL^T (ilqr.hh:126), restated in ldlt4_pivoted_solve
       double xs[4];
@@ -735,6 +769,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
 // ---------------------------------------------------------------------------------------------
 constexpr int BW2_REC = 128;                   // doubles reserved for a record (symmetric layouts: stride <= 128)
 constexpr int BW2_BUF = BW2_REC + CTAB_SIZE;   // one ring slot: record, then the constant operand table
+#ifdef QILQR_WITH_BACKWARD2  // diagnostics build only (make diag): the product takes k_backward4 at every batch size up to 8192
 template <typename S>
 __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n,
                                                    int force) {
@@ -898,11 +933,9 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
                    Qu3 = row_bcast<15>(ghat);
       const double l10 = f[64], l20 = f[65], l30 = f[66], l21 = f[67], l31 = f[68], l32 = f[69], i0 = f[70],
                    i1 = f[71], i2 = f[72], i3 = f[73];
-      const double y0 = Qu0, y1 = Qu1 - l10 * y0, y2 = Qu2 - l20 * y0 - l21 * y1,
-                   y3 = Qu3 - l30 * y0 - l31 * y1 - l32 * y2;
-      const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
-                   x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
-      const double k0 = -x0, k1 = -x1, k2 = -x2, k3 = -x3;  // feed-forward (ilqr.hh:128), in every lane
+      double kff[4];
+      ldlt4_solve_neg(Ldlt4{l10, l20, l30, l21, l31, l32, i0, i1, i2, i3}, Qu0, Qu1, Qu2, Qu3, kff);
+      const double k0 = kff[0], k1 = kff[1], k2 = kff[2], k3 = kff[3];  // feed-forward (ilqr.hh:128), in every lane
       const sv2 w0 = {(S)k0, (S)k1}, w1 = {(S)k2, (S)k3};
       *kdst0 = w0;
       *kdst1 = w1;
@@ -974,16 +1007,10 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
     const double m_n0 = nb[off[0]], m_n1 = nb[off[1]], m_n2 = nb[off[2]], cx_n0 = nb[off[3]], cx_n1 = nb[off[4]],
                  cx_n2 = nb[off[5]];
     QSTAMP(0);  // operand reads issued
-    d4 T = {0.0, 0.0, 0.0, 0.0};
-    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0], m[0], T, 0, 0, 0);
-    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1], m[1], T, 0, 0, 0);
-    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2], m[2], T, 0, 0, 0);
+    const d4 T = bw_tile_T(va, m);
     QKEEP(T[0]); QKEEP(T[3]);
     QSTAMP(1);  // T = V M
-    d4 H = {cx[0], cx[1], cx[2], cuu};
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
+    d4 H = bw_tile_H(m, T, cx, cuu);
     QKEEP(H[0]); QKEEP(H[3]);
     QSTAMP(2);  // H
     double Quu[16], Qu_unused[4], col[4];
@@ -994,27 +1021,9 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
     bcast_quu_row<3>(col, 0.0, Quu, Qu_unused);
     QKEEP(Quu[15]); QKEEP(Quu[0]); QKEEP(col[3]);
     QSTAMP(4);  // gather + broadcast of Q_uu
-    // LDL^T of the lower triangle of Q_uu (ilqr.hh:126), as in k_backward
-    const double i0 = rcp_nr(Quu[0]);
-    const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
-    const double d1 = Quu[5] - l10 * Quu[4];
-    const double i1 = rcp_nr(d1);
-    const double c21 = Quu[9] - l20 * Quu[4], c31 = Quu[13] - l30 * Quu[4];
-    const double l21 = c21 * i1, l31 = c31 * i1;
-    const double d2 = Quu[10] - l20 * Quu[8] - l21 * c21;
-    const double i2 = rcp_nr(d2);
-    const double c32 = Quu[14] - l30 * Quu[8] - l31 * c21;
-    const double l32 = c32 * i2;
-    const double d3 = Quu[15] - l30 * Quu[12] - l31 * c31 - l32 * c32;
-    const double i3 = rcp_nr(d3);
+    const Ldlt4 f4 = ldlt4_factor(Quu);  // (ilqr.hh:126; unpivoted: see ldlt4_factor)
     double kcol[4];
-    {
-      const double y0 = col[0], y1 = col[1] - l10 * y0, y2 = col[2] - l20 * y0 - l21 * y1,
-                   y3 = col[3] - l30 * y0 - l31 * y1 - l32 * y2;
-      const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
-                   x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
-      kcol[0] = -x0; kcol[1] = -x1; kcol[2] = -x2; kcol[3] = -x3;  // K[:, j] (ilqr.hh:127)
-    }
+    ldlt4_solve_neg(f4, col[0], col[1], col[2], col[3], kcol);  // K[:, j] (ilqr.hh:127)
     QKEEP(kcol[0]); QKEEP(kcol[3]);
     QSTAMP(5);  // factorisation + solve
     {
@@ -1028,8 +1037,8 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
     double *f = kf[i & 1];
     f[4 * j] = kcol[0]; f[4 * j + 1] = kcol[1]; f[4 * j + 2] = kcol[2]; f[4 * j + 3] = kcol[3];
     if (lane == 0) {
-      f[64] = l10; f[65] = l20; f[66] = l30; f[67] = l21; f[68] = l31; f[69] = l32;
-      f[70] = i0; f[71] = i1; f[72] = i2; f[73] = i3;
+      f[64] = f4.l10; f[65] = f4.l20; f[66] = f4.l30; f[67] = f4.l21; f[68] = f4.l31; f[69] = f4.l32;
+      f[70] = f4.i0; f[71] = f4.i1; f[72] = f4.i2; f[73] = f4.i3;
     }
     // V_xx = Q_xx + Q_xu K: A[j][kk] = Q_xu[j][kk] = H[12 + kk][j] is accumulator register 3
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(H[3], sel4(kcol, kk), H, 0, 0, 0);
@@ -1047,6 +1056,7 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
     for (int k = 0; k < 8; ++k) st.stamps[(long)b * 8 + k] = stamp_sum[k];
 #endif
 }
+#endif  // QILQR_WITH_BACKWARD2
 
 // ---------------------------------------------------------------------------------------------
 // k_backward4: k_backward2 with ONE gradient wavefront and ONE loader wavefront for FOUR trajectories
@@ -1136,11 +1146,9 @@ __device__ __forceinline__ double bw4_gradient_wave(double (&ring)[4][4][BW2_BUF
     const double Qu0 = row_bcast<12>(ghat), Qu1 = row_bcast<13>(ghat), Qu2 = row_bcast<14>(ghat),
                  Qu3 = row_bcast<15>(ghat);
     vx = ghat + ((c0 * Qu0 + c1 * Qu1) + (c2 * Qu2 + c3 * Qu3));  // V_x = Q_x + K^T Q_u: the recurrence ends here
-    const double y0 = Qu0, y1 = Qu1 - l10 * y0, y2 = Qu2 - l20 * y0 - l21 * y1,
-                 y3 = Qu3 - l30 * y0 - l31 * y1 - l32 * y2;
-    const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
-                 x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
-    const double k0 = -x0, k1 = -x1, k2 = -x2, k3 = -x3;  // feed-forward (ilqr.hh:128)
+    double kff[4];
+    ldlt4_solve_neg(Ldlt4{l10, l20, l30, l21, l31, l32, i0, i1, i2, i3}, Qu0, Qu1, Qu2, Qu3, kff);
+    const double k0 = kff[0], k1 = kff[1], k2 = kff[2], k3 = kff[3];  // feed-forward (ilqr.hh:128)
     const sv2 w0 = {(S)k0, (S)k1}, w1 = {(S)k2, (S)k3};
     *kdst0 = w0;
     *kdst1 = w1;
@@ -1275,16 +1283,10 @@ __device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], d
     const double *nb = ring[w][(i > 0 ? i - 1 : 0) & 3];
     const double m_n0 = nb[off[0]], m_n1 = nb[off[1]], m_n2 = nb[off[2]], cx_n0 = nb[off[3]], cx_n1 = nb[off[4]],
                  cx_n2 = nb[off[5]];
-    d4 T = {0.0, 0.0, 0.0, 0.0};
-    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0], m[0], T, 0, 0, 0);
-    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1], m[1], T, 0, 0, 0);
-    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2], m[2], T, 0, 0, 0);
+    const d4 T = bw_tile_T(va, m);
     QKEEP(T[0]); QKEEP(T[3]);
     QSTAMP(0);  // ring reads issued, T = V M
-    d4 H = {cx[0], cx[1], cx[2], cuu};
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
+    d4 H = bw_tile_H(m, T, cx, cuu);
     QKEEP(H[0]); QKEEP(H[3]);
     QSTAMP(1);  // H = C + M^T T
     double Quu[16], Qu_unused[4], col[4];
@@ -1295,27 +1297,9 @@ __device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], d
     bcast_quu_row<3>(col, 0.0, Quu, Qu_unused);
     QKEEP(Quu[0]); QKEEP(Quu[15]); QKEEP(col[3]);
     QSTAMP(2);  // gather + Q_uu broadcast
-    // LDL^T of the lower triangle of Q_uu (ilqr.hh:126), as in k_backward
-    const double i0 = rcp_nr(Quu[0]);
-    const double l10 = Quu[4] * i0, l20 = Quu[8] * i0, l30 = Quu[12] * i0;
-    const double d1 = Quu[5] - l10 * Quu[4];
-    const double i1 = rcp_nr(d1);
-    const double c21 = Quu[9] - l20 * Quu[4], c31 = Quu[13] - l30 * Quu[4];
-    const double l21 = c21 * i1, l31 = c31 * i1;
-    const double d2 = Quu[10] - l20 * Quu[8] - l21 * c21;
-    const double i2 = rcp_nr(d2);
-    const double c32 = Quu[14] - l30 * Quu[8] - l31 * c21;
-    const double l32 = c32 * i2;
-    const double d3 = Quu[15] - l30 * Quu[12] - l31 * c31 - l32 * c32;
-    const double i3 = rcp_nr(d3);
+    const Ldlt4 f4 = ldlt4_factor(Quu);  // (ilqr.hh:126; unpivoted: see ldlt4_factor)
     double kcol[4];
-    {
-      const double y0 = col[0], y1 = col[1] - l10 * y0, y2 = col[2] - l20 * y0 - l21 * y1,
-                   y3 = col[3] - l30 * y0 - l31 * y1 - l32 * y2;
-      const double x3 = y3 * i3, x2 = y2 * i2 - l32 * x3, x1 = y1 * i1 - l21 * x2 - l31 * x3,
-                   x0 = y0 * i0 - l10 * x1 - l20 * x2 - l30 * x3;
-      kcol[0] = -x0; kcol[1] = -x1; kcol[2] = -x2; kcol[3] = -x3;  // K[:, j] (ilqr.hh:127)
-    }
+    ldlt4_solve_neg(f4, col[0], col[1], col[2], col[3], kcol);  // K[:, j] (ilqr.hh:127)
     QKEEP(kcol[0]); QKEEP(kcol[3]);
     QSTAMP(4);  // LDL^T + solve
     {
@@ -1329,8 +1313,8 @@ __device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], d
     double *f = kf[w][i & 1];
     f[4 * j] = kcol[0]; f[4 * j + 1] = kcol[1]; f[4 * j + 2] = kcol[2]; f[4 * j + 3] = kcol[3];
     if (lane == 0) {
-      f[64] = l10; f[65] = l20; f[66] = l30; f[67] = l21; f[68] = l31; f[69] = l32;
-      f[70] = i0; f[71] = i1; f[72] = i2; f[73] = i3;
+      f[64] = f4.l10; f[65] = f4.l20; f[66] = f4.l30; f[67] = f4.l21; f[68] = f4.l31; f[69] = f4.l32;
+      f[70] = f4.i0; f[71] = f4.i1; f[72] = f4.i2; f[73] = f4.i3;
     }
     QSTAMP(5);  // gain stores, hand-off to G
     // V_xx = Q_xx + Q_xu K: A[j][kk] = Q_xu[j][kk] = H[12 + kk][j] is accumulator register 3
@@ -1964,6 +1948,11 @@ struct DevWave {
 #define R16_LOADS_DONE() __builtin_amdgcn_s_waitcnt(0x0F70)
 constexpr int R16_RING = 4;
 constexpr int R16_SPIN_MAX = 1 << 22;
+#ifdef QILQR_DIAG
+// diagnostics build: the knot whose velocity hand-off a step wavefront withholds (-1: none), so that the other wavefront's
+// bounded spin runs out and the block's abort path is taken (tests/test_gpu_robustness.py)
+__device__ int g_r16_stall_knot = -1;
+#endif
 constexpr int R16_CHUNK = 16;  // knots per "stored and visible" announcement of wave A (k_solve4's linearisation follows it)
 enum { R16_F_PROD = 0, R16_F_V, R16_F_T, R16_F_K0, R16_F_K1, R16_F_ABORT, R16_NFLAGS };
 enum { X_V = 0, X_T = 1 };
@@ -2184,6 +2173,9 @@ __device__ __forceinline__ void r16_wave_X(R16Lds &sh, const ModelConsts<double>
     if (__builtin_expect(advance, 1)) {  // (the post also tells P that knot i's operand slot is free)
       sh.xch[X_V][(i + 1) & 3][0][lane] = VLn;
       sh.xch[X_V][(i + 1) & 3][1][lane] = VWn;
+#ifdef QILQR_DIAG
+      if (i != g_r16_stall_knot)  // fault injection (qilqr_debug_set_rollout_stall): this hand-off is never announced
+#endif
       r16_flag_post(sh, R16_F_V, i + 1, lane);
     }
     if (wa) ok_[oa] = (S)st;
@@ -2258,6 +2250,11 @@ __global__ __launch_bounds__(192) void k_rollout16(ModelConsts<double> c, BatchS
   const double TT = ld0(tt_elem(lane)), QQ = ld0(qq_elem(lane)), VL = ld0(vl_elem(lane)), VW = ld0(vw_elem(lane));
   R16_LOADS_DONE();
   r16_wave_X<S, false>(sh, c, role, TT, QQ, VL, VW, out, live, n, lane, stamps);
+  // A step wavefront comes back early when a hand-off it waited for never arrived (every spin is bounded: the grid drains
+  // instead of hanging).  The candidate of the block's trajectories is then incomplete: say so where the host looks after
+  // every solve, so that the call fails loudly instead of iterating on stale knots.
+  if (__builtin_expect(r16_flag_read(sh, R16_F_ABORT) != 0, 0) && lane == 0 && st.host_error)
+    __hip_atomic_store(st.host_error, (1ull << 32) | (unsigned)blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2417,4 +2414,6 @@ __global__ void k_seed_search(BatchState st, int B, const double *cost, const do
 
 }  // namespace qilqr
 
+#ifdef QILQR_WITH_SOLVE4  // diagnostics build only (make diag): the one-launch solve, measured behind the rounds
 #include "solve4.h"
+#endif

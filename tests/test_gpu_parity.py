@@ -14,7 +14,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle import oracle as orc  # noqa: E402  (the checker)
-from quadrotorilqr_amd import capi, problems as pb  # noqa: E402
+from quadrotorilqr_amd import capi, problems as pb
+from tests.diag_lib import capi_diag  # the diagnostics build: k_solve4, k_backward2  # noqa: E402
 
 G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_golden.npz"))
 
@@ -232,7 +233,7 @@ def test_two_wave_backward_matches_single_wave():
         cfg = pb.config2(B=B, N=n, seed=3)
         if dense:
             cfg["Q"], cfg["R"] = Qd, Rd
-        two = capi.from_config(cfg, precision=prec)
+        two = capi_diag().from_config(cfg, precision=prec, force_general=3)  # k_backward2 (diagnostics build)
         one = capi.from_config(cfg, precision=prec, force_general=2)
         trajs = two.forward_sim(cfg["init"], np.zeros((B, n, 52)), 1.0)
         g2, t2 = two.backwards_pass(trajs)
@@ -470,7 +471,7 @@ def test_levenberg_marquardt_restarts_match_oracle(kernel):
     o.set_regularisation(1.0, 4.0, 1e6)
     ref = o.solve_batch(cfg["init"], n_threads=8)
     assert (ref["status"] != 3).all() and (ref["n_bwd"] > ref["iters"] + 1).sum() >= 8
-    s = capi.from_config(cfg, force_general=kernel)
+    s = (capi_diag() if kernel == 3 else capi).from_config(cfg, force_general=kernel)  # (3 = k_backward2: diagnostics build)
     off = s.solve_batch(cfg["init"])  # default: off, the reference's behaviour
     np.testing.assert_array_equal(off["status"], plain["status"])
     np.testing.assert_array_equal(off["n_bwd"], plain["n_bwd"])
@@ -610,14 +611,14 @@ def test_config2_full_size_properties():
     out_p = s.solve_batch(cfg["init"][perm])
     np.testing.assert_array_equal(out_p["traj"], out["traj"][perm])
     np.testing.assert_array_equal(out_p["iters"], out["iters"][perm])
-    # A batch of one gives the same result as the same problem inside the batch.  Not the same bits: the
-    # backward kernel is chosen by batch size (k_backward2 below 512 trajectories, k_backward4 from there) and the
-    # two sum the twelve terms of M^T V_x in different orders; measured difference 2e-15.
+    # A batch of one gives the same result as the same problem inside the batch (the same backward kernel up to 8192
+    # trajectories since round 3; beyond, the one-wavefront kernel sums the twelve terms of M^T V_x in another order,
+    # measured difference 2e-15).
     one = s.solve_batch(cfg["init"][17:18])
     assert one["iters"][0] == out["iters"][17] and one["status"][0] == out["status"][17]
     np.testing.assert_allclose(one["traj"][0], out["traj"][17], rtol=0, atol=1e-11)
     # with the kernel held fixed the bits are the same
-    fixed = capi.from_config(cfg, force_general=3)
+    fixed = capi.from_config(cfg, force_general=4)
     np.testing.assert_array_equal(fixed.solve_batch(cfg["init"][17:18])["traj"][0], fixed.solve_batch(cfg["init"])["traj"][17])
     # warm start from the optimum is a fixed point: at most two more iterations, same cost
     again = s.solve_batch(out["traj"])
@@ -759,7 +760,7 @@ def test_randomised_models_and_horizons_match_oracle(seed, restarts=False, persi
         opts["ls_max_iters"] = int(r.integers(1, 4))
         reg = (float(r.choice([0.1, 1.0, 10.0])), float(r.choice([2.0, 4.0, 10.0])), float(r.choice([1e3, 1e6])))
     cfg = dict(model=model, Q=Q, R=R, dt=dt, options=opts, desired=desired, init=init)
-    s, o = capi.from_config(cfg, persistent=persistent), oracle_for(cfg)
+    s, o = (capi_diag() if persistent == 1 else capi).from_config(cfg, persistent=persistent), oracle_for(cfg)
     if reg:
         s.set_regularisation(*reg)
         o.set_regularisation(*reg)
@@ -802,7 +803,7 @@ def test_persistent_solve_is_one_launch_and_matches_the_rounds():
         c = dict(cfg, options=dict(cfg["options"], populate_debug=True))  # (the cost history)
         if precision == "f32":
             c["options"] = dict(c["options"], rtol=1e-5, atol=1e-5)
-        pers = capi.from_config(c, persistent=1, profile=1, precision=precision)
+        pers = capi_diag().from_config(c, persistent=1, profile=1, precision=precision)
         rnds = capi.from_config(c, persistent=2, precision=precision)
         for desired in (None, desired_batch):
             pers.profile_reset()

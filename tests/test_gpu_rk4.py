@@ -75,8 +75,9 @@ def test_rk4_refuses_mixed_precision_and_bad_values():
         capi.from_config(cfg, precision="f32").set_integrator(1)
     with pytest.raises(TypeError, match="integrator must be"):
         capi.from_config(cfg).set_integrator(2)
-    # persistent = 1 with the extension quietly takes the rounds (k_solve4 is the Euler path)
-    s = capi.from_config(cfg, persistent=1, profile=1)
+    # persistent = 1 with the extension quietly takes the rounds (k_solve4 is the Euler path; diagnostics build)
+    from tests.diag_lib import capi_diag
+    s = capi_diag().from_config(cfg, persistent=1, profile=1)
     s.set_integrator(1)
     s.solve_batch(cfg["init"])
     assert s.profile_get()["solve_launches"] == 0

@@ -124,3 +124,41 @@ def test_fractional_max_iters_counts_like_the_reference_loop():
     traj, info = s.solve(cfg["init"][0])
     assert info["iters"] == 3 and len(info["debug_costs"]) == 3 and len(info["debug_trajs"]) == 3
     np.testing.assert_array_equal(info["debug_trajs"][-1], traj)
+
+
+def test_a_lost_hand_off_in_the_rollout_ends_the_call_with_an_error_not_a_hang():
+    """k_rollout16's wavefronts hand values to each other through LDS progress words; every wait is a BOUNDED spin, so that
+    a hand-off that never comes drains the grid instead of hanging the GPU.  The diagnostics build can withhold one
+    (qilqr_debug_set_rollout_stall): the waiting wavefront's spin runs out, the block raises its abort word, every role
+    leaves, the kernel reports the block through pinned memory, and the host turns that into QILQR_ERR_HIP -- the call
+    fails loudly, nothing iterates on the stale candidate, and the handle works again once the fault is removed."""
+    import time
+    from tests.diag_lib import capi_diag
+    d = capi_diag()
+    cfg = pb.config2(B=8, N=30, seed=5)
+    s = d.from_config(cfg, single_wave_rollout=3)           # k_rollout16 at every size
+    good = s.solve_batch(cfg["init"])
+    assert np.isin(good["status"], [0, 1]).all()
+    gains = np.zeros((8, 30, 52))
+    rolled = s.forward_sim(cfg["init"], gains, 1.0)
+    lib = d.load()
+    assert lib.qilqr_debug_set_rollout_stall(s._h, 7) == 0    # the velocity hand-off of knot 7 is never announced
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="hand-off between the wavefronts of block"):
+        s.forward_sim(cfg["init"], gains, 1.0)
+    with pytest.raises(RuntimeError, match="results of this call are invalid"):
+        s.solve_batch(cfg["init"])
+    assert time.perf_counter() - t0 < 60.0                     # bounded: a fraction of a second per abandoned launch
+    assert lib.qilqr_debug_set_rollout_stall(s._h, -1) == 0
+    np.testing.assert_array_equal(s.forward_sim(cfg["init"], gains, 1.0), rolled)
+    again = s.solve_batch(cfg["init"])
+    for k in ("status", "iters", "cost", "traj"):
+        np.testing.assert_array_equal(again[k], good[k], err_msg=k)
+
+
+def test_the_product_build_refuses_the_kernels_of_the_diagnostics_build():
+    cfg = pb.config2(B=4, N=10)
+    with pytest.raises(TypeError, match="diagnostics build"):
+        capi.from_config(cfg, persistent=1)
+    with pytest.raises(TypeError, match="diagnostics build"):
+        capi.from_config(cfg, force_general=3)
