@@ -409,11 +409,18 @@ __device__ __forceinline__ Ldlt4 ldlt4_factor(const double (&Quu)[16]) {
   return f;
 }
 // x = -Q_uu^-1 rhs with those factors: a column of K (ilqr.hh:127) or the feed-forward k (:128)
+// (Solved for the right-hand side -r: the signs ride on the operands of the multiply-adds instead of four negations at the end.
+// fma(-a, b, -c) = -fma(a, b, c) exactly, so every intermediate is the exact negative of the plain solve's and the result has
+// the same bits.)
 __device__ __forceinline__ void ldlt4_solve_neg(const Ldlt4 &f, double r0, double r1, double r2, double r3, double (&x)[4]) {
-  const double y0 = r0, y1 = r1 - f.l10 * y0, y2 = r2 - f.l20 * y0 - f.l21 * y1, y3 = r3 - f.l30 * y0 - f.l31 * y1 - f.l32 * y2;
-  const double x3 = y3 * f.i3, x2 = y2 * f.i2 - f.l32 * x3, x1 = y1 * f.i1 - f.l21 * x2 - f.l31 * x3,
-               x0 = y0 * f.i0 - f.l10 * x1 - f.l20 * x2 - f.l30 * x3;
-  x[0] = -x0; x[1] = -x1; x[2] = -x2; x[3] = -x3;
+  const double y1 = __builtin_fma(f.l10, r0, -r1);                                                        // y0 = -r0
+  const double y2 = __builtin_fma(-f.l21, y1, __builtin_fma(f.l20, r0, -r2));
+  const double y3 = __builtin_fma(-f.l32, y2, __builtin_fma(-f.l31, y1, __builtin_fma(f.l30, r0, -r3)));
+  const double x3 = y3 * f.i3;
+  const double x2 = __builtin_fma(-f.l32, x3, y2 * f.i2);
+  const double x1 = __builtin_fma(-f.l31, x3, __builtin_fma(-f.l21, x2, y1 * f.i1));
+  const double x0 = __builtin_fma(-f.l30, x3, __builtin_fma(-f.l20, x2, __builtin_fma(-f.l10, x1, -(r0 * f.i0))));
+  x[0] = x0; x[1] = x1; x[2] = x2; x[3] = x3;
 }
 
 // SYM = true: Q and R are exactly symmetric, so V_xx and H are symmetric to rounding and the
@@ -1129,6 +1136,8 @@ __device__ __forceinline__ double bw4_gradient_wave(double (&ring)[4][4][BW2_BUF
     for (int r = 0; r < 12; ++r) m[r] = mp[r][SLOT * BW2_BUF];
     const double gcj = gp[SLOT * BW2_BUF];
     asm volatile("" ::: "memory");
+    // (K row-major from the sixteen lanes kk == 0 only -- 128 contiguous bytes per row, no bank conflicts, a quarter of the
+    // bytes -- measures the same: 70.6 against 70.3 us per launch, profiles/r03_ab_backward.txt)
     const double c0 = f[4 * j], c1 = f[4 * j + 1], c2 = f[4 * j + 2], c3 = f[4 * j + 3];  // K[:, j]
     const double l10 = f[64], l20 = f[65], l30 = f[66], l21 = f[67], l31 = f[68], l32 = f[69], i0 = f[70],
                  i1 = f[71], i2 = f[72], i3 = f[73];
@@ -1270,7 +1279,7 @@ __device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], d
   // slower (71.5 -> 77 us per launch at B = 1024; MI355X_MICROARCH.md, "code-placement sensitivity").  Pin it to a
   // 64-byte boundary.
 #ifndef QILQR_BW4_PHASE
-#define QILQR_BW4_PHASE 1  // s_nop s behind the boundary: the phase measured fastest of 0..7 (71.6 us; the others 72.0 - 73.6)
+#define QILQR_BW4_PHASE 0  // s_nop s behind the boundary: the phase measured fastest of 0..7 (round 3, profiles/microbench/ab.py: 70.0 us; 6: 70.1, 2: 70.2, 4: 71.2, 5: 71.4, 3 and 7: 71.7, 1 -- the fastest of round 2's code -- 71.9)
 #endif
   asm volatile(".p2align 6\n\t.rept %0\n\ts_nop 0\n\t.endr" ::"n"(QILQR_BW4_PHASE));
 #ifdef QILQR_STAMPS
@@ -1278,6 +1287,12 @@ __device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], d
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real0)::"memory");
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
+  // (Round 3 measured this loop unrolled by four -- ring slot and hand-off parity as immediate offsets, the two operand
+  // register sets alternating: 147 -> 124 instructions per knot, no copies, no address arithmetic -- at 71.4 us per launch
+  // against 70.2 for the rolled loop, every code phase tried (profiles/r03_ab_backward.txt): the wave is not bound by the
+  // number of instructions it issues but by the latencies between them -- seven dependent matrix instructions, the
+  // reciprocal chains of the factorisation, the cross-lane gathers -- and a four times longer loop body costs more in
+  // instruction fetch than the 23 instructions return.)
   for (int i = n - 1; i >= 0; --i) {
     // operands of knot i-1, for the next iteration (the slot was filled during the previous interval)
     const double *nb = ring[w][(i > 0 ? i - 1 : 0) & 3];
