@@ -386,6 +386,14 @@ __device__ __forceinline__ d4 bw_tile_H(const double (&m)[3], const d4 &T, const
   H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
   return H;
 }
+// (Round 3 tried to take the factorisation off the matrix instructions' chain: rows 12..15 of H -- [Q_ux | Q_uu] -- are complete
+// after the kc = 2 product alone, because J_u is zero in rows 0..7, so the gather, the LDL^T and the solve could run while the
+// other two products execute.  It does not pay and cannot: v_mfma_f64 and the fp64 vector instructions use the SAME double-
+// precision units of a SIMD (profiles/microbench/coissue.hip: an fp64 FMA beside an fp64 MFMA takes 8.7 cycles instead of 4.7),
+// so interleaving them gains nothing -- 72.0 us per launch against 65.4 with one live trajectory per block -- and the
+// compiler's schedule for it also reused the matrix instruction's source tile for vector results while it was in flight
+// (results NaN).  A matrix wave's floor is its fp64 work: 7 x 64 cycles of MFMA plus ~60 fp64 vector instructions, plus the
+// latencies between them; the 23 integer / move instructions the unrolled loop removes ride in their shadow.)
 // LDL^T of the lower triangle of Q_uu WITHOUT pivoting (the symmetric-weight kernels: Q_uu = 2 R + J_u^T V_xx J_u is positive
 // definite there; Eigen's LDLT, ilqr.hh:126, pivots on the diagonal -- the same factors in exact arithmetic; the general kernel
 // pivots, backward_layout.h).  Reciprocals of the pivots by rcp_nr.
@@ -1232,14 +1240,19 @@ __device__ __forceinline__ void bw4_loader_wave(double (&ring)[4][4][BW2_BUF], c
     }
     if (i - 3 >= 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) q[j] = rec_pair(j, i - 3);
+      for (int j = 0; j < 4; ++j) {
+#ifdef QILQR_TIMING_SHRINK  // timing-only build: pairs 32.. are never fetched
+        if (j >= 2) continue;
+#endif
+        q[j] = rec_pair(j, i - 3);
+      }
     }
     __syncthreads();
   }
 }
 // M_w: the matrix recursion of one trajectory (ring / kf row w).  cuu: the lane's entry of C_uu = 2 R (+ mu on the diagonal,
 // lm_restart) in accumulator register 3 (row 12 + kk, column j >= 12), zero elsewhere.
-template <typename S>
+template <typename S, bool UNROLL = false>
 __device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], double (&kf)[4][2][80], const RecLayout &L, int w,
                                                 bool run, S *gains, S *dump4, double cuu, int n, int lane,
                                                 unsigned long long *stamps_out) {
@@ -1287,21 +1300,21 @@ __device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], d
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real0)::"memory");
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
-  // (Round 3 measured this loop unrolled by four -- ring slot and hand-off parity as immediate offsets, the two operand
-  // register sets alternating: 147 -> 124 instructions per knot, no copies, no address arithmetic -- at 71.4 us per launch
-  // against 70.2 for the rolled loop, every code phase tried (profiles/r03_ab_backward.txt): the wave is not bound by the
-  // number of instructions it issues but by the latencies between them -- seven dependent matrix instructions, the
-  // reciprocal chains of the factorisation, the cross-lane gathers -- and a four times longer loop body costs more in
-  // instruction fetch than the 23 instructions return.)
-  for (int i = n - 1; i >= 0; --i) {
-    // operands of knot i-1, for the next iteration (the slot was filled during the previous interval)
-    const double *nb = ring[w][(i > 0 ? i - 1 : 0) & 3];
-    const double m_n0 = nb[off[0]], m_n1 = nb[off[1]], m_n2 = nb[off[2]], cx_n0 = nb[off[3]], cx_n1 = nb[off[4]],
-                 cx_n2 = nb[off[5]];
-    const d4 T = bw_tile_T(va, m);
+  // One knot.  (mc, cc): its operands, in registers; (mn, cn): the operands of the next knot (i - 1), requested here from ring
+  // slot `ns` (filled during the previous interval); par: i & 1, the hand-off buffer.  ns and par are ints in the rolled loop
+  // and compile-time constants in the unrolled one (immediate offsets of the LDS instructions).
+  const double *rp[6];  // the lane's six operand addresses in ring slot 0
+#pragma unroll
+  for (int k = 0; k < 6; ++k) rp[k] = &ring[w][0][off[k]];
+  double *const kfw = &kf[w][0][0];
+  auto knot = [&](auto ns, auto par, double (&mc)[3], double (&cc)[3], double (&mn)[3], double (&cn)[3]) {
+    const int so = (int)ns * BW2_BUF;
+    mn[0] = rp[0][so]; mn[1] = rp[1][so]; mn[2] = rp[2][so];
+    cn[0] = rp[3][so]; cn[1] = rp[4][so]; cn[2] = rp[5][so];
+    const d4 T = bw_tile_T(va, mc);
     QKEEP(T[0]); QKEEP(T[3]);
     QSTAMP(0);  // ring reads issued, T = V M
-    d4 H = bw_tile_H(m, T, cx, cuu);
+    d4 H = bw_tile_H(mc, T, cc, cuu);
     QKEEP(H[0]); QKEEP(H[3]);
     QSTAMP(1);  // H = C + M^T T
     double Quu[16], Qu_unused[4], col[4];
@@ -1325,7 +1338,7 @@ __device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], d
       gdst1 -= gstep;
     }
     // hand K and the factors to G (the four lanes of a column hold the same K[:, j]: same address, same data)
-    double *f = kf[w][i & 1];
+    double *f = kfw + (int)par * 80;
     f[4 * j] = kcol[0]; f[4 * j + 1] = kcol[1]; f[4 * j + 2] = kcol[2]; f[4 * j + 3] = kcol[3];
     if (lane == 0) {
       f[64] = f4.l10; f[65] = f4.l20; f[66] = f4.l30; f[67] = f4.l21; f[68] = f4.l31; f[69] = f4.l32;
@@ -1336,12 +1349,91 @@ __device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], d
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(H[3], sel4(kcol, kk), H, 0, 0, 0);
 #pragma unroll
     for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
-    m[0] = m_n0; m[1] = m_n1; m[2] = m_n2;
-    cx[0] = cx_n0; cx[1] = cx_n1; cx[2] = cx_n2;
-    QKEEP(va[0]); QKEEP(m[2]);
+    QKEEP(va[0]); QKEEP(mn[2]);
     QSTAMP(6);  // V_xx MFMA, next operands
     __syncthreads();
     QSTAMP(7);  // barrier
+  };
+  // Two forms of the loop.  Rolled: 147 instructions per knot.  Unrolled by four -- ring slot and hand-off parity as immediate
+  // offsets, the two operand register sets alternating: no copies, no address arithmetic, 124 instructions per knot.  Which
+  // is faster depends on what bounds the wave (profiles/r03_ab_backward.txt).  With one block per CU (B = 1024) a matrix wave
+  // is alone on its SIMD and bound by the LATENCIES between its instructions -- seven dependent matrix instructions, the
+  // reciprocal chains of the factorisation, the cross-lane gathers --, 23 fewer instructions return nothing and the four
+  // times longer loop body costs instruction fetch: 71.4 us per launch unrolled against 70.2 rolled, every code phase tried.
+  // With four blocks per CU (B > 4096) the SIMD interleaves four matrix waves and is bound by what they ISSUE: there the
+  // unrolled loop is the faster one.  The instantiation decides (UNROLL = the many-blocks build of k_backward4).
+  double mn[3], cn[3];
+  int i = n - 1;
+  if constexpr (UNROLL) {
+    // the first n mod 4 knots, until the knot index is 3 mod 4
+    for (; i >= 0 && (i & 3) != 3; --i) {
+      knot((i > 0 ? i - 1 : 0) & 3, i & 1, m, cx, mn, cn);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { m[k] = mn[k]; cx[k] = cn[k]; }
+    }
+    typedef std::integral_constant<int, 0> C0;
+    typedef std::integral_constant<int, 1> C1;
+    typedef std::integral_constant<int, 2> C2;
+    typedef std::integral_constant<int, 3> C3;
+    for (; i >= 3; i -= 4) {
+      knot(C2(), C1(), m, cx, mn, cn);    // knot 4 q + 3 (slot 3); next operands from slot 2
+      knot(C1(), C0(), mn, cn, m, cx);    // knot 4 q + 2
+      knot(C0(), C1(), m, cx, mn, cn);    // knot 4 q + 1
+      knot(C3(), C0(), mn, cn, m, cx);    // knot 4 q; the next pass starts in slot 3 (after knot 0: read and never used)
+    }
+  } else {
+    // (the rolled loop is written out, not built from `knot`: the same statements through the lambda schedule 1.3 us per
+    // launch slower -- this loop is that sensitive to the order the compiler picks)
+    for (; i >= 0; --i) {
+      // operands of knot i-1, for the next iteration (the slot was filled during the previous interval)
+      const double *nb = ring[w][(i > 0 ? i - 1 : 0) & 3];
+      const double m_n0 = nb[off[0]], m_n1 = nb[off[1]], m_n2 = nb[off[2]], cx_n0 = nb[off[3]], cx_n1 = nb[off[4]],
+                   cx_n2 = nb[off[5]];
+      const d4 T = bw_tile_T(va, m);
+      QKEEP(T[0]); QKEEP(T[3]);
+      QSTAMP(0);  // ring reads issued, T = V M
+      d4 H = bw_tile_H(m, T, cx, cuu);
+      QKEEP(H[0]); QKEEP(H[3]);
+      QSTAMP(1);  // H = C + M^T T
+      double Quu[16], Qu_unused[4], col[4];
+      gather_rows(H[3], col);
+      bcast_quu_row<0>(col, 0.0, Quu, Qu_unused);
+      bcast_quu_row<1>(col, 0.0, Quu, Qu_unused);
+      bcast_quu_row<2>(col, 0.0, Quu, Qu_unused);
+      bcast_quu_row<3>(col, 0.0, Quu, Qu_unused);
+      QKEEP(Quu[0]); QKEEP(Quu[15]); QKEEP(col[3]);
+      QSTAMP(2);  // gather + Q_uu broadcast
+      const Ldlt4 f4 = ldlt4_factor(Quu);  // (ilqr.hh:126; unpivoted: see ldlt4_factor)
+      double kcol[4];
+      ldlt4_solve_neg(f4, col[0], col[1], col[2], col[3], kcol);  // K[:, j] (ilqr.hh:127)
+      QKEEP(kcol[0]); QKEEP(kcol[3]);
+      QSTAMP(4);  // LDL^T + solve
+      {
+        const sv2 w0 = {(S)kcol[0], (S)kcol[1]}, w1 = {(S)kcol[2], (S)kcol[3]};
+        *gdst0 = w0;
+        *gdst1 = w1;
+        gdst0 -= gstep;
+        gdst1 -= gstep;
+      }
+      // hand K and the factors to G (the four lanes of a column hold the same K[:, j]: same address, same data)
+      double *f = kf[w][i & 1];
+      f[4 * j] = kcol[0]; f[4 * j + 1] = kcol[1]; f[4 * j + 2] = kcol[2]; f[4 * j + 3] = kcol[3];
+      if (lane == 0) {
+        f[64] = f4.l10; f[65] = f4.l20; f[66] = f4.l30; f[67] = f4.l21; f[68] = f4.l31; f[69] = f4.l32;
+        f[70] = f4.i0; f[71] = f4.i1; f[72] = f4.i2; f[73] = f4.i3;
+      }
+      QSTAMP(5);  // gain stores, hand-off to G
+      // V_xx = Q_xx + Q_xu K: A[j][kk] = Q_xu[j][kk] = H[12 + kk][j] is accumulator register 3
+      H = __builtin_amdgcn_mfma_f64_16x16x4f64(H[3], sel4(kcol, kk), H, 0, 0, 0);
+#pragma unroll
+      for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
+      m[0] = m_n0; m[1] = m_n1; m[2] = m_n2;
+      cx[0] = cx_n0; cx[1] = cx_n1; cx[2] = cx_n2;
+      QKEEP(va[0]); QKEEP(m[2]);
+      QSTAMP(6);  // V_xx MFMA, next operands
+      __syncthreads();
+      QSTAMP(7);  // barrier
+    }
   }
 #ifdef QILQR_STAMPS
   {
@@ -1558,8 +1650,11 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
     const int j = lane & 15, kk = lane >> 4;
     // register 3 <-> row 12 + kk: C_uu = 2 R (+ mu on the diagonal, lm_restart)
     const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] + ((j - 12 == kk) ? mu : 0.0) : 0.0;
-    bw4_matrix_wave<S>(ring, kf, L, w, s_run[w] != 0, (S *)st.gains + knot_base<true>(b, n, 52), (S *)st.dump + 4 * (long)b, cuu, n,
-                       lane, st.stamps ? st.stamps + (long)(b0 + w) * 8 : nullptr);
+#ifndef QILQR_BW4_UNROLL_MANY
+#define QILQR_BW4_UNROLL_MANY 1
+#endif
+    bw4_matrix_wave<S, (WAVES >= 6) && QILQR_BW4_UNROLL_MANY>(ring, kf, L, w, s_run[w] != 0, (S *)st.gains + knot_base<true>(b, n, 52),
+                                                             (S *)st.dump + 4 * (long)b, cuu, n, lane, st.stamps ? st.stamps + (long)(b0 + w) * 8 : nullptr);
   }
 }
 
