@@ -1244,6 +1244,9 @@ __device__ __forceinline__ void bw4_loader_wave(double (&ring)[4][4][BW2_BUF], c
 #ifdef QILQR_TIMING_SHRINK  // timing-only build: pairs 32.. are never fetched
         if (j >= 2) continue;
 #endif
+#ifdef QILQR_TIMING_NOLOADS  // timing-only build: the loader fetches nothing inside the loop (what do its loads' latencies cost?)
+        continue;
+#endif
         q[j] = rec_pair(j, i - 3);
       }
     }
