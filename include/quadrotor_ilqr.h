@@ -76,12 +76,13 @@ typedef struct {
   int32_t sync_every; /* 1: the host waits for every round's count of active trajectories; k > 1 (default 2 when no
                          configuration is given): it reads the count k rounds late, i.e. keeps the stream k rounds
                          ahead of the device (k <= 6).  The results do not depend on it. */
-  int32_t force_general; /* backward kernel.  0: by the weights and the batch (symmetric Q, R: k_backward2 -- a matrix
-                            and a gradient wavefront per trajectory -- below 512 trajectories, k_backward4 -- one
-                            gradient and one loader wavefront per four trajectories -- up to 8192, one wavefront
-                            per trajectory beyond; non-symmetric Q or R: the general kernel); 1: the general kernel even
-                            when Q, R are symmetric; 2: the one-wavefront kernel for symmetric weights
-                            (k_backward<true>); 3: k_backward2; 4: k_backward4.
+  int32_t force_general; /* backward kernel.  0: by the weights and the batch (symmetric Q, R: k_backward4 in its fused form --
+                            four wavefronts that each carry the matrix and the gradient recursion of a trajectory, plus a
+                            loader wavefront, per four trajectories -- up to 4096 trajectories; in its six-wavefront form --
+                            four matrix wavefronts, one gradient and one loader wavefront -- up to 8192; one wavefront per
+                            trajectory beyond; non-symmetric Q or R: the general kernel); 1: the general kernel even when
+                            Q, R are symmetric; 2: the one-wavefront kernel for symmetric weights (k_backward<true>);
+                            3: k_backward2 (diagnostics build only); 4: k_backward4, six wavefronts; 5: k_backward4, fused.
                             WHICH ARITHMETIC A CALLER GETS.  The general kernel evaluates ilqr.hh:118-140 in the
                             reference's own forms: Q_uu factored by Eigen's diagonally pivoted LDL^T (largest |d_ii| of
                             the trailing block, first on ties), V_x = Q_x - K^T Q_uu k, V_xx = Q_xx - K^T Q_uu K, not

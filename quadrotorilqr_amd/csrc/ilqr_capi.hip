@@ -370,18 +370,23 @@ int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag, 
 }
 // Which backward kernel a call with `load_B` trajectories in flight takes (symmetric weights), by how many trajectories share
 // the chip's 1024 SIMDs:
-//   up to 8192: k_backward4 (four matrix wavefronts, one gradient and one loader wavefront per four trajectories)
-//   beyond: one wavefront per trajectory (the matrix pipe is the bound)
+//   up to 4096: k_backward4<.., FUSED>: four wavefronts that each carry the matrix AND the gradient recursion of a trajectory,
+//               and one loader wavefront, per four trajectories (the wavefronts are bound by latencies, the gradient's 40
+//               instructions ride along: +0.3 to +1.7 % of a whole solve against the form below, profiles/r03_ab_backward.txt)
+//   up to 8192: k_backward4: four matrix wavefronts, ONE gradient wavefront and the loader per four trajectories, knot loop
+//               unrolled (four blocks per CU: the SIMDs are bound by what their wavefronts issue, and one gradient wavefront
+//               for four trajectories issues a quarter: 426k against 408k solves/s at 8192)
+//   beyond: one wavefront per trajectory (k_backward<true>)
 // k_backward2 (a matrix and a gradient wavefront per trajectory) was the choice below 512 trajectories in rounds 1 and 2; it
-// wins nowhere by more than 2 % (whole solves, tiles of four: 62.3k against 61.1k solves/s at 256, 85.3k against 86.3k at 512,
-// 104.5k against 106.9k at 640) and lives in the diagnostics build now (force_general = 3 there).
+// wins nowhere by more than 2 % and lives in the diagnostics build (force_general = 3 there).
 // The Runge-Kutta extension and non-symmetric weights take the one-wavefront kernel at every size.
-enum BackwardKind { BW_FOUR, BW_TWO, BW_ONE };
+enum BackwardKind { BW_FOUR, BW_TWO, BW_ONE, BW_FUSED };
 BackwardKind backward_kind(const qilqr_solver *s, long load_B) {
   if (s->integrator == 1 || !s->symmetric) return BW_ONE;
 #ifdef QILQR_WITH_BACKWARD2
   if (s->dev.force_general == 3) return BW_TWO;
 #endif
+  if (s->dev.force_general == 5 || (s->dev.force_general == 0 && load_B <= 4096)) return BW_FUSED;
   if (s->dev.force_general == 4 || (s->dev.force_general != 2 && load_B <= 8192)) return BW_FOUR;
   return BW_ONE;
 }
@@ -399,7 +404,18 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
   // (the records were linearised in the placement this choice reads: begin_batch sets st.layout.tiled from the same function;
   // the one-wavefront kernel addresses its operands through rec_elem and reads either)
   const BackwardKind kind = s->st.layout.tiled ? backward_kind(s, load_B) : BW_ONE;
-  if (kind == BW_FOUR) {
+  if (kind == BW_FUSED) {
+    // four matrix-and-gradient wavefronts + one loader wavefront per four trajectories
+    const bool many = load_B > 4096;
+    if (s->f32 && many)
+      launch(s, K_BACKWARD, (k_backward4<float, 6, true>), dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n, force);
+    else if (s->f32)
+      launch(s, K_BACKWARD, (k_backward4<float, 5, true>), dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n, force);
+    else if (many)
+      launch(s, K_BACKWARD, (k_backward4<double, 6, true>), dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n, force);
+    else
+      launch(s, K_BACKWARD, (k_backward4<double, 5, true>), dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n, force);
+  } else if (kind == BW_FOUR) {
     // four matrix wavefronts + one gradient wavefront + one loader wavefront per four trajectories
     // (register budget by how many blocks the chip has to hold: see k_backward4)
     const bool many = load_B > 4096;

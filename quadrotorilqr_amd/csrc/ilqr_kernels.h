@@ -1451,15 +1451,118 @@ __device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], d
 #endif
 }
 
+// MG_w: matrix AND gradient recursion of one trajectory in one wavefront (k_backward4<.., FUSED = true>): the arithmetic of the
+// one-wavefront kernel k_backward<true> -- gradient by three multiply-adds and two permlane butterflies, k solved in lane 12
+// with the lane's own factors, V_x = Q_x + K^T Q_u -- with its seven operands from the LDS ring the loader wave fills
+// (ring row w; no gradient wavefront, no hand-off of K and the factors).  Returns Q_u^T k summed over the knots.
+template <typename S>
+__device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], const RecLayout &L, int w, bool run, S *gains, S *dump4,
+                                                double cuu, int n, int lane) {
+  typedef typename GA<S>::v2 sv2;
+  typedef typename GA<S>::ptr2 gptr2;
+  __builtin_amdgcn_s_setprio(3);
+  const int j = lane & 15, kk = lane >> 4;
+  int off[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    int src;
+    if (k < 3) src = m_source_tab(4 * k + kk, j);
+    else if (k < 6) src = (j < 12) ? cxx_source_tab(L, 4 * (k - 3) + kk, j) : -1 - CTAB_ZERO;
+    else src = L.off_g + j;
+    off[k] = (src >= 0) ? src : BW2_REC + (-1 - src);
+  }
+  // gain slots of this lane: lanes (j < 12, kk = 0) own column j of K, lane (12, 0) owns k; the others write to the dump slot
+  const bool gowner = run && (kk == 0 && j <= 12);
+  const int ge0 = (j < 12) ? 4 + 4 * j : 0;
+  gptr2 gdst0 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0, 52) : dump4);
+  gptr2 gdst1 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0 + 2, 52) : dump4 + 2);
+  const long gstep = gowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
+  double va[3] = {0.0, 0.0, 0.0};   // V_xx[j][4 kc + kk]  (A operand)
+  double vxl[3] = {0.0, 0.0, 0.0};  // V_x[4 kc + kk]
+  double QuTk = 0.0;
+  __syncthreads();  // rings and constant tables are filled
+  if (!run) {
+    for (int i = n - 1; i >= 0; --i) __syncthreads();  // nothing to do in this round: keep the block's barriers company
+    return 0.0;
+  }
+  double m[3], cx[3], gcj;
+  {
+    const double *buf = ring[w][(n - 1) & 3];
+    m[0] = buf[off[0]]; m[1] = buf[off[1]]; m[2] = buf[off[2]];
+    cx[0] = buf[off[3]]; cx[1] = buf[off[4]]; cx[2] = buf[off[5]];
+    gcj = buf[off[6]];
+  }
+  asm volatile(".p2align 6");
+  for (int i = n - 1; i >= 0; --i) {
+    const double *nb = ring[w][(i > 0 ? i - 1 : 0) & 3];
+    const double m_n0 = nb[off[0]], m_n1 = nb[off[1]], m_n2 = nb[off[2]], cx_n0 = nb[off[3]], cx_n1 = nb[off[4]],
+                 cx_n2 = nb[off[5]], g_n = nb[off[6]];
+    const d4 T = bw_tile_T(va, m);
+    d4 H = bw_tile_H(m, T, cx, cuu);
+    // [Q_x ; Q_u] = [C_x ; C_u] + M^T V_x
+    double part = m[0] * vxl[0] + m[1] * vxl[1] + m[2] * vxl[2];
+    part = xor16_sum(part);
+    part = xor32_sum(part);
+    const double ghat = gcj + part;
+    double Quu[16], Qu[4], col[4], rhs[4];
+    gather_rows(H[3], col);
+    bcast_quu_row<0>(col, ghat, Quu, Qu);
+    bcast_quu_row<1>(col, ghat, Quu, Qu);
+    bcast_quu_row<2>(col, ghat, Quu, Qu);
+    bcast_quu_row<3>(col, ghat, Quu, Qu);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) rhs[a] = (j == 12) ? Qu[a] : col[a];  // lane 12: feed-forward
+    const Ldlt4 f4 = ldlt4_factor(Quu);
+    double kcol[4];
+    ldlt4_solve_neg(f4, rhs[0], rhs[1], rhs[2], rhs[3], kcol);  // K[:, j] (ilqr.hh:127); k in lane 12 (:128)
+    {
+      const sv2 w0 = {(S)kcol[0], (S)kcol[1]}, w1 = {(S)kcol[2], (S)kcol[3]};
+#ifdef QILQR_TIMING_NOSTORES  // timing-only build: the gains are written once, after the loop
+      if (i == 0) {
+#endif
+      *gdst0 = w0;
+      *gdst1 = w1;
+#ifdef QILQR_TIMING_NOSTORES
+      }
+#endif
+      gdst0 -= gstep;
+      gdst1 -= gstep;
+    }
+    QuTk += rhs[0] * kcol[0] + rhs[1] * kcol[1] + rhs[2] * kcol[2] + rhs[3] * kcol[3];  // (lane 12's sum is Q_u^T k)
+    const double vx = ghat + (kcol[0] * Qu[0] + kcol[1] * Qu[1] + kcol[2] * Qu[2] + kcol[3] * Qu[3]);  // V_x = Q_x + K^T Q_u
+#ifdef QILQR_FUSED_DPP_SHUFFLE  // experiment: V_x[4 kc + kk] by row broadcasts and a select instead of ds_bpermute (no LDS)
+    {
+      const double b0[4] = {row_bcast<0>(vx), row_bcast<1>(vx), row_bcast<2>(vx), row_bcast<3>(vx)};
+      const double b1[4] = {row_bcast<4>(vx), row_bcast<5>(vx), row_bcast<6>(vx), row_bcast<7>(vx)};
+      const double b2[4] = {row_bcast<8>(vx), row_bcast<9>(vx), row_bcast<10>(vx), row_bcast<11>(vx)};
+      vxl[0] = sel4(b0, kk); vxl[1] = sel4(b1, kk); vxl[2] = sel4(b2, kk);
+    }
+#else
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) vxl[kc] = __shfl(vx, 4 * kc + kk);  // V_x[r] lives in lanes with j == r
+#endif
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(H[3], sel4(kcol, kk), H, 0, 0, 0);  // V_xx = Q_xx + Q_xu K
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
+    m[0] = m_n0; m[1] = m_n1; m[2] = m_n2;
+    cx[0] = cx_n0; cx[1] = cx_n1; cx[2] = cx_n2;
+    gcj = g_n;
+    __syncthreads();
+  }
+  return bcast_lane(QuTk, 12);
+}
+
 // WAVES: register budget in waves per SIMD.  5 (90 registers, nothing spilled): three blocks per CU, the fastest single
 // block; 6 (80 registers, four of them spilled outside the knot loop): four blocks per CU -- with 33 KB of LDS per block the
 // registers are what decides -- for the launches that have more than three blocks per CU to run (B = 8192 in two parts:
 // 404 000 -> 412 000 solves/s; nothing at 4096, -0.5 % at 1024)
-template <typename S, int WAVES>
+// FUSED: five wavefronts per block -- MG_0..MG_3 (matrix and gradient recursion of a trajectory in one wavefront, bw4_fused_wave)
+// and the loader L -- instead of six (M_0..M_3, G, L).
+template <typename S, int WAVES, bool FUSED = false>
 __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_backward4(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n,
                                                    int force) {
   const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0..3: matrix wave of trajectory b0 + w; 4: G; 5: L
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0..3: matrix wave of trajectory b0 + w; 4: G (FUSED: L); 5: L
   const int b0 = xcd_local_block(blockIdx.x, gridDim.x) * 4;
   __shared__ int s_run[4], s_cur[4], s_iters[4], s_act[4];
   __shared__ double s_cost[4];
@@ -1599,8 +1702,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
     return;
   }
 
-  bw4_fill_ctab<S>(ring, st.ctab, 384);
-  if (w == 4) {
+  bw4_fill_ctab<S>(ring, st.ctab, FUSED ? 320 : 384);
+  if (!FUSED && w == 4) {
     // ------------------------------------------------------------------ G: gradients of four trajectories
     const int g = lane >> 4, j = lane & 15;
     const int bg = (b0 + g < B) ? b0 + g : B - 1;  // a valid stand-in for a missing trajectory (never stored)
@@ -1633,7 +1736,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
     return;
   }
 
-  if (w == 5) {
+  if (w == (FUSED ? 4 : 5)) {
     // ------------------------------------------------------------------ L: knot records of four trajectories
     // a trajectory with nothing to do this round is streamed as a duplicate of the block's first running one (the wave stays
     // branch-free and the duplicate's loads hit the lines the original just fetched: no HBM traffic for records nobody uses)
@@ -1645,6 +1748,37 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
       rec[g] = (const S *)st.lin[s_cur[gs]] + rec_base(L, b0 + gs, n);
     }
     bw4_loader_wave<S>(ring, L, rec[0], rec[1], rec[2], rec[3], n, lane);
+    if (FUSED && lane == 0 && block_act) atomicAdd(active_counter(st), block_act);  // (the gradient wave's job otherwise)
+    return;
+  }
+  if constexpr (FUSED) {
+    // ------------------------------------------------------------------ MG_w: matrix and gradient recursion of trajectory b0 + w
+    const int b = (b0 + w < B) ? b0 + w : B - 1;
+    const int j = lane & 15, kk = lane >> 4;
+    const bool run = s_run[w] != 0;
+    const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] + ((j - 12 == kk) ? mu : 0.0) : 0.0;
+    const double QuTk = bw4_fused_wave<S>(ring, L, w, run, (S *)st.gains + knot_base<true>(b, n, 52), (S *)st.dump + 4 * (long)b, cuu, n, lane);
+    if (lane == 0 && run) {
+      st.terms[2 * b] = QuTk;
+      st.terms[2 * b + 1] = -QuTk;  // k^T Quu k = -Q_u^T k for the exact solve (see k_backward)
+      st.n_bwd[b] += 1;
+      if (!force) {
+        const double cost_now = s_cost[w];
+        const int iters_now = s_iters[w];
+        st.prev_cost[b] = cost_now;  // ilqr.hh:61
+        if (iters_now > 0 && is_converged(p, cost_now, cost_now + cost_reduction(QuTk, -QuTk, 1.0))) {
+          st.status[b] = 0;  // ilqr.hh:66-68
+          st.flags[b] = 0;
+        } else if (iters_now > 0 && p.ls_max_iters <= 0) {
+          st.status[b] = 3;  // line_search with no trial allowed throws at once
+          st.flags[b] = 0;
+        } else {
+          st.alpha[b] = 1.0;
+          st.trial[b] = 0;
+          st.flags[b] = F_ACTIVE | F_SEARCH;
+        }
+      }
+    }
     return;
   }
   // -------------------------------------------------------------------- M_w: matrix recursion of trajectory b0 + w

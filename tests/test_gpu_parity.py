@@ -257,6 +257,17 @@ def test_two_wave_backward_matches_single_wave():
         np.testing.assert_allclose(o2["cost"], o1["cost"], rtol=1e-9 if prec == "f64" else 1e-4)
         # k_backward4: one gradient wavefront for four trajectories (blocks of four: B is not always a multiple); it reads the
         # records k_backward2 reads
+        # ... and its fused form (matrix and gradient recursion in one wavefront: the one-wavefront kernel's gradient order)
+        fused = capi.from_config(cfg, precision=prec, force_general=5)
+        g5, t5 = fused.backwards_pass(trajs)
+        np.testing.assert_allclose(t5, t2, rtol=1e-11 if prec == "f64" else 1e-6, atol=1e-300)
+        np.testing.assert_allclose(g5, g2, rtol=1e-9 if prec == "f64" else 1e-5, atol=(1e-11 if prec == "f64" else 1e-5) * max(np.abs(g2).max(), 1e-300))
+        o5 = fused.solve_batch(cfg["init"])
+        if prec == "f64":
+            np.testing.assert_array_equal(o5["status"], o2["status"])
+            np.testing.assert_array_equal(o5["iters"], o2["iters"])
+            np.testing.assert_array_equal(o5["n_fwd"], o2["n_fwd"])
+        np.testing.assert_allclose(o5["cost"], o2["cost"], rtol=1e-9 if prec == "f64" else 1e-4)
         four = capi.from_config(cfg, precision=prec, force_general=4)
         g4, t4 = four.backwards_pass(trajs)
         np.testing.assert_allclose(t4, t2, rtol=1e-11, atol=1e-300)
@@ -458,7 +469,7 @@ def _restart_cfg(B=24, n=30, ls_max_iters=1, seed=7):
     return cfg
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 5])
 def test_levenberg_marquardt_restarts_match_oracle(kernel):
     """qilqr_set_regularisation (an extension; the oracle states it, no reference
     behaviour to match): with one trial per line search most problems exhaust it and restart with mu on the
