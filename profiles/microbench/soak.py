@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity soak: the randomised GPU test of tests/test_gpu_parity.py over many more seeds, with every
-backward kernel (automatic, k_backward2, k_backward4, one wavefront, general) and rollout kernel forced in turn, the one-launch solve, and with Levenberg-Marquardt restarts on (few trials per line search).
+backward kernel of the product (automatic, k_backward4 six-wavefront and fused, one wavefront, general -- with Eigen's pivoted
+LDL^T since round 3) and rollout kernel forced in turn, sub-batches on three streams, and with Levenberg-Marquardt restarts on
+(few trials per line search).  (k_backward2 and k_solve4 live in the diagnostics build: tests/test_gpu_parity.py covers them.)
 usage: python profiles/microbench/soak.py [first_seed [n_seeds]]"""
 import sys
 
@@ -13,12 +15,10 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 orig = capi.from_config
 bad = 0
-for label, kw in [("automatic", {}), ("k_backward2", dict(force_general=3)), ("k_backward4", dict(force_general=4)), 
+for label, kw in [("automatic", {}), ("k_backward4 six waves", dict(force_general=4)), ("k_backward4 fused", dict(force_general=5)),
                   ("one wavefront", dict(force_general=2)), ("general", dict(force_general=1)),
                   ("k_rollout", dict(single_wave_rollout=1)), ("k_rollout3", dict(single_wave_rollout=2)), ("k_rollout16", dict(single_wave_rollout=3)),
-                  ("k_solve4", dict(persistent=1)), ("restarts, k_solve4", dict(persistent=1)),
-
-                  ("three streams", dict(streams=3)), ("restarts", dict()), ("restarts, k_backward2", dict(force_general=3)),
+                  ("three streams", dict(streams=3)), ("restarts", dict()), ("restarts, six waves", dict(force_general=4)),
                   ("restarts, one wavefront", dict(force_general=2)), ("restarts, general", dict(force_general=1))]:
     capi.from_config = lambda cfg, _kw=kw, **k: orig(cfg, **{**_kw, **k})
     fails = 0
@@ -28,7 +28,7 @@ for label, kw in [("automatic", {}), ("k_backward2", dict(force_general=3)), ("k
         except AssertionError as e:
             fails += 1
             print(label, "seed", seed, "FAILED:", str(e).splitlines()[:4])
-    print(f"{label:14s}: {count - fails}/{count} seeds agree with the oracle")
+    print(f"{label:24s}: {count - fails}/{count} seeds agree with the oracle")
     bad += fails
 capi.from_config = orig
 print("soak done, failures:", bad)
