@@ -58,6 +58,7 @@ struct qilqr_solver {
   qilqr_device_config dev;
   int n_desired = 0;
   bool symmetric = false;  // Q == Q^T and R == R^T exactly: transpose-free backward kernel
+  bool q_diag = false;     // Q exactly diagonal: the cost half of k_linearize scales rows instead of multiplying by Q (same bits)
   RecLayout layout;        // knot record layout chosen from the structure of Q
   void *d_desired = nullptr;    // shared desired trajectory, storage precision
   void *d_ctab = nullptr;       // constant operand table of k_backward, storage precision
@@ -350,6 +351,15 @@ int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag, 
     return QILQR_OK;
   }
   // (the placement of the records, s->st.layout.tiled, was chosen with the call's backward kernel: records_tiled)
+  if (layout_kind(s->layout) == 2 && s->q_diag && !s->f32) {
+    // diagonal Q: the record of kind 2, cheaper arithmetic, the same bits in fp64 (tests/test_gpu_parity.py).  (Not in the
+    // mixed mode: there the two instantiations differ in the last fp32 bit of a third of the knot costs -- the compiler
+    // contracts the single-precision expressions differently -- and "the same results whatever the weights' structure" is
+    // worth more than 1 % of k_linearize.)
+    if (s->st.layout.tiled) QILQR_LAUNCH_LIN(double, 3, true, s->consts, (const ModelConsts<double> *)s->d_consts);
+    else QILQR_LAUNCH_LIN(double, 3, false, s->consts, (const ModelConsts<double> *)s->d_consts);
+    return QILQR_OK;
+  }
   switch (layout_kind(s->layout) + (s->f32 ? 3 : 0) + (s->st.layout.tiled ? 6 : 0)) {
     case 0: QILQR_LAUNCH_LIN(double, 0, false, s->consts, (const ModelConsts<double> *)s->d_consts); break;
     case 1: QILQR_LAUNCH_LIN(double, 1, false, s->consts, (const ModelConsts<double> *)s->d_consts); break;
@@ -1008,6 +1018,11 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
         if (i < 6 && k >= 6) ur0 = ur0 && (Q[i * 12 + k] == 0.0);
       }
     s->layout = make_layout(qsym && dc.force_general != 1, ur0);
+    bool diag = true;
+    for (int i = 0; i < 12; ++i)
+      for (int k = 0; k < 12; ++k)
+        if (i != k) diag = diag && (Q[i * 12 + k] == 0.0);
+    s->q_diag = diag && std::getenv("QILQR_NO_DIAG_Q") == nullptr;  // (the environment switch: A/B and the bit-identity test)
   }
   s->n_desired = n_desired;
 

@@ -203,6 +203,17 @@ int hh_linearize_tiled(const ModelConsts<double> *c, const int *lay, const doubl
   return TILE;
 }
 long hh_rec_count(int B, int n, int stride) { return rec_count(B, n, stride); }
+// the cost half of one knot through the instantiation `kind` of linearize_cost (0 general, 1 symmetric, 2 block-diagonal,
+// 3 diagonal Q: the record of 2); rec: LIN_MAX_STRIDE doubles, pre-filled by the caller; returns the knot cost
+double hh_linearize_cost_kind(const ModelConsts<double> *c, int kind, const double *pt, const double *pd, double *rec) {
+  PlainRecWriter<double> w{rec};
+  switch (kind) {
+    case 0: return linearize_cost<0>(c->Q, c->R, pt, pd, w);
+    case 1: return linearize_cost<1>(c->Q, c->R, pt, pd, w);
+    case 2: return linearize_cost<2>(c->Q, c->R, pt, pd, w);
+    default: return linearize_cost<3>(c->Q, c->R, pt, pd, w);
+  }
+}
 void hh_rollout(const ModelConsts<double> *c, const double *traj, const double *gains, double alpha, double *out,
                 int n) {
   rollout_problem<false>(*c, traj, gains, alpha, out, n);

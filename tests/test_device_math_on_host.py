@@ -546,3 +546,32 @@ def test_pivoted_ldlt_of_the_general_kernel_is_eigens(hh):
         x = np.zeros(4)
         hh.hh_ldlt4_pivoted_solve(P(np.ascontiguousarray(2 * R)), P(np.ascontiguousarray(2 * R @ du)), P(x))
         assert np.abs(x - du).max() < 1e-13
+
+
+def test_diagonal_weights_instantiation_gives_the_block_diagonal_one_bit_for_bit(hh):
+    """linearize_cost<3> (round 3: Q exactly diagonal -- the reference's demo and tests -- so J^T Q is a row scaling) against
+    linearize_cost<2> (Q symmetric with zero pose x velocity blocks) on the same diagonal Q: the sums of <2> add products with
+    exact zeros to the products <3> keeps, so every entry of the record and the knot cost are the same numbers."""
+    r = np.random.default_rng(8)
+    model = dict(mass_kg=1.1, inertia=np.diag([1.0, 1.3, 0.8]), arm_length_m=0.7, torque_to_thrust_ratio_m=0.1, g_mpss=9.81)
+    Q = np.diag(r.uniform(0.5, 120.0, 12))
+    R = np.diag(r.uniform(0.5, 2.0, 4))
+    c = consts(hh, model, Q, R, 0.1)
+    hh.hh_linearize_cost_kind.restype = C.c_double
+    stride = hh.hh_lin_stride()
+    for trial in range(200):
+        big = trial % 4 == 3   # large rotations: the closed-form branches of Log and of the Jacobian coefficients
+        def knot():
+            p = np.zeros(18)
+            p[1:4] = r.uniform(-2, 2, 3)
+            ax = r.normal(size=3); ax /= np.linalg.norm(ax)
+            ang = r.uniform(-3.0, 3.0) if big else r.uniform(-0.4, 0.4)
+            p[4] = np.cos(ang / 2); p[5:8] = np.sin(ang / 2) * ax
+            p[8:14] = r.normal(size=6); p[14:18] = r.uniform(0, 5, 4)
+            return p
+        pt, pd = knot(), knot()
+        rec2, rec3 = np.full(stride, 7.0), np.full(stride, 7.0)
+        c2 = hh.hh_linearize_cost_kind(P(c), C.c_int(2), P(pt), P(pd), P(rec2))
+        c3 = hh.hh_linearize_cost_kind(P(c), C.c_int(3), P(pt), P(pd), P(rec3))
+        assert c2 == c3
+        np.testing.assert_array_equal(rec3, rec2)   # (+0.0 == -0.0: the sign of a zero is the one thing that may differ)
