@@ -646,6 +646,9 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
         }
         if ((unsigned)v == 0) break;
         if (on_count && (rc = (*on_count)((unsigned)v))) return rc;
+        // (Round 3 tried following the device ONE round behind in the tail, where a round takes well over 100 us and the host
+        // needs about 15 to enqueue the next: one round of three empty launches fewer after the last trajectory has finished --
+        // 36 rounds instead of 37 -- and no measurable difference, 5.223 against 5.221 ms per solve.  `lag` stays fixed.)
       }
     }
   }

@@ -27,7 +27,7 @@
 // QILQR_REFETCH(): what was read from memory before this point is read again after it rather than kept in
 // registers (the weights are used in several passes; keeping all of them live spills).
 // QILQR_PIN(x): x is computed here, not sunk to its first use (which would leave its operands live).
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(QILQR_NO_SCHED_FENCES)
 #define QILQR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define QILQR_REFETCH() asm volatile("" ::: "memory")
 #define QILQR_PIN(x) asm volatile("" : "+v"(x))
