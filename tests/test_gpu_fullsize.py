@@ -95,6 +95,57 @@ def test_config4_one_gpu_shard_full_size():
     np.testing.assert_allclose(o7["cost"], r7["cost"], rtol=1e-9)
 
 
+def test_config4_whole_batch_in_eight_shards_gathered_over_rccl():
+    """BASELINE.json configs[3] as specified -- ONE batch of 65 536 problems, 100 knots, fp64, seed 4, contiguous shards of
+    8 192, the converged trajectories gathered in one GPU's memory over RCCL -- through the C ABI a C++ host would call
+    (qilqr_solve_batch_sharded_device), with the eight shards on the one GPU of this box (eight solvers, eight host threads, a
+    one-rank communicator: the calls, the grouping and the offsets of a node; the wire of a node has not been measured).
+    Every problem converges; the gathered rows are the single-shard solve's bits for the first and the last shard; a sample
+    over the whole batch agrees with the oracle."""
+    import ctypes as C
+    B, n, shards = 65536, 100, 8
+    cfg = pb.config2(B=B, N=n, seed=4)
+    many = capi.sharded_from_config(cfg, devices=[0] * shards)
+    assert many.set_transport("rccl").startswith("rccl: ncclSend / ncclRecv, 1 rank")
+    hip = C.CDLL("libamdhip64.so.7")
+    ptrs = {}
+    shapes = dict(traj=((B, n, 18), np.float64), cost=((B,), np.float64), status=((B,), np.int32), iters=((B,), np.int32),
+                  n_bwd=((B,), np.int32), n_fwd=((B,), np.int32))
+    for k, (sh, dt) in shapes.items():
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(int(np.prod(sh)) * np.dtype(dt).itemsize)) == 0
+        ptrs[k] = p
+    try:
+        ms = many.solve_batch_gathered(cfg["init"], *(ptrs[k].value for k in ("traj", "cost", "status", "iters", "n_bwd", "n_fwd")), root=3)
+        assert 0.0 <= ms < 1e3
+        out = {}
+        for k, (sh, dt) in shapes.items():
+            a = np.empty(sh, dtype=dt)
+            assert hip.hipMemcpy(a.ctypes.data_as(C.c_void_p), ptrs[k], C.c_size_t(a.nbytes), C.c_int(2)) == 0
+            out[k] = a
+    finally:
+        for p in ptrs.values():
+            hip.hipFree(p)
+        many.close()
+    assert np.isfinite(out["traj"]).all() and np.isfinite(out["cost"]).all()
+    assert np.isin(out["status"], [0, 1]).all()
+    check_passthrough(out, cfg["init"])
+    # shards 0 and 7 against a single solver on the same 8192 problems: the same bits
+    one = capi.from_config(pb.config2(B=8192, N=n, seed=4))
+    for r in (0, 7):
+        lo = 8192 * r
+        ref = one.solve_batch(cfg["init"][lo:lo + 8192])
+        for k in ("status", "iters", "n_bwd", "n_fwd", "cost", "traj"):
+            np.testing.assert_array_equal(out[k][lo:lo + 8192], ref[k], err_msg=f"shard {r} {k}")
+    # a sample over the whole batch against the oracle
+    idx = np.arange(37, B, 1024)
+    oref = oracle_for(cfg).solve_batch(cfg["init"][idx], n_threads=8)
+    for k in ("status", "iters", "n_bwd", "n_fwd"):
+        np.testing.assert_array_equal(out[k][idx], oref[k], err_msg=k)
+    np.testing.assert_allclose(out["cost"][idx], oref["cost"], rtol=1e-9)
+    np.testing.assert_allclose(out["traj"][idx], oref["traj"], atol=1e-6)
+
+
 def test_config5_full_size_long_horizon_stress():
     """BASELINE.json configs[4]: B = 4096, N = 500.  Half A (2048, model A hover) is well posed for the symmetric
     kernels; half B (2048, the demo's box-climb at 50 s with random starts) diverges on the unchecked first step and
