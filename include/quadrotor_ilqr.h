@@ -104,7 +104,8 @@ typedef struct {
                         matrix core, cost sums / Armijo / convergence tests in fp64 (BASELINE.json configs[2]) */
   int32_t streams; /* batch solves with sync_every > 1: number of contiguous sub-batches that run their rounds on
                       their own HIP streams (their kernels are bound by different resources and overlap);
-                      0 = automatic (2 from 4096 trajectories on, else 1: see auto_parts in ilqr_capi.hip), at most 8 */
+                      0 = automatic (1 below 4096 trajectories, 2 from there on, 4 between 4096 and 16384 when the process
+                      runs with GPU_MAX_HW_QUEUES >= 8: see auto_parts in ilqr_capi.hip), at most 8 */
   int32_t persistent; /* the solve as ONE launch (k_solve4: blocks of eight wavefronts own four trajectories each from the
                          first linearisation to the exit status, no rounds, no host in the loop; symmetric weights only):
                          0 = the rounds of three launches at every batch size (by measurement they are level or ahead at every size

@@ -8,6 +8,9 @@ import os
 import sys
 import time
 
+# every sub-batch stream gets a hardware queue of its own (set before the HIP runtime starts, as bench.py does: DESIGN.md section 5)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 

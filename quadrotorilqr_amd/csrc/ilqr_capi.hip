@@ -711,13 +711,22 @@ struct PartScope {
     s->stream = stream0;
   }
 };
+// hardware queues HIP multiplexes this process's streams onto: GPU_MAX_HW_QUEUES as the runtime read it at start-up (default 4)
+int hw_queues() {
+  const char *e = std::getenv("GPU_MAX_HW_QUEUES");
+  const int q = e ? std::atoi(e) : 4;
+  return q > 0 ? q : 4;
+}
 int auto_parts(const qilqr_solver *s, long B) {
   const long tiles = (B + 63) / 64;
   // Measured (MI355X, N = 100): up to a few thousand trajectories every kernel is latency-bound and sharing
-  // SIMDs with another part's kernels only slows both (B = 1024: 138k solves/s on one stream, 136k on two,
-  // 132k on four); from about 4096 on two parts gain 4-5% (B = 8192: 335k -> 352k, B = 65536: 499k -> 518k).
-  // More than two need more hardware queues than HIP creates by default (GPU_MAX_HW_QUEUES).
-  int want = s->dev.streams > 0 ? s->dev.streams : (B >= 4096 ? 2 : 1);
+  // SIMDs with another part's kernels only slows both (B = 1024, round 3: 194k solves/s on one stream, 168k on two,
+  // 153k on four); from 4096 on two parts gain 4-5%.  Between 4096 and 16384 FOUR parts are better still when
+  // every part's stream has a hardware queue of its own -- GPU_MAX_HW_QUEUES=8 in the environment before the runtime
+  // starts (bench.py sets it): 5120: 366k against 356k solves/s, 6144: 403k / 377k, 7168: 437k / 406k,
+  // 8192: 461k / 429k, 10240: 441k / 424k, 12288: 472k / 460k; level at 4096, 16384 and 65536; with HIP's default four queues
+  // the parts collide with each other and with the caller's streams and two are the safer choice.
+  int want = s->dev.streams > 0 ? s->dev.streams : (B >= 4096 ? ((B > 4096 && B < 16384 && hw_queues() >= 8) ? 4 : 2) : 1);
   if (want > qilqr_solver::MAX_PARTS) want = qilqr_solver::MAX_PARTS;
   while (want > 1 && tiles < 2 * want) --want;  // at least two tiles per part
   return want;
