@@ -355,6 +355,55 @@ def main():
                 "warmup_avg_launch_us": {k: round(calib[k + "_ms"] * 1e3 / max(calib[k + "_launches"], 1), 2)
                                          for k in ("backward", "rollout", "solve")},
             }
+        # ---- the saturated machine: the shard one GPU solves in configs[3] (never `value`).  First of the extra legs: HIP hands
+        # hardware queues to streams in the order the streams are created and does not give a destroyed stream's place back, so
+        # behind the handles of the other legs this solver's four sub-batch streams can end up sharing queues (385 000 instead of
+        # 444 000-460 000 solves/s)
+        large = None
+        if not args.no_large_batch and world == 1 and not strong:
+            LB = 8192
+            lcfg = pb.config2(B=LB, N=N, seed=4)
+            ls = capi.from_config(lcfg, device=dev.index, profile=2, sync_every=args.sync_every)
+            linit = torch.from_numpy(lcfg["init"]).to(dev)
+            lbuf = (torch.empty_like(linit), torch.empty(LB, dtype=torch.float64, device=dev),
+                    [torch.empty(LB, dtype=torch.int32, device=dev) for _ in range(4)])
+            t_settle = time.perf_counter()  # untimed solves first: the legs before this one leave the GPU idle for seconds and its clocks low
+            while True:
+                ls.solve_batch_device(linit, lbuf[0], lbuf[1], *lbuf[2])
+                if (time.perf_counter() - t_settle) * 1e3 >= args.settle_ms:
+                    break
+            ls.profile_reset()
+            reps = 3
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                ls.solve_batch_device(linit, lbuf[0], lbuf[1], *lbuf[2])
+            tl = (time.perf_counter() - t1) / reps
+            lp = ls.profile_get()
+            lb_, lf_ = float(lbuf[2][2].sum().item()) * N * reps, float(lbuf[2][3].sum().item()) * N * reps
+            lk = kernel_table(lp, lb_, lf_)
+            per = {}
+            for k, kd in lk.items():
+                if kd["launches"] == 0:
+                    continue
+                tf, gb = rates(kd)
+                per[k] = {"avg_launch_us": kd["ms"] * 1e3 / max(kd["launches"], 1), "launches": kd["launches"],
+                          "fp64_frac": tf / FP64_PEAK_TFLOPS, "hbm_frac": gb / HBM_PEAK_GBS}
+            if lp["linearize_launches"]:
+                per["k_linearize"] = {"avg_launch_us": lp["linearize_ms"] * 1e3 / max(lp["linearize_launches"], 1),
+                                      "launches": lp["linearize_launches"]}
+            ls.profile_mode(0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                ls.solve_batch_device(linit, lbuf[0], lbuf[1], *lbuf[2])
+            tl0 = (time.perf_counter() - t1) / reps
+            large = {"what": f"B = {LB}, N = {N}, fp64, seed 4 (the shard one GPU solves in configs[3]); device-resident, {reps} repeats",
+                     "value": LB / tl0, "unit": "solves/s", "ms_per_solve": tl0 * 1e3,
+                     "ms_per_solve_with_every_kernel_timed": tl * 1e3, "kernels": per,
+                     "status_counts": np.bincount(lbuf[2][0].cpu().numpy(), minlength=4).tolist()}
+            ls.close()
+            del linit, lbuf
         # ---- CPU baseline: the oracle on this host's cores, bounded sample of the same workload
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
@@ -404,52 +453,6 @@ def main():
                    "pageable_buffers": {"value": B / tp, "ms_per_solve": tp * 1e3},
                    "parity_with_device_path": bool(np.array_equal(hout["cost"], out_cost[(step_no[0] - 1) & 1].cpu().numpy()))}
             plain.close()
-        # ---- the saturated machine: the shard one GPU solves in configs[3] (never `value`)
-        large = None
-        if not args.no_large_batch and world == 1 and not strong:
-            LB = 8192
-            lcfg = pb.config2(B=LB, N=N, seed=4)
-            ls = capi.from_config(lcfg, device=dev.index, profile=2, sync_every=args.sync_every)
-            linit = torch.from_numpy(lcfg["init"]).to(dev)
-            lbuf = (torch.empty_like(linit), torch.empty(LB, dtype=torch.float64, device=dev),
-                    [torch.empty(LB, dtype=torch.int32, device=dev) for _ in range(4)])
-            t_settle = time.perf_counter()  # untimed solves first: the legs before this one leave the GPU idle for seconds and its clocks low
-            while True:
-                ls.solve_batch_device(linit, lbuf[0], lbuf[1], *lbuf[2])
-                if (time.perf_counter() - t_settle) * 1e3 >= args.settle_ms:
-                    break
-            ls.profile_reset()
-            reps = 3
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                ls.solve_batch_device(linit, lbuf[0], lbuf[1], *lbuf[2])
-            tl = (time.perf_counter() - t1) / reps
-            lp = ls.profile_get()
-            lb_, lf_ = float(lbuf[2][2].sum().item()) * N * reps, float(lbuf[2][3].sum().item()) * N * reps
-            lk = kernel_table(lp, lb_, lf_)
-            per = {}
-            for k, kd in lk.items():
-                if kd["launches"] == 0:
-                    continue
-                tf, gb = rates(kd)
-                per[k] = {"avg_launch_us": kd["ms"] * 1e3 / max(kd["launches"], 1), "launches": kd["launches"],
-                          "fp64_frac": tf / FP64_PEAK_TFLOPS, "hbm_frac": gb / HBM_PEAK_GBS}
-            if lp["linearize_launches"]:
-                per["k_linearize"] = {"avg_launch_us": lp["linearize_ms"] * 1e3 / max(lp["linearize_launches"], 1),
-                                      "launches": lp["linearize_launches"]}
-            ls.profile_mode(0)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                ls.solve_batch_device(linit, lbuf[0], lbuf[1], *lbuf[2])
-            tl0 = (time.perf_counter() - t1) / reps
-            large = {"what": f"B = {LB}, N = {N}, fp64, seed 4 (the shard one GPU solves in configs[3]); device-resident, {reps} repeats",
-                     "value": LB / tl0, "unit": "solves/s", "ms_per_solve": tl0 * 1e3,
-                     "ms_per_solve_with_every_kernel_timed": tl * 1e3, "kernels": per,
-                     "status_counts": np.bincount(lbuf[2][0].cpu().numpy(), minlength=4).tolist()}
-            ls.close()
-            del linit, lbuf
         # ---- extra, outside the timed region and never `value`: a stream of such batches with several in flight
         # (one solver handle and one host thread per batch in flight): the tail of one batch -- a few trajectories
         # still iterating on an almost idle chip -- overlaps the head of the next
