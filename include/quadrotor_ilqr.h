@@ -82,7 +82,10 @@ typedef struct {
                             four matrix wavefronts, one gradient and one loader wavefront -- up to 8192; one wavefront per
                             trajectory beyond; non-symmetric Q or R: the general kernel); 1: the general kernel even when
                             Q, R are symmetric; 2: the one-wavefront kernel for symmetric weights (k_backward<true>);
-                            3: k_backward2 (diagnostics build only); 4: k_backward4, six wavefronts; 5: k_backward4, fused.
+                            3: k_backward2 (diagnostics build only); 4: k_backward4, six wavefronts; 5: k_backward4, fused
+                            (its wavefronts meet through tagged LDS slots, no block barrier in the knot loop: what 0
+                            selects); 6: k_backward4, fused, with a block barrier per knot (same bits as 5; kept as
+                            its A/B partner).
                             WHICH ARITHMETIC A CALLER GETS.  The general kernel evaluates ilqr.hh:118-140 in the
                             reference's own forms: Q_uu factored by Eigen's diagonally pivoted LDL^T (largest |d_ii| of
                             the trailing block, first on ties), V_x = Q_x - K^T Q_uu k, V_xx = Q_xx - K^T Q_uu K, not

@@ -161,6 +161,9 @@ int device_error(qilqr_solver *s) {
   const unsigned long long v = __atomic_load_n(w, __ATOMIC_ACQUIRE);
   if (!v) return QILQR_OK;
   __atomic_store_n(w, 0ull, __ATOMIC_RELEASE);
+  if ((v >> 32) == 2)
+    return fail(QILQR_ERR_HIP, "k_backward4: a hand-off between the wavefronts of block " + std::to_string((unsigned)v) +
+                                   " never arrived (bounded spin ran out); its gains are void and the results of this call are invalid");
   return fail(QILQR_ERR_HIP, "k_rollout16: a hand-off between the wavefronts of block " + std::to_string((unsigned)v) +
                                  " never arrived (bounded spin ran out); its rollout was abandoned and the results of this call are invalid");
 }
@@ -396,7 +399,7 @@ BackwardKind backward_kind(const qilqr_solver *s, long load_B) {
 #ifdef QILQR_WITH_BACKWARD2
   if (s->dev.force_general == 3) return BW_TWO;
 #endif
-  if (s->dev.force_general == 5 || (s->dev.force_general == 0 && load_B <= 4096)) return BW_FUSED;
+  if (s->dev.force_general == 5 || s->dev.force_general == 6 || (s->dev.force_general == 0 && load_B <= 4096)) return BW_FUSED;
   if (s->dev.force_general == 4 || (s->dev.force_general != 2 && load_B <= 8192)) return BW_FOUR;
   return BW_ONE;
 }
@@ -415,16 +418,23 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
   // the one-wavefront kernel addresses its operands through rec_elem and reads either)
   const BackwardKind kind = s->st.layout.tiled ? backward_kind(s, load_B) : BW_ONE;
   if (kind == BW_FUSED) {
-    // four matrix-and-gradient wavefronts + one loader wavefront per four trajectories
-    const bool many = load_B > 4096;
-    if (s->f32 && many)
-      launch(s, K_BACKWARD, (k_backward4<float, 6, true>), dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n, force);
-    else if (s->f32)
-      launch(s, K_BACKWARD, (k_backward4<float, 5, true>), dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n, force);
-    else if (many)
-      launch(s, K_BACKWARD, (k_backward4<double, 6, true>), dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n, force);
-    else
-      launch(s, K_BACKWARD, (k_backward4<double, 5, true>), dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n, force);
+    // four matrix-and-gradient wavefronts + one loader wavefront per four trajectories; without block barriers in the knot
+    // loop unless force_general = 6 asks for them (the A/B partner)
+    const bool many = load_B > 4096, barriers = s->dev.force_general == 6;
+#define QILQR_LAUNCH_FUSED(S, W, FREE) \
+  launch(s, K_BACKWARD, (k_backward4<S, W, true, FREE>), dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n, force)
+    if (barriers) {
+      if (s->f32 && many) QILQR_LAUNCH_FUSED(float, 6, false);
+      else if (s->f32) QILQR_LAUNCH_FUSED(float, 5, false);
+      else if (many) QILQR_LAUNCH_FUSED(double, 6, false);
+      else QILQR_LAUNCH_FUSED(double, 5, false);
+    } else {
+      if (s->f32 && many) QILQR_LAUNCH_FUSED(float, 6, true);
+      else if (s->f32) QILQR_LAUNCH_FUSED(float, 5, true);
+      else if (many) QILQR_LAUNCH_FUSED(double, 6, true);
+      else QILQR_LAUNCH_FUSED(double, 5, true);
+    }
+#undef QILQR_LAUNCH_FUSED
   } else if (kind == BW_FOUR) {
     // four matrix wavefronts + one gradient wavefront + one loader wavefront per four trajectories
     // (register budget by how many blocks the chip has to hold: see k_backward4)
@@ -1404,7 +1414,7 @@ int qilqr_backwards_pass(qilqr_solver *s, const double *traj, int32_t B, int32_t
   HIP_TRY(hipMemcpyAsync(terms, s->st.terms, sizeof(double) * 2 * B, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   HIP_TRY(hipGetLastError());
-  return QILQR_OK;
+  return device_error(s);
 }
 
 int qilqr_forward_sim(qilqr_solver *s, const double *traj, const double *gains, const double *alpha, int32_t B,
@@ -1894,6 +1904,13 @@ int qilqr_debug_set_rollout_stall(qilqr_solver *s, int32_t knot) {
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_r16_stall_knot), &knot, sizeof(int)));
+  return QILQR_OK;
+}
+// the same for k_backward4's barrier-free form: the loader withholds the tags of record `rec` (-1: none again)
+int qilqr_debug_set_backward_stall(qilqr_solver *s, int32_t rec) {
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_bw4_stall_rec), &rec, sizeof(int)));
   return QILQR_OK;
 }
 // diagnostic build only (make diag; profiles/microbench/beside.py): the rollout kernel of the

@@ -1197,9 +1197,32 @@ __device__ __forceinline__ double bw4_gradient_wave(double (&ring)[4][4][BW2_BUF
 // (each trajectory has its own current buffer, hence a base per lane) -- and the lane writes its sixteen bytes to ring
 // entries 2 pair, 2 pair + 1 of ring g.  Pairs beyond the record are clamped to its last pair and land in entries nobody
 // reads.
-template <typename S>
+//
+// FREE (the fused form's product path): no block barrier inside the knot loop.  The five wavefronts of a block meet through
+// 24 words of LDS instead (prog[]):
+//   prog[w], w = 0..3   MG_w has finished this many knots + 1 (so: it no longer reads the slots of older records)
+//   prog[4]             records the loader has placed (diagnostic)
+//   prog[5]             somebody's bounded wait ran out: the block's results are void, the host is told (BatchState::host_error)
+//   prog[8 + 4 g + slot] tag of ring g's slot: the ordinal t of the record it holds (record t is knot n - 1 - t), -1 before
+// L writes a record's pairs, then the four tags (LDS operations of one wavefront execute in order); MG_w reads the tag of the
+// slot it is about to take its next operands from and only then the operands.  L overwrites a slot once every live MG wave
+// has finished the knot that read it.  With the barrier, every wavefront of the block waited for the slowest at every knot
+// (1 live wave: 66.9 us per launch at N = 100, 4 live: 73.8); without it each matrix wave runs at its own pace: 68.1 with
+// four live, 78.6 against 83.7 at B = 1024 (profiles/r03_ab_backward.txt).  All waits are bounded spins.
+constexpr int BW4_SPIN_MAX = 1 << 22;
+#ifdef QILQR_DIAG
+// diagnostics build: the record ordinal whose tags the loader withholds (-1: none), so that the matrix wavefronts' bounded
+// waits run out (tests/test_gpu_robustness.py)
+__device__ int g_bw4_stall_rec = -1;
+#endif
+__device__ __forceinline__ int bw4_prog_read(int *prog, int k) { return __hip_atomic_load(&prog[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void bw4_prog_post(int *prog, int k, int v, int lane) {
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_store(&prog[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <typename S, bool FREE = false>
 __device__ __forceinline__ void bw4_loader_wave(double (&ring)[4][4][BW2_BUF], const RecLayout &L, const S *rec0, const S *rec1,
-                                                const S *rec2, const S *rec3, int n, int lane) {
+                                                const S *rec2, const S *rec3, int n, int lane, int *prog = nullptr, int live = 0) {
   static_assert(BW2_BUF % 2 == 0 && BW2_REC == 128, "ring entries are written in aligned pairs, 64 of them per record slot");
   typedef typename GA<S>::v2 rv2;
   typedef typename GA<S>::cptr2 rptr2;
@@ -1230,7 +1253,50 @@ __device__ __forceinline__ void bw4_loader_wave(double (&ring)[4][4][BW2_BUF], c
     put(j, n - 1, a);
     if (n >= 2) put(j, n - 2, b_);
   }
+  if constexpr (FREE) {
+    if (lane == 0) prog[4] = n >= 2 ? 2 : 1;
+  }
   __syncthreads();  // rings and constant tables are filled
+  if constexpr (FREE) {
+    auto wait_slot = [&](int t) -> bool {
+      if (t < 4) return true;
+      int spins = 0;
+      for (;;) {
+        int lo = 1 << 30;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+          if ((live >> w) & 1) {
+            const int c = bw4_prog_read(prog, w);
+            lo = c < lo ? c : lo;
+          }
+        if (lo >= t - 3) break;
+        if (bw4_prog_read(prog, 5) || ++spins > BW4_SPIN_MAX) {
+          bw4_prog_post(prog, 5, 1, lane);
+          return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      asm volatile("" ::: "memory");
+      return true;
+    };
+    for (int t = 2; t < n; ++t) {
+      const int i = n - 1 - t;
+      if (!wait_slot(t)) return;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) put(j, i, q[j]);
+      asm volatile("" ::: "memory");
+#ifdef QILQR_DIAG
+      if (t != g_bw4_stall_rec)  // fault injection (qilqr_debug_set_backward_stall)
+#endif
+      if (lane < 4) __hip_atomic_store(&prog[8 + 4 * lane + (i & 3)], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (t + 1 < n) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = rec_pair(j, i - 1);
+      }
+      bw4_prog_post(prog, 4, t + 1, lane);
+    }
+    return;
+  }
   for (int i = n - 1; i >= 0; --i) {
     // first the four pieces requested one interval ago, then the next four requests: the wait in front of
     // the LDS writes is for loads that are all older than anything in flight
@@ -1455,9 +1521,9 @@ __device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], d
 // one-wavefront kernel k_backward<true> -- gradient by three multiply-adds and two permlane butterflies, k solved in lane 12
 // with the lane's own factors, V_x = Q_x + K^T Q_u -- with its seven operands from the LDS ring the loader wave fills
 // (ring row w; no gradient wavefront, no hand-off of K and the factors).  Returns Q_u^T k summed over the knots.
-template <typename S>
+template <typename S, bool FREE = false>
 __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], const RecLayout &L, int w, bool run, S *gains, S *dump4,
-                                                double cuu, int n, int lane) {
+                                                double cuu, int n, int lane, int *prog = nullptr) {
   typedef typename GA<S>::v2 sv2;
   typedef typename GA<S>::ptr2 gptr2;
   __builtin_amdgcn_s_setprio(3);
@@ -1482,7 +1548,8 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
   double QuTk = 0.0;
   __syncthreads();  // rings and constant tables are filled
   if (!run) {
-    for (int i = n - 1; i >= 0; --i) __syncthreads();  // nothing to do in this round: keep the block's barriers company
+    if constexpr (!FREE)
+      for (int i = n - 1; i >= 0; --i) __syncthreads();  // nothing to do in this round: keep the block's barriers company
     return 0.0;
   }
   double m[3], cx[3], gcj;
@@ -1493,10 +1560,20 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
     gcj = buf[off[6]];
   }
   asm volatile(".p2align 6");
+  bool dead = false;  // (barrier-free form) the loader stopped answering: finish the loop unchecked, then report
   for (int i = n - 1; i >= 0; --i) {
     const double *nb = ring[w][(i > 0 ? i - 1 : 0) & 3];
-    const double m_n0 = nb[off[0]], m_n1 = nb[off[1]], m_n2 = nb[off[2]], cx_n0 = nb[off[3]], cx_n1 = nb[off[4]],
-                 cx_n2 = nb[off[5]], g_n = nb[off[6]];
+    double m_n0, m_n1, m_n2, cx_n0, cx_n1, cx_n2, g_n;
+    int tag = 0;
+    unsigned tag_addr = 0;
+    const int slot_word = 8 + 4 * w + ((i > 0 ? i - 1 : 0) & 3), want = n - 1 - i + 1;
+    if constexpr (FREE) {
+      // requested in front of the three matrix instructions ...
+      tag_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int *)&prog[slot_word];
+      asm volatile("ds_read_b32 %0, %1" : "=v"(tag) : "v"(tag_addr) : "memory");
+    } else {
+      m_n0 = nb[off[0]]; m_n1 = nb[off[1]]; m_n2 = nb[off[2]]; cx_n0 = nb[off[3]]; cx_n1 = nb[off[4]]; cx_n2 = nb[off[5]]; g_n = nb[off[6]];
+    }
     const d4 T = bw_tile_T(va, m);
     d4 H = bw_tile_H(m, T, cx, cuu);
     // [Q_x ; Q_u] = [C_x ; C_u] + M^T V_x
@@ -1504,6 +1581,24 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
     part = xor16_sum(part);
     part = xor32_sum(part);
     const double ghat = gcj + part;
+    auto check_and_read = [&]() {
+  if constexpr (FREE) {
+        __builtin_amdgcn_sched_barrier(0);
+        // ... looked at behind them; the operand reads only behind that
+        int tag_s;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %0, %1" : "=s"(tag_s) : "v"(tag) : "memory");
+        if (__builtin_expect(i > 0 && want >= 2 && !dead && tag_s != want, 0)) {
+          int spins = 0;
+          do {
+            asm volatile("ds_read_b32 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, %0" : "=&v"(tag), "=s"(tag_s) : "v"(tag_addr) : "memory");
+            if (++spins > BW4_SPIN_MAX) dead = true;
+          } while (tag_s != want && !dead);
+        }
+        asm volatile("" ::: "memory");
+        m_n0 = nb[off[0]]; m_n1 = nb[off[1]]; m_n2 = nb[off[2]]; cx_n0 = nb[off[3]]; cx_n1 = nb[off[4]]; cx_n2 = nb[off[5]]; g_n = nb[off[6]];
+      }
+    };
+    check_and_read();
     double Quu[16], Qu[4], col[4], rhs[4];
     gather_rows(H[3], col);
     bcast_quu_row<0>(col, ghat, Quu, Qu);
@@ -1547,8 +1642,11 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
     m[0] = m_n0; m[1] = m_n1; m[2] = m_n2;
     cx[0] = cx_n0; cx[1] = cx_n1; cx[2] = cx_n2;
     gcj = g_n;
-    __syncthreads();
+    if constexpr (FREE) bw4_prog_post(prog, w, n - 1 - i + 2, lane);
+    else __syncthreads();
   }
+  if constexpr (FREE)
+    if (dead) bw4_prog_post(prog, 5, 1, lane);
   return bcast_lane(QuTk, 12);
 }
 
@@ -1558,7 +1656,7 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
 // 404 000 -> 412 000 solves/s; nothing at 4096, -0.5 % at 1024)
 // FUSED: five wavefronts per block -- MG_0..MG_3 (matrix and gradient recursion of a trajectory in one wavefront, bw4_fused_wave)
 // and the loader L -- instead of six (M_0..M_3, G, L).
-template <typename S, int WAVES, bool FUSED = false>
+template <typename S, int WAVES, bool FUSED = false, bool FREE = false>
 __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_backward4(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n,
                                                    int force) {
   const int lane = threadIdx.x & 63;
@@ -1570,6 +1668,8 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   // while G reads slot (i+1) & 3
   __shared__ __attribute__((aligned(16))) double ring[4][4][BW2_BUF];
   __shared__ double kf[4][2][80];
+  __shared__ int prog[24];
+  if (FREE && threadIdx.x < 24) prog[threadIdx.x] = (threadIdx.x < 4) ? 1 : ((threadIdx.x >= 8) ? -1 : 0);
   const RecLayout L = st.layout;
 
   // ---- every matrix wave settles its own trajectory's pending candidate (as in k_backward2)
@@ -1747,8 +1847,10 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
       const int gs = s_run[g] ? g : first;
       rec[g] = (const S *)st.lin[s_cur[gs]] + rec_base(L, b0 + gs, n);
     }
-    bw4_loader_wave<S>(ring, L, rec[0], rec[1], rec[2], rec[3], n, lane);
+    bw4_loader_wave<S, FREE>(ring, L, rec[0], rec[1], rec[2], rec[3], n, lane, prog, s_run[0] | (s_run[1] << 1) | (s_run[2] << 2) | (s_run[3] << 3));
     if (FUSED && lane == 0 && block_act) atomicAdd(active_counter(st), block_act);  // (the gradient wave's job otherwise)
+    if (FREE && lane == 0 && bw4_prog_read(prog, 5) && st.host_error)
+      __hip_atomic_store(st.host_error, (2ull << 32) | (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
   if constexpr (FUSED) {
@@ -1757,7 +1859,9 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
     const int j = lane & 15, kk = lane >> 4;
     const bool run = s_run[w] != 0;
     const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] + ((j - 12 == kk) ? mu : 0.0) : 0.0;
-    const double QuTk = bw4_fused_wave<S>(ring, L, w, run, (S *)st.gains + knot_base<true>(b, n, 52), (S *)st.dump + 4 * (long)b, cuu, n, lane);
+    const double QuTk = bw4_fused_wave<S, FREE>(ring, L, w, run, (S *)st.gains + knot_base<true>(b, n, 52), (S *)st.dump + 4 * (long)b, cuu, n, lane, prog);
+    if (FREE && lane == 0 && bw4_prog_read(prog, 5) && st.host_error)
+      __hip_atomic_store(st.host_error, (2ull << 32) | (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (lane == 0 && run) {
       st.terms[2 * b] = QuTk;
       st.terms[2 * b + 1] = -QuTk;  // k^T Quu k = -Q_u^T k for the exact solve (see k_backward)

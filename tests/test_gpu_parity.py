@@ -268,6 +268,15 @@ def test_two_wave_backward_matches_single_wave():
             np.testing.assert_array_equal(o5["iters"], o2["iters"])
             np.testing.assert_array_equal(o5["n_fwd"], o2["n_fwd"])
         np.testing.assert_allclose(o5["cost"], o2["cost"], rtol=1e-9 if prec == "f64" else 1e-4)
+        # the fused form with a block barrier per knot instead of tagged slots (force_general = 6): the same instructions on
+        # the same operands, hence the same bits
+        barr = capi.from_config(cfg, precision=prec, force_general=6)
+        g6, t6 = barr.backwards_pass(trajs)
+        np.testing.assert_array_equal(g6, g5)
+        np.testing.assert_array_equal(t6, t5)
+        o6 = barr.solve_batch(cfg["init"])
+        for k in ("status", "iters", "n_fwd", "cost", "traj"):
+            np.testing.assert_array_equal(o6[k], o5[k], err_msg=k)
         four = capi.from_config(cfg, precision=prec, force_general=4)
         g4, t4 = four.backwards_pass(trajs)
         np.testing.assert_allclose(t4, t2, rtol=1e-11, atol=1e-300)
@@ -469,7 +478,7 @@ def _restart_cfg(B=24, n=30, ls_max_iters=1, seed=7):
     return cfg
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 5, 6])
 def test_levenberg_marquardt_restarts_match_oracle(kernel):
     """qilqr_set_regularisation (an extension; the oracle states it, no reference
     behaviour to match): with one trial per line search most problems exhaust it and restart with mu on the

@@ -156,6 +156,38 @@ def test_a_lost_hand_off_in_the_rollout_ends_the_call_with_an_error_not_a_hang()
         np.testing.assert_array_equal(again[k], good[k], err_msg=k)
 
 
+def test_a_withheld_record_in_the_backward_pass_ends_the_call_with_an_error_not_a_hang():
+    """k_backward4's fused form has no block barrier in its knot loop: the loader wavefront tags every ring slot it fills and
+    the four matrix wavefronts read the tag in front of the operands; both sides wait in BOUNDED spins.  The diagnostics build
+    can withhold one record's tags (qilqr_debug_set_backward_stall): the matrix wavefronts' waits run out, they finish the
+    loop unchecked so that the grid drains, the block reports itself through pinned memory and the host returns
+    QILQR_ERR_HIP; with the fault removed the handle gives the results it gave before."""
+    import time
+    from tests.diag_lib import capi_diag
+    d = capi_diag()
+    cfg = pb.config2(B=8, N=30, seed=5)
+    s = d.from_config(cfg, force_general=5)
+    good = s.solve_batch(cfg["init"])
+    assert np.isin(good["status"], [0, 1]).all()
+    trajs = s.forward_sim(cfg["init"], np.zeros((8, 30, 52)), 1.0)
+    gains = s.backwards_pass(trajs)
+    lib = d.load()
+    assert lib.qilqr_debug_set_backward_stall(s._h, 11) == 0   # the tags of the twelfth record from the end never appear
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="k_backward4: a hand-off between the wavefronts of block"):
+        s.backwards_pass(trajs)
+    with pytest.raises(RuntimeError, match="results of this call are invalid"):
+        s.solve_batch(cfg["init"])
+    assert time.perf_counter() - t0 < 60.0
+    assert lib.qilqr_debug_set_backward_stall(s._h, -1) == 0
+    again_gains = s.backwards_pass(trajs)
+    for a, b in zip(again_gains if isinstance(again_gains, tuple) else (again_gains,), gains if isinstance(gains, tuple) else (gains,)):
+        np.testing.assert_array_equal(a, b)
+    again = s.solve_batch(cfg["init"])
+    for k in ("status", "iters", "cost", "traj"):
+        np.testing.assert_array_equal(again[k], good[k], err_msg=k)
+
+
 def test_the_product_build_refuses_the_kernels_of_the_diagnostics_build():
     cfg = pb.config2(B=4, N=10)
     with pytest.raises(TypeError, match="diagnostics build"):
