@@ -1200,7 +1200,8 @@ __device__ __forceinline__ double bw4_gradient_wave(double (&ring)[4][4][BW2_BUF
 //
 // FREE (the fused form's product path): no block barrier inside the knot loop.  The five wavefronts of a block meet through
 // 24 words of LDS instead (prog[]):
-//   prog[w], w = 0..3   MG_w has finished this many knots + 1 (so: it no longer reads the slots of older records)
+//   prog[w], w = 0..3   MG_w holds the operands of this many records in registers or is done with them (1 after its prologue,
+//                       k + 2 after the knot of record k): the slots of those records may be overwritten
 //   prog[4]             records the loader has placed (diagnostic)
 //   prog[5]             somebody's bounded wait ran out: the block's results are void, the host is told (BatchState::host_error)
 //   prog[8 + 4 g + slot] tag of ring g's slot: the ordinal t of the record it holds (record t is knot n - 1 - t), -1 before
@@ -1559,6 +1560,7 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
     cx[0] = buf[off[3]]; cx[1] = buf[off[4]]; cx[2] = buf[off[5]];
     gcj = buf[off[6]];
   }
+  if constexpr (FREE) bw4_prog_post(prog, w, 1, lane);  // record 0 is in registers (the loader may reuse its slot)
   asm volatile(".p2align 6");
   bool dead = false;  // (barrier-free form) the loader stopped answering: finish the loop unchecked, then report
   for (int i = n - 1; i >= 0; --i) {
@@ -1569,8 +1571,10 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
     const int slot_word = 8 + 4 * w + ((i > 0 ? i - 1 : 0) & 3), want = n - 1 - i + 1;
     if constexpr (FREE) {
       // requested in front of the three matrix instructions ...
+      // (an ordinary load: the compiler keeps count of it, wherever it moves or copies the register it lands in)
       tag_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int *)&prog[slot_word];
-      asm volatile("ds_read_b32 %0, %1" : "=v"(tag) : "v"(tag_addr) : "memory");
+      tag = bw4_prog_read(prog, slot_word);
+      __builtin_amdgcn_sched_barrier(0);  // (the request stays here: 80.4 against 85.3 us per launch with all 1024 live)
     } else {
       m_n0 = nb[off[0]]; m_n1 = nb[off[1]]; m_n2 = nb[off[2]]; cx_n0 = nb[off[3]]; cx_n1 = nb[off[4]]; cx_n2 = nb[off[5]]; g_n = nb[off[6]];
     }
@@ -1585,8 +1589,7 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
   if constexpr (FREE) {
         __builtin_amdgcn_sched_barrier(0);
         // ... looked at behind them; the operand reads only behind that
-        int tag_s;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %0, %1" : "=s"(tag_s) : "v"(tag) : "memory");
+        int tag_s = __builtin_amdgcn_readfirstlane(tag);
         if (__builtin_expect(i > 0 && want >= 2 && !dead && tag_s != want, 0)) {
           int spins = 0;
           do {
@@ -1669,7 +1672,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   __shared__ __attribute__((aligned(16))) double ring[4][4][BW2_BUF];
   __shared__ double kf[4][2][80];
   __shared__ int prog[24];
-  if (FREE && threadIdx.x < 24) prog[threadIdx.x] = (threadIdx.x < 4) ? 1 : ((threadIdx.x >= 8) ? -1 : 0);
+  if (FREE && threadIdx.x < 24) prog[threadIdx.x] = (threadIdx.x >= 8) ? -1 : 0;
   const RecLayout L = st.layout;
 
   // ---- every matrix wave settles its own trajectory's pending candidate (as in k_backward2)
