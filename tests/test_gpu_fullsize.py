@@ -190,3 +190,20 @@ def test_config5_full_size_long_horizon_stress():
     rb = oracle_for(b150).solve_batch(b150["init"][jdx], n_threads=8)
     gb = capi.from_config(b150).solve_batch(b150["init"][jdx])
     assert np.isin(rb["status"], [2, 3]).all() and np.isin(gb["status"], [2, 3]).all()
+
+
+@pytest.mark.parametrize("kernel", [0, 4, 5, 6])
+def test_repeated_full_size_solves_give_the_same_bits(kernel):
+    """The wavefronts of k_backward4 hand operands to each other through LDS (ring slots, progress words, tags); a race there
+    shows as results that change from one solve of the same batch to the next, and it shows where the chip is full: 8192
+    trajectories, four blocks to a CU, both register budgets of the kernel (round 3: a slot tag loaded by an asm statement
+    was copied while the load was in flight in the 80-register build -- 180 / 198 / 219 rounds for the same batch).  Every
+    form of the kernel, the batch of configs[3]'s one-GPU shard, five solves: bit-identical outputs."""
+    cfg = pb.config2(B=8192, N=100, seed=4)
+    s = capi.from_config(cfg, force_general=kernel)
+    first = s.solve_batch(cfg["init"])
+    assert np.isin(first["status"], [0, 1]).all()
+    for _ in range(4):
+        again = s.solve_batch(cfg["init"])
+        for k in ("status", "iters", "n_bwd", "n_fwd", "cost", "traj"):
+            np.testing.assert_array_equal(again[k], first[k], err_msg=k)
