@@ -381,6 +381,18 @@ QILQR_HD void discrete_step(const ModelConsts<T> &c, T t[3], T q[4], T v[6], con
 
 template <typename T>
 QILQR_HD void se3_rminus_fast(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T tau[6]);
+// What the cost half of the linearisation needs of a rotation error theta three times over -- for J_l^-1 inside x (-) x_d,
+// for the blocks of J_r^-1 and for Barfoot's Q block: formed ONCE, where the Log is taken (se3_rminus_part1).  Beyond the
+// series' range (half a radian: every early knot of a random start) each of the three used to take its own square root,
+// sine, cosine and divisions of the same angle: 8.4 us for a lone wavefront on that path against 4.1 on the series'.
+template <typename T>
+struct RotScalars {
+  T th2, c;          // theta^2 as the Log formed it; the coefficient of J^-1 = I -+ W/2 + c W^2
+  T theta, sn, cs;   // theta, sin theta, cos theta: defined when trig is set
+  bool trig;         // theta^2 beyond the range of the series (EXP_MAX)
+};
+template <typename T>
+QILQR_HD void se3_rminus_fast(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T tau[6], RotScalars<T> &rs);
 template <typename T>
 struct Series;
 template <typename T>
@@ -436,6 +448,39 @@ QILQR_HD void so3_ljacinv_fast(const T th[3], T J[9]) {  // I - W/2 + c W^2
   J[0] += 1; J[4] += 1; J[8] += 1;
   so3_sym_part(th, th2, c, J);
 }
+// I - W/2 + c W^2 with the coefficient c(theta^2) already known (it is an even function of theta: the same for th and -th)
+template <typename T>
+QILQR_HD void so3_ljacinv_with(const T th[3], T c, T J[9]) {
+  const T th2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2];
+  skew3(th, J);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) J[i] *= T(-0.5);
+  J[0] += 1; J[4] += 1; J[8] += 1;
+  so3_sym_part(th, th2, c, J);
+}
+template <typename T>
+QILQR_HD void se3_fillQ_body(const T rho[3], const T th[3], T th2, T B, T C, T D, T Qm[9]);
+// se3_fillQ_fast with theta, sin theta and cos theta taken from where the Log was formed (rs belongs to th or to -th)
+template <typename T>
+QILQR_HD void se3_fillQ_with(const T rho[3], const T th[3], const RotScalars<T> &rs, T Qm[9]) {
+  const T th2 = rs.th2;
+  T B, C, D;
+  if (!(th2 > Eps<T>::manif)) {
+    B = T(1. / 6.) - th2 / T(120);
+    C = T(-1. / 24.) + th2 / T(720);
+    D = T(-1. / 120.);
+  } else if (!rs.trig) {
+    B = poly8(Series<T>::jac_b, th2);
+    C = poly8(Series<T>::fillq_C, th2);
+    D = poly8(Series<T>::fillq_D, th2);
+  } else {
+    const T theta = rs.theta, s = rs.sn, co = rs.cs;
+    B = (theta - s) / (th2 * theta);
+    C = (T(1) - th2 / T(2) - co) / (th2 * th2);
+    D = T(0.5) * (C - T(3) * (theta - s - th2 * theta / T(6)) / (th2 * th2 * theta));
+  }
+  se3_fillQ_body(rho, th, th2, B, C, D, Qm);
+}
 // Q(rho, th) = V/2 + B (rho th^T + th rho^T) - 2 B s I - (B + C) s W - C (n th^T - th n^T) + 2 D s W^2,
 // s = th.rho, n = th x rho  (Barfoot eq. 102 with the products of skew matrices written out)
 template <typename T>
@@ -457,6 +502,10 @@ QILQR_HD void se3_fillQ_fast(const T rho[3], const T th[3], T Qm[9]) {
     C = (T(1) - th2 / T(2) - co) / (th2 * th2);
     D = T(0.5) * (C - T(3) * (theta - s - th2 * theta / T(6)) / (th2 * th2 * theta));
   }
+  se3_fillQ_body(rho, th, th2, B, C, D, Qm);
+}
+template <typename T>
+QILQR_HD void se3_fillQ_body(const T rho[3], const T th[3], T th2, T B, T C, T D, T Qm[9]) {
   const T s = th[0] * rho[0] + th[1] * rho[1] + th[2] * rho[2];
   T n[3], V[9], W[9];
   cross3(th, rho, n);
@@ -608,10 +657,13 @@ QILQR_HD int cxx_source(const RecLayout &L, int row, int col, const double *Q, d
 // DIAG: Q is exactly diagonal (the reference's demo and tests: Q = diag): sq[j] = dx[j] Q[j][j].  The general sum would add
 // products with exact zeros to that one product, which changes nothing: the same bits (up to the sign of a zero).
 template <bool BLOCKDIAG, typename T, bool DIAG = false>
-QILQR_HD T knot_cost(const T *Q, const T *R, const T *pt, const T *pd, T dx[12], T du[4], T sq[12], T sr[4]) {
+QILQR_HD T knot_cost(const T *Q, const T *R, const T *pt, const T *pd, T dx[12], T du[4], T sq[12], T sr[4],
+                     RotScalars<T> *rs = nullptr) {
   const T qx[4] = {pt[5], pt[6], pt[7], pt[4]};
   const T qd[4] = {pd[5], pd[6], pd[7], pd[4]};
-  se3_rminus_fast(pt + 1, qx, pd + 1, qd, dx);  // x (-) x_d; exactly zero at zero error
+  // x (-) x_d; exactly zero at zero error
+  if (rs) se3_rminus_fast(pt + 1, qx, pd + 1, qd, dx, *rs);
+  else se3_rminus_fast(pt + 1, qx, pd + 1, qd, dx);
 #pragma unroll
   for (int i = 0; i < 6; ++i) dx[6 + i] = pt[8 + i] - pd[8 + i];
 #pragma unroll
@@ -879,14 +931,15 @@ QILQR_HD T linearize_cost(const T *Q, const T *R, const T *pt, const T *pd, W &w
   constexpr bool DIAG = (LK == 3);
   // ---- cost: dx = x (-) x_d, J = blkdiag(Jri(tau_c), I6), Jri = [[a, -b],[0, a]] (3x3 blocks)
   T dx[12], du[4], sq[12], sr[4];
-  const T cost = knot_cost<(LK >= 2), T, DIAG>(Q, R, pt, pd, dx, du, sq, sr);
+  RotScalars<T> rs;
+  const T cost = knot_cost<(LK >= 2), T, DIAG>(Q, R, pt, pd, dx, du, sq, sr, &rs);
   T a[9], nb[9];  // Jri blocks: a = rjacinv of the rotation, nb = -a Q(-tau) a
   {
     T Li[9], Qm[9], aq[9];
-    so3_ljacinv_fast(dx + 3, Li);
+    so3_ljacinv_with(dx + 3, rs.c, Li);  // (c, theta, sin, cos: as the Log inside knot_cost formed them)
     transpose3(Li, a);  // rjacinv = ljacinv^T
     T nrho[3] = {-dx[0], -dx[1], -dx[2]}, nth[3] = {-dx[3], -dx[4], -dx[5]};
-    se3_fillQ_fast(nrho, nth, Qm);
+    se3_fillQ_with(nrho, nth, rs, Qm);
     mat3_mul(a, Qm, aq);
     mat3_mul(aq, a, nb);
 #pragma unroll
@@ -1089,7 +1142,7 @@ QILQR_HD void quat_rotate(const T q[4], const T v[3], T o[3]) {
 // Jl^-1(theta) to td.
 template <typename T, typename SR>
 QILQR_HD void se3_rminus_part1(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T td[3], T th[3], T &c,
-                               const SR &sr) {
+                               const SR &sr, RotScalars<T> *rs = nullptr) {
 #if defined(__clang__)
 #pragma clang fp contract(off)  // x (-) x must be exactly zero (cost_test.cc:27-39)
 #endif
@@ -1126,7 +1179,19 @@ QILQR_HD void se3_rminus_part1(const T ty[3], const T qy[4], const T tx[3], cons
     // manif's closed form, evaluated as manif does (it is ill-conditioned near theta = pi, where
     // only the same evaluation order reproduces the same digits)
     const T theta = sqrt(th2);
-    c = T(1) / th2 - (T(1) + cos(theta)) / (T(2) * theta * sin(theta));
+    const T cs = cos(theta), sn = sin(theta);
+    c = T(1) / th2 - (T(1) + cs) / (T(2) * theta * sn);
+    if (rs) { rs->theta = theta; rs->sn = sn; rs->cs = cs; }
+  }
+  if (rs) {
+    rs->th2 = th2;
+    rs->c = c;
+    rs->trig = th2 > Series<T>::EXP_MAX;
+    if (rs->trig && !(th2 > Series<T>::JINV_MAX)) {  // (the band between the two series' limits)
+      rs->theta = sqrt(th2);
+      rs->cs = cos(rs->theta);
+      rs->sn = sin(rs->theta);
+    }
   }
   th[0] = qd[0] * coeff; th[1] = qd[1] * coeff; th[2] = qd[2] * coeff;
 }
@@ -1156,6 +1221,12 @@ template <typename T>
 QILQR_HD void se3_rminus_fast(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T tau[6]) {
   T td[3], c;
   se3_rminus_part1(ty, qy, tx, qx, td, tau + 3, c);
+  se3_rminus_part2(td, tau + 3, c, tau);
+}
+template <typename T>
+QILQR_HD void se3_rminus_fast(const T ty[3], const T qy[4], const T tx[3], const T qx[4], T tau[6], RotScalars<T> &rs) {
+  T td[3], c;
+  se3_rminus_part1(ty, qy, tx, qx, td, tau + 3, c, Series<T>(), &rs);
   se3_rminus_part2(td, tau + 3, c, tau);
 }
 
