@@ -594,8 +594,9 @@ def test_unnormalised_initial_quaternion_is_value_error():
 
 
 def test_ragged_and_edge_sizes():
-    # N = 1 (a single knot: no dynamics step at all), N = 2, B = 1, B not a multiple of 64
-    for B, n in [(1, 1), (3, 2), (65, 7), (130, 5)]:
+    # N = 1 (a single knot: no dynamics step at all), N = 2, B = 1, B not a multiple of 64; N = 3, 4, 6: horizons around the
+    # four slots of k_backward4's operand ring (the loader's first tagged record, its first reuse of a slot)
+    for B, n in [(1, 1), (3, 2), (65, 7), (130, 5), (2, 3), (5, 4), (7, 6)]:
         cfg = pb.config2(B=B, N=n, seed=9)
         s = capi.from_config(cfg)
         out = s.solve_batch(cfg["init"])
