@@ -2584,11 +2584,19 @@ __global__ __launch_bounds__(192) void k_rollout16(ModelConsts<double> c, BatchS
   const int row = lane >> 4;
   const int blk = xcd_local_block(blockIdx.x, gridDim.x);
   const int b = blk * 4 + row;
-  const bool live = (b < B) && (!need_flag || (st.flags[b < B ? b : 0] & need_flag));
+  // the flag, the buffer selector and the step size of the lane's own trajectory are requested together: one memory latency,
+  // not two, in front of the first knot's loads (a dead row takes the values of the row it aliases from that row's lanes)
+  const int bq = b < B ? b : 0;
+  const int fl_own = st.flags[bq], cur_own = st.cur[bq];
+  const double alpha_own = st.alpha[bq];
+  const bool live = (b < B) && (!need_flag || (fl_own & need_flag));
   const unsigned long long livemask = __ballot(live);
   if (livemask == 0ull) return;  // identical in the three waves: block-uniform
-  const int bs = live ? b : blk * 4 + ((__ffsll((long long)livemask) - 1) >> 4);  // dead rows alias the first live one
-  const int cur = st.cur[bs];
+  const int first_live = (__ffsll((long long)livemask) - 1) >> 4;
+  const int bs = live ? b : blk * 4 + first_live;  // dead rows alias the first live one
+  const int src_lane = (live ? row : first_live) << 4;
+  const int cur = __shfl(cur_own, src_lane);
+  const double alpha = __shfl(alpha_own, src_lane);
   const S *traj = (const S *)st.traj[cur] + knot_base<true>(bs, n, 18);
   const S *gains = (const S *)st.gains + knot_base<true>(bs, n, 52);
   S *out = (S *)st.traj[cur ^ 1] + knot_base<true>(bs, n, 18);
@@ -2597,7 +2605,7 @@ __global__ __launch_bounds__(192) void k_rollout16(ModelConsts<double> c, BatchS
   __syncthreads();
   unsigned long long *stamps = st.stamps ? st.stamps + ((long)blk * 3 + role) * 8 : nullptr;
   if (role == 2) {
-    r16_wave_P<S>(sh, traj, gains, out, st.alpha[bs], live, n, lane, stamps);
+    r16_wave_P<S>(sh, traj, gains, out, alpha, live, n, lane, stamps);
     return;
   }
   auto ld0 = [&](int e) -> double { return e >= 0 ? (double)traj[knot_elem<true>(0, e, 18)] : 0.0; };
