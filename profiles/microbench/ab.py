@@ -38,7 +38,7 @@ def main():
             seed = int(v)
         elif k == "reps":
             reps = int(v)
-        elif k in ("force_general", "single_wave_rollout", "streams"):
+        elif k in ("force_general", "single_wave_rollout", "streams", "persistent"):
             extra[k] = int(v)
         else:
             path = v or (os.path.join(ROOT, "quadrotorilqr_amd", "lib", "libquadrotor_ilqr.so") if k == "product" else
