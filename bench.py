@@ -48,7 +48,7 @@ BYTES_BWD_KNOT, BYTES_FWD_KNOT, BYTES_IO_KNOT = 86 * 8.0, 103 * 8.0, 53 * 8.0
 # The PMC summary `roofline.traffic` is read from: named explicitly, and only used when its tag is this round's
 # (profiles/run_rocprof.sh <tag> writes profiles/<tag>_rocprof_summary.json from the same bench command).
 ROUND_TAG = "r03"
-TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r03f_rocprof_summary.json")
+TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r03h_rocprof_summary.json")
 
 
 def kernel_table(prof, n_bwd_knots, n_fwd_knots):
@@ -58,6 +58,12 @@ def kernel_table(prof, n_bwd_knots, n_fwd_knots):
         return {"k_solve4": dict(ms=prof["solve_ms"], launches=prof["solve_launches"], seen=prof["solve_seen"],
                                  flops=FLOP_BWD_KNOT * n_bwd_knots + FLOP_FWD_KNOT * n_fwd_knots,
                                  bytes=BYTES_BWD_KNOT * n_bwd_knots + BYTES_FWD_KNOT * n_fwd_knots)}
+    if prof.get("rollout_launches", 0) == 0 and prof.get("backward_launches", 0) > 0:
+        # k_backward_rollout: the backward pass and the rollout of a round in one launch (one block of four trajectories per CU:
+        # up to 1024 trajectories) -- its work is both passes' knots, its time both serial chains
+        return {"k_backward_rollout": dict(ms=prof["backward_ms"], launches=prof["backward_launches"], seen=prof["backward_seen"],
+                                           flops=FLOP_BWD_KNOT * n_bwd_knots + FLOP_FWD_KNOT * n_fwd_knots,
+                                           bytes=BYTES_BWD_KNOT * n_bwd_knots + BYTES_FWD_KNOT * n_fwd_knots)}
     return {
         "k_backward": dict(ms=prof["backward_ms"], launches=prof["backward_launches"], seen=prof["backward_seen"],
                            flops=FLOP_BWD_KNOT * n_bwd_knots, bytes=BYTES_BWD_KNOT * n_bwd_knots),
@@ -338,7 +344,7 @@ def main():
             traffic, traffic_src = read_traffic(dom, B, N)
             # k_backward (and the persistent solve, which contains it) is matrix-core work (fp64 MFMA); k_rollout has none:
             # its bound is the bytes it moves
-            if dom in ("k_backward", "k_solve4"):
+            if dom in ("k_backward", "k_backward_rollout", "k_solve4"):
                 bound = dict(bound="mfma", achieved=tflops, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=tflops / FP64_PEAK_TFLOPS)
             else:
                 bound = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)

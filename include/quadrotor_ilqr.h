@@ -85,7 +85,10 @@ typedef struct {
                             3: k_backward2 (diagnostics build only); 4: k_backward4, six wavefronts; 5: k_backward4, fused
                             (its wavefronts meet through tagged LDS slots, no block barrier in the knot loop: what 0
                             selects); 6: k_backward4, fused, with a block barrier per knot (same bits as 5; kept as
-                            its A/B partner).
+                            its A/B partner).  When the round's kernels are the fused k_backward4 and k_rollout16 and
+                            every block of four trajectories has a CU to itself (B <= 4 x the device's CUs: 1024 on
+                            MI355X), the two are ONE launch (k_backward_rollout: the block's backward pass, a block
+                            barrier, the rollout of its own four trajectories; same arithmetic, same bits).
                             WHICH ARITHMETIC A CALLER GETS.  The general kernel evaluates ilqr.hh:118-140 in the
                             reference's own forms: Q_uu factored by Eigen's diagonally pivoted LDL^T (largest |d_ii| of
                             the trailing block, first on ties), V_x = Q_x - K^T Q_uu k, V_xx = Q_xx - K^T Q_uu K, not

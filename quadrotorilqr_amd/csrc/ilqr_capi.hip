@@ -495,6 +495,27 @@ int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
   }
   return QILQR_OK;
 }
+// k_backward_rollout (ilqr_kernels.h): the backward pass and the rollout of a round in one launch, when every block of four
+// trajectories has a CU to itself (the rollout's register budget allows one block per CU) and the round's kernels are the
+// fused k_backward4 and k_rollout16 anyway.  QILQR_FUSE_BACKWARD_ROLLOUT=0 in the environment keeps them apart (A/B).
+bool fuse_backward_rollout(const qilqr_solver *s, long B) {
+  static const bool off = [] {
+    const char *e = std::getenv("QILQR_FUSE_BACKWARD_ROLLOUT");
+    return e && e[0] == '0';
+  }();
+  const long load_B = std::max(B, s->total_B);
+  if (off || s->integrator != 0 || !s->symmetric || !s->st.layout.tiled) return false;
+  if (!(s->dev.force_general == 0 || s->dev.force_general == 5) || backward_kind(s, load_B) != BW_FUSED) return false;
+  if (!(s->dev.single_wave_rollout == 0 || s->dev.single_wave_rollout == 3) || load_B > R16_MAX_B) return false;
+  return cdiv(load_B, 4) <= (unsigned)s->num_cus;
+}
+int launch_backward_rollout(qilqr_solver *s, long B, long n) {
+  if (s->f32)
+    launch(s, K_BACKWARD, k_backward_rollout<float>, dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n);
+  else
+    launch(s, K_BACKWARD, k_backward_rollout<double>, dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n);
+  return QILQR_OK;
+}
 int launch_accept(qilqr_solver *s, long B, long n, int ls_only) {
   launch(s, K_OTHER, k_accept, dim3(cdiv(B, 64)), dim3(64), s->params, s->st, (int)B, (int)n,
                      ls_only);
@@ -632,9 +653,14 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
     // device, so the GPU never waits for a host round trip.  Rounds enqueued past the end find nothing
     // to do.
     for (int k = 0; k < 8; ++k) s->h_active[k] = 0;
+    const bool fused = fuse_backward_rollout(s, B);
     for (long round = 0; round < max_rounds; ++round) {
-      if ((rc = launch_backward(s, B, n, 0))) return rc;
-      if ((rc = launch_rollout(s, B, n, F_SEARCH))) return rc;
+      if (fused) {
+        if ((rc = launch_backward_rollout(s, B, n))) return rc;
+      } else {
+        if ((rc = launch_backward(s, B, n, 0))) return rc;
+        if ((rc = launch_rollout(s, B, n, F_SEARCH))) return rc;
+      }
       if ((rc = launch_linearize(s, B, n, 1, F_SEARCH, (int)(round & 0x3fffffff)))) return rc;
       if (round >= lag) {
         const long old = round - lag;

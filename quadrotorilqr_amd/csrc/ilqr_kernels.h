@@ -1662,244 +1662,12 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
 template <typename S, int WAVES, bool FUSED = false, bool FREE = false>
 __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_backward4(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n,
                                                    int force) {
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0..3: matrix wave of trajectory b0 + w; 4: G (FUSED: L); 5: L
-  const int b0 = xcd_local_block(blockIdx.x, gridDim.x) * 4;
-  __shared__ int s_run[4], s_cur[4], s_iters[4], s_act[4];
-  __shared__ double s_cost[4];
-  // four slots per trajectory: in interval i the matrix wave reads slot (i-1) & 3 and writes slot (i-2) & 3
-  // while G reads slot (i+1) & 3
-  __shared__ __attribute__((aligned(16))) double ring[4][4][BW2_BUF];
-  __shared__ double kf[4][2][80];
-  __shared__ int prog[24];
-  if (FREE && threadIdx.x < 24) prog[threadIdx.x] = (threadIdx.x >= 8) ? -1 : 0;
-  const RecLayout L = st.layout;
-
-  // ---- every matrix wave settles its own trajectory's pending candidate (as in k_backward2)
-  double mu = 0.0;  // of matrix wave w's trajectory (lm_restart)
-  if (w < 4) {
-    const int b = b0 + w;
-    bool run = false;
-    int cur = 0, iters_now = 0, act = 0;
-    double cost_now = 0.0;
-    if (b < B) {
-      int fl = st.flags[b];
-      cur = st.cur[b];
-      const int it0 = st.iters[b];
-      const int trial0 = st.trial[b];
-      const double prev_cost0 = st.prev_cost[b], alpha0 = st.alpha[b];
-      const double term0 = st.terms[2 * b], term1 = st.terms[2 * b + 1];
-      cost_now = st.cost[b];
-      const int n_fwd0 = st.n_fwd[b];
-      mu = (p.mu_init > 0.0) ? st.mu[b] : 0.0;
-      // the knot costs of the first 128 knots of BOTH buffers are requested here, with the scalars above, not
-      // after `cur` has arrived (one memory latency less in front of the recursion)
-      double kc_early[2][2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int i = 64 * h + lane;
-          kc_early[k][h] = (i < n) ? st.knot_cost[k][cost_index(b, i, n)] : 0.0;
-        }
-      bool restart = false;
-      bool settle = false, accept = false, count_active = false, known = true;
-      int status = -1;
-      double new_cost = 0.0;
-      if (!force) {
-        if (fl & F_SEARCH) {
-          settle = true;
-          const double *kc = st.knot_cost[cur ^ 1];
-          // left to right (ilqr.hh:89-95).  64 lanes hold 64 knot costs; they go through this wave's own ring
-          // slot (nobody touches it before the first barrier) and every lane adds them up in order from
-          // broadcast reads, eight requested at a time: 0.5 us for 100 knots, against 3.5 us when each value
-          // is fetched with a pair of v_readlane inside a rolled loop
-          double *scr = &ring[w][0][0];
-          auto add_chunk = [&](double v, int cnt) {
-            scr[lane] = v;
-            int t = 0;
-            for (; t + 8 <= cnt; t += 8) {
-              double x[8];
-#pragma unroll
-              for (int e = 0; e < 8; ++e) x[e] = scr[t + e];
-#pragma unroll
-              for (int e = 0; e < 8; ++e) new_cost += x[e];
-            }
-            for (; t < cnt; ++t) new_cost += scr[t];
-          };
-          add_chunk((cur ^ 1) ? kc_early[1][0] : kc_early[0][0], n < 64 ? n : 64);
-          if (n > 64) add_chunk((cur ^ 1) ? kc_early[1][1] : kc_early[0][1], n < 128 ? n - 64 : 64);
-          for (int base = 128; base < n; base += 64) {
-            const int i = base + lane;
-            add_chunk((i < n) ? kc[cost_index(b, i, n)] : 0.0, (n - base < 64) ? n - base : 64);
-          }
-          if (it0 == 0) {
-            accept = true;  // ilqr.hh:71-73
-          } else {
-            const double desired = p.reduction_frac * cost_reduction(term0, term1, alpha0);
-            accept = (new_cost - prev_cost0 < desired);  // ilqr.hh:186
-          }
-          if (accept) {
-            cur ^= 1;
-            fl = F_ACTIVE;
-            cost_now = new_cost;
-            mu = lm_relax(p, mu);
-            if (it0 > 0 && is_converged(p, prev_cost0, new_cost)) {
-              status = 1;  // ilqr.hh:82-84
-              fl = 0;
-            } else if (!((double)(it0 + 1) < p.max_iters)) {
-              status = 2;  // ilqr.hh:86
-              fl = 0;
-            }
-          } else if (trial0 + 1 >= p.ls_max_iters) {
-            if (lm_restart(p, mu)) {
-              restart = true;  // same iterate, larger mu: the recursion runs again
-              fl = F_ACTIVE;
-            } else {
-              status = 3;  // ilqr.hh:191-193
-              fl = 0;
-            }
-          }
-          count_active = (fl & F_ACTIVE) != 0;
-        } else if (fl == F_ACTIVE) {
-          count_active = true;
-        } else {
-          known = false;  // nothing to do for this trajectory
-        }
-      }
-      run = known && (force || !settle || ((accept || restart) && fl != 0));
-      iters_now = (settle && accept) ? it0 + 1 : it0;
-      if (lane == 0 && known) {  // only this wave has read these words
-        if (settle) {
-          if (p.mu_init > 0.0) st.mu[b] = mu;
-          st.n_fwd[b] = n_fwd0 + 1;
-          if (accept) {
-            st.cur[b] = cur;
-            st.cost[b] = new_cost;
-            if (st.cost_hist && it0 < st.hist_cap) st.cost_hist[(long)b * st.hist_cap + it0] = new_cost;
-            st.iters[b] = it0 + 1;
-          } else {
-            st.trial[b] = trial0 + 1;
-            st.alpha[b] = alpha0 * p.step_update;  // ilqr.hh:189
-          }
-          if (status >= 0) st.status[b] = status;
-          st.flags[b] = fl;
-        }
-        act = count_active ? 1 : 0;
-      }
-    }
-    if (lane == 0) {
-      s_act[w] = act;
-      s_run[w] = run ? 1 : 0;
-      s_cur[w] = cur;
-      s_iters[w] = iters_now;
-      s_cost[w] = cost_now;
-    }
-  }
-  __syncthreads();
-  // one add per block, and where nobody waits for it: here for a block that has no recursion to run, at the
-  // end of the gradient wave otherwise
-  const int block_act = s_act[0] + s_act[1] + s_act[2] + s_act[3];
-  if ((s_run[0] | s_run[1] | s_run[2] | s_run[3]) == 0) {  // block-uniform
-    if (threadIdx.x == 0 && block_act) atomicAdd(active_counter(st), block_act);
-    return;
-  }
-
-  bw4_fill_ctab<S>(ring, st.ctab, FUSED ? 320 : 384);
-  if (!FUSED && w == 4) {
-    // ------------------------------------------------------------------ G: gradients of four trajectories
-    const int g = lane >> 4, j = lane & 15;
-    const int bg = (b0 + g < B) ? b0 + g : B - 1;  // a valid stand-in for a missing trajectory (never stored)
-    const bool grun = s_run[g] != 0;
-    const double QuTk = bw4_gradient_wave<S>(ring, kf, L, (S *)st.gains + knot_base<true>(bg, n, 52), (S *)st.dump + 4 * (long)bg, grun,
-                                             n, lane);
-    if (j == 0 && grun) {
-      const int b = b0 + g;
-      st.terms[2 * b] = QuTk;
-      st.terms[2 * b + 1] = -QuTk;  // k^T Quu k = -Q_u^T k for the exact solve (see k_backward)
-      st.n_bwd[b] += 1;
-      if (!force) {
-        const double cost_now = s_cost[g];
-        const int iters_now = s_iters[g];
-        st.prev_cost[b] = cost_now;  // ilqr.hh:61
-        if (iters_now > 0 && is_converged(p, cost_now, cost_now + cost_reduction(QuTk, -QuTk, 1.0))) {
-          st.status[b] = 0;  // ilqr.hh:66-68
-          st.flags[b] = 0;
-        } else if (iters_now > 0 && p.ls_max_iters <= 0) {
-          st.status[b] = 3;  // line_search with no trial allowed throws at once
-          st.flags[b] = 0;
-        } else {
-          st.alpha[b] = 1.0;
-          st.trial[b] = 0;
-          st.flags[b] = F_ACTIVE | F_SEARCH;
-        }
-      }
-    }
-    if (lane == 0 && block_act) atomicAdd(active_counter(st), block_act);
-    return;
-  }
-
-  if (w == (FUSED ? 4 : 5)) {
-    // ------------------------------------------------------------------ L: knot records of four trajectories
-    // a trajectory with nothing to do this round is streamed as a duplicate of the block's first running one (the wave stays
-    // branch-free and the duplicate's loads hit the lines the original just fetched: no HBM traffic for records nobody uses)
-    const int first = s_run[0] ? 0 : (s_run[1] ? 1 : (s_run[2] ? 2 : 3));
-    const S *rec[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int gs = s_run[g] ? g : first;
-      rec[g] = (const S *)st.lin[s_cur[gs]] + rec_base(L, b0 + gs, n);
-    }
-    bw4_loader_wave<S, FREE>(ring, L, rec[0], rec[1], rec[2], rec[3], n, lane, prog, s_run[0] | (s_run[1] << 1) | (s_run[2] << 2) | (s_run[3] << 3));
-    if (FUSED && lane == 0 && block_act) atomicAdd(active_counter(st), block_act);  // (the gradient wave's job otherwise)
-    if (FREE && lane == 0 && bw4_prog_read(prog, 5) && st.host_error)
-      __hip_atomic_store(st.host_error, (2ull << 32) | (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return;
-  }
-  if constexpr (FUSED) {
-    // ------------------------------------------------------------------ MG_w: matrix and gradient recursion of trajectory b0 + w
-    const int b = (b0 + w < B) ? b0 + w : B - 1;
-    const int j = lane & 15, kk = lane >> 4;
-    const bool run = s_run[w] != 0;
-    const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] + ((j - 12 == kk) ? mu : 0.0) : 0.0;
-    const double QuTk = bw4_fused_wave<S, FREE>(ring, L, w, run, (S *)st.gains + knot_base<true>(b, n, 52), (S *)st.dump + 4 * (long)b, cuu, n, lane, prog);
-    if (FREE && lane == 0 && bw4_prog_read(prog, 5) && st.host_error)
-      __hip_atomic_store(st.host_error, (2ull << 32) | (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (lane == 0 && run) {
-      st.terms[2 * b] = QuTk;
-      st.terms[2 * b + 1] = -QuTk;  // k^T Quu k = -Q_u^T k for the exact solve (see k_backward)
-      st.n_bwd[b] += 1;
-      if (!force) {
-        const double cost_now = s_cost[w];
-        const int iters_now = s_iters[w];
-        st.prev_cost[b] = cost_now;  // ilqr.hh:61
-        if (iters_now > 0 && is_converged(p, cost_now, cost_now + cost_reduction(QuTk, -QuTk, 1.0))) {
-          st.status[b] = 0;  // ilqr.hh:66-68
-          st.flags[b] = 0;
-        } else if (iters_now > 0 && p.ls_max_iters <= 0) {
-          st.status[b] = 3;  // line_search with no trial allowed throws at once
-          st.flags[b] = 0;
-        } else {
-          st.alpha[b] = 1.0;
-          st.trial[b] = 0;
-          st.flags[b] = F_ACTIVE | F_SEARCH;
-        }
-      }
-    }
-    return;
-  }
-  // -------------------------------------------------------------------- M_w: matrix recursion of trajectory b0 + w
-  {
-    const int b = (b0 + w < B) ? b0 + w : B - 1;
-    const int j = lane & 15, kk = lane >> 4;
-    // register 3 <-> row 12 + kk: C_uu = 2 R (+ mu on the diagonal, lm_restart)
-    const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] + ((j - 12 == kk) ? mu : 0.0) : 0.0;
-#ifndef QILQR_BW4_UNROLL_MANY
-#define QILQR_BW4_UNROLL_MANY 1
-#endif
-    bw4_matrix_wave<S, (WAVES >= 6) && QILQR_BW4_UNROLL_MANY>(ring, kf, L, w, s_run[w] != 0, (S *)st.gains + knot_base<true>(b, n, 52),
-                                                             (S *)st.dump + 4 * (long)b, cuu, n, lane, st.stamps ? st.stamps + (long)(b0 + w) * 8 : nullptr);
-  }
+  // (the body lives in a file of its own because k_backward_rollout contains it too, as statements of the kernel function:
+  // called as a device function it loses what the compiler knows about pointers that come from kernel arguments -- every
+  // global access became a flat one -- and the six-wavefront form's results changed)
+#define BW4_RETURN return
+#include "backward4_body.inc"
+#undef BW4_RETURN
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2578,45 +2346,34 @@ __device__ __forceinline__ void r16_wave_X(R16Lds &sh, const ModelConsts<double>
 
 template <typename S>
 __global__ __launch_bounds__(192) void k_rollout16(ModelConsts<double> c, BatchState st, int B, int n, int need_flag) {
-  using namespace r16;
-  const int lane = threadIdx.x & 63;
-  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: X_0 (even knots), 1: X_1 (odd knots), 2: P
-  const int row = lane >> 4;
-  const int blk = xcd_local_block(blockIdx.x, gridDim.x);
-  const int b = blk * 4 + row;
-  // the flag, the buffer selector and the step size of the lane's own trajectory are requested together: one memory latency,
-  // not two, in front of the first knot's loads (a dead row takes the values of the row it aliases from that row's lanes)
-  const int bq = b < B ? b : 0;
-  const int fl_own = st.flags[bq], cur_own = st.cur[bq];
-  const double alpha_own = st.alpha[bq];
-  const bool live = (b < B) && (!need_flag || (fl_own & need_flag));
-  const unsigned long long livemask = __ballot(live);
-  if (livemask == 0ull) return;  // identical in the three waves: block-uniform
-  const int first_live = (__ffsll((long long)livemask) - 1) >> 4;
-  const int bs = live ? b : blk * 4 + first_live;  // dead rows alias the first live one
-  const int src_lane = (live ? row : first_live) << 4;
-  const int cur = __shfl(cur_own, src_lane);
-  const double alpha = __shfl(alpha_own, src_lane);
-  const S *traj = (const S *)st.traj[cur] + knot_base<true>(bs, n, 18);
-  const S *gains = (const S *)st.gains + knot_base<true>(bs, n, 52);
-  S *out = (S *)st.traj[cur ^ 1] + knot_base<true>(bs, n, 18);
-  __shared__ R16Lds sh;
-  if (threadIdx.x < R16_NFLAGS) sh.flags[threadIdx.x] = 0;
-  __syncthreads();
-  unsigned long long *stamps = st.stamps ? st.stamps + ((long)blk * 3 + role) * 8 : nullptr;
-  if (role == 2) {
-    r16_wave_P<S>(sh, traj, gains, out, alpha, live, n, lane, stamps);
-    return;
+#define R16_RETURN return
+#include "rollout16_body.inc"
+#undef R16_RETURN
+}
+// k_backward_rollout: the two in ONE launch for batches whose blocks of four trajectories all fit the chip at once (one block
+// per CU: the rollout's 214 registers): the block's backward pass (fused, barrier-free form), a block barrier, then the
+// rollout of its own four trajectories by wavefronts 0..2 -- gains, flags, step sizes written and read by the same CU.  One
+// launch boundary and one kernel start fewer per round.
+template <typename S>
+__global__ __launch_bounds__(320) void k_backward_rollout(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n) {
+  {
+    constexpr int WAVES = 5;
+    constexpr bool FUSED = true, FREE = true;
+    const int force = 0;
+    (void)WAVES;
+#define BW4_RETURN goto backward_done
+#include "backward4_body.inc"
+#undef BW4_RETURN
   }
-  auto ld0 = [&](int e) -> double { return e >= 0 ? (double)traj[knot_elem<true>(0, e, 18)] : 0.0; };
-  const double TT = ld0(tt_elem(lane)), QQ = ld0(qq_elem(lane)), VL = ld0(vl_elem(lane)), VW = ld0(vw_elem(lane));
-  R16_LOADS_DONE();
-  r16_wave_X<S, false>(sh, c, role, TT, QQ, VL, VW, out, live, n, lane, stamps);
-  // A step wavefront comes back early when a hand-off it waited for never arrived (every spin is bounded: the grid drains
-  // instead of hanging).  The candidate of the block's trajectories is then incomplete: say so where the host looks after
-  // every solve, so that the call fails loudly instead of iterating on stale knots.
-  if (__builtin_expect(r16_flag_read(sh, R16_F_ABORT) != 0, 0) && lane == 0 && st.host_error)
-    __hip_atomic_store(st.host_error, (1ull << 32) | (unsigned)blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+backward_done:
+  __syncthreads();  // (every wavefront comes out of the backward pass; its stores are visible to the block)
+  if (threadIdx.x >= 192) return;
+  {
+    const int need_flag = F_SEARCH;
+#define R16_RETURN return
+#include "rollout16_body.inc"
+#undef R16_RETURN
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
