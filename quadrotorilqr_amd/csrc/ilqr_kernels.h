@@ -1561,7 +1561,10 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
     gcj = buf[off[6]];
   }
   if constexpr (FREE) bw4_prog_post(prog, w, 1, lane);  // record 0 is in registers (the loader may reuse its slot)
-  asm volatile(".p2align 6");
+#ifndef QILQR_FUSED_PHASE
+#define QILQR_FUSED_PHASE 2  // s_nop s behind the 64-byte boundary in front of the knot loop (the loop is sensitive to where it sits: see bw4_matrix_wave); B = 1024, whole solves, builds interleaved: 0: 5.003 ms, 1: 4.982, 2: 4.967, 3: 5.012, 4: 4.986, 6: 5.003, 8: 4.999
+#endif
+  asm volatile(".p2align 6\n\t.rept %0\n\ts_nop 0\n\t.endr" ::"n"(QILQR_FUSED_PHASE));
   bool dead = false;  // (barrier-free form) the loader stopped answering: finish the loop unchecked, then report
   for (int i = n - 1; i >= 0; --i) {
     const double *nb = ring[w][(i > 0 ? i - 1 : 0) & 3];
