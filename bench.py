@@ -356,6 +356,10 @@ def main():
                 "alg_bytes_per_launch": kd["bytes"] / max(kd["seen"], 1),
                 "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
                 "flops": {"achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS},
+                **({"note": "k_backward_rollout = the backward pass and the rollout of a round in one launch (up to 1024 trajectories); its "
+                            "work is both passes' algorithmic flops, its time both serial chains.  Launched apart "
+                            "(QILQR_FUSE_BACKWARD_ROLLOUT=0) the backward kernel alone runs at 20.6 % of the fp64 peak (68.9 us per launch) and "
+                            "the rollout at 51.8 us: profiles/r03f_rocprof_summary.txt"} if dom == "k_backward_rollout" else {}),
                 "kernels_ms": {k: round(v["ms"], 3) for k, v in kern.items()}
                               | {"k_linearize": round(prof["linearize_ms"], 3), "other": round(prof["other_ms"], 3)},
                 "warmup_avg_launch_us": {k: round(calib[k + "_ms"] * 1e3 / max(calib[k + "_launches"], 1), 2)
