@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -509,6 +510,17 @@ bool fuse_backward_rollout(const qilqr_solver *s, long B) {
   if (!(s->dev.single_wave_rollout == 0 || s->dev.single_wave_rollout == 3) || load_B > R16_MAX_B) return false;
   return cdiv(load_B, 4) <= (unsigned)s->num_cus;
 }
+// Batch solves in flight on a device, over all the handles of the process.  The combined kernel takes a whole CU per block of
+// four trajectories (the rollout's register budget): alone on the chip that is +3 to +4 % of a solve, beside other solves'
+// kernels it is in their way -- three handles in flight: 306 000-311 000 solves/s with it, 340 000 without.  A solve that
+// finds another one in flight on its device therefore launches the two kernels apart (same bits either way).
+std::atomic<int> g_solves_in_flight[16];
+struct InFlight {
+  std::atomic<int> &n;
+  int at_entry;
+  explicit InFlight(int device) : n(g_solves_in_flight[(unsigned)device & 15u]), at_entry(n.fetch_add(1, std::memory_order_relaxed) + 1) {}
+  ~InFlight() { n.fetch_sub(1, std::memory_order_relaxed); }
+};
 int launch_backward_rollout(qilqr_solver *s, long B, long n) {
   if (s->f32)
     launch(s, K_BACKWARD, k_backward_rollout<float>, dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n);
@@ -653,7 +665,8 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
     // device, so the GPU never waits for a host round trip.  Rounds enqueued past the end find nothing
     // to do.
     for (int k = 0; k < 8; ++k) s->h_active[k] = 0;
-    const bool fused = fuse_backward_rollout(s, B);
+    const InFlight in_flight(s->device);
+    const bool fused = fuse_backward_rollout(s, B) && in_flight.at_entry == 1;
     for (long round = 0; round < max_rounds; ++round) {
       if (fused) {
         if ((rc = launch_backward_rollout(s, B, n))) return rc;
