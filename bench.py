@@ -23,6 +23,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
   large_batch   the same solver at B = 8192 per GPU (the shard of configs[3]): solves/s and, per kernel, the average
                 launch time and the fractions of the fp64 and HBM peaks -- the saturated-machine view
   serving       several batches in flight (independent handles): measured after the timed region, never `value`
+  single_solve  the reference's own call pattern (quadrotor_ilqr_binding.cc:34-41, quadrotor_ilqr.py:306): ONE problem per
+                call -- BASELINE.json configs[0] (100 knots, model D, initial = desired) through src.quadrotor_ilqr_binding with
+                protobuf messages, populate_debug on (the reference's default) and off, beside the oracle on one host core
+  reference_faithful  configs[1] on the kernel that evaluates ilqr.hh:126-133 in the reference's own forms (force_general = 1:
+                Eigen's pivoted LDL^T, unsymmetrised V_xx) and one non-symmetric-Q run (cost.hh:30-34 allows it)
 """
 import argparse
 import json
@@ -95,6 +100,86 @@ def read_traffic(dom, B, N):
         return None, None
 
 
+def single_solve_leg(device, args):
+    """BASELINE.json configs[0] as the reference runs it (quadrotor_ilqr.py:256-306 at horizon_s = 10: 100 knots, model D,
+    initial = desired, default options) through src.quadrotor_ilqr_binding.QuadrotorILQR.solve with protobuf messages --
+    populate_debug on (the reference's default) and off -- and the same problem on the oracle, one host core."""
+    import src.demo as demo
+    from src.quadrotor_ilqr_binding import QuadrotorILQR
+    from quadrotorilqr_amd import problems as pb
+    from oracle import oracle as orc
+    c0 = pb.config1(10.0)
+    m = c0["model"]
+    desired = demo.trajectory_message(c0["desired"])
+    out = {"what": "BASELINE.json configs[0]: one problem per call, 100 knots, model D (demo constants), initial = desired; "
+                   "QuadrotorILQR.solve through the pybind11 surface with protobuf messages in and out; median of 5 calls"}
+    for key, dbg in (("populate_debug_on", True), ("populate_debug_off", False)):
+        ilqr = QuadrotorILQR(m["mass_kg"], m["inertia"], m["arm_length_m"], m["torque_to_thrust_ratio_m"], m["g_mpss"],
+                             c0["Q"], c0["R"], desired, c0["dt"], demo.options_message(dict(c0["options"], populate_debug=dbg)))
+        ilqr.solve(desired)
+        ts = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            traj_msg, debug = ilqr.solve(desired)
+            ts.append(time.perf_counter() - t1)
+        out[key] = {"ms_per_solve": float(np.median(ts)) * 1e3, "debug_entries": len(debug.iter_debugs)}
+        if dbg:
+            out["final_cost"] = float(debug.iter_debugs[-1].cost) if len(debug.iter_debugs) else None
+    ref = orc.OracleSolver(orc.model_params(**m), c0["Q"], c0["R"], c0["desired"], c0["dt"], orc.options(**c0["options"]))
+    ts = []
+    for _ in range(3):
+        t1 = time.perf_counter()
+        r = ref.solve(c0["desired"], debug=True)
+        ts.append(time.perf_counter() - t1)
+    out["cpu_oracle_one_core"] = {"ms_per_solve": float(np.median(ts)) * 1e3, "iters": int(r["iters"]), "n_fwd": int(r["n_fwd"]),
+                                  "final_cost": float(r["cost"])}
+    out["debug_on_over_off"] = out["populate_debug_on"]["ms_per_solve"] / out["populate_debug_off"]["ms_per_solve"]
+    out["gpu_over_cpu_time"] = out["populate_debug_on"]["ms_per_solve"] / out["cpu_oracle_one_core"]["ms_per_solve"]
+    return out
+
+
+def reference_faithful_leg(cfg, dev, default_cost, args):
+    """configs[1] with force_general = 1 -- Q_uu by Eigen's diagonally pivoted LDL^T, V_x = Q_x - K^T Q_uu k and
+    V_xx = Q_xx - K^T Q_uu K not symmetrised (ilqr.hh:126-133 as written) -- against the default kernels and the oracle; and
+    the same batch with a NON-symmetric Q (cost.hh:30-34 takes any Q), which only this kernel serves."""
+    import torch
+    from quadrotorilqr_amd import capi
+    from oracle import oracle as orc
+    B = cfg["init"].shape[0]
+    init = torch.from_numpy(cfg["init"]).to(dev)
+    bufs = (torch.empty_like(init), torch.empty(B, dtype=torch.float64, device=dev), [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(4)])
+    out = {}
+    r = np.random.default_rng(7)
+    Qn = cfg["Q"] + 0.05 * np.triu(r.uniform(-1, 1, (12, 12)), 1)  # not symmetric
+    for key, c, kw in (("symmetric_weights_force_general_1", cfg, dict(force_general=1)), ("non_symmetric_Q", dict(cfg, Q=Qn), {})):
+        sv = capi.from_config(c, device=dev.index, sync_every=args.sync_every, **kw)
+        for _ in range(2):
+            sv.solve_batch_device(init, bufs[0], bufs[1], *bufs[2])
+        reps = 5
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            sv.solve_batch_device(init, bufs[0], bufs[1], *bufs[2])
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t1) / reps
+        cost = bufs[1].cpu().numpy()
+        sample = 64
+        ref = orc.OracleSolver(orc.model_params(**c["model"]), c["Q"], c["R"], c["desired"], c["dt"],
+                               orc.options(**c["options"])).solve_batch(c["init"][:sample], n_threads=max(1, min(os.cpu_count() or 1, 64)))
+        st = bufs[2][0].cpu().numpy()
+        out[key] = {"value": B / t, "unit": "solves/s", "ms_per_solve": t * 1e3,
+                    "max_rel_cost_diff_vs_oracle": float(np.max(np.abs(cost[:sample] - ref["cost"]) / np.abs(ref["cost"]))),
+                    "oracle_sample": sample,
+                    "same_status_iters_as_oracle": int(np.sum((st[:sample] == ref["status"]) & (bufs[2][1].cpu().numpy()[:sample] == ref["iters"]))),
+                    "status_counts": np.bincount(st, minlength=4).tolist()}
+        if key.startswith("symmetric"):
+            out[key]["max_rel_cost_diff_vs_default_kernels"] = float(np.max(np.abs(cost - default_cost) / np.abs(default_cost)))
+        sv.close()
+    out["what"] = (f"B = {B}, N = {cfg['init'].shape[1]}, device-resident, 5 repeats: k_backward<false> (one wavefront per trajectory, dense records, "
+                   "Eigen's pivoted LDL^T, the reference's unsymmetrised V_xx) with the default rollout and linearisation kernels")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +206,8 @@ def main():
     ap.add_argument("--serving-batches", type=int, default=18)
     ap.add_argument("--no-host-to-host", action="store_true", help="skip the host-buffers-in / host-buffers-out measurement (never part of value)")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the B = 8192 measurement (never part of value)")
+    ap.add_argument("--no-single-solve", action="store_true", help="skip the one-problem-per-call measurement through the binding (never part of value)")
+    ap.add_argument("--no-reference-faithful", action="store_true", help="skip the force_general = 1 / non-symmetric-Q measurement (never part of value)")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP events around the kernels (roofline = null)")
     args = ap.parse_args()
 
@@ -365,11 +452,12 @@ def main():
                 "warmup_avg_launch_us": {k: round(calib[k + "_ms"] * 1e3 / max(calib[k + "_launches"], 1), 2)
                                          for k in ("backward", "rollout", "solve")},
             }
-        # ---- the saturated machine: the shard one GPU solves in configs[3] (never `value`).  First of the extra legs: HIP hands
-        # hardware queues to streams in the order the streams are created and does not give a destroyed stream's place back, so
-        # behind the handles of the other legs this solver's four sub-batch streams can end up sharing queues (385 000 instead of
-        # 444 000-460 000 solves/s)
+        # ---- the extra legs (never `value`).  HIP hands hardware queues to streams in the order the streams are created and does
+        # not give a destroyed stream's place back: the B = 8192 solver's four sub-batch streams are therefore created FIRST
+        # (behind other handles they end up sharing queues: 385 000 instead of 444 000-460 000 solves/s), by one untimed solve;
+        # then host_to_host is MEASURED first, on a fresh handle, before any other leg has left streams or work behind.
         large = None
+        ls = None
         if not args.no_large_batch and world == 1 and not strong:
             LB = 8192
             lcfg = pb.config2(B=LB, N=N, seed=4)
@@ -377,6 +465,49 @@ def main():
             linit = torch.from_numpy(lcfg["init"]).to(dev)
             lbuf = (torch.empty_like(linit), torch.empty(LB, dtype=torch.float64, device=dev),
                     [torch.empty(LB, dtype=torch.int32, device=dev) for _ in range(4)])
+            ls.solve_batch_device(linit, lbuf[0], lbuf[1], *lbuf[2])
+            torch.cuda.synchronize()
+        # ---- the metric as SURVEY.md section 8(d) defines it: host buffers in -> host buffers out (never `value`).  Pinned and
+        # pageable buffers alternate call by call; median and 90th percentile of >= 30 calls each.
+        h2h = None
+        if not args.no_host_to_host and world == 1:
+            hin = capi.host_array(cfg["init"].shape)
+            hin[...] = cfg["init"]
+            hout = dict(traj=capi.host_array(cfg["init"].shape), cost=capi.host_array((B,)),
+                        **{k: capi.host_array((B,), np.int32) for k in ("status", "iters", "n_bwd", "n_fwd")})
+            plain = capi.from_config(cfg, device=dev.index, sync_every=args.sync_every)
+            pg = cfg["init"].copy()  # the same through pageable buffers (HIP stages the copies itself)
+            t_settle = time.perf_counter()
+            while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:  # clocks and both paths warm
+                plain.solve_batch(hin, out=hout)
+                plain.solve_batch(pg)
+            reps = max(30, args.steps)
+            tpin, tpag, tdev = [], [], []
+            for _ in range(reps):
+                t1 = time.perf_counter()
+                plain.solve_batch(hin, out=hout)
+                tpin.append(time.perf_counter() - t1)
+                t1 = time.perf_counter()
+                plain.solve_batch(pg)
+                tpag.append(time.perf_counter() - t1)
+                t1 = time.perf_counter()  # and the device-resident call of `value`, same handle state, same moment
+                solver.solve_batch_device(init, out_traj[0], out_cost[0], out_i[0], out_i[1], out_i[2], out_i[3])
+                tdev.append(time.perf_counter() - t1)
+            tpin, tpag, tdev = (np.array(t) * 1e3 for t in (tpin, tpag, tdev))
+            th = float(np.median(tpin))
+            h2h = {"value": B / th * 1e3, "unit": "solves/s", "ms_per_solve": th, "ms_p90": float(np.percentile(tpin, 90)),
+                   "ms_min": float(tpin.min()),
+                   "what": f"qilqr_solve_batch, B = {B}: quaternion checks + H2D + solve + D2H, pinned host buffers; median of {reps} calls, "
+                           "first of the extra legs, alternating with the pageable-buffer call and the device-resident call",
+                   "bytes_in": int(cfg["init"].nbytes), "bytes_out": int(cfg["init"].nbytes + B * 24),
+                   "pageable_buffers": {"value": B / float(np.median(tpag)) * 1e3, "ms_per_solve": float(np.median(tpag)),
+                                        "ms_p90": float(np.percentile(tpag, 90))},
+                   "device_resident_same_moment": {"ms_per_solve": float(np.median(tdev)), "ms_p90": float(np.percentile(tdev, 90))},
+                   "over_device_resident_ms": th - float(np.median(tdev)),
+                   "parity_with_device_path": bool(np.array_equal(hout["cost"], out_cost[0].cpu().numpy()))}
+            plain.close()
+        # ---- the saturated machine: the shard one GPU solves in configs[3] (never `value`)
+        if ls is not None:
             t_settle = time.perf_counter()  # untimed solves first: the legs before this one leave the GPU idle for seconds and its clocks low
             while True:
                 ls.solve_batch_device(linit, lbuf[0], lbuf[1], *lbuf[2])
@@ -437,32 +568,6 @@ def main():
                    "sample": f"first {sample} of the {B} problems of rank 0 x {reps} repeats, {cores} threads, {tc:.2f} s; "
                              f"single thread: {16 / t1c:.1f} solves/s on 16 problems",
                    "parity_max_rel_cost_err": float(np.max(np.abs(got - r["cost"]) / np.abs(r["cost"])))}
-        # ---- the metric as SURVEY.md section 8(d) defines it: host buffers in -> host buffers out (never `value`)
-        h2h = None
-        if not args.no_host_to_host and world == 1:
-            hin = capi.host_array(cfg["init"].shape)
-            hin[...] = cfg["init"]
-            hout = dict(traj=capi.host_array(cfg["init"].shape), cost=capi.host_array((B,)),
-                        **{k: capi.host_array((B,), np.int32) for k in ("status", "iters", "n_bwd", "n_fwd")})
-            plain = capi.from_config(cfg, device=dev.index, sync_every=args.sync_every)
-            plain.solve_batch(hin, out=hout)
-            reps = max(3, min(args.steps, 10))
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                plain.solve_batch(hin, out=hout)
-            th = (time.perf_counter() - t1) / reps
-            pg = cfg["init"].copy()  # the same through pageable buffers (HIP stages the copies itself)
-            plain.solve_batch(pg)
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                plain.solve_batch(pg)
-            tp = (time.perf_counter() - t1) / reps
-            h2h = {"value": B / th, "unit": "solves/s", "ms_per_solve": th * 1e3,
-                   "what": f"qilqr_solve_batch, B = {B}: quaternion checks + H2D + solve + D2H, pinned host buffers, {reps} repeats",
-                   "bytes_in": int(cfg["init"].nbytes), "bytes_out": int(cfg["init"].nbytes + B * 24),
-                   "pageable_buffers": {"value": B / tp, "ms_per_solve": tp * 1e3},
-                   "parity_with_device_path": bool(np.array_equal(hout["cost"], out_cost[(step_no[0] - 1) & 1].cpu().numpy()))}
-            plain.close()
         # ---- extra, outside the timed region and never `value`: a stream of such batches with several in flight
         # (one solver handle and one host thread per batch in flight): the tail of one batch -- a few trajectories
         # still iterating on an almost idle chip -- overlaps the head of the next
@@ -496,6 +601,14 @@ def main():
                 serving[f"in_flight_{k}"] = per * k * B / (time.perf_counter() - t1)
                 for w in ws:
                     w[0].close()
+        # ---- the reference's own call pattern: one problem per call through the pybind11 surface (never `value`)
+        single = None
+        if not args.no_single_solve and world == 1 and not strong:
+            single = single_solve_leg(dev.index, args)
+        # ---- the kernel that evaluates ilqr.hh:126-133 in the reference's own forms (never `value`)
+        faithful = None
+        if not args.no_reference_faithful and world == 1 and not strong:
+            faithful = reference_faithful_leg(cfg, dev, out_cost[(step_no[0] - 1) & 1].cpu().numpy(), args)
         if strong:
             workload = (f"BASELINE.json configs[3]: ONE batch of {B_total} random SE(3) starts -> hover, {N} knots, fp64, model A, "
                         f"seed 4, contiguous shards of {sizes[0]} per GPU")
@@ -521,6 +634,7 @@ def main():
             "shard_rounds": shard_rounds_list,  # per shard: rollouts of its slowest problem (the straggler sets a shard's time)
             "same_shard": same_shard,
             "roofline": roofline, "cpu_baseline": cpu, "host_to_host": h2h, "large_batch": large, "serving": serving,
+            "single_solve": single, "reference_faithful": faithful,
         }
         print(json.dumps(line))
     if world > 1:

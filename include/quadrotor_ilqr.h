@@ -84,8 +84,8 @@ typedef struct {
                             Q, R are symmetric; 2: the one-wavefront kernel for symmetric weights (k_backward<true>);
                             3: k_backward2 (diagnostics build only); 4: k_backward4, six wavefronts; 5: k_backward4, fused
                             (its wavefronts meet through tagged LDS slots, no block barrier in the knot loop: what 0
-                            selects); 6: k_backward4, fused, with a block barrier per knot (same bits as 5; kept as
-                            its A/B partner).  When the round's kernels are the fused k_backward4 and k_rollout16 and
+                            selects up to 4096 trajectories; forced, it is used at every size); 6: retired in round 4
+                            (the fused form with a block barrier per knot: refused by name).  When the round's kernels are the fused k_backward4 and k_rollout16 and
                             every block of four trajectories has a CU to itself (B <= 4 x the device's CUs: 1024 on
                             MI355X), the two are ONE launch (k_backward_rollout: the block's backward pass, a block
                             barrier, the rollout of its own four trajectories; same arithmetic, same bits).
@@ -273,9 +273,13 @@ int qilqr_solve_batch_sharded(qilqr_sharded *h, const double *init, const double
  * `root` (devices[root]), B x n x 18 doubles / B doubles / B int32, any of them may be NULL.  Every shard's rows travel from
  * its solver's staging buffers straight into their place in the root's arrays -- ragged shards, no padding, no second
  * copy -- as soon as that shard has finished, by the handle's transport:
- *   QILQR_TRANSPORT_RCCL       ncclSend on the shard's device / ncclRecv on the root's, one group per call, over one
- *                              communicator per distinct device (ncclCommInitAll: all in this process); librccl.so.1 is
- *                              loaded when the first communicator is needed
+ *   QILQR_TRANSPORT_RCCL       ncclSend on the shard's device / ncclRecv on the root's, ONE GROUP PER SHARD, enqueued by that
+ *                              shard's own host thread the moment its solve is enqueued (behind an event on its stream: a
+ *                              shard's rows travel while slower shards still solve), over one communicator per distinct
+ *                              device (ncclCommInitAll: all in this process); librccl.so.1 is loaded when the first
+ *                              communicator is needed.  Exercised with ONE rank so far (every shard on the one GPU of the
+ *                              test box: self send / receive); the multi-rank path has not run on hardware -- its schedule
+ *                              (ranks, offsets, counts) is checked on the CPU through qilqr_gather_schedule
  *   QILQR_TRANSPORT_PEER_COPY  hipMemcpyPeerAsync
  *   QILQR_TRANSPORT_AUTO       (default) RCCL when the shards sit on more than one device, device copies when they all share
  *                              one; falls back to peer copies if RCCL cannot be loaded or initialised
@@ -290,6 +294,18 @@ const char *qilqr_sharded_transport(qilqr_sharded *h);
 int qilqr_solve_batch_sharded_device(qilqr_sharded *h, const double *init, const double *desired_batch, int32_t B, int32_t n,
                                      int32_t root, double *d_out_traj, double *d_out_cost, int32_t *d_out_status,
                                      int32_t *d_out_iters, int32_t *d_out_n_bwd, int32_t *d_out_n_fwd, double *gather_ms);
+
+/* The transfers qilqr_solve_batch_sharded_device issues for a batch of B problems of n knots over n_shards shards on `devices`
+ * (HIP ordinals; equal ordinals share a communicator rank, ranks numbered in order of first appearance), gathered on shard
+ * `root`'s device -- computed, not issued: no device is touched, so a host without eight GPUs can check the schedule of eight.
+ * arrays: bit mask of the outputs asked for (1 traj, 2 cost, 4 status, 8 iters, 16 n_bwd, 32 n_fwd).  out receives 7 int64 per
+ * transfer, {shard, array (0 traj .. 5 n_fwd), src_rank, dst_rank, src_off, dst_off, count} -- offsets and counts in elements
+ * of the array's type; src_off into the shard's staging buffer (the four int32 arrays sit one behind the other there), dst_off
+ * into the root's array -- shard by shard in the order a shard enqueues them (at run time each shard's transfers are ONE
+ * ncclGroup of send / receive pairs, or peer copies, enqueued by the shard's own host thread behind its solve).  Returns the
+ * number of transfers (at most `cap` are written; out may be NULL), -1 on bad arguments. */
+int qilqr_gather_schedule(int32_t B, int32_t n, const int32_t *devices, int32_t n_shards, int32_t root, uint32_t arrays,
+                          int64_t *out, int32_t cap);
 
 /* ABI version of this header */
 int qilqr_abi_version(void);

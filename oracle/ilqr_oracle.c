@@ -875,6 +875,38 @@ static int is_converged(const orc_options *o, double cost, double new_cost) {
   return 0;
 }
 
+/* ---- the comparisons a solve's control flow depends on, with their margins (iteration and trial counts
+ * "must match except where the deciding margin is < 1e-9 relative (log those cases)").  A margin is the distance of the compared
+ * quantity from the value at which the comparison flips, relative to the iteration's cost -- the scale on which two
+ * implementations of the same arithmetic differ (their costs agree to about 1e-13 relative, so a comparison of cost differences
+ * can only come out differently when it is that close to flipping).  Recording changes nothing in the solve. */
+typedef struct {
+  orc_decision *dec;
+  int cap, n;
+  int n_bwd, n_fwd; /* passes completed when the comparison is made */
+} DecLog;
+static void dec_push(DecLog *log, int kind, int iter, int trial, int result, double lhs, double rhs, double margin) {
+  if (!log) return;
+  if (log->dec && log->n < log->cap) {
+    orc_decision *d = &log->dec[log->n];
+    d->kind = kind; d->iter = iter; d->trial = trial; d->result = result;
+    d->lhs = lhs; d->rhs = rhs; d->margin = margin;
+    d->n_bwd = log->n_bwd; d->n_fwd = log->n_fwd;
+  }
+  ++log->n;
+}
+/* margin of is_converged(cost, new_cost): converged -> the larger slack of the tests that hold; not converged -> the smaller
+ * excess of the two (both fail), each as a cost difference over |cost| */
+static double converged_margin(const orc_options *o, double cost, double new_cost) {
+  const double d = fabs(cost - new_cost), c = fabs(cost);
+  const double sa = o->rtol * c - d, sb = o->atol - d; /* slack of the relative / the absolute test (positive: holds) */
+  const int a = d / c < o->rtol, b = d < o->atol;
+  double m;
+  if (a || b) m = (a && b) ? (sa > sb ? sa : sb) : (a ? sa : sb);
+  else m = (-sa < -sb) ? -sa : -sb;
+  return c > 0.0 ? fabs(m) / c : fabs(m);
+}
+
 static double knot_cost(const orc_solver *s, const double *pt, int i, double *Cx, double *Cu,
                         double *Cxx, double *Cuu, double *Cxu) {
   State x, xd;
@@ -1014,9 +1046,9 @@ int orc_forward_sim(const orc_solver *s, const double *traj, int n, const double
 }
 
 /* ilqr.hh:174-194 */
-int orc_line_search(const orc_solver *s, const double *traj, int n, double cost,
+static int line_search_logged(const orc_solver *s, const double *traj, int n, double cost,
                     const double *gains, const double terms[2], double *out_traj,
-                    double *out_cost, double *out_step, int *out_trials) {
+                    double *out_cost, double *out_step, int *out_trials, DecLog *log, int iter) {
   double step = 1.0;
   for (int i = 0; i < s->opt.ls_max_iters; ++i) {
     orc_forward_sim(s, traj, n, gains, step, out_traj);
@@ -1024,6 +1056,9 @@ int orc_line_search(const orc_solver *s, const double *traj, int n, double cost,
     const int rc = orc_cost_trajectory(s, out_traj, n, &new_cost);
     if (rc) return -rc;
     const double desired = s->opt.desired_reduction_frac * cost_reduction(terms, step);
+    if (log) ++log->n_fwd;
+    dec_push(log, ORC_DEC_ARMIJO, iter, i, new_cost - cost < desired, new_cost - cost, desired,
+             fabs((new_cost - cost) - desired) / (fabs(cost) > 0.0 ? fabs(cost) : 1.0));
     if (new_cost - cost < desired) {
       *out_cost = new_cost;
       *out_step = step;
@@ -1035,11 +1070,16 @@ int orc_line_search(const orc_solver *s, const double *traj, int n, double cost,
   if (out_trials) *out_trials = s->opt.ls_max_iters;
   return ORC_STATUS_LINE_SEARCH_FAILED;
 }
+int orc_line_search(const orc_solver *s, const double *traj, int n, double cost,
+                    const double *gains, const double terms[2], double *out_traj,
+                    double *out_cost, double *out_step, int *out_trials) {
+  return line_search_logged(s, traj, n, cost, gains, terms, out_traj, out_cost, out_step, out_trials, 0, 0);
+}
 
 /* ilqr.hh:53-87 */
-int orc_solve(const orc_solver *s, const double *init, int n, double *out_traj, double *out_cost,
+static int solve_logged(const orc_solver *s, const double *init, int n, double *out_traj, double *out_cost,
               int *out_status, int *out_iters, int *out_n_bwd, int *out_n_fwd,
-              double *cost_hist, double *debug_trajs, int cap, int *out_n_hist) {
+              double *cost_hist, double *debug_trajs, int cap, int *out_n_hist, DecLog *log) {
   if (n <= 0) return ORC_ERR_INVALID;
   if (n > s->n_desired) return ORC_ERR_LENGTH_MISMATCH;
   const size_t tsz = sizeof(double) * ORC_PT * (size_t)n;
@@ -1055,8 +1095,12 @@ int orc_solve(const orc_solver *s, const double *init, int n, double *out_traj, 
     double terms[2];
     orc_backwards_pass_reg(s, traj, n, mu, gains, terms);
     ++n_bwd;
+    if (log) { log->n_bwd = n_bwd; log->n_fwd = n_fwd; }
     const double cost = new_cost;
     const double expected_new_cost = cost + cost_reduction(terms, 1.0);
+    if (i > 0)
+      dec_push(log, ORC_DEC_EXPECTED, i, 0, is_converged(&s->opt, cost, expected_new_cost), cost, expected_new_cost,
+               converged_margin(&s->opt, cost, expected_new_cost));
     if (i > 0 && is_converged(&s->opt, cost, expected_new_cost)) {
       status = ORC_STATUS_CONVERGED_EXPECTED;
       break;
@@ -1069,8 +1113,8 @@ int orc_solve(const orc_solver *s, const double *init, int n, double *out_traj, 
     } else {
       double step;
       int trials = 0;
-      const int ls = orc_line_search(s, traj, n, cost, gains, terms, cand, &new_cost, &step,
-                                     &trials);
+      const int ls = line_search_logged(s, traj, n, cost, gains, terms, cand, &new_cost, &step,
+                                        &trials, log, i);
       n_fwd += trials;
       if (ls == ORC_STATUS_LINE_SEARCH_FAILED) {
         new_cost = cost;
@@ -1097,6 +1141,10 @@ int orc_solve(const orc_solver *s, const double *init, int n, double *out_traj, 
       if (debug_trajs) memcpy(debug_trajs + (size_t)n_hist * ORC_PT * n, traj, tsz);
     }
     ++n_hist;
+    if (log) log->n_fwd = n_fwd;
+    if (i > 0)
+      dec_push(log, ORC_DEC_CONVERGED, i, 0, is_converged(&s->opt, cost, new_cost), cost, new_cost,
+               converged_margin(&s->opt, cost, new_cost));
     if (i > 0 && is_converged(&s->opt, cost, new_cost)) {
       status = ORC_STATUS_CONVERGED;
       break;
@@ -1114,6 +1162,23 @@ int orc_solve(const orc_solver *s, const double *init, int n, double *out_traj, 
   free(cand);
   free(gains);
   return ORC_OK;
+}
+
+int orc_solve(const orc_solver *s, const double *init, int n, double *out_traj, double *out_cost,
+              int *out_status, int *out_iters, int *out_n_bwd, int *out_n_fwd,
+              double *cost_hist, double *debug_trajs, int cap, int *out_n_hist) {
+  return solve_logged(s, init, n, out_traj, out_cost, out_status, out_iters, out_n_bwd, out_n_fwd, cost_hist, debug_trajs, cap,
+                      out_n_hist, 0);
+}
+/* the same solve, every comparison its control flow took recorded with its margin (dec[dec_cap]; *n_dec = how many there were) */
+int orc_solve_decisions(const orc_solver *s, const double *init, int n, double *out_traj, double *out_cost,
+                        int *out_status, int *out_iters, int *out_n_bwd, int *out_n_fwd, double *cost_hist, int cap,
+                        int *out_n_hist, orc_decision *dec, int dec_cap, int *n_dec) {
+  DecLog log = {dec, dec_cap, 0, 0, 0};
+  const int rc = solve_logged(s, init, n, out_traj, out_cost, out_status, out_iters, out_n_bwd, out_n_fwd, cost_hist, 0, cap,
+                              out_n_hist, &log);
+  if (n_dec) *n_dec = log.n;
+  return rc;
 }
 
 /* ------------------------------------------------------------------ */

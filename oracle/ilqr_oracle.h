@@ -153,6 +153,24 @@ int orc_solve(const orc_solver *s, const double *init, int n, double *out_traj,
               int *out_n_fwd, double *cost_hist, double *debug_trajs, int cap,
               int *out_n_hist);
 
+/* One comparison a solve's control flow depended on, with its margin: the distance of the compared quantity from the value at
+ * which the comparison flips, as a cost difference over |cost| of the iteration (counts "must match
+ * except where the deciding margin is < 1e-9 relative").  kind: ORC_DEC_EXPECTED = is_converged(cost, cost + dJ(1)) at the top of
+ * iteration iter (ilqr.hh:66), ORC_DEC_ARMIJO = new_cost - cost < frac dJ(alpha) of trial `trial` (:186), ORC_DEC_CONVERGED =
+ * is_converged(cost, new_cost) behind the accepted step (:82).  lhs / rhs: the two costs (convergence tests) or the two sides
+ * of the Armijo inequality. */
+#define ORC_DEC_EXPECTED 0
+#define ORC_DEC_ARMIJO 1
+#define ORC_DEC_CONVERGED 2
+typedef struct {
+  int kind, iter, trial, result;
+  int n_bwd, n_fwd; /* backward passes / rollouts completed when the comparison is made (an Armijo test counts its own rollout) */
+  double lhs, rhs, margin;
+} orc_decision;
+int orc_solve_decisions(const orc_solver *s, const double *init, int n, double *out_traj, double *out_cost,
+                        int *out_status, int *out_iters, int *out_n_bwd, int *out_n_fwd, double *cost_hist, int cap,
+                        int *out_n_hist, orc_decision *dec, int dec_cap, int *n_dec);
+
 /* batch over independent problems, n_threads host threads (pthreads).
  * init: B x n x 18; desired shared (from create).  Used only for cpu_baseline timing. */
 int orc_solve_batch(const orc_solver *s, const double *init, int B, int n, double *out_traj,

@@ -35,6 +35,15 @@ class ModelParams(C.Structure):
     ]
 
 
+class Decision(C.Structure):
+    """orc_decision (ilqr_oracle.h): one comparison a solve's control flow depended on, with its margin"""
+    _fields_ = [("kind", C.c_int), ("iter", C.c_int), ("trial", C.c_int), ("result", C.c_int), ("n_bwd", C.c_int),
+                ("n_fwd", C.c_int), ("lhs", C.c_double), ("rhs", C.c_double), ("margin", C.c_double)]
+
+
+DEC_EXPECTED, DEC_ARMIJO, DEC_CONVERGED = 0, 1, 2
+
+
 class Options(C.Structure):
     _fields_ = [
         ("step_update", C.c_double),
@@ -350,6 +359,27 @@ class OracleSolver:
         return dict(traj=out, cost=c.value, status=st.value, iters=it.value, n_bwd=nb.value,
                     n_fwd=nf.value, cost_hist=hist[:k].copy(),
                     debug_trajs=dbg[:k].copy() if debug else None)
+
+    def solve_decisions(self, init):
+        """solve() plus every comparison its control flow took (ilqr.hh:66, :186, :82) with the margin by which it came out
+        the way it did, as a cost difference over |cost|: list of dicts in evaluation order."""
+        init = _d(init).reshape(-1, 18)
+        n = len(init)
+        cap = int(self.opt.max_iters) + 1
+        dcap = (cap + 1) * (2 + max(int(self.opt.ls_max_iters), 1))
+        out = np.zeros_like(init)
+        hist = np.zeros(cap)
+        dec = (Decision * dcap)()
+        c = C.c_double()
+        st, it, nb, nf, nh, nd = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._check(lib().orc_solve_decisions(self._h, _p(init), C.c_int(n), _p(out), C.byref(c), C.byref(st), C.byref(it),
+                                              C.byref(nb), C.byref(nf), _p(hist), C.c_int(cap), C.byref(nh), dec,
+                                              C.c_int(dcap), C.byref(nd)))
+        assert nd.value <= dcap
+        decisions = [dict(kind=d.kind, iter=d.iter, trial=d.trial, result=bool(d.result), n_bwd=d.n_bwd, n_fwd=d.n_fwd,
+                          lhs=d.lhs, rhs=d.rhs, margin=d.margin) for d in dec[:nd.value]]
+        return dict(traj=out, cost=c.value, status=st.value, iters=it.value, n_bwd=nb.value, n_fwd=nf.value,
+                    cost_hist=hist[:min(nh.value, cap)].copy(), decisions=decisions)
 
     def solve_batch(self, init, n_threads=1):
         init = _d(init)

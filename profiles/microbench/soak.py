@@ -15,7 +15,7 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 orig = capi.from_config
 bad = 0
-for label, kw in [("automatic", {}), ("k_backward4 six waves", dict(force_general=4)), ("k_backward4 fused", dict(force_general=5)), ("fused, with barriers", dict(force_general=6)),
+for label, kw in [("automatic", {}), ("k_backward4 six waves", dict(force_general=4)), ("k_backward4 fused", dict(force_general=5)),
                   ("one wavefront", dict(force_general=2)), ("general", dict(force_general=1)),
                   ("k_rollout", dict(single_wave_rollout=1)), ("k_rollout3", dict(single_wave_rollout=2)), ("k_rollout16", dict(single_wave_rollout=3)),
                   ("three streams", dict(streams=3)), ("restarts", dict()), ("restarts, six waves", dict(force_general=4)), ("restarts, fused", dict(force_general=5)),

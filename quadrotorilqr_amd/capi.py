@@ -41,7 +41,7 @@ EXPORTS = (
     "qilqr_device", "qilqr_stream", "qilqr_stream_wait_event", "qilqr_host_alloc", "qilqr_host_free",
     "qilqr_sharded_create", "qilqr_sharded_create_mask", "qilqr_sharded_destroy", "qilqr_sharded_count", "qilqr_sharded_solver",
     "qilqr_shard_range", "qilqr_solve_batch_sharded",
-    "qilqr_sharded_set_transport", "qilqr_sharded_transport", "qilqr_solve_batch_sharded_device",
+    "qilqr_sharded_set_transport", "qilqr_sharded_transport", "qilqr_solve_batch_sharded_device", "qilqr_gather_schedule",
     "qilqr_abi_version",
 )
 
@@ -460,6 +460,22 @@ class QuadrotorILQRSharded:
         if rc:
             _raise(rc)
         return ms.value
+
+
+def gather_schedule(B, n, devices, root=0, arrays=63):
+    """qilqr_gather_schedule: the transfers of qilqr_solve_batch_sharded_device for these shards, computed without touching a
+    device -- list of dicts {shard, array, src_rank, dst_rank, src_off, dst_off, count}"""
+    dv = np.ascontiguousarray(devices, dtype=np.int32)
+    fn = load().qilqr_gather_schedule
+    fn.restype = C.c_int
+    args = (C.c_int32(B), C.c_int32(n), dv.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(len(dv)), C.c_int32(root), C.c_uint32(arrays))
+    cnt = fn(*args, None, C.c_int32(0))
+    if cnt < 0:
+        raise ValueError("qilqr_gather_schedule: bad arguments")
+    out = np.zeros((max(cnt, 1), 7), dtype=np.int64)
+    fn(*args, out.ctypes.data_as(C.POINTER(C.c_int64)), C.c_int32(cnt))
+    keys = ("shard", "array", "src_rank", "dst_rank", "src_off", "dst_off", "count")
+    return [dict(zip(keys, (int(v) for v in row))) for row in out[:cnt]]
 
 
 def sharded_from_config(cfg, devices=(0,), **kw):

@@ -98,6 +98,10 @@ struct qilqr_solver {
   size_t early_cap = 0;                   // B it was allocated for
   char *d_late = nullptr, *h_late = nullptr;  // compact rows of the trajectories that finished late: device block, pinned host block
   size_t late_bytes = 0;
+  // ILQRDebug ring of the single-problem solve (k_debug_capture), device memory, grow-only
+  double *dbg_trajs = nullptr, *dbg_cost = nullptr;
+  int *dbg_seen = nullptr;
+  size_t dbg_traj_cap = 0, dbg_cost_cap = 0;
   // profiling
   std::vector<EventPair> events;
   size_t events_used = 0;
@@ -400,7 +404,7 @@ BackwardKind backward_kind(const qilqr_solver *s, long load_B) {
 #ifdef QILQR_WITH_BACKWARD2
   if (s->dev.force_general == 3) return BW_TWO;
 #endif
-  if (s->dev.force_general == 5 || s->dev.force_general == 6 || (s->dev.force_general == 0 && load_B <= 4096)) return BW_FUSED;
+  if (s->dev.force_general == 5 || (s->dev.force_general == 0 && load_B <= 4096)) return BW_FUSED;
   if (s->dev.force_general == 4 || (s->dev.force_general != 2 && load_B <= 8192)) return BW_FOUR;
   return BW_ONE;
 }
@@ -419,22 +423,12 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
   // the one-wavefront kernel addresses its operands through rec_elem and reads either)
   const BackwardKind kind = s->st.layout.tiled ? backward_kind(s, load_B) : BW_ONE;
   if (kind == BW_FUSED) {
-    // four matrix-and-gradient wavefronts + one loader wavefront per four trajectories; without block barriers in the knot
-    // loop unless force_general = 6 asks for them (the A/B partner)
-    const bool many = load_B > 4096, barriers = s->dev.force_general == 6;
-#define QILQR_LAUNCH_FUSED(S, W, FREE) \
-  launch(s, K_BACKWARD, (k_backward4<S, W, true, FREE>), dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n, force)
-    if (barriers) {
-      if (s->f32 && many) QILQR_LAUNCH_FUSED(float, 6, false);
-      else if (s->f32) QILQR_LAUNCH_FUSED(float, 5, false);
-      else if (many) QILQR_LAUNCH_FUSED(double, 6, false);
-      else QILQR_LAUNCH_FUSED(double, 5, false);
-    } else {
-      if (s->f32 && many) QILQR_LAUNCH_FUSED(float, 6, true);
-      else if (s->f32) QILQR_LAUNCH_FUSED(float, 5, true);
-      else if (many) QILQR_LAUNCH_FUSED(double, 6, true);
-      else QILQR_LAUNCH_FUSED(double, 5, true);
-    }
+    // four matrix-and-gradient wavefronts + one loader wavefront per four trajectories, no block barrier in the knot loop
+    // (one register budget: the pipelined knot carries the previous knot's tail and does not fit 80 registers)
+#define QILQR_LAUNCH_FUSED(S) \
+  launch(s, K_BACKWARD, (k_backward4<S, 5, true, true>), dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n, force)
+    if (s->f32) QILQR_LAUNCH_FUSED(float);
+    else QILQR_LAUNCH_FUSED(double);
 #undef QILQR_LAUNCH_FUSED
   } else if (kind == BW_FOUR) {
     // four matrix wavefronts + one gradient wavefront + one loader wavefront per four trajectories
@@ -514,12 +508,16 @@ bool fuse_backward_rollout(const qilqr_solver *s, long B) {
 // four trajectories (the rollout's register budget): alone on the chip that is +3 to +4 % of a solve, beside other solves'
 // kernels it is in their way -- three handles in flight: 306 000-311 000 solves/s with it, 340 000 without.  A solve that
 // finds another one in flight on its device therefore launches the two kernels apart (same bits either way).
-std::atomic<int> g_solves_in_flight[16];
+// The choice is made again for every round a solve enqueues (a solve that is joined by another one changes over at its next round;
+// the count covers the window in which a solve's host loop enqueues rounds -- the last `sync_every` rounds of a call that
+// returns before its stream has drained are outside it).
+constexpr int MAX_TRACKED_DEVICES = 64;  // (HIP ordinals of one process; a node has 8)
+std::atomic<int> g_solves_in_flight[MAX_TRACKED_DEVICES];
 struct InFlight {
   std::atomic<int> &n;
-  int at_entry;
-  explicit InFlight(int device) : n(g_solves_in_flight[(unsigned)device & 15u]), at_entry(n.fetch_add(1, std::memory_order_relaxed) + 1) {}
+  explicit InFlight(int device) : n(g_solves_in_flight[(unsigned)device % MAX_TRACKED_DEVICES]) { n.fetch_add(1, std::memory_order_relaxed); }
   ~InFlight() { n.fetch_sub(1, std::memory_order_relaxed); }
+  bool alone() const { return n.load(std::memory_order_relaxed) == 1; }
 };
 int launch_backward_rollout(qilqr_solver *s, long B, long n) {
   if (s->f32)
@@ -625,7 +623,7 @@ int fire_early_out(qilqr_solver *s, long B, long n, EarlyOut *eo, unsigned activ
 }
 
 // The outer loop of ILQR::solve (ilqr.hh:53-87) for trajectories already in st.traj[0].
-// on_round (optional) is called after every synchronised round (debug capture).
+// on_round is called behind every round's backward pass (and rollout), in both modes: debug capture enqueues its kernel there.
 // drain = false: return as soon as the host knows that no trajectory is active; the caller enqueues
 // its own work behind the rounds still in flight and waits for the stream itself.
 // on_count (optional): called with the count of running trajectories each time the free-running loop learns one.
@@ -666,14 +664,15 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
     // to do.
     for (int k = 0; k < 8; ++k) s->h_active[k] = 0;
     const InFlight in_flight(s->device);
-    const bool fused = fuse_backward_rollout(s, B) && in_flight.at_entry == 1;
+    const bool can_fuse = fuse_backward_rollout(s, B);
     for (long round = 0; round < max_rounds; ++round) {
-      if (fused) {
+      if (can_fuse && in_flight.alone()) {
         if ((rc = launch_backward_rollout(s, B, n))) return rc;
       } else {
         if ((rc = launch_backward(s, B, n, 0))) return rc;
         if ((rc = launch_rollout(s, B, n, F_SEARCH))) return rc;
       }
+      if ((rc = on_round())) return rc;  // (debug capture of the single solve: one more launch, nothing waited for)
       if ((rc = launch_linearize(s, B, n, 1, F_SEARCH, (int)(round & 0x3fffffff)))) return rc;
       if (round >= lag) {
         const long old = round - lag;
@@ -694,6 +693,13 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
           __builtin_ia32_pause();
         }
         if ((unsigned)v == 0) break;
+        // a block that gave up a hand-off (BatchState::host_error) voids the call: stop enqueuing rounds on void gains -- each
+        // could burn a full bounded spin -- let what is in flight finish, and report
+        if (__atomic_load_n(s->h_active + 8 * (1 + qilqr_solver::MAX_PARTS), __ATOMIC_ACQUIRE)) {
+          (void)hipStreamSynchronize(s->stream);
+          if (s->early_stream) (void)hipStreamSynchronize(s->early_stream);
+          return device_error(s);
+        }
         if (on_count && (rc = (*on_count)((unsigned)v))) return rc;
         // (Round 3 tried following the device ONE round behind in the tail, where a round takes well over 100 us and the host
         // needs about 15 to enqueue the next: one round of three empty launches fewer after the last trajectory has finished --
@@ -761,10 +767,15 @@ struct PartScope {
   }
 };
 // hardware queues HIP multiplexes this process's streams onto: GPU_MAX_HW_QUEUES as the runtime read it at start-up (default 4)
+// Latched at the first qilqr_create of the process (the runtime reads the variable once, when it starts: a value put into
+// the environment later -- os.environ after the first GPU call -- changes nothing in the runtime and must change nothing here)
 int hw_queues() {
-  const char *e = std::getenv("GPU_MAX_HW_QUEUES");
-  const int q = e ? std::atoi(e) : 4;
-  return q > 0 ? q : 4;
+  static const int latched = [] {
+    const char *e = std::getenv("GPU_MAX_HW_QUEUES");
+    const int q = e ? std::atoi(e) : 4;
+    return q > 0 ? q : 4;
+  }();
+  return latched;
 }
 int auto_parts(const qilqr_solver *s, long B) {
   const long tiles = (B + 63) / 64;
@@ -1051,6 +1062,8 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   if (dc.persistent == 1)
     return fail(QILQR_ERR_INVALID_ARG, "persistent = 1 (k_solve4, the one-launch solve) is in the diagnostics build: make -C quadrotorilqr_amd/csrc diag");
 #endif
+  if (dc.force_general == 6)
+    return fail(QILQR_ERR_INVALID_ARG, "force_general = 6 (the fused k_backward4 with a block barrier per knot) was retired in round 4: 5 is the fused form");
 #ifndef QILQR_WITH_BACKWARD2
   if (dc.force_general == 3)
     return fail(QILQR_ERR_INVALID_ARG, "force_general = 3 (k_backward2) is in the diagnostics build: make -C quadrotorilqr_amd/csrc diag");
@@ -1152,6 +1165,9 @@ void qilqr_destroy(qilqr_solver *s) {
   if (s->d_early) (void)hipFree(s->d_early);
   if (s->d_late) (void)hipFree(s->d_late);
   if (s->h_late) (void)hipHostFree(s->h_late);
+  if (s->dbg_trajs) (void)hipFree(s->dbg_trajs);
+  if (s->dbg_cost) (void)hipFree(s->dbg_cost);
+  if (s->dbg_seen) (void)hipFree(s->dbg_seen);
   if (s->stage_traj) (void)hipFree(s->stage_traj);
   if (s->stage_des) (void)hipFree(s->stage_des);
   if (s->stage_cost) (void)hipFree(s->stage_cost);
@@ -1390,32 +1406,48 @@ int qilqr_solve(qilqr_solver *s, const double *init, int32_t n, double *out_traj
   if ((rc = check_quaternions(init, n, "initial trajectory"))) return rc;
   if ((rc = begin_batch(s, 1, n, nullptr))) return rc;
   if ((rc = upload_tiled(s, init, s->st.traj[0], 1, n, 18))) return rc;
-  int seen = 0;
   const bool want_debug = s->options.populate_debug && debug_cap > 0 && (debug_cost || debug_trajs);
+  if (want_debug) {
+    // the ring lives in device memory (k_debug_capture appends to it behind every round's settle step); one download at the end
+    const size_t want_t = debug_trajs ? (size_t)debug_cap * n * 18 : 0, want_c = (size_t)debug_cap;
+    if (want_t > s->dbg_traj_cap) {
+      if (s->dbg_trajs) (void)hipFree(s->dbg_trajs);
+      s->dbg_trajs = nullptr;
+      s->dbg_traj_cap = 0;
+      HIP_TRY(hipMalloc((void **)&s->dbg_trajs, sizeof(double) * want_t));
+      s->dbg_traj_cap = want_t;
+    }
+    if (want_c > s->dbg_cost_cap) {
+      if (s->dbg_cost) (void)hipFree(s->dbg_cost);
+      s->dbg_cost = nullptr;
+      s->dbg_cost_cap = 0;
+      HIP_TRY(hipMalloc((void **)&s->dbg_cost, sizeof(double) * want_c));
+      s->dbg_cost_cap = want_c;
+    }
+    if (!s->dbg_seen) HIP_TRY(hipMalloc((void **)&s->dbg_seen, sizeof(int)));
+    HIP_TRY(hipMemsetAsync(s->dbg_seen, 0, sizeof(int), s->stream));
+  }
   auto capture = [&]() -> int {
     // ilqr.hh:78-80: one entry per completed forward pass (accepted iteration)
     if (!want_debug) return QILQR_OK;
-    int it = 0;
-    HIP_TRY(hipMemcpy(&it, s->st.iters, sizeof(int), hipMemcpyDeviceToHost));
-    if (it > seen) {
-      if (seen < debug_cap) {
-        if (debug_cost) HIP_TRY(hipMemcpy(debug_cost + seen, s->st.cost, sizeof(double), hipMemcpyDeviceToHost));
-        if (debug_trajs) {
-          int rc2 = download_tiled(s, debug_trajs + (size_t)seen * 18 * n, s->st.traj[0], s->st.traj[1], s->st.cur, 0, 1,
-                                   n, 18);
-          if (rc2) return rc2;
-        }
-      }
-      seen = it;
-    }
+    if (s->f32)
+      launch(s, K_OTHER, k_debug_capture<float>, dim3(1), dim3(256), s->st, (int)n, debug_trajs ? s->dbg_trajs : nullptr, s->dbg_cost, s->dbg_seen, (int)debug_cap);
+    else
+      launch(s, K_OTHER, k_debug_capture<double>, dim3(1), dim3(256), s->st, (int)n, debug_trajs ? s->dbg_trajs : nullptr, s->dbg_cost, s->dbg_seen, (int)debug_cap);
     return QILQR_OK;
   };
-  if ((rc = run_solve(s, 1, n, want_debug ? 1 : s->dev.sync_every, capture))) return rc;
-  int status = 0, iters = 0;
+  if ((rc = run_solve(s, 1, n, s->dev.sync_every, capture))) return rc;
+  int status = 0, iters = 0, seen = 0;
   double cost = 0;
   HIP_TRY(hipMemcpy(&status, s->st.status, sizeof(int), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(&iters, s->st.iters, sizeof(int), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(&cost, s->st.cost, sizeof(double), hipMemcpyDeviceToHost));
+  if (want_debug) {
+    HIP_TRY(hipMemcpy(&seen, s->dbg_seen, sizeof(int), hipMemcpyDeviceToHost));
+    const int have = seen < debug_cap ? seen : debug_cap;
+    if (have > 0 && debug_cost) HIP_TRY(hipMemcpy(debug_cost, s->dbg_cost, sizeof(double) * have, hipMemcpyDeviceToHost));
+    if (have > 0 && debug_trajs) HIP_TRY(hipMemcpy(debug_trajs, s->dbg_trajs, sizeof(double) * (size_t)have * n * 18, hipMemcpyDeviceToHost));
+  }
   if (s->dev.profile) drain_events(s);
   if (n_debug) *n_debug = want_debug ? (seen < debug_cap ? seen : debug_cap) : 0;
   if (status == QILQR_STATUS_LINE_SEARCH_FAILED)
@@ -1614,6 +1646,7 @@ struct qilqr_sharded {
   std::vector<ncclComm_t> comms;         // per distinct device (RCCL transport)
   std::vector<hipStream_t> gstream;      // per distinct device: the stream the gather of that device's shards runs on
   std::vector<hipEvent_t> done;          // per shard: its solve (and gather kernel) have finished
+  std::mutex gather_mutex;               // the shards' host threads enqueue their transfers one at a time (shared communicators / streams)
   std::string info;
 };
 
@@ -1681,7 +1714,32 @@ struct ShardCall {
   double *out_traj, *out_cost;
   int32_t *out_status, *out_iters, *out_n_bwd, *out_n_fwd;
   bool host_out;
+  int32_t root = -1;  // !host_out: the out_* arrays are device arrays on devices[root]; every shard sends its rows there itself
 };
+// One transfer of the gather: `count` elements of array `array` (0 traj, 1 cost, 2 status, 3 iters, 4 n_bwd, 5 n_fwd) from
+// element src_off of shard `shard`'s staging buffer (rank src_rank of the communicator = the shard's device) to element dst_off
+// of the root's array (rank dst_rank).  The whole schedule is a function of (B, n, shards, root, which arrays, ranks) alone --
+// qilqr_gather_schedule below exposes it so that a test can check it for eight distinct devices without any.
+struct GatherPiece {
+  int32_t shard, array, src_rank, dst_rank;
+  int64_t src_off, dst_off, count;
+};
+inline void gather_schedule_of_shard(int32_t B, int32_t n, int32_t k, int32_t r, int32_t root, const int *rank_of, unsigned arrays,
+                                     std::vector<GatherPiece> *out) {
+  int32_t b0 = 0, cnt = 0;
+  (void)qilqr_shard_range(B, k, r, &b0, &cnt);
+  if (cnt == 0) return;
+  const int64_t row = (int64_t)n * 18;
+  if (arrays & 1u) out->push_back({r, 0, rank_of[r], rank_of[root], 0, (int64_t)b0 * row, (int64_t)cnt * row});
+  if (arrays & 2u) out->push_back({r, 1, rank_of[r], rank_of[root], 0, (int64_t)b0, (int64_t)cnt});
+  for (int q = 0; q < 4; ++q)  // the four int32 arrays sit one behind the other in the shard's staging block: [4][cnt]
+    if (arrays & (4u << q)) out->push_back({r, 2 + q, rank_of[r], rank_of[root], (int64_t)q * cnt, (int64_t)b0, (int64_t)cnt});
+}
+// enqueue shard r's transfers behind its solve (called from the shard's own host thread as soon as the solve is enqueued and
+// its completion event recorded: the rows travel while slower shards still solve).  RCCL: ONE group per shard -- a send on the
+// shard's communicator and a receive on the root's for each piece; communicators and gather streams are shared between
+// shards (every shard receives on the root's), so the enqueue is serialised by the handle's mutex.
+int enqueue_shard_gather(qilqr_sharded *h, const ShardCall &c, int32_t r);
 void run_shard(qilqr_sharded *h, const ShardCall &c, int32_t r, int *rc_out, std::string *msg_out) {
   const int32_t k = (int32_t)h->solvers.size();
   int32_t b0 = 0, cnt = 0;
@@ -1697,6 +1755,7 @@ void run_shard(qilqr_sharded *h, const ShardCall &c, int32_t r, int *rc_out, std
   } else {
     rc = solve_batch_staged(h->solvers[r], c.init + to, c.desired ? c.desired + to : nullptr, cnt, c.n);
     if (rc == QILQR_OK && hipEventRecord(h->done[r], h->solvers[r]->stream) != hipSuccess) rc = fail(QILQR_ERR_HIP, "hipEventRecord");
+    if (rc == QILQR_OK && c.root >= 0) rc = enqueue_shard_gather(h, c, r);
   }
   *rc_out = rc;
   if (rc != QILQR_OK) *msg_out = g_last_error;  // (thread-local: carried back to the caller)
@@ -1847,6 +1906,84 @@ const char *qilqr_sharded_transport(qilqr_sharded *h) {
 // a shard on the root's own device is a send and a receive on the same communicator.  Peer-copy transport:
 // hipMemcpyPeerAsync.  Either way the transfer of a shard starts when that shard's solve has finished (stream-ordered
 // behind its `done` event), not when the slowest has.
+extern "C++" {
+namespace {
+int enqueue_shard_gather(qilqr_sharded *h, const ShardCall &c, int32_t r) {
+  const int32_t k = (int32_t)h->solvers.size();
+  const unsigned arrays = (c.out_traj ? 1u : 0u) | (c.out_cost ? 2u : 0u) | (c.out_status ? 4u : 0u) | (c.out_iters ? 8u : 0u) |
+                          (c.out_n_bwd ? 16u : 0u) | (c.out_n_fwd ? 32u : 0u);
+  std::vector<GatherPiece> sched;
+  gather_schedule_of_shard(c.B, c.n, k, r, c.root, h->rank_of.data(), arrays, &sched);
+  if (sched.empty()) return QILQR_OK;
+  qilqr_solver *s = h->solvers[r];
+  const int rr = h->rank_of[c.root], root_dev = h->device[c.root];
+  hipStream_t gs = h->gstream[h->rank_of[r]], rs = h->gstream[rr];
+  void *dst_base[6] = {c.out_traj, c.out_cost, c.out_status, c.out_iters, c.out_n_bwd, c.out_n_fwd};
+  const void *src_base[6] = {s->stage_traj, s->stage_cost, s->stage_int, s->stage_int, s->stage_int, s->stage_int};
+  std::lock_guard<std::mutex> lock(h->gather_mutex);
+  HIP_TRY(hipSetDevice(h->device[r]));
+  HIP_TRY(hipStreamWaitEvent(gs, h->done[r], 0));
+  if (h->resolved == QILQR_TRANSPORT_RCCL) {
+    // the receives run on the root's gather stream: it must not start them before this shard's rows exist either
+    if (rs != gs) {
+      HIP_TRY(hipSetDevice(root_dev));
+      HIP_TRY(hipStreamWaitEvent(rs, h->done[r], 0));
+      HIP_TRY(hipSetDevice(h->device[r]));
+    }
+    Rccl &R = rccl();
+    ncclResult_t st = R.GroupStart();
+    for (const GatherPiece &pc : sched) {
+      if (st != ncclSuccess) break;
+      const size_t es = pc.array < 2 ? sizeof(double) : sizeof(int32_t);
+      const ncclDataType_t ty = pc.array < 2 ? ncclDouble : ncclInt32;
+      st = R.Send((const char *)src_base[pc.array] + es * pc.src_off, (size_t)pc.count, ty, pc.dst_rank, h->comms[pc.src_rank], gs);
+      if (st == ncclSuccess) st = R.Recv((char *)dst_base[pc.array] + es * pc.dst_off, (size_t)pc.count, ty, pc.src_rank, h->comms[pc.dst_rank], rs);
+    }
+    const ncclResult_t st_end = R.GroupEnd();
+    if (st == ncclSuccess) st = st_end;
+    if (st != ncclSuccess) return fail(QILQR_ERR_HIP, std::string("RCCL gather: ") + R.GetErrorString(st));
+  } else {
+    for (const GatherPiece &pc : sched) {
+      const size_t es = pc.array < 2 ? sizeof(double) : sizeof(int32_t);
+      HIP_TRY(hipMemcpyPeerAsync((char *)dst_base[pc.array] + es * pc.dst_off, root_dev, (const char *)src_base[pc.array] + es * pc.src_off,
+                                 h->device[r], es * (size_t)pc.count, gs));
+    }
+  }
+  return QILQR_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+// The transfers qilqr_solve_batch_sharded_device issues, without issuing them (no device is touched): for a batch of B problems of
+// n knots over n_shards shards whose devices are `devices` (ordinals; equal ordinals share a communicator rank, numbered in order
+// of first appearance), root shard `root`, arrays = bit mask (1 traj, 2 cost, 4 status, 8 iters, 16 n_bwd, 32 n_fwd).  out:
+// 7 x int64 per transfer = {shard, array, src_rank, dst_rank, src_off, dst_off, count} in the order they are enqueued per shard
+// (shard by shard here; at run time every shard's group goes out when that shard's solve has).  Returns the number of transfers
+// (out may be NULL or shorter: cap entries are written).
+int qilqr_gather_schedule(int32_t B, int32_t n, const int32_t *devices, int32_t n_shards, int32_t root, uint32_t arrays, int64_t *out,
+                          int32_t cap) {
+  if (B <= 0 || n <= 0 || n_shards <= 0 || !devices || root < 0 || root >= n_shards) return fail(QILQR_ERR_INVALID_ARG, "bad argument"), -1;
+  try {
+    std::vector<int> uniq, rank_of(n_shards);
+    for (int32_t r = 0; r < n_shards; ++r) {
+      size_t u = 0;
+      while (u < uniq.size() && uniq[u] != devices[r]) ++u;
+      if (u == uniq.size()) uniq.push_back(devices[r]);
+      rank_of[r] = (int)u;
+    }
+    std::vector<GatherPiece> sched;
+    for (int32_t r = 0; r < n_shards; ++r) gather_schedule_of_shard(B, n, n_shards, r, root, rank_of.data(), arrays, &sched);
+    for (size_t i = 0; i < sched.size() && out && (int32_t)i < cap; ++i) {
+      const GatherPiece &pc = sched[i];
+      const int64_t row[7] = {pc.shard, pc.array, pc.src_rank, pc.dst_rank, pc.src_off, pc.dst_off, pc.count};
+      for (int q = 0; q < 7; ++q) out[7 * i + q] = row[q];
+    }
+    return (int)sched.size();
+  } catch (...) {
+    return fail(QILQR_ERR_INVALID_ARG, "out of host memory"), -1;
+  }
+}
+
 int qilqr_solve_batch_sharded_device(qilqr_sharded *h, const double *init, const double *desired_batch, int32_t B, int32_t n,
                                      int32_t root, double *d_out_traj, double *d_out_cost, int32_t *d_out_status,
                                      int32_t *d_out_iters, int32_t *d_out_n_bwd, int32_t *d_out_n_fwd, double *gather_ms) {
@@ -1858,62 +1995,45 @@ int qilqr_solve_batch_sharded_device(qilqr_sharded *h, const double *init, const
   try {
     int rc = sharded_ensure_gather_path(h);
     if (rc) return rc;
-    const ShardCall c{init, desired_batch, B, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false};
-    if ((rc = run_all_shards(h, c))) {
-      for (qilqr_solver *s : h->solvers) {  // nothing of a failed call stays in flight
+    ShardCall c{init, desired_batch, B, n, d_out_traj, d_out_cost, d_out_status, d_out_iters, d_out_n_bwd, d_out_n_fwd, false};
+    c.root = root;
+    auto settle_everything = [&]() {  // nothing of a failed call stays in flight: solver streams AND gather streams
+      for (qilqr_solver *s : h->solvers) {
         (void)hipSetDevice(s->device);
         (void)hipStreamSynchronize(s->stream);
+        if (s->early_stream) (void)hipStreamSynchronize(s->early_stream);
       }
+      for (size_t u = 0; u < h->uniq.size(); ++u) {
+        (void)hipSetDevice(h->uniq[u]);
+        (void)hipStreamSynchronize(h->gstream[u]);
+      }
+    };
+    if ((rc = run_all_shards(h, c))) {  // (every shard has enqueued its own transfers behind its solve: enqueue_shard_gather)
+      settle_everything();
       return rc;
     }
-    const int rr = h->rank_of[root], root_dev = h->device[root];
-    hipStream_t rs = h->gstream[rr];
-    // the pieces: (source on the shard's device, destination on the root's, bytes), six arrays per shard
-    struct Piece { const void *src; void *dst; size_t count; ncclDataType_t type; size_t bytes; };
-    std::vector<std::vector<Piece>> pieces(k);
+    std::vector<std::vector<int>> pieces(k);  // (only whether a shard has rows)
     for (int32_t r = 0; r < k; ++r) {
       int32_t b0 = 0, cnt = 0;
       (void)qilqr_shard_range(B, k, r, &b0, &cnt);
-      if (cnt == 0) continue;
-      qilqr_solver *s = h->solvers[r];
-      HIP_TRY(hipSetDevice(h->device[r]));
-      HIP_TRY(hipStreamWaitEvent(h->gstream[h->rank_of[r]], h->done[r], 0));
-      const size_t row = (size_t)n * 18;
-      if (d_out_traj) pieces[r].push_back({s->stage_traj, d_out_traj + (size_t)b0 * row, (size_t)cnt * row, ncclDouble, sizeof(double) * cnt * row});
-      if (d_out_cost) pieces[r].push_back({s->stage_cost, d_out_cost + b0, (size_t)cnt, ncclDouble, sizeof(double) * cnt});
-      int32_t *outs[4] = {d_out_status, d_out_iters, d_out_n_bwd, d_out_n_fwd};
-      for (int q = 0; q < 4; ++q)
-        if (outs[q]) pieces[r].push_back({s->stage_int + (size_t)q * cnt, outs[q] + b0, (size_t)cnt, ncclInt32, sizeof(int32_t) * cnt});
+      if (cnt > 0) pieces[r].push_back(1);
     }
-    if (h->resolved == QILQR_TRANSPORT_RCCL) {
-      Rccl &R = rccl();
-      ncclResult_t st = R.GroupStart();
-      for (int32_t r = 0; r < k && st == ncclSuccess; ++r)
-        for (const Piece &pc : pieces[r]) {
-          st = R.Send(pc.src, pc.count, pc.type, rr, h->comms[h->rank_of[r]], h->gstream[h->rank_of[r]]);
-          if (st == ncclSuccess) st = R.Recv(pc.dst, pc.count, pc.type, h->rank_of[r], h->comms[rr], rs);
-          if (st != ncclSuccess) break;
-        }
-      const ncclResult_t st_end = R.GroupEnd();
-      if (st == ncclSuccess) st = st_end;
-      if (st != ncclSuccess) return fail(QILQR_ERR_HIP, std::string("RCCL gather: ") + R.GetErrorString(st));
-    } else {
-      for (int32_t r = 0; r < k; ++r) {
-        HIP_TRY(hipSetDevice(h->device[r]));
-        for (const Piece &pc : pieces[r])
-          HIP_TRY(hipMemcpyPeerAsync(pc.dst, root_dev, pc.src, h->device[r], pc.bytes, h->gstream[h->rank_of[r]]));
-      }
-    }
-    // exposed gather time: from the moment the last solve has finished to the moment the root holds every row
+    // exposed gather time: from the moment the SLOWEST solve has finished to the moment the root holds every row (the faster
+    // shards' rows have been travelling since their own solves finished)
+    auto sync_or_settle = [&](hipError_t e, const char *what) -> int {
+      if (e == hipSuccess) return QILQR_OK;
+      settle_everything();
+      return fail(QILQR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    };
     for (int32_t r = 0; r < k; ++r)
       if (!pieces[r].empty()) {
-        HIP_TRY(hipSetDevice(h->device[r]));
-        HIP_TRY(hipEventSynchronize(h->done[r]));
+        if ((rc = sync_or_settle(hipSetDevice(h->device[r]), "hipSetDevice"))) return rc;
+        if ((rc = sync_or_settle(hipEventSynchronize(h->done[r]), "hipEventSynchronize"))) return rc;
       }
     const auto t0 = std::chrono::steady_clock::now();
     for (size_t u = 0; u < h->uniq.size(); ++u) {
-      HIP_TRY(hipSetDevice(h->uniq[u]));
-      HIP_TRY(hipStreamSynchronize(h->gstream[u]));
+      if ((rc = sync_or_settle(hipSetDevice(h->uniq[u]), "hipSetDevice"))) return rc;
+      if ((rc = sync_or_settle(hipStreamSynchronize(h->gstream[u]), "hipStreamSynchronize (gather)"))) return rc;
     }
     if (gather_ms) *gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (qilqr_solver *s : h->solvers)

@@ -1308,12 +1308,6 @@ __device__ __forceinline__ void bw4_loader_wave(double (&ring)[4][4][BW2_BUF], c
     if (i - 3 >= 0) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-#ifdef QILQR_TIMING_SHRINK  // timing-only build: pairs 32.. are never fetched
-        if (j >= 2) continue;
-#endif
-#ifdef QILQR_TIMING_NOLOADS  // timing-only build: the loader fetches nothing inside the loop (what do its loads' latencies cost?)
-        continue;
-#endif
         q[j] = rec_pair(j, i - 3);
       }
     }
@@ -1361,10 +1355,7 @@ __device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], d
   // The knot loop is sensitive to where its instruction stream sits: the same code shifted by 4 bytes (mod 8) runs 7 %
   // slower (71.5 -> 77 us per launch at B = 1024; MI355X_MICROARCH.md, "code-placement sensitivity").  Pin it to a
   // 64-byte boundary.
-#ifndef QILQR_BW4_PHASE
-#define QILQR_BW4_PHASE 0  // s_nop s behind the boundary: the phase measured fastest of 0..7 (round 3, profiles/microbench/ab.py: 70.0 us; 6: 70.1, 2: 70.2, 4: 71.2, 5: 71.4, 3 and 7: 71.7, 1 -- the fastest of round 2's code -- 71.9)
-#endif
-  asm volatile(".p2align 6\n\t.rept %0\n\ts_nop 0\n\t.endr" ::"n"(QILQR_BW4_PHASE));
+  asm volatile(".p2align 6");  // (the loop is sensitive to where it sits; phase 0 behind a 64-byte boundary measured fastest of 0..7 in round 3: profiles/r03_ab_backward.txt)
 #ifdef QILQR_STAMPS
   unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev, real0;
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real0)::"memory");
@@ -1521,10 +1512,27 @@ __device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], d
 // MG_w: matrix AND gradient recursion of one trajectory in one wavefront (k_backward4<.., FUSED = true>): the arithmetic of the
 // one-wavefront kernel k_backward<true> -- gradient by three multiply-adds and two permlane butterflies, k solved in lane 12
 // with the lane's own factors, V_x = Q_x + K^T Q_u -- with its seven operands from the LDS ring the loader wave fills
-// (ring row w; no gradient wavefront, no hand-off of K and the factors).  Returns Q_u^T k summed over the knots.
-template <typename S, bool FREE = false>
+// (ring row w; no gradient wavefront, no hand-off of K and the factors; no block barrier in the knot loop: the loader tags
+// every ring slot it fills, the wave looks at the tag of its next record's slot before it reads the operands, every wait a
+// bounded spin).  Returns Q_u^T k summed over the knots.
+// The knot is SOFTWARE-PIPELINED around the six matrix instructions (round 4).  A lone wavefront issues in
+// order, and what profiles/r04_knot_anatomy.txt shows is a knot whose pieces simply add up (1640 cycles: 6 + 1 MFMA 500, the
+// 4x4 solve 300, tag check and operand reads 280, gather and broadcasts 140, stores / Q_u^T k / V_x / shuffles 140, ...): the
+// compiler issues T's three products back to back, then everything else.  But a chained v_mfma_f64_16x16x4_f64 cannot issue
+// before its predecessor has finished (64 cycles, mfma_chain.hip), and in between the wavefront is free to issue anything
+// that does not touch the tile -- so everything that is NOT on the chain V_xx -> T -> H -> gather -> solve -> V_xx is issued
+// in those gaps, one group behind each product, the groups held in place by scheduling barriers:
+//     T1 | V_x of the PREVIOUS knot (its K and Q_u are carried over)     T2 | its shuffles, Q_u^T k
+//     T3 | the previous knot's gain stores, H's start values             H1 | M^T V_x, three multiply-adds
+//     H2 | the two butterflies, Q_x / Q_u                                H3 | tag check, next operands from the ring, progress
+// then the chain's own part: row gather, Q_uu broadcasts, LDL^T, solve, operand select, V_xx.  The first knot carries zeros in
+// (V_x = 0, a store to the dump slot); the last knot's tail runs behind the loop.  Same arithmetic, same order of operations
+// per value as the round-3 loop.  (Measured, profiles/microbench/mfma_shadow.hip: between two chained products a wavefront's own
+// integer / move / DPP / permlane instructions cost 1.5-3 cycles each instead of 4-5; fp64 instructions hide nothing -- they
+// share the double-precision units with the products.)
+template <typename S>
 __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], const RecLayout &L, int w, bool run, S *gains, S *dump4,
-                                                double cuu, int n, int lane, int *prog = nullptr) {
+                                                          double cuu, int n, int lane, int *prog, unsigned long long *stamps_out = nullptr) {
   typedef typename GA<S>::v2 sv2;
   typedef typename GA<S>::ptr2 gptr2;
   __builtin_amdgcn_s_setprio(3);
@@ -1538,21 +1546,18 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
     else src = L.off_g + j;
     off[k] = (src >= 0) ? src : BW2_REC + (-1 - src);
   }
-  // gain slots of this lane: lanes (j < 12, kk = 0) own column j of K, lane (12, 0) owns k; the others write to the dump slot
   const bool gowner = run && (kk == 0 && j <= 12);
   const int ge0 = (j < 12) ? 4 + 4 * j : 0;
-  gptr2 gdst0 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0, 52) : dump4);
-  gptr2 gdst1 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0 + 2, 52) : dump4 + 2);
+  // the gains of a knot are stored one iteration late: st* = where the carried gains go (the dump slot in front of the first knot)
+  gptr2 st0 = (gptr2)dump4, st1 = (gptr2)(dump4 + 2);
+  gptr2 nx0 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0, 52) : dump4);
+  gptr2 nx1 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0 + 2, 52) : dump4 + 2);
   const long gstep = gowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
   double va[3] = {0.0, 0.0, 0.0};   // V_xx[j][4 kc + kk]  (A operand)
   double vxl[3] = {0.0, 0.0, 0.0};  // V_x[4 kc + kk]
   double QuTk = 0.0;
   __syncthreads();  // rings and constant tables are filled
-  if (!run) {
-    if constexpr (!FREE)
-      for (int i = n - 1; i >= 0; --i) __syncthreads();  // nothing to do in this round: keep the block's barriers company
-    return 0.0;
-  }
+  if (!run) return 0.0;
   double m[3], cx[3], gcj;
   {
     const double *buf = ring[w][(n - 1) & 3];
@@ -1560,51 +1565,79 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
     cx[0] = buf[off[3]]; cx[1] = buf[off[4]]; cx[2] = buf[off[5]];
     gcj = buf[off[6]];
   }
-  if constexpr (FREE) bw4_prog_post(prog, w, 1, lane);  // record 0 is in registers (the loader may reuse its slot)
-#ifndef QILQR_FUSED_PHASE
-#define QILQR_FUSED_PHASE 2  // s_nop s behind the 64-byte boundary in front of the knot loop (the loop is sensitive to where it sits: see bw4_matrix_wave); B = 1024, whole solves, builds interleaved: 0: 5.003 ms, 1: 4.982, 2: 4.967, 3: 5.012, 4: 4.986, 6: 5.003, 8: 4.999
+  bw4_prog_post(prog, w, 1, lane);  // record 0 is in registers (the loader may reuse its slot)
+  double kp[4] = {0.0, 0.0, 0.0, 0.0}, Qup[4] = {0.0, 0.0, 0.0, 0.0}, ghp = 0.0;  // the previous knot's K column, Q_u, Q_x
+#define QSB() __builtin_amdgcn_sched_barrier(0)
+  asm volatile(".p2align 6");
+  bool dead = false;
+#ifdef QILQR_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
-  asm volatile(".p2align 6\n\t.rept %0\n\ts_nop 0\n\t.endr" ::"n"(QILQR_FUSED_PHASE));
-  bool dead = false;  // (barrier-free form) the loader stopped answering: finish the loop unchecked, then report
   for (int i = n - 1; i >= 0; --i) {
     const double *nb = ring[w][(i > 0 ? i - 1 : 0) & 3];
-    double m_n0, m_n1, m_n2, cx_n0, cx_n1, cx_n2, g_n;
-    int tag = 0;
-    unsigned tag_addr = 0;
     const int slot_word = 8 + 4 * w + ((i > 0 ? i - 1 : 0) & 3), want = n - 1 - i + 1;
-    if constexpr (FREE) {
-      // requested in front of the three matrix instructions ...
-      // (an ordinary load: the compiler keeps count of it, wherever it moves or copies the register it lands in)
-      tag_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int *)&prog[slot_word];
-      tag = bw4_prog_read(prog, slot_word);
-      __builtin_amdgcn_sched_barrier(0);  // (the request stays here: 80.4 against 85.3 us per launch with all 1024 live)
-    } else {
-      m_n0 = nb[off[0]]; m_n1 = nb[off[1]]; m_n2 = nb[off[2]]; cx_n0 = nb[off[3]]; cx_n1 = nb[off[4]]; cx_n2 = nb[off[5]]; g_n = nb[off[6]];
+    const unsigned tag_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int *)&prog[slot_word];
+    int tag = bw4_prog_read(prog, slot_word);  // an ordinary load: the compiler keeps count of it
+    QSB();
+    d4 T = {0.0, 0.0, 0.0, 0.0};
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0], m[0], T, 0, 0, 0);
+    QSB();
+    // K^T Q_u of the previous knot: V_x = Q_x + K^T Q_u in every lane, and in lane 12 -- whose column is k and whose right-hand
+    // side was Q_u -- the same sum is Q_u^T k (one sum for both; nobody reads the other lanes' Q_u^T k)
+    const double ktq = kp[0] * Qup[0] + kp[1] * Qup[1] + kp[2] * Qup[2] + kp[3] * Qup[3];
+    const double vx = ghp + ktq;
+    QSB();
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1], m[1], T, 0, 0, 0);
+    QSB();
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) vxl[kc] = __shfl(vx, 4 * kc + kk);  // V_x[r] lives in lanes with j == r
+    QuTk += ktq;  // (lane 12's is Q_u^T k)
+    QSB();
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2], m[2], T, 0, 0, 0);
+    QSB();
+    {
+      const sv2 w0 = {(S)kp[0], (S)kp[1]}, w1 = {(S)kp[2], (S)kp[3]};
+      *st0 = w0;
+      *st1 = w1;
+      st0 = nx0; st1 = nx1;
+      nx0 -= gstep; nx1 -= gstep;
     }
-    const d4 T = bw_tile_T(va, m);
-    d4 H = bw_tile_H(m, T, cx, cuu);
-    // [Q_x ; Q_u] = [C_x ; C_u] + M^T V_x
-    double part = m[0] * vxl[0] + m[1] * vxl[1] + m[2] * vxl[2];
+    d4 H = {cx[0], cx[1], cx[2], cuu};
+    QKEEP(T[0]); QKEEP(vxl[0]); QKEEP(vxl[2]); QKEEP(QuTk);
+    QSTAMP(0);  // T (3 MFMA) with the previous knot's V_x, shuffles, Q_u^T k, stores in the gaps
+    QSB();
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
+    QSB();
+    double part = m[0] * vxl[0] + m[1] * vxl[1] + m[2] * vxl[2];  // [Q_x ; Q_u] = [C_x ; C_u] + M^T V_x
+    QSB();
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
+    QSB();
     part = xor16_sum(part);
     part = xor32_sum(part);
     const double ghat = gcj + part;
-    auto check_and_read = [&]() {
-  if constexpr (FREE) {
-        __builtin_amdgcn_sched_barrier(0);
-        // ... looked at behind them; the operand reads only behind that
-        int tag_s = __builtin_amdgcn_readfirstlane(tag);
-        if (__builtin_expect(i > 0 && want >= 2 && !dead && tag_s != want, 0)) {
-          int spins = 0;
-          do {
-            asm volatile("ds_read_b32 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, %0" : "=&v"(tag), "=s"(tag_s) : "v"(tag_addr) : "memory");
-            if (++spins > BW4_SPIN_MAX) dead = true;
-          } while (tag_s != want && !dead);
-        }
-        asm volatile("" ::: "memory");
-        m_n0 = nb[off[0]]; m_n1 = nb[off[1]]; m_n2 = nb[off[2]]; cx_n0 = nb[off[3]]; cx_n1 = nb[off[4]]; cx_n2 = nb[off[5]]; g_n = nb[off[6]];
+    QSB();
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
+    QKEEP(H[3]); QKEEP(ghat);
+    QSTAMP(1);  // H (3 MFMA) with M^T V_x and the butterflies in the gaps
+    QSB();
+    double m_n0, m_n1, m_n2, cx_n0, cx_n1, cx_n2, g_n;
+    {
+      int tag_s = __builtin_amdgcn_readfirstlane(tag);
+      if (__builtin_expect(i > 0 && want >= 2 && !dead && tag_s != want, 0)) {
+        int spins = 0;
+        do {
+          asm volatile("ds_read_b32 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, %0" : "=&v"(tag), "=s"(tag_s) : "v"(tag_addr) : "memory");
+          if (++spins > BW4_SPIN_MAX) dead = true;
+        } while (tag_s != want && !dead);
       }
-    };
-    check_and_read();
+      asm volatile("" ::: "memory");
+      m_n0 = nb[off[0]]; m_n1 = nb[off[1]]; m_n2 = nb[off[2]]; cx_n0 = nb[off[3]]; cx_n1 = nb[off[4]]; cx_n2 = nb[off[5]]; g_n = nb[off[6]];
+      bw4_prog_post(prog, w, n - 1 - i + 2, lane);  // (the LDS executes a wavefront's operations in order: behind the reads)
+    }
+    QKEEP(m_n0); QKEEP(g_n);
+    QSTAMP(2);  // tag check, next operands, progress
+    QSB();
     double Quu[16], Qu[4], col[4], rhs[4];
     gather_rows(H[3], col);
     bcast_quu_row<0>(col, ghat, Quu, Qu);
@@ -1613,46 +1646,37 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
     bcast_quu_row<3>(col, ghat, Quu, Qu);
 #pragma unroll
     for (int a = 0; a < 4; ++a) rhs[a] = (j == 12) ? Qu[a] : col[a];  // lane 12: feed-forward
+    QKEEP(rhs[0]); QKEEP(rhs[3]); QKEEP(Quu[15]);
+    QSTAMP(3);  // row gather, Q_uu / Q_u broadcasts, right-hand sides
     const Ldlt4 f4 = ldlt4_factor(Quu);
     double kcol[4];
     ldlt4_solve_neg(f4, rhs[0], rhs[1], rhs[2], rhs[3], kcol);  // K[:, j] (ilqr.hh:127); k in lane 12 (:128)
-    {
-      const sv2 w0 = {(S)kcol[0], (S)kcol[1]}, w1 = {(S)kcol[2], (S)kcol[3]};
-#ifdef QILQR_TIMING_NOSTORES  // timing-only build: the gains are written once, after the loop
-      if (i == 0) {
-#endif
-      *gdst0 = w0;
-      *gdst1 = w1;
-#ifdef QILQR_TIMING_NOSTORES
-      }
-#endif
-      gdst0 -= gstep;
-      gdst1 -= gstep;
-    }
-    QuTk += rhs[0] * kcol[0] + rhs[1] * kcol[1] + rhs[2] * kcol[2] + rhs[3] * kcol[3];  // (lane 12's sum is Q_u^T k)
-    const double vx = ghat + (kcol[0] * Qu[0] + kcol[1] * Qu[1] + kcol[2] * Qu[2] + kcol[3] * Qu[3]);  // V_x = Q_x + K^T Q_u
-#ifdef QILQR_FUSED_DPP_SHUFFLE  // experiment: V_x[4 kc + kk] by row broadcasts and a select instead of ds_bpermute (no LDS)
-    {
-      const double b0[4] = {row_bcast<0>(vx), row_bcast<1>(vx), row_bcast<2>(vx), row_bcast<3>(vx)};
-      const double b1[4] = {row_bcast<4>(vx), row_bcast<5>(vx), row_bcast<6>(vx), row_bcast<7>(vx)};
-      const double b2[4] = {row_bcast<8>(vx), row_bcast<9>(vx), row_bcast<10>(vx), row_bcast<11>(vx)};
-      vxl[0] = sel4(b0, kk); vxl[1] = sel4(b1, kk); vxl[2] = sel4(b2, kk);
-    }
-#else
-#pragma unroll
-    for (int kc = 0; kc < 3; ++kc) vxl[kc] = __shfl(vx, 4 * kc + kk);  // V_x[r] lives in lanes with j == r
-#endif
+    QKEEP(kcol[0]); QKEEP(kcol[3]);
+    QSTAMP(4);  // LDL^T and solve
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(H[3], sel4(kcol, kk), H, 0, 0, 0);  // V_xx = Q_xx + Q_xu K
 #pragma unroll
     for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
+    QKEEP(va[0]); QKEEP(va[2]);
+    QSTAMP(5);  // operand select, V_xx MFMA
     m[0] = m_n0; m[1] = m_n1; m[2] = m_n2;
     cx[0] = cx_n0; cx[1] = cx_n1; cx[2] = cx_n2;
     gcj = g_n;
-    if constexpr (FREE) bw4_prog_post(prog, w, n - 1 - i + 2, lane);
-    else __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { kp[a] = kcol[a]; Qup[a] = Qu[a]; }
+    ghp = ghat;
   }
-  if constexpr (FREE)
-    if (dead) bw4_prog_post(prog, 5, 1, lane);
+#undef QSB
+  {  // the last knot's tail
+    const sv2 w0 = {(S)kp[0], (S)kp[1]}, w1 = {(S)kp[2], (S)kp[3]};
+    *st0 = w0;
+    *st1 = w1;
+    QuTk += kp[0] * Qup[0] + kp[1] * Qup[1] + kp[2] * Qup[2] + kp[3] * Qup[3];
+  }
+#ifdef QILQR_STAMPS
+  if (lane == 0 && stamps_out)
+    for (int k = 0; k < 8; ++k) stamps_out[k] = stamp_sum[k];
+#endif
+  if (dead) bw4_prog_post(prog, 5, 1, lane);
   return bcast_lane(QuTk, 12);
 }
 
@@ -2006,14 +2030,7 @@ struct DevWave {
   template <int L> static __device__ __forceinline__ V bc(V x) { return __builtin_amdgcn_mov_dpp(x, 0x150 + L, 0xf, 0xf, false); }
   // acc + x[lane L of the row] * m
   template <int L> static __device__ __forceinline__ V fm(V acc, V src, V m) {
-#ifdef QILQR_R16_ASM_FMAC
-    // one v_fmac_f64_dpp; s_nop 1 = the two wait states a DPP read needs behind a VALU write of its source (the
-    // compiler does not see the DPP read inside the asm)
-    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(L));
-    return acc;
-#else
     return __builtin_fma(bc<L>(src), m, acc);
-#endif
   }
   // acc + sum_c src[lane L0 + c of the row] * m_c as a chain of v_fmac_f64_dpp (one instruction per term; the compiler
   // itself emits v_mov_b64_dpp + v_fma_f64, two).  The compiler's hazard recogniser does not look inside the asm, so the block
@@ -2474,6 +2491,34 @@ __global__ void k_gather(BatchState st, int B, int n, double *out_traj, double *
     if (out_n_bwd) out_n_bwd[row] = st.n_bwd[b];
     if (out_n_fwd) out_n_fwd[row] = st.n_fwd[b];
   }
+}
+// ILQRDebug on the device (ilqr.hh:78-80: one entry per completed forward pass, the accepted trajectory and its cost) for the
+// single-problem solve: launched behind every round's backward pass (whose settle step is where an iteration completes), one
+// block; when trajectory 0 has completed an iteration since the last look, its current trajectory -- in the buffer the next
+// rollout does not write -- and cost go to row `seen` of the ring, plain [n][18] layout.  No host round trip: the rounds stay
+// free-running and the ring is downloaded once, after the solve (round 4; round 3 synchronised every round and copied from
+// the host).
+template <typename S>
+__global__ void k_debug_capture(BatchState st, int n, double *dbg_trajs, double *dbg_cost, int *dbg_seen, int cap) {
+  __shared__ int s_seen;
+  if (threadIdx.x == 0) s_seen = *dbg_seen;
+  __syncthreads();
+  const int seen = s_seen, it = st.iters[0];
+  if (it <= seen) return;
+  if (seen < cap) {
+    typedef typename GA<S>::v2 sv2;
+    const S *t = (const S *)st.traj[st.cur[0]] + knot_base<true>(0, n, 18);
+    double *o = dbg_trajs ? dbg_trajs + (size_t)seen * n * 18 : nullptr;
+    if (o)
+      for (int kp = threadIdx.x; kp < n * 9; kp += blockDim.x) {
+        const int i = kp / 9, pr = kp - 9 * i;
+        const sv2 v = *reinterpret_cast<const sv2 *>(t + knot_elem<true>(i, 2 * pr, 18));
+        o[2 * kp] = (double)v.x;
+        o[2 * kp + 1] = (double)v.y;
+      }
+    if (threadIdx.x == 0 && dbg_cost) dbg_cost[seen] = st.cost[0];
+  }
+  if (threadIdx.x == 0) *dbg_seen = it;  // (every thread took `seen` from shared memory in front of the barrier's other side)
 }
 // The copy-back of a host-buffer batch solve in two parts (qilqr_solve_batch): k_mark_final, on the solver's stream between two
 // rounds, notes which trajectories have reached their exit status (nothing of theirs changes any more); those are gathered

@@ -603,9 +603,6 @@ struct TiledRecWriter {
   mutable T pend = T(0);
   mutable int pend_k = -1;  // the even entry that is waiting, or -1
   QILQR_HD void put(int k, T v) const {
-#ifdef QILQR_TIMING_SHRINK  // timing-only build (results garbage): entry pairs 32..45 are never written (a 530-byte record)
-    if ((k >> 1) >= 32) return;
-#endif
     if ((k & 1) == 0) {
       flush();
       pend = v;

@@ -31,19 +31,33 @@ def shard_of_step(rank, step, world):
     return (rank + step) % world
 
 
-_warmed_groups = set()
+import weakref
+
+_warmed_groups = weakref.WeakSet()  # process groups whose communicator exists (the objects themselves: an id() can be reused)
+_WORLD_ATTR = "_qilqr_rendezvous_done"
 
 
 def _first_call_rendezvous(t, group):
     """Once per process group: one tiny all-reduce that every rank enters.  The NCCL (RCCL) communicator of a group is
     created lazily by the first operation on it and every rank must take part in that creation; a ragged gather in
     which some shard is empty (B < world) is entered by the root and the non-empty ranks only, so without this the
-    first such call could wait for ranks that never come."""
-    key = id(group) if group is not None else None
-    if key in _warmed_groups:
-        return
+    first such call could wait for ranks that never come.  Keyed on the group OBJECT (the default group: on the object
+    torch.distributed holds for it, so destroy_process_group + a new init_process_group starts over)."""
+    g = group if group is not None else dist.distributed_c10d._get_default_group()
+    try:
+        if g in _warmed_groups:
+            return
+    except TypeError:  # (a group object that cannot be weakly referenced: fall back to an attribute on it)
+        if getattr(g, _WORLD_ATTR, False):
+            return
     dist.all_reduce(torch.zeros(1, dtype=torch.float32, device=t.device), group=group)
-    _warmed_groups.add(key)
+    try:
+        _warmed_groups.add(g)
+    except TypeError:
+        try:
+            setattr(g, _WORLD_ATTR, True)
+        except Exception:
+            pass  # (the rendezvous is then repeated on every call: correct, one small all-reduce slower)
 
 
 def gather_to_root(t, sizes, dst=0, group=None, out=None, shard_of_rank=None):
@@ -61,6 +75,9 @@ def gather_to_root(t, sizes, dst=0, group=None, out=None, shard_of_rank=None):
     if world == 1:
         return t
     rank = dist.get_rank(group)
+    # before anything that can raise on ONE rank: a rank that leaves here with an exception must not leave the others inside the
+    # all-reduce
+    _first_call_rendezvous(t, group)
     if shard_of_rank is None:
         shard_of_rank = list(range(world))
     if sorted(shard_of_rank) != list(range(world)):
@@ -72,7 +89,6 @@ def gather_to_root(t, sizes, dst=0, group=None, out=None, shard_of_rank=None):
     if t.shape[0] != sizes[mine]:
         raise ValueError(f"rank {rank} holds shard {mine} of {sizes[mine]} rows but passed {t.shape[0]}")
     t = t.contiguous()
-    _first_call_rendezvous(t, group)
     # ranks are ranks of `group` throughout; the point-to-point operations address their peers by global rank
     peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     if rank != dst:

@@ -115,3 +115,57 @@ def test_product_does_not_reference_the_oracle():
                     if re.search(r"ilqr_oracle|from oracle|import oracle|orc_", txt):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_gather_schedule_of_eight_distinct_devices_against_a_mock_table():
+    """The send / receive schedule of qilqr_solve_batch_sharded_device for EIGHT distinct devices (no such node in this pool:
+    the multi-rank RCCL path has not run on hardware) against a table worked out here from the documented rule -- contiguous
+    shards, the first B % shards one problem larger; a shard's device = its communicator rank; rows go from element 0 of the
+    shard's staging buffers to the shard's rows of the root's arrays; the four int32 arrays sit [4][count] in one staging
+    block -- for ragged batches, a root in the middle, repeated ordinals (two shards on one device share a rank), fewer
+    problems than shards, and a subset of the outputs.  No device is touched (qilqr_gather_schedule computes, nothing else)."""
+    def mock(B, n, devices, root, arrays):
+        uniq = []
+        for d in devices:
+            if d not in uniq:
+                uniq.append(d)
+        rank = [uniq.index(d) for d in devices]
+        k = len(devices)
+        rows = []
+        for r in range(k):
+            cnt = B // k + (1 if r < B % k else 0)
+            b0 = r * (B // k) + min(r, B % k)
+            if cnt == 0:
+                continue
+            if arrays & 1:
+                rows.append(dict(shard=r, array=0, src_rank=rank[r], dst_rank=rank[root], src_off=0, dst_off=b0 * n * 18, count=cnt * n * 18))
+            if arrays & 2:
+                rows.append(dict(shard=r, array=1, src_rank=rank[r], dst_rank=rank[root], src_off=0, dst_off=b0, count=cnt))
+            for q in range(4):
+                if arrays & (4 << q):
+                    rows.append(dict(shard=r, array=2 + q, src_rank=rank[r], dst_rank=rank[root], src_off=q * cnt, dst_off=b0, count=cnt))
+        return rows
+
+    cases = [(65536, 100, list(range(8)), 0, 63), (65537, 100, list(range(8)), 3, 63), (1000, 37, [7, 6, 5, 4, 3, 2, 1, 0], 7, 63),
+             (5, 10, list(range(8)), 2, 63), (4099, 50, [0, 1, 0, 1, 2, 2, 3, 3], 4, 63), (8192, 100, list(range(8)), 0, 1 | 2),
+             (777, 20, [0, 1, 2, 3, 4, 5, 6, 7], 5, 4 | 32)]
+    for B, n, devices, root, arrays in cases:
+        got = capi.gather_schedule(B, n, devices, root, arrays)
+        assert got == mock(B, n, devices, root, arrays), (B, n, devices, root, arrays)
+        # the pieces of one array tile the root's array exactly once, in shard order, and every rank is a device of the list
+        for a in range(6):
+            pcs = [p for p in got if p["array"] == a]
+            if not pcs:
+                continue
+            unit = n * 18 if a == 0 else 1
+            assert pcs[0]["dst_off"] == 0 and sum(p["count"] for p in pcs) == B * unit
+            for p, q in zip(pcs, pcs[1:]):
+                assert q["dst_off"] == p["dst_off"] + p["count"] and q["shard"] > p["shard"]
+        assert all(0 <= p["src_rank"] < len(set(devices)) and p["dst_rank"] == got[0]["dst_rank"] for p in got)
+    # the shard rule is the one-process-per-GPU rule (sharding.shard_range)
+    from quadrotorilqr_amd import sharding
+    for B, k in ((65537, 8), (5, 8), (1000, 3)):
+        sched = capi.gather_schedule(B, 1, list(range(k)), 0, 2)
+        assert [(p["dst_off"], p["dst_off"] + p["count"]) for p in sched] == [sharding.shard_range(B, r, k) for r in range(k) if sharding.shard_range(B, r, k)[1] > sharding.shard_range(B, r, k)[0]]
+    with pytest.raises(ValueError):
+        capi.gather_schedule(10, 5, [0, 1], root=2)

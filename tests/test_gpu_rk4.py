@@ -60,7 +60,7 @@ def test_rk4_solves_match_oracle(seed):
         o.set_regularisation(1.0, 4.0, 1e6)
     out = s.solve_batch(cfg["init"])
     ref = o.solve_batch(cfg["init"], n_threads=8)
-    assert_same_exit_paths(out, ref, allow=0.1)
+    assert_same_exit_paths(out, ref, o, cfg["init"])
     same = out["iters"] == ref["iters"]
     np.testing.assert_allclose(out["cost"][same], ref["cost"][same], rtol=1e-8)
     np.testing.assert_allclose(out["traj"][same], ref["traj"][same], atol=1e-6)
