@@ -52,8 +52,8 @@ FLOP_BWD_KNOT, FLOP_FWD_KNOT = 30000.0, 1250.0
 BYTES_BWD_KNOT, BYTES_FWD_KNOT, BYTES_IO_KNOT = 86 * 8.0, 103 * 8.0, 53 * 8.0
 # The PMC summary `roofline.traffic` is read from: named explicitly, and only used when its tag is this round's
 # (profiles/run_rocprof.sh <tag> writes profiles/<tag>_rocprof_summary.json from the same bench command).
-ROUND_TAG = "r03"
-TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r03i_rocprof_summary.json")
+ROUND_TAG = "r04"
+TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r04a_rocprof_summary.json")
 
 
 def kernel_table(prof, n_bwd_knots, n_fwd_knots):
@@ -125,6 +125,23 @@ def single_solve_leg(device, args):
         out[key] = {"ms_per_solve": float(np.median(ts)) * 1e3, "debug_entries": len(debug.iter_debugs)}
         if dbg:
             out["final_cost"] = float(debug.iter_debugs[-1].cost) if len(debug.iter_debugs) else None
+    # the same two calls at the C ABI (qilqr_solve through ctypes, arrays in and out): what the solver itself pays for the
+    # debug capture, without the protobuf encoding and parsing of 100 x 100 knots that the binding -- like the reference's
+    # pybind11_protobuf conversion -- adds on top
+    from quadrotorilqr_amd import capi
+    abi = {}
+    for key, dbg in (("populate_debug_on", True), ("populate_debug_off", False)):
+        sv = capi.from_config(dict(c0, options=dict(c0["options"], populate_debug=dbg)), device=device)
+        sv.solve(c0["desired"])
+        ts = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            _, info = sv.solve(c0["desired"])
+            ts.append(time.perf_counter() - t1)
+        abi[key] = {"ms_per_solve": float(np.median(ts)) * 1e3, "debug_entries": int(len(info["debug_costs"]))}
+        sv.close()
+    abi["debug_on_over_off"] = abi["populate_debug_on"]["ms_per_solve"] / abi["populate_debug_off"]["ms_per_solve"]
+    out["c_abi"] = abi
     ref = orc.OracleSolver(orc.model_params(**m), c0["Q"], c0["R"], c0["desired"], c0["dt"], orc.options(**c0["options"]))
     ts = []
     for _ in range(3):
@@ -174,6 +191,23 @@ def reference_faithful_leg(cfg, dev, default_cost, args):
                     "status_counts": np.bincount(st, minlength=4).tolist()}
         if key.startswith("symmetric"):
             out[key]["max_rel_cost_diff_vs_default_kernels"] = float(np.max(np.abs(cost - default_cost) / np.abs(default_cost)))
+        else:
+            # With Q != Q^T the reference's C_x = 2 J^T Q dx (cost.hh:47-52) is not the gradient of its own cost dx^T Q dx (that is
+            # J^T (Q + Q^T) dx): most of these solves -- in the oracle as here -- end in line-search exhaustion after 100 halvings of
+            # the step, where acceptance is decided by rounding noise, so whole solves cannot be compared problem by problem.  What
+            # is well posed is one pass: the backward pass of the first iterate against the oracle's, and the exit classes side by side.
+            ref_o = orc.OracleSolver(orc.model_params(**c["model"]), c["Q"], c["R"], c["desired"], c["dt"], orc.options(**c["options"]))
+            g, tm = sv.backwards_pass(c["init"][:8])
+            dg, dt_ = 0.0, 0.0
+            for b in range(8):
+                go, to = ref_o.backwards_pass(c["init"][b])
+                dg = max(dg, float(np.max(np.abs(g[b] - go)) / np.max(np.abs(go))))
+                dt_ = max(dt_, float(np.max(np.abs(tm[b] - to) / np.abs(to))))
+            out[key]["one_backward_pass_vs_oracle"] = {"problems": 8, "max_gain_diff_over_largest_gain": dg, "max_rel_diff_of_cost_reduction_terms": dt_}
+            out[key]["oracle_status_counts_on_sample"] = np.bincount(ref["status"], minlength=4).tolist()
+            out[key]["status_counts_on_sample"] = np.bincount(st[:sample], minlength=4).tolist()
+            out[key]["note"] = ("Q != Q^T: the reference's gradient 2 J^T Q dx is not its cost's gradient, line searches run to exhaustion in the oracle "
+                                "and here alike (status 3) and end on rounding noise; parity is stated for one backward pass")
         sv.close()
     out["what"] = (f"B = {B}, N = {cfg['init'].shape[1]}, device-resident, 5 repeats: k_backward<false> (one wavefront per trajectory, dense records, "
                    "Eigen's pivoted LDL^T, the reference's unsymmetrised V_xx) with the default rollout and linearisation kernels")
@@ -206,6 +240,10 @@ def main():
     ap.add_argument("--serving-batches", type=int, default=18)
     ap.add_argument("--no-host-to-host", action="store_true", help="skip the host-buffers-in / host-buffers-out measurement (never part of value)")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the B = 8192 measurement (never part of value)")
+    ap.add_argument("--rehearse-nccl", action="store_true",
+                    help="N = 1 only: initialise torch.distributed with the REAL nccl (RCCL) backend at world size 1 and send every step's results "
+                         "through gather_to_root's send / receive pair addressed to rank 0 itself -- the N > 1 line's communication calls, "
+                         "communicator creation and two-HIP-runtimes process on the one GPU of a test box (never the driver's default run)")
     ap.add_argument("--no-single-solve", action="store_true", help="skip the one-problem-per-call measurement through the binding (never part of value)")
     ap.add_argument("--no-reference-faithful", action="store_true", help="skip the force_general = 1 / non-symmetric-Q measurement (never part of value)")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP events around the kernels (roofline = null)")
@@ -231,6 +269,11 @@ def main():
         dist.init_process_group("gloo" if one_device_test else "nccl", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
+        if args.rehearse_nccl:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=0, world_size=1)
     dev = torch.device("cuda", local_rank if (world > 1 and not one_device_test) else 0)
     to_wire = (lambda t: t.cpu()) if one_device_test else (lambda t: t)  # gloo gathers host tensors
 
@@ -283,7 +326,8 @@ def main():
     out_cost = [torch.empty(B, dtype=torch.float64, device=dev) for _ in range(2)]
     out_i = [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(4)]  # status, iters, n_bwd, n_fwd
     # the gathered batch on rank 0, in global problem order, allocated once
-    if world > 1 and rank == 0:
+    rehearse = world == 1 and args.rehearse_nccl
+    if (world > 1 or rehearse) and rank == 0:
         wire_dev = torch.device("cpu") if one_device_test else dev
         g_traj = torch.empty((B_total, N, 18), dtype=torch.float64, device=wire_dev)
         g_cost = torch.empty(B_total, dtype=torch.float64, device=wire_dev)
@@ -298,8 +342,8 @@ def main():
 
     def gather(k, step):
         sor = shard_at(step)
-        sharding.gather_to_root(to_wire(out_traj[k]), sizes, out=g_traj, shard_of_rank=sor)
-        sharding.gather_to_root(to_wire(out_cost[k]), sizes, out=g_cost, shard_of_rank=sor)
+        sharding.gather_to_root(to_wire(out_traj[k]), sizes, out=g_traj, shard_of_rank=sor, rehearse_self=rehearse)
+        sharding.gather_to_root(to_wire(out_cost[k]), sizes, out=g_cost, shard_of_rank=sor, rehearse_self=rehearse)
 
     def step():
         k = step_no[0] & 1
@@ -312,14 +356,14 @@ def main():
         if count_passes[0] and world > 1:  # rotating shards: the pass counts differ from step to step
             pass_knots.add_(torch.stack([out_i[2].sum(), out_i[3].sum()]).to(torch.float64))
             shard_rounds[sh] = torch.maximum(shard_rounds[sh], out_i[3].max())
-        if world > 1:  # the one exchange of the path: converged trajectories to rank 0
+        if world > 1 or rehearse:  # the one exchange of the path: converged trajectories to rank 0
             gather(k, step_no[0])
             gathered[k] = torch.cuda.Event()
             gathered[k].record()
         step_no[0] += 1
 
     def fence():
-        if world > 1:
+        if world > 1 or rehearse:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -635,9 +679,15 @@ def main():
             "same_shard": same_shard,
             "roofline": roofline, "cpu_baseline": cpu, "host_to_host": h2h, "large_batch": large, "serving": serving,
             "single_solve": single, "reference_faithful": faithful,
+            **({"rehearse_nccl": {"backend": dist.get_backend(), "world_size": 1,
+                                  "what": "every step's trajectories and costs sent to rank 0 itself through gather_to_root (ncclSend + ncclRecv in one group)"}}
+               if rehearse else {}),
         }
         print(json.dumps(line))
-    if world > 1:
+    if rehearse and rank == 0:  # the rows that went through RCCL are the rows that were sent
+        k = (step_no[0] - 1) & 1
+        assert torch.equal(g_traj, out_traj[k]) and torch.equal(g_cost, out_cost[k]), "rehearsal: gathered rows differ from the solver's"
+    if world > 1 or rehearse:
         dist.barrier()
         dist.destroy_process_group()
 

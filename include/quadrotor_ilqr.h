@@ -119,6 +119,12 @@ typedef struct {
                          2 = never (the same as 0 today) */
 } qilqr_device_config;
 
+/* One arithmetic at every batch size: the fused k_backward4 and k_rollout16 (with the tiled knot records they read) are forced,
+ * so that a problem's result does not depend on the size of the batch it is solved in, on sharding, or on sub-batch streams
+ * (the reference is trivially batching-independent: it solves one problem per call).  Costs throughput above 4096 trajectories
+ * per call, where the automatic choice takes kernels built for a full chip. */
+#define QILQR_PIN_ARITHMETIC(cfg) do { (cfg).force_general = 5; (cfg).single_wave_rollout = 3; } while (0)
+
 /* A handle owns its device workspace and stream: use it from one thread at a time (different handles are
  * independent; the reference's ILQR object is const and re-entrant). */
 typedef struct qilqr_solver qilqr_solver;
@@ -245,8 +251,14 @@ void qilqr_host_free(void *p);
  * quadrotorilqr_amd/sharding.py for the one-process-per-GPU deployment) -- and solves shard r on devices[r] from a host
  * thread of its own: its input slice goes to the device, its results come back into the caller's arrays at the shard's
  * offset (the "gather" is the copy back itself: ragged shards need no padding), the call returns when every shard has.
- * Arguments and results are those of qilqr_solve_batch, problem by problem bit-identical to a single-device solve of the
- * same batch.  A shard that fails makes the call return its error (the lowest failing shard's; text through
+ * Arguments and results are those of qilqr_solve_batch.  Problem by problem they are bit-identical to a single-device solve
+ * of the same batch WHEN SHARD AND WHOLE BATCH FALL IN THE SAME KERNEL REGIME: with the automatic choices (force_general = 0,
+ * single_wave_rollout = 0) the kernels go by the number of trajectories a call has in flight on its device (backward pass:
+ * up to 4096 / up to 8192 / beyond; rollout: up to 4096 / up to 16384 / beyond), the regimes sum M^T V_x and evaluate the
+ * rollout in different orders, and the same problem then differs in the last bits (about 2e-15 relative per pass) between,
+ * say, a batch of 65536 and its eight shards of 8192 -- the exit path of a problem that sits within rounding of a
+ * convergence threshold can differ with them.  QILQR_PIN_ARITHMETIC (below) makes every call use ONE kernel family whatever
+ * the batch size: a problem's bits then do not depend on how the caller batches or shards it.  A shard that fails makes the call return its error (the lowest failing shard's; text through
  * qilqr_last_error, prefixed with the shard and device); the other shards still complete. */
 typedef struct qilqr_sharded qilqr_sharded;
 /* dev: as for qilqr_create, its `device` field is ignored (NULL = defaults) */

@@ -10,7 +10,7 @@ set -u
 # The three runs profile configs[1] alone: bench.py's extra legs (several batches in flight, host buffers, B = 8192) lie
 # outside its timed region, run other batch sizes through other kernel variants, and would blur every per-kernel row.
 TAG=${1:-r01}; shift || true
-set -- --no-serving --no-host-to-host --no-large-batch "$@"
+set -- --no-serving --no-host-to-host --no-large-batch --no-single-solve --no-reference-faithful "$@"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

@@ -497,6 +497,9 @@ def host_array(shape, dtype=np.float64):
     return a
 
 
+PIN_ARITHMETIC = dict(force_general=5, single_wave_rollout=3)  # QILQR_PIN_ARITHMETIC of the header: one kernel family at every batch size
+
+
 def from_config(cfg, **kw):
     """Build a solver from a quadrotorilqr_amd.problems config dict."""
     m = cfg["model"]

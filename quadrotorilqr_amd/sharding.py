@@ -60,7 +60,7 @@ def _first_call_rendezvous(t, group):
             pass  # (the rendezvous is then repeated on every call: correct, one small all-reduce slower)
 
 
-def gather_to_root(t, sizes, dst=0, group=None, out=None, shard_of_rank=None):
+def gather_to_root(t, sizes, dst=0, group=None, out=None, shard_of_rank=None, rehearse_self=False):
     """Gather per-rank tensors on rank `dst` (a rank of `group`) in SHARD order.
 
     t              this rank's shard: first dimension = the size of the shard it holds
@@ -69,10 +69,27 @@ def gather_to_root(t, sizes, dst=0, group=None, out=None, shard_of_rank=None):
                    (shard_of_step) pass [shard_of_step(r, step, world) for r in range(world)], so that the
                    result is in global problem order whatever rank solved which shard
     out            optional preallocated result on the root (sum(sizes) rows), reused between calls
+    rehearse_self  world size 1 only: instead of returning t, send it to this rank itself through the backend (see below)
 
     Returns the gathered tensor on the root (rows of shard k at offset sum(sizes[:k])) and None elsewhere."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
+        if rehearse_self and dist.is_initialized():
+            # A rehearsal of the N > 1 path where only one GPU exists (bench.py --rehearse-nccl, tests/test_gpu_bench_contract.py):
+            # the group's communicator is created (first-call all-reduce) and the shard travels through ONE batched
+            # send / receive pair addressed to this rank itself -- under the nccl backend ncclSend + ncclRecv in one group on
+            # torch's RCCL, in the process that also runs the solver's HIP library -- into the rows `out` reserves for it.
+            _first_call_rendezvous(t, group)
+            t = t.contiguous()
+            if out is None:
+                out = torch.empty_like(t)
+            if dist.get_backend(group) == "gloo":  # (gloo has no pair from a rank to itself: the CPU tests get the rendezvous and a copy)
+                out[:t.shape[0]].copy_(t)
+                return out
+            me = dist.get_rank(group) if group is None else dist.get_global_rank(group, dist.get_rank(group))
+            for wk in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, me, group), dist.P2POp(dist.irecv, out[:t.shape[0]], me, group)]):
+                wk.wait()
+            return out
         return t
     rank = dist.get_rank(group)
     # before anything that can raise on ONE rank: a rank that leaves here with an exception must not leave the others inside the

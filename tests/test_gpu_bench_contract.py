@@ -110,3 +110,28 @@ def test_config3_strong_scaling_code_path_on_one_gpu():
     assert abs(j["value"] - 2050 * 1e3 / j["ms_per_step"]) / j["value"] < 1e-6
     assert "configs[3]" in j["config"]["workload"] and j["gather_ms"] > 0
     assert j["status_counts"][2] == 0 and j["status_counts"][3] == 0
+
+
+@pytest.mark.gpu
+def test_real_nccl_backend_at_world_size_one():
+    """The N > 1 line of bench.py runs over torch's RCCL (backend "nccl"), which no test could execute on a one-GPU box
+    (the two-rank tests above swap in gloo).  --rehearse-nccl runs the N = 1 workload with init_process_group("nccl") at world
+    size 1, launched the way the driver launches N > 1 (torch.distributed.run, before anything touches the GPU): communicator
+    creation by the first-call all-reduce, every step's results through gather_to_root's batched ncclSend / ncclRecv pair
+    addressed to rank 0 itself, barriers, HSA_ENABLE_IPC_MODE_LEGACY=0, and torch's HIP runtime beside the solver library's in
+    one process.  bench.py itself asserts that the rows that came back are the rows the solver wrote."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--steps", "3", "--warmup", "1", "--rehearse-nccl", "--no-serving", "--no-large-batch",
+                          "--no-host-to-host", "--no-single-solve", "--no-reference-faithful", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["rehearse_nccl"]["backend"] == "nccl" and j["value"] > 10000

@@ -723,11 +723,8 @@ def test_mixed_precision_at_headline_size():
     np.testing.assert_allclose(a["traj"], b["traj"], atol=1e-4)
 
 
-@pytest.mark.parametrize("seed", range(12))
-def test_randomised_models_and_horizons_match_oracle(seed, restarts=False, persistent=0):
-    """Random physical parameters (mass, SPD inertia, arm, rotor torque ratio, gravity), time step,
-    horizon, weights (diagonal / block-diagonal dense / fully dense symmetric, by seed) and option values;
-    random SE(3) starts towards a random hover pose."""
+def randomised_cfg(seed, restarts=False):
+    """the problem of test_randomised_models_and_horizons_match_oracle(seed): (cfg, Levenberg-Marquardt schedule or None)"""
     r = np.random.default_rng(1000 + seed)
     A = r.uniform(-0.3, 0.3, (3, 3))
     model = dict(mass_kg=r.uniform(0.5, 3.0), inertia=A @ A.T + np.diag(r.uniform(0.5, 2.0, 3)),
@@ -760,6 +757,16 @@ def test_randomised_models_and_horizons_match_oracle(seed, restarts=False, persi
         opts["ls_max_iters"] = int(r.integers(1, 4))
         reg = (float(r.choice([0.1, 1.0, 10.0])), float(r.choice([2.0, 4.0, 10.0])), float(r.choice([1e3, 1e6])))
     cfg = dict(model=model, Q=Q, R=R, dt=dt, options=opts, desired=desired, init=init)
+    return cfg, reg
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_models_and_horizons_match_oracle(seed, restarts=False, persistent=0):
+    """Random physical parameters (mass, SPD inertia, arm, rotor torque ratio, gravity), time step,
+    horizon, weights (diagonal / block-diagonal dense / fully dense symmetric, by seed) and option values;
+    random SE(3) starts towards a random hover pose."""
+    cfg, reg = randomised_cfg(seed, restarts)
+    init = cfg["init"]
     s, o = (capi_diag() if persistent == 1 else capi).from_config(cfg, persistent=persistent), oracle_for(cfg)
     if reg:
         s.set_regularisation(*reg)

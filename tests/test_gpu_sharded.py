@@ -173,3 +173,27 @@ def test_plain_c_host_gathers_over_rccl():
         assert j["bit_identical"] is True and j["transport"].startswith(said) and j["shards"] == 3 and j["converged"] == 1536
         assert 0 <= j["gather_ms_best_of_3"] < 100
         print(j)
+
+
+def test_pinned_arithmetic_gives_batching_independent_bits():
+    """QILQR_PIN_ARITHMETIC (include/quadrotor_ilqr.h; capi.PIN_ARITHMETIC): with the fused k_backward4 and k_rollout16 forced,
+    a problem's result is the same bits whether it is solved in a batch of 4500 (beyond the 4096 at which the automatic
+    choice changes kernels), in slices of 1500, 300 or alone, through sub-batch streams, or sharded -- which the automatic
+    choice does not promise (the regimes differ in the last bits)."""
+    cfg = pb.config2(B=4500, N=24, seed=12)
+    whole = capi.from_config(cfg, **capi.PIN_ARITHMETIC).solve_batch(cfg["init"])
+    assert np.isin(whole["status"], [0, 1]).all()
+    keys = ("traj", "cost", "status", "iters", "n_bwd", "n_fwd")
+    for lo, hi in ((0, 1500), (1500, 3000), (3000, 4500), (4100, 4400), (17, 18), (4499, 4500)):
+        part = capi.from_config(cfg, **capi.PIN_ARITHMETIC).solve_batch(cfg["init"][lo:hi])
+        for k in keys:
+            np.testing.assert_array_equal(part[k], whole[k][lo:hi], err_msg=f"{k} [{lo}:{hi}]")
+    streams = capi.from_config(cfg, streams=3, **capi.PIN_ARITHMETIC).solve_batch(cfg["init"])
+    sh = capi.sharded_from_config(cfg, devices=(0, 0, 0), **capi.PIN_ARITHMETIC).solve_batch(cfg["init"])
+    for k in keys:
+        np.testing.assert_array_equal(streams[k], whole[k], err_msg=k)
+        np.testing.assert_array_equal(sh[k], whole[k], err_msg=k)
+    # and the automatic choice across the 4096 boundary is NOT bit-identical in general (same results to rounding)
+    auto_whole = capi.from_config(cfg).solve_batch(cfg["init"])
+    auto_part = capi.from_config(cfg).solve_batch(cfg["init"][:1500])
+    np.testing.assert_allclose(auto_part["cost"], auto_whole["cost"][:1500], rtol=1e-9)

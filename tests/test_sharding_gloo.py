@@ -123,3 +123,43 @@ def test_gather_inside_a_subgroup_addresses_peers_by_global_rank():
         p.join(timeout=180)
         assert p.exitcode == 0
     np.testing.assert_array_equal(got, np.arange(5, dtype=np.float64).reshape(-1, 1) * 10.0)
+
+
+def _self_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    t = torch.arange(5 * 4 * 18, dtype=torch.float64).reshape(5, 4, 18)
+    out = torch.full((5, 4, 18), float("nan"), dtype=torch.float64)
+    got = sharding.gather_to_root(t, [5], out=out, rehearse_self=True)          # through the backend, to this rank itself
+    plain = sharding.gather_to_root(t, [5])                                     # the ordinary world-size-1 answer: t
+    again = sharding.gather_to_root(t * 2, [5], out=out, rehearse_self=True)    # the communicator exists: no second rendezvous
+    ok = got is out and plain is t and torch.equal(again, t * 2)
+    # a new default group after destroy_process_group is rendezvoused again (the key is the group object)
+    g0 = dist.distributed_c10d._get_default_group()
+    warmed = g0 in sharding._warmed_groups
+    dist.destroy_process_group()
+    os.environ["MASTER_PORT"] = str(port + 1)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    fresh = dist.distributed_c10d._get_default_group() not in sharding._warmed_groups
+    sharding.gather_to_root(t, [5], out=out, rehearse_self=True)
+    q.put((ok, bool(torch.equal(out, t)), warmed, fresh, dist.distributed_c10d._get_default_group() in sharding._warmed_groups))
+    dist.destroy_process_group()
+
+
+def test_world_size_one_rehearsal_sends_the_shard_to_itself_through_the_backend():
+    """bench.py --rehearse-nccl (tests/test_gpu_bench_contract.py runs it over RCCL on the GPU box): the world-size-1 gather
+    with rehearse_self goes through the process group -- first-call rendezvous, one batched send / receive pair to this rank --
+    and lands in the rows of `out`; here over gloo.  And the rendezvous bookkeeping follows the group OBJECT: a process
+    group created after destroy_process_group is warmed again."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_self_worker, args=(port, q))
+    p.start()
+    res = q.get(timeout=120)
+    p.join(60)
+    assert res == (True, True, True, True, True), res
