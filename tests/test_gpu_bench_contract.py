@@ -41,6 +41,19 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     h = j["host_to_host"]
     assert h["unit"] == "solves/s" and 0 < h["value"] < j["value"] * 1.05 and h["parity_with_device_path"] is True
     assert h["bytes_in"] == 1024 * 100 * 18 * 8 and h["pageable_buffers"]["value"] > 0
+    # (medians of interleaved calls, first of the extra legs: pinned buffers are not slower than pageable ones, and the host-buffer
+    # call costs more than the device-resident call of the same moment, by less than a millisecond)
+    assert h["ms_per_solve"] <= h["pageable_buffers"]["ms_per_solve"] * 1.02
+    assert 0.0 < h["over_device_resident_ms"] < 1.0 and h["ms_p90"] >= h["ms_per_solve"]
+    # the reference's own call pattern (one problem per call through the binding) and the reference-faithful kernel are on the line
+    ss, rf = j["single_solve"], j["reference_faithful"]
+    assert ss["populate_debug_on"]["debug_entries"] == 100 and ss["populate_debug_off"]["debug_entries"] == 0
+    assert ss["c_abi"]["debug_on_over_off"] < 1.10, ss["c_abi"]          # the device-side debug ring: within 10 % of debug off
+    assert abs(ss["final_cost"] - ss["cpu_oracle_one_core"]["final_cost"]) / ss["final_cost"] < 1e-3   # (configs[0] is chaotic: DESIGN.md section 2)
+    f1 = rf["symmetric_weights_force_general_1"]
+    assert f1["max_rel_cost_diff_vs_oracle"] < 1e-9 and f1["same_status_iters_as_oracle"] == f1["oracle_sample"]
+    assert f1["value"] * 3.0 > j["value"]                              # (not more than 3 x slower than the default kernels)
+    assert rf["non_symmetric_Q"]["one_backward_pass_vs_oracle"]["max_gain_diff_over_largest_gain"] < 1e-9
     # the saturated machine: B = 8192 in the same run, per-kernel launch times and roofline fractions
     lb = j["large_batch"]
     assert lb["value"] > j["value"] and lb["status_counts"][2] == 0 and lb["status_counts"][3] == 0
