@@ -488,9 +488,11 @@ def main():
                 "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
                 "flops": {"achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS},
                 **({"note": "k_backward_rollout = the backward pass and the rollout of a round in one launch (up to 1024 trajectories); its "
-                            "work is both passes' algorithmic flops, its time both serial chains.  Launched apart "
-                            "(QILQR_FUSE_BACKWARD_ROLLOUT=0) the backward kernel alone runs at 20.6 % of the fp64 peak (68.9 us per launch) and "
-                            "the rollout at 51.8 us: profiles/r03f_rocprof_summary.txt"} if dom == "k_backward_rollout" else {}),
+                            "work is both passes' algorithmic flops, its time both serial chains (the rollout's has no matrix work).  Launched apart "
+                            "(QILQR_FUSE_BACKWARD_ROLLOUT=0) the backward kernel alone ran at 20.6 % of the fp64 peak in round 3 (68.9 us per launch, "
+                            "profiles/r03f_rocprof_summary.txt; 67.2 us with one live wavefront per block since round 4's pipelined knot, "
+                            "profiles/r04_knot_anatomy.txt) and the rollout at 51.8 us.  The numerator is the reference's dense-as-written 30 kflop "
+                            "per backward knot; the kernel issues 7 x 2048 flop of MFMA + ~68 fp64 vector instructions per knot"} if dom == "k_backward_rollout" else {}),
                 "kernels_ms": {k: round(v["ms"], 3) for k, v in kern.items()}
                               | {"k_linearize": round(prof["linearize_ms"], 3), "other": round(prof["other_ms"], 3)},
                 "warmup_avg_launch_us": {k: round(calib[k + "_ms"] * 1e3 / max(calib[k + "_launches"], 1), 2)
