@@ -1581,6 +1581,9 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
     int tag = bw4_prog_read(prog, slot_word);  // an ordinary load: the compiler keeps count of it
     QSB();
     d4 T = {0.0, 0.0, 0.0, 0.0};
+    d4 H;
+    double Quu[16], Qu[4], col[4], rhs[4], ghat, h3;
+    double m_n0, m_n1, m_n2, cx_n0, cx_n1, cx_n2, g_n;
     T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0], m[0], T, 0, 0, 0);
     QSB();
     // K^T Q_u of the previous knot: V_x = Q_x + K^T Q_u in every lane, and in lane 12 -- whose column is k and whose right-hand
@@ -1603,25 +1606,26 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
       st0 = nx0; st1 = nx1;
       nx0 -= gstep; nx1 -= gstep;
     }
-    d4 H = {cx[0], cx[1], cx[2], cuu};
+    H = d4{cx[0], cx[1], cx[2], cuu};
     QKEEP(T[0]); QKEEP(vxl[0]); QKEEP(vxl[2]); QKEEP(QuTk);
     QSTAMP(0);  // T (3 MFMA) with the previous knot's V_x, shuffles, Q_u^T k, stores in the gaps
     QSB();
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
+    // (the kc = 2 product first: rows 12..15 of H -- result register 3 -- receive nothing from the other two, J_u being zero in
+    // rows 0..7, so the register is final one product early; the order is part of the arithmetic: every build adds in it)
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
     QSB();
     double part = m[0] * vxl[0] + m[1] * vxl[1] + m[2] * vxl[2];  // [Q_x ; Q_u] = [C_x ; C_u] + M^T V_x
     QSB();
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
     QSB();
     part = xor16_sum(part);
     part = xor32_sum(part);
-    const double ghat = gcj + part;
+    ghat = gcj + part;
     QSB();
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
     QKEEP(H[3]); QKEEP(ghat);
     QSTAMP(1);  // H (3 MFMA) with M^T V_x and the butterflies in the gaps
     QSB();
-    double m_n0, m_n1, m_n2, cx_n0, cx_n1, cx_n2, g_n;
     {
       int tag_s = __builtin_amdgcn_readfirstlane(tag);
       if (__builtin_expect(i > 0 && want >= 2 && !dead && tag_s != want, 0)) {
@@ -1638,8 +1642,8 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
     QKEEP(m_n0); QKEEP(g_n);
     QSTAMP(2);  // tag check, next operands, progress
     QSB();
-    double Quu[16], Qu[4], col[4], rhs[4];
     gather_rows(H[3], col);
+    h3 = H[3];
     bcast_quu_row<0>(col, ghat, Quu, Qu);
     bcast_quu_row<1>(col, ghat, Quu, Qu);
     bcast_quu_row<2>(col, ghat, Quu, Qu);
@@ -1653,7 +1657,7 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
     ldlt4_solve_neg(f4, rhs[0], rhs[1], rhs[2], rhs[3], kcol);  // K[:, j] (ilqr.hh:127); k in lane 12 (:128)
     QKEEP(kcol[0]); QKEEP(kcol[3]);
     QSTAMP(4);  // LDL^T and solve
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(H[3], sel4(kcol, kk), H, 0, 0, 0);  // V_xx = Q_xx + Q_xu K
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(h3, sel4(kcol, kk), H, 0, 0, 0);  // V_xx = Q_xx + Q_xu K (A = rows 12..15 of H)
 #pragma unroll
     for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
     QKEEP(va[0]); QKEEP(va[2]);
