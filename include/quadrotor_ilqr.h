@@ -117,6 +117,14 @@ typedef struct {
                          0 = the rounds of three launches at every batch size (by measurement they are level or ahead at every size
                          but one, DESIGN.md section 4: the library never selects the one-launch solve by itself), 1 = always k_solve4,
                          2 = never (the same as 0 today) */
+  int32_t compaction; /* (ABI version 6) device-resident batch solves with sync_every > 1: between a round's backward pass and its
+                         rollout the trajectories still running are moved into a dense prefix of the workspace, the finished
+                         ones they replace leaving for the caller's result arrays at once -- a batch takes as many rounds as its
+                         slowest problem and the kernels hand out work in groups of 4 and 64 trajectories that cost the same
+                         with one running as with all.  Results are bit-identical with and without.  0 = automatic (from 4096
+                         trajectories per call, while more than 512 are running), 1 = at every size and count the call allows
+                         (not with populate_debug's cost history, per-problem desired trajectories, or the copy-back under the
+                         tail of qilqr_solve_batch), -1 = never */
 } qilqr_device_config;
 
 /* One arithmetic at every batch size: the fused k_backward4 and k_rollout16 (with the tiled knot records they read) are forced,
@@ -320,6 +328,9 @@ int qilqr_gather_schedule(int32_t B, int32_t n, const int32_t *devices, int32_t 
                           int64_t *out, int32_t cap);
 
 /* ABI version of this header */
+/* trajectories moved by the compaction (qilqr_device_config.compaction) in the last batch solve of this handle; 0 when it was
+ * off for that call.  Waits for the handle's stream. */
+int qilqr_compaction_moves(qilqr_solver *s, int64_t *moves);
 int qilqr_abi_version(void);
 
 #ifdef __cplusplus

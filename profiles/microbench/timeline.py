@@ -26,7 +26,7 @@ for r in rows:
         cur = []
     cur.append(r)
 solves.append(cur)
-for si, sv in enumerate(solves[-3:]):
+for si, sv in enumerate(solves[-int(os.environ.get('TIMELINE_SOLVES', '3')):]):
     t0, t1 = sv[0][0], max(r[1] for r in sv)
     busy = defaultdict(float)
     cnt = defaultdict(int)

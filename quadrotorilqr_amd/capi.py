@@ -42,7 +42,7 @@ EXPORTS = (
     "qilqr_sharded_create", "qilqr_sharded_create_mask", "qilqr_sharded_destroy", "qilqr_sharded_count", "qilqr_sharded_solver",
     "qilqr_shard_range", "qilqr_solve_batch_sharded",
     "qilqr_sharded_set_transport", "qilqr_sharded_transport", "qilqr_solve_batch_sharded_device", "qilqr_gather_schedule",
-    "qilqr_abi_version",
+    "qilqr_abi_version", "qilqr_compaction_moves",
 )
 
 
@@ -60,7 +60,7 @@ class Options(C.Structure):
 class DeviceConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("profile", C.c_int32), ("sync_every", C.c_int32),
                 ("force_general", C.c_int32), ("single_wave_rollout", C.c_int32), ("precision", C.c_int32),
-                ("streams", C.c_int32), ("persistent", C.c_int32)]
+                ("streams", C.c_int32), ("persistent", C.c_int32), ("compaction", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -128,7 +128,7 @@ def _raise(rc, ls_max_iters=None):
 
 
 def _create_args(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired, options, device, profile,
-                 sync_every, force_general, single_wave_rollout, precision, streams, persistent):
+                 sync_every, force_general, single_wave_rollout, precision, streams, persistent, compaction=0):
     """the C structures of qilqr_create / qilqr_sharded_create; sets self.options and self.desired"""
     m = Model()
     m.mass_kg = mass_kg
@@ -154,7 +154,7 @@ def _create_args(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m,
     self.options = dict(options)
     self.desired = _d(desired).reshape(-1, KNOT)
     dc = DeviceConfig(int(device), int(profile), int(sync_every), int(force_general),
-                      int(single_wave_rollout), {"f64": 0, "f32": 1}[precision], int(streams), int(persistent))
+                      int(single_wave_rollout), {"f64": 0, "f32": 1}[precision], int(streams), int(persistent), int(compaction))
     return m, Q, R, o, dc
 
 
@@ -176,10 +176,10 @@ class QuadrotorILQRBatch:
 
     def __init__(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired,
                  dt_s, options, device=0, profile=0, sync_every=2, force_general=False,
-                 single_wave_rollout=False, precision="f64", streams=0, persistent=0):
+                 single_wave_rollout=False, precision="f64", streams=0, persistent=0, compaction=0):
         lib = load()
         m, Q, R, o, dc = _create_args(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired, options,
-                                      device, profile, sync_every, force_general, single_wave_rollout, precision, streams, persistent)
+                                      device, profile, sync_every, force_general, single_wave_rollout, precision, streams, persistent, compaction)
         self._h = C.c_void_p()
         rc = lib.qilqr_create(C.byref(m), _p(Q), _p(R), _p(self.desired), C.c_int32(len(self.desired)),
                               C.c_double(dt_s), C.byref(o), C.byref(dc), C.byref(self._h))
@@ -344,6 +344,14 @@ class QuadrotorILQRBatch:
         if rc:
             _raise(rc)
 
+    def compaction_moves(self):
+        """trajectories the compaction moved in the last batch solve (qilqr_compaction_moves)"""
+        m = C.c_int64()
+        rc = load().qilqr_compaction_moves(self._h, C.byref(m))
+        if rc:
+            _raise(rc)
+        return m.value
+
     def set_regularisation(self, mu_init, mu_factor=10.0, mu_max=1e6):
         """Levenberg-Marquardt restarts (an extension the reference lacks; mu_init = 0 switches it off):
         see qilqr_set_regularisation in include/quadrotor_ilqr.h"""
@@ -375,10 +383,10 @@ class QuadrotorILQRSharded:
 
     def __init__(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired, dt_s, options,
                  devices=(0,), profile=0, sync_every=2, force_general=False, single_wave_rollout=False, precision="f64",
-                 streams=0, persistent=0):
+                 streams=0, persistent=0, compaction=0):
         lib = load()
         m, Q, R, o, dc = _create_args(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired, options,
-                                      0, profile, sync_every, force_general, single_wave_rollout, precision, streams, persistent)
+                                      0, profile, sync_every, force_general, single_wave_rollout, precision, streams, persistent, compaction)
         self.devices = [int(d) for d in devices]
         arr = (C.c_int32 * len(self.devices))(*self.devices)
         self._h = C.c_void_p()

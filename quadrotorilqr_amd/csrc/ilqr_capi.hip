@@ -109,6 +109,11 @@ struct qilqr_solver {
   unsigned prof_seen[K_KINDS] = {0, 0, 0, 0, 0};  // launches of each kind seen by the sampler
   int prof_n[K_KINDS] = {0, 0, 0, 0, 0};
   int num_cus = 256;  // compute units of the device (grid of the persistent solve)
+  // compaction of the live trajectories (k_compact_plan / k_compact_move): on for the duration of a device-resident batch
+  // solve that qualifies (compaction_for_call), with the caller's result arrays for the trajectories that leave early
+  bool compact = false;
+  qilqr::CompactOut compact_out{};
+  std::vector<long> plan_heads;  // where the plans of the last batch solve's (sub-)batches start in st.plan (qilqr_debug_compaction_moves)
 };
 
 namespace {
@@ -236,6 +241,9 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
   if ((rc = dalloc(s, &st.n_fwd, cB))) return rc;
   if ((rc = dalloc(s, &st.counters, COUNT_WORDS))) return rc;
   if ((rc = dalloc_s(s, &st.dump, 4 * cB))) return rc;
+  if ((rc = dalloc(s, &st.orig, cB))) return rc;
+  if ((rc = dalloc(s, &st.plan, (size_t)PLAN_HEAD * (qilqr_solver::MAX_PARTS + 2) + 2 * (size_t)cB))) return rc;
+  st.row0 = 0;
 #ifdef QILQR_STAMPS
   if ((rc = dalloc(s, &st.stamps, 8 * cB))) return rc;
 #else
@@ -532,6 +540,23 @@ int launch_accept(qilqr_solver *s, long B, long n, int ls_only) {
   return QILQR_OK;
 }
 
+// ---- compaction of the live trajectories (ilqr_kernels.h, k_compact_plan): between a round's backward pass and its rollout.
+// Worth its two launches while the live trajectories fill more blocks than the device runs side by side; below
+// COMPACT_STOP running trajectories every kernel of a round is a lone dependent chain whatever the slots are.
+constexpr unsigned COMPACT_STOP = 512;
+constexpr long COMPACT_MIN_B = 4096;  // automatic (qilqr_device_config.compaction = 0) from this many trajectories per call
+inline unsigned compact_stop(const qilqr_solver *s) { return s->dev.compaction == 1 ? 0u : COMPACT_STOP; }
+int launch_compact(qilqr_solver *s, long B, long n) {
+  launch(s, K_OTHER, k_compact_plan, dim3(1), dim3(1024), s->st, (int)B);
+  const unsigned grid = std::min<unsigned>(cdiv(B, 8), 1024u);
+  const int with_records = s->params.mu_init > 0.0 ? 1 : 0;  // a restart runs the recursion on the current records again
+  if (s->f32)
+    launch(s, K_OTHER, k_compact_move<float>, dim3(grid), dim3(256), s->st, (int)B, (int)n, s->compact_out, with_records);
+  else
+    launch(s, K_OTHER, k_compact_move<double>, dim3(grid), dim3(256), s->st, (int)B, (int)n, s->compact_out, with_records);
+  return QILQR_OK;
+}
+
 int read_active(qilqr_solver *s, int *n_active) {
   HIP_TRY(hipMemcpyAsync(s->h_counters, s->st.counters + COUNT_BASE, sizeof(int) * COUNT_STRIPES, hipMemcpyDeviceToHost,
                          s->stream));
@@ -664,12 +689,15 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
     // to do.
     for (int k = 0; k < 8; ++k) s->h_active[k] = 0;
     const InFlight in_flight(s->device);
-    const bool can_fuse = fuse_backward_rollout(s, B);
+    const bool can_fuse = fuse_backward_rollout(s, B) && !s->compact;  // (compaction works between the two halves)
+    if (s->compact) s->plan_heads.push_back(0);
+    unsigned seen_active = (unsigned)B;  // the last count the host has read (the count only falls)
     for (long round = 0; round < max_rounds; ++round) {
       if (can_fuse && in_flight.alone()) {
         if ((rc = launch_backward_rollout(s, B, n))) return rc;
       } else {
         if ((rc = launch_backward(s, B, n, 0))) return rc;
+        if (s->compact && seen_active > compact_stop(s) && (rc = launch_compact(s, B, n))) return rc;
         if ((rc = launch_rollout(s, B, n, F_SEARCH))) return rc;
       }
       if ((rc = on_round())) return rc;  // (debug capture of the single solve: one more launch, nothing waited for)
@@ -693,6 +721,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
           __builtin_ia32_pause();
         }
         if ((unsigned)v == 0) break;
+        seen_active = (unsigned)v;
         // a block that gave up a hand-off (BatchState::host_error) voids the call: stop enqueuing rounds on void gains -- each
         // could burn a full bounded spin -- let what is in flight finish, and report
         if (__atomic_load_n(s->h_active + 8 * (1 + qilqr_solver::MAX_PARTS), __ATOMIC_ACQUIRE)) {
@@ -728,6 +757,7 @@ struct Part {
   long nb;        // trajectories in the part
   unsigned long long *h_active;
   bool done;
+  unsigned seen_active;  // the last count of running trajectories the host has read
 };
 // the workspace of trajectories [b0, b0 + nb), b0 a multiple of 64
 BatchState slice_state(const qilqr_solver *s, long b0, long n, int part) {
@@ -749,6 +779,9 @@ BatchState slice_state(const qilqr_solver *s, long b0, long n, int part) {
   v.host_active = s->d_active + 8 * (1 + part);
   if (w.cost_hist) v.cost_hist = w.cost_hist + b0 * w.hist_cap;
   v.dump = adv(w.dump, 4 * b0);
+  v.orig = w.orig + b0;
+  v.row0 = w.row0 + (int)b0;
+  v.plan = w.plan + PLAN_HEAD * (part + 1) + 2 * b0;  // (part p's plan ends where part p + 1's begins)
   if (w.stamps) v.stamps = w.stamps + 8 * b0;
   return v;
 }
@@ -815,6 +848,8 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
     part.nb = b1 - b0;
     part.h_active = s->h_active + 8 * (1 + p);
     part.done = false;
+    part.seen_active = (unsigned)part.nb;
+    if (s->compact) s->plan_heads.push_back(part.st.plan - s->st.plan);
     for (int k = 0; k < 8; ++k) part.h_active[k] = 0;
     parts.push_back(part);
   }
@@ -837,6 +872,7 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
         if (part.done) continue;
         PartScope scope(s, part);
         if ((rc = launch_backward(s, part.nb, n, 0))) return rc;
+        if (s->compact && part.seen_active > compact_stop(s) && (rc = launch_compact(s, part.nb, n))) return rc;
         if ((rc = launch_rollout(s, part.nb, n, F_SEARCH))) return rc;
         if ((rc = launch_linearize(s, part.nb, n, 1, F_SEARCH, (int)(round & 0x3fffffff)))) return rc;
       }
@@ -859,6 +895,7 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
           }
           __builtin_ia32_pause();
         }
+        part.seen_active = (unsigned)v;
         if ((unsigned)v == 0) {
           part.done = true;
           --remaining;
@@ -945,6 +982,16 @@ int solve_batch_device_impl(qilqr_solver *s, const double *d_init, const double 
   const bool persistent = use_persistent(s, B);
   if ((rc = to_tiled(s, d_init, s->st.traj[0], B, n, 18, persistent ? s->st.counters : nullptr))) return rc;
   const int nparts = (s->dev.sync_every > 1) ? auto_parts(s, B) : 1;
+  // compaction: free-running rounds only (the host never waits for a plan), not beside the copy-back under the tail (it gathers by
+  // slot), the per-iteration cost history (rows by slot) or per-problem desired trajectories (they would have to move along)
+  s->compact = s->dev.compaction >= 0 && s->dev.sync_every > 1 && !persistent && !s->st.cost_hist && !s->st.desired_tiled && !s->early_out &&
+               0.0 < s->params.max_iters && (s->dev.compaction == 1 || B >= COMPACT_MIN_B);
+  s->compact_out = CompactOut{d_out_traj, d_out_cost, d_out_status, d_out_iters, d_out_n_bwd, d_out_n_fwd};
+  s->plan_heads.clear();
+  struct CompactScope {  // (every return below leaves the flag off for the other entry points)
+    qilqr_solver *s;
+    ~CompactScope() { s->compact = false; }
+  } compact_scope{s};
   if (persistent) {
     if ((rc = launch_solve4(s, B, n))) return rc;
   } else if (nparts > 1) {
@@ -971,7 +1018,8 @@ int solve_batch_device_impl(qilqr_solver *s, const double *d_init, const double 
       return QILQR_OK;  // (drain is false on this path: the caller waits for both streams)
     }
   }
-  if ((rc = gather(s, B, n, d_out_traj, d_out_cost, d_out_status, d_out_iters, d_out_n_bwd, d_out_n_fwd)))
+  if ((rc = gather(s, B, n, d_out_traj, d_out_cost, d_out_status, d_out_iters, d_out_n_bwd, d_out_n_fwd, nullptr, 0,
+                   s->compact ? s->st.orig : nullptr)))  // (with compaction: by the row a slot's trajectory came from)
     return rc;
   if (!drain) return QILQR_OK;
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1033,7 +1081,7 @@ int solve_batch_staged(qilqr_solver *s, const double *init, const double *desire
 
 extern "C" {
 
-int qilqr_abi_version(void) { return 5; }
+int qilqr_abi_version(void) { return 6; }
 
 const char *qilqr_last_error(void) { return g_last_error.c_str(); }
 
@@ -1054,7 +1102,7 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(QILQR_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
-  qilqr_device_config dc = {0, 0, 2, 0, 0, 0, 0, 0};
+  qilqr_device_config dc = {0, 0, 2, 0, 0, 0, 0, 0, 0};
   if (dev) dc = *dev;
   if (dc.device < 0 || dc.device >= ndev) return fail(QILQR_ERR_INVALID_ARG, "bad device ordinal");
   if (dc.sync_every < 1) dc.sync_every = 1;
@@ -1062,6 +1110,7 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   if (dc.persistent == 1)
     return fail(QILQR_ERR_INVALID_ARG, "persistent = 1 (k_solve4, the one-launch solve) is in the diagnostics build: make -C quadrotorilqr_amd/csrc diag");
 #endif
+  if (dc.compaction < -1 || dc.compaction > 1) return fail(QILQR_ERR_INVALID_ARG, "compaction is -1 (never), 0 (automatic) or 1 (whenever possible)");
   if (dc.force_general == 6)
     return fail(QILQR_ERR_INVALID_ARG, "force_general = 6 (the fused k_backward4 with a block barrier per knot) was retired in round 4: 5 is the fused form");
 #ifndef QILQR_WITH_BACKWARD2
@@ -1803,7 +1852,7 @@ int qilqr_sharded_create(const qilqr_model *model, const double *Q, const double
   try {
     h = new qilqr_sharded();
     for (int32_t r = 0; r < n_devices; ++r) {
-      qilqr_device_config dc = {0, 0, 2, 0, 0, 0, 0, 0};
+      qilqr_device_config dc = {0, 0, 2, 0, 0, 0, 0, 0, 0};
       if (dev) dc = *dev;
       dc.device = devices[r];
       qilqr_solver *s = nullptr;
@@ -2044,6 +2093,20 @@ int qilqr_solve_batch_sharded_device(qilqr_sharded *h, const double *init, const
   } catch (...) {
     return fail(QILQR_ERR_INVALID_ARG, "qilqr_solve_batch_sharded_device: out of host memory");
   }
+}
+
+// trajectories k_compact_move moved in the last batch solve of this handle (0: compaction was off, or nothing finished early)
+int qilqr_compaction_moves(qilqr_solver *s, int64_t *moves) {
+  if (!s || !moves) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  *moves = 0;
+  for (long head : s->plan_heads) {
+    int m = 0;
+    HIP_TRY(hipMemcpy(&m, s->st.plan + head + 2, sizeof(int), hipMemcpyDeviceToHost));
+    *moves += m;
+  }
+  return QILQR_OK;
 }
 
 #ifdef QILQR_STAMPS

@@ -77,6 +77,11 @@ struct BatchState {
   const void *ctab;      // constant operand table (backward_layout.h)
   void *dump;            // [B][4] write-only sink for the lanes of k_backward that own no gain entry
   unsigned long long *stamps;  // diagnostic build only (-DQILQR_STAMPS): [B][8] cycle sums per section of k_backward
+  // compaction of the live trajectories (k_compact_plan / k_compact_move): the caller's row of the trajectory in slot b
+  // (-1: the slot's trajectory has moved away), the first row of this (sub-)batch, and the plan of the current round
+  int *orig;
+  int row0;
+  int *plan;  // [0] moves, [16 ..] destination slots, [16 + B ..] source slots
 };
 
 __device__ __forceinline__ int *active_counter(const BatchState &st) {
@@ -113,16 +118,14 @@ struct GA {  // global address space views of storage type S
 #endif
 
 // Workgroups go to the eight XCDs round-robin by blockIdx, and every XCD has an L2 of its own.  The kernels that give a
-// block to FOUR trajectories (k_rollout16, k_backward4) hand XCD x the contiguous range of logical blocks that its hardware
-// blocks x, x + 8, ... enumerate, so that a block of k_rollout16 finds the gains in the L2 its k_backward4 block wrote
-// them through, and the candidate it writes is where the next k_backward4 block looks for it.  (Introduced when tiles were
-// 64 trajectories wide and sixteen blocks shared every line -- counters, B = 1024: FETCH_SIZE per launch 53 MB with the
-// identity map, 31 with this one; with tiles of four it keeps producer and consumer of a tile on one XCD.)
-__device__ __forceinline__ int xcd_local_block(unsigned hw_block, unsigned nblocks) {
-  constexpr unsigned XCDS = 8;
-  const unsigned x = hw_block % XCDS, k = hw_block / XCDS, per = nblocks / XCDS, rem = nblocks % XCDS;
-  return (int)(x * per + (x < rem ? x : rem) + k);
-}
+// block to FOUR trajectories (k_rollout16, k_backward4) take logical block = hardware block: block g of either kernel runs
+// on XCD g mod 8, so a block of k_rollout16 finds the gains in the L2 its k_backward4 block wrote them through.
+// (Rounds 2-3 handed XCD x a CONTIGUOUS range of logical blocks -- introduced when tiles were 64 trajectories wide and
+// sixteen blocks shared every line: FETCH_SIZE per launch 53 MB with the identity map, 31 with that one.  With tiles of four
+// no two blocks share a line and the two maps measure the same at every batch size (profiles/r04_compaction.txt); the
+// contiguous map is wrong for a batch whose live trajectories are a dense prefix -- k_compact_* below -- which it would
+// put on the first XCDs only: a batch sorted longest-first ran its backward passes 16 % SLOWER than unsorted with it.)
+__device__ __forceinline__ int xcd_local_block(unsigned hw_block, unsigned /*nblocks*/) { return (int)hw_block; }
 __device__ __forceinline__ bool is_converged(const SolveParams &p, double cost, double new_cost) {
   // ilqr.hh:196-205 (cost == 0 gives NaN < rtol == false and falls through to atol)
   if (fabs(cost - new_cost) / fabs(cost) < p.rtol) return true;
@@ -294,6 +297,8 @@ __global__ void k_init(SolveParams p, BatchState st, int B, int n) {
   st.terms[2 * b + 1] = 0.0;
   st.status[b] = 2;  // QILQR_STATUS_MAX_ITERS unless an exit path fires
   st.flags[b] = (0.0 < p.max_iters) ? F_ACTIVE : 0;
+  if (st.orig) st.orig[b] = st.row0 + b;
+  if (b == 0 && st.plan) st.plan[2] = 0;  // trajectories moved by k_compact_move in this solve (qilqr_debug_compaction_moves)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2499,6 +2504,7 @@ __global__ void k_gather(BatchState st, int B, int n, double *out_traj, double *
   if (kp >= n * 9 || b >= B) return;
   if (mask && mask[b] != want) return;
   const long row = row_of ? row_of[b] : b;
+  if (row < 0) return;  // (compaction: the slot's trajectory has moved to another slot, or left through k_compact_move)
   if (out_traj) {
     typedef typename GA<S>::v2 sv2;
     const int i = kp / 9, pr = kp - 9 * i;
@@ -2515,6 +2521,140 @@ __global__ void k_gather(BatchState st, int B, int n, double *out_traj, double *
     if (out_n_fwd) out_n_fwd[row] = st.n_fwd[b];
   }
 }
+// ---------------------------------------------------------------------------------------------
+// Compaction of the live trajectories (round 4; large batches only -- the host decides, ilqr_capi.hip compaction_on).
+// A batch takes as many rounds as its slowest problem (configs[3]: 45 for a mean of 12.4 iterations), and the kernels give
+// out work in groups of slots -- k_backward4 four to a block, k_linearize and k_rollout3 sixty-four to a wavefront -- that cost
+// the same with one live trajectory as with all: by round 15 a quarter of the trajectories are live and they still occupy
+// 71 % of the blocks of four and every group of 64.  Between a round's backward pass (whose settle step is where a
+// trajectory gets its exit status) and its rollout, the live trajectories are therefore moved into a dense prefix of the
+// slots: k_compact_plan (one block) pairs the holes among the first L slots (L = the live count) with the live slots
+// behind them; k_compact_move (one block per pair) first gathers the result of the hole's finished trajectory -- if it has
+// one -- into the CALLER's arrays, then copies the live trajectory's state: its current trajectory, its gains, its scalars
+// (and its knot records when Levenberg-Marquardt restarts are on: a restart runs the recursion on them again; otherwise the
+// next records a live trajectory needs are the ones k_linearize is about to write).  Every kernel addresses a trajectory by
+// its slot, none by its row: st.orig carries the row along and k_gather puts the results where they belong.  A trajectory
+// moves at most once per round and only from behind the prefix into it, so over a solve at most B trajectories move.  The
+// arithmetic of a trajectory does not depend on its slot: results are bit-identical with and without (GPU tests).
+// ---------------------------------------------------------------------------------------------
+constexpr int PLAN_HEAD = 16;
+__global__ __launch_bounds__(1024) void k_compact_plan(BatchState st, int B) {
+  __shared__ int s_a[1024], s_b[1024];
+  __shared__ int s_L;
+  const int t = threadIdx.x;
+  const int per = (B + 1023) / 1024;
+  const int b0 = t * per < B ? t * per : B, b1 = (b0 + per < B) ? b0 + per : B;
+  auto scan = [&](int (&a)[1024]) {  // inclusive, in place
+    for (int off = 1; off < 1024; off <<= 1) {
+      __syncthreads();
+      const int v = (t >= off) ? a[t - off] : 0;
+      __syncthreads();
+      a[t] += v;
+    }
+    __syncthreads();
+  };
+  int live = 0;
+  for (int b = b0; b < b1; ++b) live += (st.flags[b] & F_ACTIVE) ? 1 : 0;
+  s_a[t] = live;
+  scan(s_a);
+  if (t == 1023) s_L = s_a[1023];
+  __syncthreads();
+  const int L = s_L;
+  int holes = 0, movers = 0;
+  for (int b = b0; b < b1; ++b) {
+    const bool alive = (st.flags[b] & F_ACTIVE) != 0;
+    if (b < L) holes += alive ? 0 : 1;
+    else movers += alive ? 1 : 0;
+  }
+  __syncthreads();
+  s_a[t] = holes;
+  s_b[t] = movers;
+  scan(s_a);
+  scan(s_b);
+  int hk = s_a[t] - holes, mk = s_b[t] - movers;  // exclusive ranks
+  int *dst = st.plan + PLAN_HEAD, *src = st.plan + PLAN_HEAD + B;
+  for (int b = b0; b < b1; ++b) {
+    const bool alive = (st.flags[b] & F_ACTIVE) != 0;
+    if (b < L) { if (!alive) dst[hk++] = b; }
+    else if (alive) src[mk++] = b;
+  }
+  if (t == 1023) {  // (as many holes in front of L as live slots behind it)
+    st.plan[0] = s_b[1023];
+    st.plan[1] = L;
+    st.plan[2] += s_b[1023];
+  }
+}
+struct CompactOut {  // the caller's result arrays (device pointers, any may be null): k_gather's
+  double *traj, *cost;
+  int *status, *iters, *n_bwd, *n_fwd;
+};
+template <typename S>
+__global__ __launch_bounds__(256) void k_compact_move(BatchState st, int B, int n, CompactOut out, int with_records) {
+  typedef typename GA<S>::v2 sv2;
+  const int M = st.plan[0];
+  const int t = threadIdx.x;
+  for (int k = blockIdx.x; k < M; k += gridDim.x) {
+    const int dst = st.plan[PLAN_HEAD + k], src = st.plan[PLAN_HEAD + B + k];
+    const long row = st.orig[dst];
+    const int cd = st.cur[dst], cs = st.cur[src];
+    // 1. the finished trajectory in the hole leaves for the caller's arrays
+    if (row >= 0) {
+      if (out.traj) {
+        const S *tp = (const S *)st.traj[cd] + knot_base<true>(dst, n, 18);
+        double *o = out.traj + row * n * 18;
+        for (int q = t; q < n * 9; q += blockDim.x) {
+          const sv2 v = *reinterpret_cast<const sv2 *>(tp + (long)q * TILE2);
+          o[2 * q] = (double)v.x;
+          o[2 * q + 1] = (double)v.y;
+        }
+      }
+      if (t == 0) {
+        if (out.cost) out.cost[row] = st.cost[dst];
+        if (out.status) out.status[row] = st.status[dst];
+        if (out.iters) out.iters[row] = st.iters[dst];
+        if (out.n_bwd) out.n_bwd[row] = st.n_bwd[dst];
+        if (out.n_fwd) out.n_fwd[row] = st.n_fwd[dst];
+      }
+    }
+    __syncthreads();  // (the hole's current trajectory may sit in the buffer the copy writes)
+    // 2. the live trajectory moves in
+    {
+      const S *a = (const S *)st.traj[cs] + knot_base<true>(src, n, 18);
+      S *b = (S *)st.traj[cs] + knot_base<true>(dst, n, 18);
+      for (int q = t; q < n * 9; q += blockDim.x) *reinterpret_cast<sv2 *>(b + (long)q * TILE2) = *reinterpret_cast<const sv2 *>(a + (long)q * TILE2);
+      const S *ga = (const S *)st.gains + knot_base<true>(src, n, 52);
+      S *gb = (S *)st.gains + knot_base<true>(dst, n, 52);
+      for (int q = t; q < n * 26; q += blockDim.x) *reinterpret_cast<sv2 *>(gb + (long)q * TILE2) = *reinterpret_cast<const sv2 *>(ga + (long)q * TILE2);
+      if (with_records) {
+        const RecLayout &L = st.layout;
+        const S *ra = (const S *)st.lin[cs] + rec_base(L, src, n);
+        S *rb = (S *)st.lin[cs] + rec_base(L, dst, n);
+        const long step = L.tiled ? TILE2 : 2;
+        for (int q = t; q < n * (L.stride / 2); q += blockDim.x) *reinterpret_cast<sv2 *>(rb + q * step) = *reinterpret_cast<const sv2 *>(ra + q * step);
+      }
+    }
+    if (t == 0) {
+      st.cur[dst] = cs;
+      st.cost[dst] = st.cost[src];
+      st.prev_cost[dst] = st.prev_cost[src];
+      st.terms[2 * dst] = st.terms[2 * src];
+      st.terms[2 * dst + 1] = st.terms[2 * src + 1];
+      st.alpha[dst] = st.alpha[src];
+      st.mu[dst] = st.mu[src];
+      st.trial[dst] = st.trial[src];
+      st.status[dst] = st.status[src];
+      st.iters[dst] = st.iters[src];
+      st.n_bwd[dst] = st.n_bwd[src];
+      st.n_fwd[dst] = st.n_fwd[src];
+      st.orig[dst] = st.orig[src];
+      st.flags[dst] = st.flags[src];
+      st.flags[src] = 0;
+      st.orig[src] = -1;
+    }
+    __syncthreads();
+  }
+}
+
 // ILQRDebug on the device (ilqr.hh:78-80: one entry per completed forward pass, the accepted trajectory and its cost) for the
 // single-problem solve: launched behind every round's backward pass (whose settle step is where an iteration completes), one
 // block; when trajectory 0 has completed an iteration since the last look, its current trajectory -- in the buffer the next

@@ -87,7 +87,7 @@ int main(int argc, char **argv) {
   double *ref_traj = malloc(sizeof(double) * cnt), *ref_cost = malloc(sizeof(double) * B);
   int32_t *ref_int = malloc(sizeof(int32_t) * 4 * B);
   qilqr_solver *one = NULL;
-  qilqr_device_config dc = {devices[root], 0, 2, 0, 0, 0, 0, 0};
+  qilqr_device_config dc = {devices[root], 0, 2, 0, 0, 0, 0, 0, 0};
   CHECK_Q(qilqr_create(&model, Q, R, desired, n, dt, &opt, &dc, &one));
   CHECK_Q(qilqr_solve_batch(one, init, NULL, B, n, ref_traj, ref_cost, ref_int, ref_int + B, ref_int + 2 * B, ref_int + 3 * B));
   qilqr_destroy(one);
