@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--sync-every", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="HIP events around every kernel, not only the two candidates for dominant kernel")
-    ap.add_argument("--rollout", type=int, default=-1, help="rollout kernel (qilqr_device_config.single_wave_rollout): 0 by the batch (k_rollout16 up to 4096 trajectories, k_rollout3 up to 16384, k_rollout beyond), "
+    ap.add_argument("--rollout", type=int, default=-1, help="rollout kernel (qilqr_device_config.single_wave_rollout): 0 by the batch (k_rollout16 up to 4096 trajectories, k_rollout3 beyond), "
                                                              "1 k_rollout, 2 k_rollout3, 3 k_rollout16 (default: library default)")
     ap.add_argument("--backward", type=int, default=0, help="diagnostic: backward kernel (qilqr_device_config.force_general: 0 automatic, 1 general, 2 one wavefront per trajectory, 3 k_backward2 (diagnostics build), 4 k_backward4 six wavefronts, 5 fused, 6 fused with block barriers)")
     ap.add_argument("--persistent", type=int, default=0, help="qilqr_device_config.persistent: 0 / 2 rounds of three launches (the product), 1 the solve as one launch (k_solve4: loads the diagnostics build of the library)")

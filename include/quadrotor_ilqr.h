@@ -79,8 +79,9 @@ typedef struct {
   int32_t force_general; /* backward kernel.  0: by the weights and the batch (symmetric Q, R: k_backward4 in its fused form --
                             four wavefronts that each carry the matrix and the gradient recursion of a trajectory, plus a
                             loader wavefront, per four trajectories -- up to 4096 trajectories; in its six-wavefront form --
-                            four matrix wavefronts, one gradient and one loader wavefront -- up to 8192; one wavefront per
-                            trajectory beyond; non-symmetric Q or R: the general kernel); 1: the general kernel even when
+                            four matrix wavefronts, one gradient and one loader wavefront -- beyond (until ABI version 6 one wavefront
+                            per trajectory took over above 8192: with the running trajectories compacted, see `compaction`, the blocks of
+                            four are ahead at every size); non-symmetric Q or R: the general kernel); 1: the general kernel even when
                             Q, R are symmetric; 2: the one-wavefront kernel for symmetric weights (k_backward<true>);
                             3: k_backward2 (diagnostics build only); 4: k_backward4, six wavefronts; 5: k_backward4, fused
                             (its wavefronts meet through tagged LDS slots, no block barrier in the knot loop: what 0
@@ -103,15 +104,15 @@ typedef struct {
                             beyond, where the reference's results are rounding noise. */
   int32_t single_wave_rollout; /* rollout kernel: 0 (default) = by the batch: sixteen lanes per trajectory, four
                                   trajectories per block (k_rollout16) up to 4096 trajectories, a lane per trajectory
-                                  in three cooperating wavefronts (k_rollout3) up to 16384, in one wavefront (k_rollout)
-                                  beyond; 1 = k_rollout; 2 = k_rollout3; 3 = k_rollout16 */
+                                  in three cooperating wavefronts (k_rollout3) beyond; 1 = k_rollout (a lane per trajectory, one
+                                  wavefront: the Runge-Kutta extension's kernel); 2 = k_rollout3; 3 = k_rollout16 */
   int32_t precision; /* 0: fp64 everywhere (reference parity).  1: mixed: trajectories, gains and knot records
                         stored in fp32, rollout and linearisation computed in fp32, Riccati recursion on the fp64
                         matrix core, cost sums / Armijo / convergence tests in fp64 (BASELINE.json configs[2]) */
   int32_t streams; /* batch solves with sync_every > 1: number of contiguous sub-batches that run their rounds on
                       their own HIP streams (their kernels are bound by different resources and overlap);
-                      0 = automatic (1 below 4096 trajectories, 2 from there on, 4 between 4096 and 16384 when the process
-                      runs with GPU_MAX_HW_QUEUES >= 8: see auto_parts in ilqr_capi.hip), at most 8 */
+                      0 = automatic (1 below 4096 trajectories, 2 at 4096, beyond 4 when the process runs with
+                      GPU_MAX_HW_QUEUES >= 8 and 2 otherwise: see auto_parts in ilqr_capi.hip), at most 8 */
   int32_t persistent; /* the solve as ONE launch (k_solve4: blocks of eight wavefronts own four trajectories each from the
                          first linearisation to the exit status, no rounds, no host in the loop; symmetric weights only):
                          0 = the rounds of three launches at every batch size (by measurement they are level or ahead at every size
@@ -121,8 +122,9 @@ typedef struct {
                          rollout the trajectories still running are moved into a dense prefix of the workspace, the finished
                          ones they replace leaving for the caller's result arrays at once -- a batch takes as many rounds as its
                          slowest problem and the kernels hand out work in groups of 4 and 64 trajectories that cost the same
-                         with one running as with all.  Results are bit-identical with and without.  0 = automatic (from 4096
-                         trajectories per call, while more than 512 are running), 1 = at every size and count the call allows
+                         with one running as with all.  Results are bit-identical with and without.  0 = automatic (whenever the
+                         round's backward pass is a k_backward4 launch of its own, i.e. symmetric weights and more than 1024
+                         trajectories, while more than 512 of a sub-batch are running), 1 = at every size and count the call allows
                          (not with populate_debug's cost history, per-problem desired trajectories, or the copy-back under the
                          tail of qilqr_solve_batch), -1 = never */
 } qilqr_device_config;
@@ -261,10 +263,10 @@ void qilqr_host_free(void *p);
  * offset (the "gather" is the copy back itself: ragged shards need no padding), the call returns when every shard has.
  * Arguments and results are those of qilqr_solve_batch.  Problem by problem they are bit-identical to a single-device solve
  * of the same batch WHEN SHARD AND WHOLE BATCH FALL IN THE SAME KERNEL REGIME: with the automatic choices (force_general = 0,
- * single_wave_rollout = 0) the kernels go by the number of trajectories a call has in flight on its device (backward pass:
- * up to 4096 / up to 8192 / beyond; rollout: up to 4096 / up to 16384 / beyond), the regimes sum M^T V_x and evaluate the
- * rollout in different orders, and the same problem then differs in the last bits (about 2e-15 relative per pass) between,
- * say, a batch of 65536 and its eight shards of 8192 -- the exit path of a problem that sits within rounding of a
+ * single_wave_rollout = 0) the kernels go by the number of trajectories a call has in flight on its device (up to 4096:
+ * the fused k_backward4 and k_rollout16; beyond: the six-wavefront k_backward4 and k_rollout3), the two regimes sum M^T V_x and
+ * evaluate the rollout in different orders, and the same problem then differs in the last bits (about 2e-15 relative per pass)
+ * between, say, a batch of 8192 and its eight shards of 1024 (a batch of 65536 and its shards of 8192 are one regime) -- the exit path of a problem that sits within rounding of a
  * convergence threshold can differ with them.  QILQR_PIN_ARITHMETIC (below) makes every call use ONE kernel family whatever
  * the batch size: a problem's bits then do not depend on how the caller batches or shards it.  A shard that fails makes the call return its error (the lowest failing shard's; text through
  * qilqr_last_error, prefixed with the shard and device); the other shards still complete. */

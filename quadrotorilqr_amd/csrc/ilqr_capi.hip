@@ -399,10 +399,13 @@ int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag, 
 //   up to 4096: k_backward4<.., FUSED>: four wavefronts that each carry the matrix AND the gradient recursion of a trajectory,
 //               and one loader wavefront, per four trajectories (the wavefronts are bound by latencies, the gradient's 40
 //               instructions ride along: +0.3 to +1.7 % of a whole solve against the form below, profiles/r03_ab_backward.txt)
-//   up to 8192: k_backward4: four matrix wavefronts, ONE gradient wavefront and the loader per four trajectories, knot loop
+//   beyond:     k_backward4: four matrix wavefronts, ONE gradient wavefront and the loader per four trajectories, knot loop
 //               unrolled (four blocks per CU: the SIMDs are bound by what their wavefronts issue, and one gradient wavefront
 //               for four trajectories issues a quarter: 426k against 408k solves/s at 8192)
-//   beyond: one wavefront per trajectory (k_backward<true>)
+// Until round 4 the one-wavefront kernel (k_backward<true>) took over above 8192 trajectories: a block per trajectory wastes
+// nothing on finished neighbours.  With the live trajectories compacted (k_compact_*) the blocks of four are full, and the
+// six-wavefront form is ahead at every size measured (profiles/r04_compaction.txt: 12288: 554k against 464k solves/s,
+// 16384: 593k / 512k, 65536: 654k / 587k); the one-wavefront kernel stays for force_general = 2.
 // k_backward2 (a matrix and a gradient wavefront per trajectory) was the choice below 512 trajectories in rounds 1 and 2; it
 // wins nowhere by more than 2 % and lives in the diagnostics build (force_general = 3 there).
 // The Runge-Kutta extension and non-symmetric weights take the one-wavefront kernel at every size.
@@ -413,7 +416,7 @@ BackwardKind backward_kind(const qilqr_solver *s, long load_B) {
   if (s->dev.force_general == 3) return BW_TWO;
 #endif
   if (s->dev.force_general == 5 || (s->dev.force_general == 0 && load_B <= 4096)) return BW_FUSED;
-  if (s->dev.force_general == 4 || (s->dev.force_general != 2 && load_B <= 8192)) return BW_FOUR;
+  if (s->dev.force_general != 2) return BW_FOUR;
   return BW_ONE;
 }
 // The knot records are placed for their reader (se3_math.h, rec_base): tiled for the kernels that stage them through LDS
@@ -474,13 +477,15 @@ int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
   // Which rollout kernel, by how many trajectories share the chip (qilqr_device_config.single_wave_rollout):
   //   k_rollout16  sixteen lanes per trajectory, four trajectories per block: the shortest chain per trajectory and a
   //                block on every CU from 1024 trajectories on; up to R16_MAX_B trajectories
-  //   k_rollout3   a lane per trajectory, three cooperating wavefronts per 64 trajectories
-  //   k_rollout    a lane per trajectory, one wavefront: the highest throughput, above 16384 trajectories
+  //   k_rollout3   a lane per trajectory, three cooperating wavefronts per 64 trajectories: beyond
+  //   k_rollout    a lane per trajectory, one wavefront (the Runge-Kutta extension; forced).  It was the choice above 16384
+  //                trajectories until the live trajectories were compacted: with full wavefronts k_rollout3 is ahead there too
+  //                (65536: 698k against 655k solves/s, 16384: 596k / 543k, profiles/r04_compaction.txt)
   const long load_B = std::max(B, s->total_B);
   const int choice = s->dev.single_wave_rollout;
   if (s->integrator == 1) {  // the Runge-Kutta extension: the lane-per-trajectory kernel only
     launch(s, K_ROLLOUT, (k_rollout<double, 1>), dim3(cdiv(B, 64)), dim3(64), s->consts, s->st, (int)B, (int)n, need_flag);
-  } else if (choice == 1 || (choice == 0 && load_B > 16384)) {  // (a forced choice is honoured at every batch size)
+  } else if (choice == 1) {  // (a forced choice is honoured at every batch size; until round 4 also the choice above 16384)
     if (s->f32)
       launch(s, K_ROLLOUT, (k_rollout<float, 0>), dim3(cdiv(B, 64)), dim3(64), s->constsf, s->st, (int)B, (int)n, need_flag);
     else
@@ -543,12 +548,18 @@ int launch_accept(qilqr_solver *s, long B, long n, int ls_only) {
 // ---- compaction of the live trajectories (ilqr_kernels.h, k_compact_plan): between a round's backward pass and its rollout.
 // Worth its two launches while the live trajectories fill more blocks than the device runs side by side; below
 // COMPACT_STOP running trajectories every kernel of a round is a lone dependent chain whatever the slots are.
-constexpr unsigned COMPACT_STOP = 512;
-constexpr long COMPACT_MIN_B = 4096;  // automatic (qilqr_device_config.compaction = 0) from this many trajectories per call
+#ifndef QILQR_COMPACT_STOP
+#define QILQR_COMPACT_STOP 512
+#endif
+constexpr unsigned COMPACT_STOP = QILQR_COMPACT_STOP;
+// Automatic (qilqr_device_config.compaction = 0): whenever the round's backward pass is a k_backward4 (blocks of four trajectories)
+// and not part of the combined launch of B <= 1024 -- measured, one configuration per process (profiles/r04_compaction.txt): 1280:
+// +5 %, 2048: +5.5 %, 3072: +13 %, 4096: +8 %, 8192: +6 %; with the one-wavefront backward kernel (general weights, the Runge-Kutta
+// extension, force_general = 2), whose blocks hold one trajectory, it gains nothing (12288-32768: -2 to +1 %) and stays off.
 inline unsigned compact_stop(const qilqr_solver *s) { return s->dev.compaction == 1 ? 0u : COMPACT_STOP; }
 int launch_compact(qilqr_solver *s, long B, long n) {
   launch(s, K_OTHER, k_compact_plan, dim3(1), dim3(1024), s->st, (int)B);
-  const unsigned grid = std::min<unsigned>(cdiv(B, 8), 1024u);
+  const unsigned grid = std::min<unsigned>(cdiv(B, 2), 2048u);  // (work items: COMPACT_SPLIT per pair; the kernel strides over them)
   const int with_records = s->params.mu_init > 0.0 ? 1 : 0;  // a restart runs the recursion on the current records again
   if (s->f32)
     launch(s, K_OTHER, k_compact_move<float>, dim3(grid), dim3(256), s->st, (int)B, (int)n, s->compact_out, with_records);
@@ -819,7 +830,9 @@ int auto_parts(const qilqr_solver *s, long B) {
   // starts (bench.py sets it): 5120: 366k against 356k solves/s, 6144: 403k / 377k, 7168: 437k / 406k,
   // 8192: 461k / 429k, 10240: 441k / 424k, 12288: 472k / 460k; level at 4096, 16384 and 65536; with HIP's default four queues
   // the parts collide with each other and with the caller's streams and two are the safer choice.
-  int want = s->dev.streams > 0 ? s->dev.streams : (B >= 4096 ? ((B > 4096 && B < 16384 && hw_queues() >= 8) ? 4 : 2) : 1);
+  // Round 4 (compaction, k_backward4 and k_rollout3 at every size beyond 4096): four parts are ahead at 16384 and 65536 as well
+  // (596k against 591k, 698k against 686k).
+  int want = s->dev.streams > 0 ? s->dev.streams : (B >= 4096 ? ((B > 4096 && hw_queues() >= 8) ? 4 : 2) : 1);
   if (want > qilqr_solver::MAX_PARTS) want = qilqr_solver::MAX_PARTS;
   while (want > 1 && tiles < 2 * want) --want;  // at least two tiles per part
   return want;
@@ -985,7 +998,8 @@ int solve_batch_device_impl(qilqr_solver *s, const double *d_init, const double 
   // compaction: free-running rounds only (the host never waits for a plan), not beside the copy-back under the tail (it gathers by
   // slot), the per-iteration cost history (rows by slot) or per-problem desired trajectories (they would have to move along)
   s->compact = s->dev.compaction >= 0 && s->dev.sync_every > 1 && !persistent && !s->st.cost_hist && !s->st.desired_tiled && !s->early_out &&
-               0.0 < s->params.max_iters && (s->dev.compaction == 1 || B >= COMPACT_MIN_B);
+               0.0 < s->params.max_iters &&
+               (s->dev.compaction == 1 || (!fuse_backward_rollout(s, B) && backward_kind(s, B) != BW_ONE && s->st.layout.tiled));
   s->compact_out = CompactOut{d_out_traj, d_out_cost, d_out_status, d_out_iters, d_out_n_bwd, d_out_n_fwd};
   s->plan_heads.clear();
   struct CompactScope {  // (every return below leaves the flag off for the other entry points)

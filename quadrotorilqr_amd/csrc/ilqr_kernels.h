@@ -2538,65 +2538,107 @@ __global__ void k_gather(BatchState st, int B, int n, double *out_traj, double *
 // arithmetic of a trajectory does not depend on its slot: results are bit-identical with and without (GPU tests).
 // ---------------------------------------------------------------------------------------------
 constexpr int PLAN_HEAD = 16;
+// inclusive scan over the 1024 threads of a block (sixteen wavefronts): shuffles inside a wavefront, the sixteen totals through LDS
+template <typename T>
+__device__ __forceinline__ T block_scan_1024(T v, T (&tot)[16], T *total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const T u = __shfl_up(v, off);
+    if (lane >= off) v += u;
+  }
+  __syncthreads();  // (tot may still be read from the previous scan)
+  if (lane == 63) tot[w] = v;
+  __syncthreads();
+  T base = 0, all = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const T x = tot[k];
+    if (k < w) base += x;
+    all += x;
+  }
+  *total = all;
+  return v + base;
+}
 __global__ __launch_bounds__(1024) void k_compact_plan(BatchState st, int B) {
-  __shared__ int s_a[1024], s_b[1024];
-  __shared__ int s_L;
+  __shared__ int s_tot[16];
+  __shared__ unsigned long long s_tot2[16];
   const int t = threadIdx.x;
   const int per = (B + 1023) / 1024;
   const int b0 = t * per < B ? t * per : B, b1 = (b0 + per < B) ? b0 + per : B;
-  auto scan = [&](int (&a)[1024]) {  // inclusive, in place
-    for (int off = 1; off < 1024; off <<= 1) {
-      __syncthreads();
-      const int v = (t >= off) ? a[t - off] : 0;
-      __syncthreads();
-      a[t] += v;
-    }
-    __syncthreads();
-  };
+  // (a thread's flags are consecutive words: at most 64 of them for 65536 slots; they stay in the L2 between the two passes)
   int live = 0;
   for (int b = b0; b < b1; ++b) live += (st.flags[b] & F_ACTIVE) ? 1 : 0;
-  s_a[t] = live;
-  scan(s_a);
-  if (t == 1023) s_L = s_a[1023];
-  __syncthreads();
-  const int L = s_L;
-  int holes = 0, movers = 0;
+  int L;
+  (void)block_scan_1024(live, s_tot, &L);
+  // holes among the first L slots (low word) and live slots behind them (high word), ranked in one scan
+  unsigned long long hm = 0;
   for (int b = b0; b < b1; ++b) {
     const bool alive = (st.flags[b] & F_ACTIVE) != 0;
-    if (b < L) holes += alive ? 0 : 1;
-    else movers += alive ? 1 : 0;
+    if (b < L) hm += alive ? 0ull : 1ull;
+    else hm += alive ? (1ull << 32) : 0ull;
   }
-  __syncthreads();
-  s_a[t] = holes;
-  s_b[t] = movers;
-  scan(s_a);
-  scan(s_b);
-  int hk = s_a[t] - holes, mk = s_b[t] - movers;  // exclusive ranks
+  unsigned long long all;
+  const unsigned long long incl = block_scan_1024(hm, s_tot2, &all);
+  int hk = (int)(unsigned)(incl - hm), mk = (int)((incl - hm) >> 32);  // exclusive ranks
   int *dst = st.plan + PLAN_HEAD, *src = st.plan + PLAN_HEAD + B;
   for (int b = b0; b < b1; ++b) {
     const bool alive = (st.flags[b] & F_ACTIVE) != 0;
     if (b < L) { if (!alive) dst[hk++] = b; }
     else if (alive) src[mk++] = b;
   }
-  if (t == 1023) {  // (as many holes in front of L as live slots behind it)
-    st.plan[0] = s_b[1023];
+  if (t == 0) {  // (as many holes in front of L as live slots behind it)
+    const int M = (int)(all >> 32);
+    st.plan[0] = M;
     st.plan[1] = L;
-    st.plan[2] += s_b[1023];
+    st.plan[2] += M;
   }
 }
 struct CompactOut {  // the caller's result arrays (device pointers, any may be null): k_gather's
   double *traj, *cost;
   int *status, *iters, *n_bwd, *n_fwd;
 };
+// 16-byte pieces q0 <= q < q1 of a tiled (step = TILE2) or plain (step = 2) run, four loads in flight per thread
+template <typename S>
+__device__ __forceinline__ void copy_pieces(const S *a, S *b, long step, int q0, int q1) {
+  typedef typename GA<S>::v2 sv2;
+  const int t = threadIdx.x, nt = blockDim.x;
+  int q = q0 + t;
+  for (; q + 3 * nt < q1; q += 4 * nt) {
+    sv2 v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = *reinterpret_cast<const sv2 *>(a + (long)(q + e * nt) * step);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) *reinterpret_cast<sv2 *>(b + (long)(q + e * nt) * step) = v[e];
+  }
+  for (; q < q1; q += nt) *reinterpret_cast<sv2 *>(b + (long)q * step) = *reinterpret_cast<const sv2 *>(a + (long)q * step);
+}
+// Work item = (pair k, part c of COMPACT_SPLIT): every part copies its share of the trajectory, gains (and records); part 0
+// also sends off the hole's finished trajectory FIRST and writes the scalars.  The parts of a pair touch disjoint bytes --
+// except that the hole's current trajectory may sit in the buffer the copy writes: the trajectory is therefore copied by
+// part 0 alone, behind its gather; the gains and records, which a finished trajectory no longer needs, by all parts.
+constexpr int COMPACT_SPLIT = 4;
 template <typename S>
 __global__ __launch_bounds__(256) void k_compact_move(BatchState st, int B, int n, CompactOut out, int with_records) {
   typedef typename GA<S>::v2 sv2;
   const int M = st.plan[0];
   const int t = threadIdx.x;
-  for (int k = blockIdx.x; k < M; k += gridDim.x) {
+  for (int item = blockIdx.x; item < M * COMPACT_SPLIT; item += gridDim.x) {
+    const int k = item / COMPACT_SPLIT, c = item - k * COMPACT_SPLIT;
     const int dst = st.plan[PLAN_HEAD + k], src = st.plan[PLAN_HEAD + B + k];
+    const int cs = st.cur[src];
+    {
+      const int ng = n * 26, g0 = (int)((long)ng * c / COMPACT_SPLIT), g1 = (int)((long)ng * (c + 1) / COMPACT_SPLIT);
+      copy_pieces<S>((const S *)st.gains + knot_base<true>(src, n, 52), (S *)st.gains + knot_base<true>(dst, n, 52), TILE2, g0, g1);
+      if (with_records) {
+        const RecLayout &L = st.layout;
+        const int nr = n * (L.stride / 2), r0 = (int)((long)nr * c / COMPACT_SPLIT), r1 = (int)((long)nr * (c + 1) / COMPACT_SPLIT);
+        copy_pieces<S>((const S *)st.lin[cs] + rec_base(L, src, n), (S *)st.lin[cs] + rec_base(L, dst, n), L.tiled ? TILE2 : 2, r0, r1);
+      }
+    }
+    if (c != 0) continue;  // (block-uniform)
     const long row = st.orig[dst];
-    const int cd = st.cur[dst], cs = st.cur[src];
+    const int cd = st.cur[dst];
     // 1. the finished trajectory in the hole leaves for the caller's arrays
     if (row >= 0) {
       if (out.traj) {
@@ -2618,21 +2660,7 @@ __global__ __launch_bounds__(256) void k_compact_move(BatchState st, int B, int 
     }
     __syncthreads();  // (the hole's current trajectory may sit in the buffer the copy writes)
     // 2. the live trajectory moves in
-    {
-      const S *a = (const S *)st.traj[cs] + knot_base<true>(src, n, 18);
-      S *b = (S *)st.traj[cs] + knot_base<true>(dst, n, 18);
-      for (int q = t; q < n * 9; q += blockDim.x) *reinterpret_cast<sv2 *>(b + (long)q * TILE2) = *reinterpret_cast<const sv2 *>(a + (long)q * TILE2);
-      const S *ga = (const S *)st.gains + knot_base<true>(src, n, 52);
-      S *gb = (S *)st.gains + knot_base<true>(dst, n, 52);
-      for (int q = t; q < n * 26; q += blockDim.x) *reinterpret_cast<sv2 *>(gb + (long)q * TILE2) = *reinterpret_cast<const sv2 *>(ga + (long)q * TILE2);
-      if (with_records) {
-        const RecLayout &L = st.layout;
-        const S *ra = (const S *)st.lin[cs] + rec_base(L, src, n);
-        S *rb = (S *)st.lin[cs] + rec_base(L, dst, n);
-        const long step = L.tiled ? TILE2 : 2;
-        for (int q = t; q < n * (L.stride / 2); q += blockDim.x) *reinterpret_cast<sv2 *>(rb + q * step) = *reinterpret_cast<const sv2 *>(ra + q * step);
-      }
-    }
+    copy_pieces<S>((const S *)st.traj[cs] + knot_base<true>(src, n, 18), (S *)st.traj[cs] + knot_base<true>(dst, n, 18), TILE2, 0, n * 9);
     if (t == 0) {
       st.cur[dst] = cs;
       st.cost[dst] = st.cost[src];
@@ -2648,13 +2676,12 @@ __global__ __launch_bounds__(256) void k_compact_move(BatchState st, int B, int 
       st.n_fwd[dst] = st.n_fwd[src];
       st.orig[dst] = st.orig[src];
       st.flags[dst] = st.flags[src];
-      st.flags[src] = 0;
-      st.orig[src] = -1;
+      st.flags[src] = 0;  // nothing runs in the slot it left, and k_gather passes it by (the other parts of the pair read
+      st.orig[src] = -1;  // the source's selector, gains and records, none of which changes here)
     }
     __syncthreads();
   }
 }
-
 // ILQRDebug on the device (ilqr.hh:78-80: one entry per completed forward pass, the accepted trajectory and its cost) for the
 // single-problem solve: launched behind every round's backward pass (whose settle step is where an iteration completes), one
 // block; when trajectory 0 has completed an iteration since the last look, its current trajectory -- in the buffer the next
