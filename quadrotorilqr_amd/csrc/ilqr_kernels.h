@@ -136,6 +136,44 @@ __device__ __forceinline__ double cost_reduction(double QuTk, double kTQuuk, dou
   return step * QuTk + step * step * kTQuuk / 2.0;  // ilqr.hh:18-22
 }
 
+// ---- The stores of the per-trajectory state machine: the settle step of a candidate (ilqr.hh:70-84, 174-194) and the arming of the
+// next line search behind a backward pass (ilqr.hh:61-68).
+// WRITTEN WITHOUT COMPLEMENTARY BRANCHES ON PURPOSE.  `if (a) st.x[b] = u; else st.y[b] = v;` with x and y of one type is turned by
+// LLVM (sinking of common code in SimplifyCFG) into ONE store through a selected address.  In the diagnosis build of rounds 3 and 4
+// (kernel bodies as __device__ functions, SolveParams by const reference: the BatchState pointers then live in scratch) the AMDGPU
+// backend selected that address per lane from two scratch offsets and left the wrong one in place for the lanes of the last branch:
+// `st.trial[b] = 0` of the arming step became `st.status[b] = 0`, the next line search started from the previous one's trial count,
+// and with one to three trials per search (Levenberg-Marquardt restarts) a solve took restarts the oracle did not -- the "flat-pointer
+// anomaly" of VERDICT r03 item 8 (profiles/r04_flat_anomaly.txt has the two instruction sequences).  The product
+// build compiled the same source correctly, by luck of its register allocation.  Here every word is stored unconditionally with a
+// selected VALUE, or under a condition that no other store of its type complements: there is nothing for that transformation to merge.
+__device__ __forceinline__ void store_settled(const BatchState &st, int b, bool accept, int cur, double new_cost, int it0, int trial0,
+                                              double alpha0, double step_update, int status, int fl) {
+  if (accept) {  // (cur has been flipped by the caller)
+    st.cur[b] = cur;
+    st.cost[b] = new_cost;
+    if (st.cost_hist && it0 < st.hist_cap) st.cost_hist[(long)b * st.hist_cap + it0] = new_cost;
+    st.iters[b] = it0 + 1;
+  }
+  st.trial[b] = accept ? trial0 : trial0 + 1;
+  st.alpha[b] = accept ? alpha0 : alpha0 * step_update;  // ilqr.hh:189
+  if (status >= 0) st.status[b] = status;
+  st.flags[b] = fl;
+}
+// behind a backward pass on the trajectory's current iterate: ilqr.hh:61 (cost), :66-68 (expected reduction below the convergence
+// thresholds: status 0), a line search that allows no trial throws at once (status 3), otherwise the search starts from alpha = 1
+__device__ __forceinline__ void arm_line_search(const SolveParams &p, const BatchState &st, int b, int iters_now, double cost_now,
+                                                double QuTk, double kTQuuk) {
+  st.prev_cost[b] = cost_now;
+  const bool conv = iters_now > 0 && is_converged(p, cost_now, cost_now + cost_reduction(QuTk, kTQuuk, 1.0));
+  const bool none = !conv && iters_now > 0 && p.ls_max_iters <= 0;
+  const bool search = !(conv || none);
+  st.alpha[b] = 1.0;  // (alpha and trial are of no consequence for a trajectory that stops here)
+  st.trial[b] = 0;
+  if (!search) st.status[b] = conv ? 0 : 3;
+  st.flags[b] = search ? (F_ACTIVE | F_SEARCH) : 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_linearize: two threads per (b, i), in different wavefronts: one writes the dynamics Jacobian
 // blocks of the knot record, the other the cost differentials and the knot cost (the kernel is bound
@@ -515,17 +553,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
       if (lane == 0) {
         if (p.mu_init > 0.0) st.mu[b] = mu;
         st.n_fwd[b] += 1;
-        if (accept) {
-          st.cur[b] = cur;
-          st.cost[b] = new_cost;
-          if (st.cost_hist && it < st.hist_cap) st.cost_hist[(long)b * st.hist_cap + it] = new_cost;
-          st.iters[b] = it + 1;
-        } else {
-          st.trial[b] = trial0 + 1;
-          st.alpha[b] = alpha * p.step_update;  // ilqr.hh:189
-        }
-        if (status >= 0) st.status[b] = status;
-        st.flags[b] = fl;
+        store_settled(st, b, accept, cur, new_cost, it, trial0, alpha, p.step_update, status, fl);
         if (fl & F_ACTIVE) atomicAdd(active_counter(st), 1);
       }
       if ((!accept && !restart) || fl == 0) return;  // back-tracking continues with the old gains, or the trajectory is done
@@ -753,20 +781,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
     st.terms[2 * b + 1] = kTQuuk;
     st.n_bwd[b] += 1;
     if (!force) {
-      const double cost = st.cost[b];
-      st.prev_cost[b] = cost;  // ilqr.hh:61
-      const int it = st.iters[b];
-      if (it > 0 && is_converged(p, cost, cost + cost_reduction(QuTk, kTQuuk, 1.0))) {
-        st.status[b] = 0;  // ilqr.hh:66-68
-        st.flags[b] = 0;
-      } else if (it > 0 && p.ls_max_iters <= 0) {
-        st.status[b] = 3;  // line_search with no trial allowed throws at once
-        st.flags[b] = 0;
-      } else {
-        st.alpha[b] = 1.0;
-        st.trial[b] = 0;
-        st.flags[b] = F_ACTIVE | F_SEARCH;
-      }
+      arm_line_search(p, st, b, st.iters[b], st.cost[b], QuTk, kTQuuk);
     }
   }
 }
@@ -872,17 +887,7 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
     if (settle) {
       if (p.mu_init > 0.0) st.mu[b] = mu;
       st.n_fwd[b] += 1;
-      if (accept) {
-        st.cur[b] = cur;
-        st.cost[b] = new_cost;
-        if (st.cost_hist && it0 < st.hist_cap) st.cost_hist[(long)b * st.hist_cap + it0] = new_cost;
-        st.iters[b] = it0 + 1;
-      } else {
-        st.trial[b] = trial0 + 1;
-        st.alpha[b] = alpha0 * p.step_update;  // ilqr.hh:189
-      }
-      if (status >= 0) st.status[b] = status;
-      st.flags[b] = fl;
+      store_settled(st, b, accept, cur, new_cost, it0, trial0, alpha0, p.step_update, status, fl);
     }
     if (count_active) atomicAdd(active_counter(st), 1);
   }
@@ -982,18 +987,7 @@ __global__ __launch_bounds__(128) void k_backward2(ModelConsts<double> c, SolveP
       st.terms[2 * b + 1] = -QuTk;  // k^T Quu k = -Q_u^T k for the exact solve (see k_backward)
       st.n_bwd[b] += 1;
       if (!force) {
-        st.prev_cost[b] = cost_now;  // ilqr.hh:61
-        if (iters_now > 0 && is_converged(p, cost_now, cost_now + cost_reduction(QuTk, -QuTk, 1.0))) {
-          st.status[b] = 0;  // ilqr.hh:66-68
-          st.flags[b] = 0;
-        } else if (iters_now > 0 && p.ls_max_iters <= 0) {
-          st.status[b] = 3;  // line_search with no trial allowed throws at once
-          st.flags[b] = 0;
-        } else {
-          st.alpha[b] = 1.0;
-          st.trial[b] = 0;
-          st.flags[b] = F_ACTIVE | F_SEARCH;
-        }
+        arm_line_search(p, st, b, iters_now, cost_now, QuTk, -QuTk);
       }
     }
     return;
@@ -2453,34 +2447,31 @@ __global__ void k_accept(SolveParams p, BatchState st, int B, int n, int ls_only
       st.cost[b] = new_cost;
       st.status[b] = 0;
       fl = 0;
-    } else if (accept) {
-      st.cur[b] = cur ^ 1;
-      st.cost[b] = new_cost;
-      if (st.cost_hist && it < st.hist_cap) st.cost_hist[(long)b * st.hist_cap + it] = new_cost;
-      st.iters[b] = it + 1;
-      st.mu[b] = lm_relax(p, st.mu[b]);
-      fl = F_ACTIVE;
-      if (it > 0 && is_converged(p, cost, new_cost)) {
-        st.status[b] = 1;  // ilqr.hh:82-84
-        fl = 0;
-      } else if (!((double)(it + 1) < p.max_iters)) {
-        st.status[b] = 2;  // ilqr.hh:86
-        fl = 0;
-      }
     } else {
-      const int trial = st.trial[b] + 1;
-      st.trial[b] = trial;
-      st.alpha[b] = alpha * p.step_update;  // ilqr.hh:189
-      if (trial >= p.ls_max_iters) {
+      // (values first, then the stores of store_settled: no store in one branch that a store of the other complements)
+      const int trial0 = st.trial[b];
+      int status = -1;
+      if (accept) {
+        st.mu[b] = lm_relax(p, st.mu[b]);
+        fl = F_ACTIVE;
+        if (it > 0 && is_converged(p, cost, new_cost)) {
+          status = 1;  // ilqr.hh:82-84
+          fl = 0;
+        } else if (!((double)(it + 1) < p.max_iters)) {
+          status = 2;  // ilqr.hh:86
+          fl = 0;
+        }
+      } else if (trial0 + 1 >= p.ls_max_iters) {
         double mu = (p.mu_init > 0.0) ? st.mu[b] : 0.0;
         if (!ls_only && lm_restart(p, mu)) {
           st.mu[b] = mu;
           fl = F_ACTIVE;  // the next backward pass runs on the same iterate with the larger mu
         } else {
-          st.status[b] = 3;  // ilqr.hh:191-193
+          status = 3;  // ilqr.hh:191-193
           fl = 0;
         }
       }
+      store_settled(st, b, accept, accept ? cur ^ 1 : cur, new_cost, it, trial0, alpha, p.step_update, status, fl);
     }
     st.flags[b] = fl;
   }
