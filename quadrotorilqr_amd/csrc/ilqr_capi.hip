@@ -242,7 +242,7 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
   if ((rc = dalloc(s, &st.counters, COUNT_WORDS))) return rc;
   if ((rc = dalloc_s(s, &st.dump, 4 * cB))) return rc;
   if ((rc = dalloc(s, &st.orig, cB))) return rc;
-  if ((rc = dalloc(s, &st.plan, (size_t)PLAN_HEAD * (qilqr_solver::MAX_PARTS + 2) + 2 * (size_t)cB))) return rc;
+  if ((rc = dalloc(s, &st.plan, (size_t)PLAN_HEAD * (qilqr_solver::MAX_PARTS + 2) + 4 * (size_t)cB))) return rc;  // (a part: head, B holes, B live slots, B / 2 pairs x 4)
   st.row0 = 0;
 #ifdef QILQR_STAMPS
   if ((rc = dalloc(s, &st.stamps, 8 * cB))) return rc;
@@ -557,9 +557,17 @@ constexpr unsigned COMPACT_STOP = QILQR_COMPACT_STOP;
 // +5 %, 2048: +5.5 %, 3072: +13 %, 4096: +8 %, 8192: +6 %; with the one-wavefront backward kernel (general weights, the Runge-Kutta
 // extension, force_general = 2), whose blocks hold one trajectory, it gains nothing (12288-32768: -2 to +1 %) and stays off.
 inline unsigned compact_stop(const qilqr_solver *s) { return s->dev.compaction == 1 ? 0u : COMPACT_STOP; }
+// Behind a round's compaction every running trajectory sits in a slot below the count of running trajectories, and the last count
+// the host has read is an upper bound of that (counts only fall): the kernels that follow are launched over that many slots instead
+// of the whole batch (in its tail a batch of 65536 otherwise pays 53 us per k_linearize launch for 100 000 blocks that find nothing
+// to do).  Whole groups of 64: k_linearize and k_rollout3 hand out 64 consecutive slots per wavefront.
+inline long slots_in_use(long bound, unsigned seen_active) {
+  const long want = std::max<long>(64, ((long)seen_active + 63) / 64 * 64);
+  return std::min(bound, want);
+}
 int launch_compact(qilqr_solver *s, long B, long n) {
   launch(s, K_OTHER, k_compact_plan, dim3(1), dim3(1024), s->st, (int)B);
-  const unsigned grid = std::min<unsigned>(cdiv(B, 2), 2048u);  // (work items: COMPACT_SPLIT per pair; the kernel strides over them)
+  const unsigned grid = std::min<unsigned>(cdiv(B, 2) * 2, 4096u);  // (work items: COMPACT_SPLIT per pair; the kernel strides over them)
   const int with_records = s->params.mu_init > 0.0 ? 1 : 0;  // a restart runs the recursion on the current records again
   if (s->f32)
     launch(s, K_OTHER, k_compact_move<float>, dim3(grid), dim3(256), s->st, (int)B, (int)n, s->compact_out, with_records);
@@ -703,16 +711,20 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
     const bool can_fuse = fuse_backward_rollout(s, B) && !s->compact;  // (compaction works between the two halves)
     if (s->compact) s->plan_heads.push_back(0);
     unsigned seen_active = (unsigned)B;  // the last count the host has read (the count only falls)
+    long used = B;                       // slots the round's kernels are launched over (slots_in_use)
     for (long round = 0; round < max_rounds; ++round) {
       if (can_fuse && in_flight.alone()) {
         if ((rc = launch_backward_rollout(s, B, n))) return rc;
       } else {
-        if ((rc = launch_backward(s, B, n, 0))) return rc;
-        if (s->compact && seen_active > compact_stop(s) && (rc = launch_compact(s, B, n))) return rc;
-        if ((rc = launch_rollout(s, B, n, F_SEARCH))) return rc;
+        if ((rc = launch_backward(s, used, n, 0))) return rc;
+        if (s->compact && seen_active > compact_stop(s)) {
+          if ((rc = launch_compact(s, used, n))) return rc;
+          used = slots_in_use(used, seen_active);
+        }
+        if ((rc = launch_rollout(s, used, n, F_SEARCH))) return rc;
       }
       if ((rc = on_round())) return rc;  // (debug capture of the single solve: one more launch, nothing waited for)
-      if ((rc = launch_linearize(s, B, n, 1, F_SEARCH, (int)(round & 0x3fffffff)))) return rc;
+      if ((rc = launch_linearize(s, used, n, 1, F_SEARCH, (int)(round & 0x3fffffff)))) return rc;
       if (round >= lag) {
         const long old = round - lag;
         const unsigned tag = (unsigned)((old & 0x3fffffff) + 1);
@@ -769,6 +781,7 @@ struct Part {
   unsigned long long *h_active;
   bool done;
   unsigned seen_active;  // the last count of running trajectories the host has read
+  long used;             // slots its kernels are launched over (slots_in_use)
 };
 // the workspace of trajectories [b0, b0 + nb), b0 a multiple of 64
 BatchState slice_state(const qilqr_solver *s, long b0, long n, int part) {
@@ -792,7 +805,7 @@ BatchState slice_state(const qilqr_solver *s, long b0, long n, int part) {
   v.dump = adv(w.dump, 4 * b0);
   v.orig = w.orig + b0;
   v.row0 = w.row0 + (int)b0;
-  v.plan = w.plan + PLAN_HEAD * (part + 1) + 2 * b0;  // (part p's plan ends where part p + 1's begins)
+  v.plan = w.plan + PLAN_HEAD * (part + 1) + 4 * b0;  // (part p's plan ends where part p + 1's begins)
   if (w.stamps) v.stamps = w.stamps + 8 * b0;
   return v;
 }
@@ -862,6 +875,7 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
     part.h_active = s->h_active + 8 * (1 + p);
     part.done = false;
     part.seen_active = (unsigned)part.nb;
+    part.used = part.nb;
     if (s->compact) s->plan_heads.push_back(part.st.plan - s->st.plan);
     for (int k = 0; k < 8; ++k) part.h_active[k] = 0;
     parts.push_back(part);
@@ -884,10 +898,13 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
       for (auto &part : parts) {
         if (part.done) continue;
         PartScope scope(s, part);
-        if ((rc = launch_backward(s, part.nb, n, 0))) return rc;
-        if (s->compact && part.seen_active > compact_stop(s) && (rc = launch_compact(s, part.nb, n))) return rc;
-        if ((rc = launch_rollout(s, part.nb, n, F_SEARCH))) return rc;
-        if ((rc = launch_linearize(s, part.nb, n, 1, F_SEARCH, (int)(round & 0x3fffffff)))) return rc;
+        if ((rc = launch_backward(s, part.used, n, 0))) return rc;
+        if (s->compact && part.seen_active > compact_stop(s)) {
+          if ((rc = launch_compact(s, part.used, n))) return rc;
+          part.used = slots_in_use(part.used, part.seen_active);
+        }
+        if ((rc = launch_rollout(s, part.used, n, F_SEARCH))) return rc;
+        if ((rc = launch_linearize(s, part.used, n, 1, F_SEARCH, (int)(round & 0x3fffffff)))) return rc;
       }
       if (round < lag) continue;
       const long old = round - lag;

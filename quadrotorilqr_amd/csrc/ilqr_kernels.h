@@ -81,7 +81,7 @@ struct BatchState {
   // (-1: the slot's trajectory has moved away), the first row of this (sub-)batch, and the plan of the current round
   int *orig;
   int row0;
-  int *plan;  // [0] moves, [16 ..] destination slots, [16 + B ..] source slots
+  int *plan;  // [0] moves, [16 ..] destination slots, [16 + B ..] source slots, [16 + 2 B ..] per pair: row, selectors (k_compact_plan)
 };
 
 __device__ __forceinline__ int *active_counter(const BatchState &st) {
@@ -2555,34 +2555,68 @@ __global__ __launch_bounds__(1024) void k_compact_plan(BatchState st, int B) {
   __shared__ int s_tot[16];
   __shared__ unsigned long long s_tot2[16];
   const int t = threadIdx.x;
-  const int per = (B + 1023) / 1024;
+  // a thread's flags are consecutive words, a multiple of four of them, read sixteen bytes at a time (at most 64 words for 65536
+  // slots: one word per load took this kernel 80 us there); they stay in the L2 between the passes
+  const int per = (((B + 1023) / 1024) + 3) & ~3;
   const int b0 = t * per < B ? t * per : B, b1 = (b0 + per < B) ? b0 + per : B;
-  // (a thread's flags are consecutive words: at most 64 of them for 65536 slots; they stay in the L2 between the two passes)
+  auto alive4 = [&](int b, bool (&al)[4]) {  // slots b .. b + 3 (b a multiple of four; beyond B: not alive)
+    if (b + 3 < B) {
+      const int4 v = *reinterpret_cast<const int4 *>(st.flags + b);
+      al[0] = (v.x & F_ACTIVE) != 0; al[1] = (v.y & F_ACTIVE) != 0; al[2] = (v.z & F_ACTIVE) != 0; al[3] = (v.w & F_ACTIVE) != 0;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) al[e] = (b + e < B) && (st.flags[b + e] & F_ACTIVE) != 0;
+    }
+  };
   int live = 0;
-  for (int b = b0; b < b1; ++b) live += (st.flags[b] & F_ACTIVE) ? 1 : 0;
+  for (int b = b0; b < b1; b += 4) {
+    bool al[4];
+    alive4(b, al);
+    live += (int)al[0] + (int)al[1] + (int)al[2] + (int)al[3];
+  }
   int L;
   (void)block_scan_1024(live, s_tot, &L);
   // holes among the first L slots (low word) and live slots behind them (high word), ranked in one scan
   unsigned long long hm = 0;
-  for (int b = b0; b < b1; ++b) {
-    const bool alive = (st.flags[b] & F_ACTIVE) != 0;
-    if (b < L) hm += alive ? 0ull : 1ull;
-    else hm += alive ? (1ull << 32) : 0ull;
+  for (int b = b0; b < b1; b += 4) {
+    bool al[4];
+    alive4(b, al);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (b + e >= B) continue;
+      if (b + e < L) hm += al[e] ? 0ull : 1ull;
+      else hm += al[e] ? (1ull << 32) : 0ull;
+    }
   }
   unsigned long long all;
   const unsigned long long incl = block_scan_1024(hm, s_tot2, &all);
   int hk = (int)(unsigned)(incl - hm), mk = (int)((incl - hm) >> 32);  // exclusive ranks
   int *dst = st.plan + PLAN_HEAD, *src = st.plan + PLAN_HEAD + B;
-  for (int b = b0; b < b1; ++b) {
-    const bool alive = (st.flags[b] & F_ACTIVE) != 0;
-    if (b < L) { if (!alive) dst[hk++] = b; }
-    else if (alive) src[mk++] = b;
+  for (int b = b0; b < b1; b += 4) {
+    bool al[4];
+    alive4(b, al);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (b + e >= B) continue;
+      if (b + e < L) { if (!al[e]) dst[hk++] = b + e; }
+      else if (al[e]) src[mk++] = b + e;
+    }
   }
-  if (t == 0) {  // (as many holes in front of L as live slots behind it)
-    const int M = (int)(all >> 32);
+  const int M = (int)(all >> 32);  // (as many holes in front of L as live slots behind it)
+  if (t == 0) {
     st.plan[0] = M;
     st.plan[1] = L;
     st.plan[2] += M;
+  }
+  // what the parts of a pair must agree on, noted before any of them runs: the row of the hole's finished trajectory (-1: none),
+  // its buffer selector, the live trajectory's selector
+  __syncthreads();  // (dst and src of a pair were written by different threads; global writes of this block, visible behind the barrier)
+  int *pair = st.plan + PLAN_HEAD + 2 * B;
+  for (int k = t; k < M; k += 1024) {
+    const int d = dst[k], sr = src[k];
+    pair[4 * k] = st.orig[d];
+    pair[4 * k + 1] = st.cur[d];
+    pair[4 * k + 2] = st.cur[sr];
   }
 }
 struct CompactOut {  // the caller's result arrays (device pointers, any may be null): k_gather's
@@ -2604,55 +2638,61 @@ __device__ __forceinline__ void copy_pieces(const S *a, S *b, long step, int q0,
   }
   for (; q < q1; q += nt) *reinterpret_cast<sv2 *>(b + (long)q * step) = *reinterpret_cast<const sv2 *>(a + (long)q * step);
 }
-// Work item = (pair k, part c of COMPACT_SPLIT): every part copies its share of the trajectory, gains (and records); part 0
-// also sends off the hole's finished trajectory FIRST and writes the scalars.  The parts of a pair touch disjoint bytes --
-// except that the hole's current trajectory may sit in the buffer the copy writes: the trajectory is therefore copied by
-// part 0 alone, behind its gather; the gains and records, which a finished trajectory no longer needs, by all parts.
-constexpr int COMPACT_SPLIT = 4;
+// Work item = (pair k, part c of COMPACT_SPLIT).  The units of a pair -- n * 9 pieces of trajectory (the hole's finished
+// trajectory out to the caller's row, then the live one in: the same thread does both for a piece, in that order, because the
+// hole's current trajectory may sit in the buffer the copy writes), n * 26 pieces of gains, and the records' -- are numbered
+// through and cut into equal parts; part 0's first thread also moves the scalars.  The parts of a pair read the pair's slots and
+// selectors as they were when the part started: k_compact_pairs (below) notes them in the plan before any part runs.
+constexpr int COMPACT_SPLIT = 8;
 template <typename S>
 __global__ __launch_bounds__(256) void k_compact_move(BatchState st, int B, int n, CompactOut out, int with_records) {
   typedef typename GA<S>::v2 sv2;
   const int M = st.plan[0];
   const int t = threadIdx.x;
+  const int *pair = st.plan + PLAN_HEAD + 2 * B;  // [k][4]: row of the hole's trajectory, its selector, the live one's selector
+  const int nt = n * 9, ng = n * 26, nr = with_records ? n * (st.layout.stride / 2) : 0;
+  const int units = nt + ng + nr;
   for (int item = blockIdx.x; item < M * COMPACT_SPLIT; item += gridDim.x) {
     const int k = item / COMPACT_SPLIT, c = item - k * COMPACT_SPLIT;
     const int dst = st.plan[PLAN_HEAD + k], src = st.plan[PLAN_HEAD + B + k];
-    const int cs = st.cur[src];
+    const long row = pair[4 * k];
+    const int cd = pair[4 * k + 1], cs = pair[4 * k + 2];
+    const int u0 = (int)((long)units * c / COMPACT_SPLIT), u1 = (int)((long)units * (c + 1) / COMPACT_SPLIT);
+    // trajectory pieces [u0, u1) ∩ [0, nt)
     {
-      const int ng = n * 26, g0 = (int)((long)ng * c / COMPACT_SPLIT), g1 = (int)((long)ng * (c + 1) / COMPACT_SPLIT);
-      copy_pieces<S>((const S *)st.gains + knot_base<true>(src, n, 52), (S *)st.gains + knot_base<true>(dst, n, 52), TILE2, g0, g1);
-      if (with_records) {
-        const RecLayout &L = st.layout;
-        const int nr = n * (L.stride / 2), r0 = (int)((long)nr * c / COMPACT_SPLIT), r1 = (int)((long)nr * (c + 1) / COMPACT_SPLIT);
-        copy_pieces<S>((const S *)st.lin[cs] + rec_base(L, src, n), (S *)st.lin[cs] + rec_base(L, dst, n), L.tiled ? TILE2 : 2, r0, r1);
-      }
-    }
-    if (c != 0) continue;  // (block-uniform)
-    const long row = st.orig[dst];
-    const int cd = st.cur[dst];
-    // 1. the finished trajectory in the hole leaves for the caller's arrays
-    if (row >= 0) {
-      if (out.traj) {
-        const S *tp = (const S *)st.traj[cd] + knot_base<true>(dst, n, 18);
-        double *o = out.traj + row * n * 18;
-        for (int q = t; q < n * 9; q += blockDim.x) {
-          const sv2 v = *reinterpret_cast<const sv2 *>(tp + (long)q * TILE2);
+      const int q1 = u1 < nt ? u1 : nt;
+      const S *dead = (const S *)st.traj[cd] + knot_base<true>(dst, n, 18);
+      const S *a = (const S *)st.traj[cs] + knot_base<true>(src, n, 18);
+      S *b = (S *)st.traj[cs] + knot_base<true>(dst, n, 18);
+      double *o = (row >= 0 && out.traj) ? out.traj + row * n * 18 : nullptr;
+      for (int q = u0 + t; q < q1; q += blockDim.x) {
+        const sv2 live = *reinterpret_cast<const sv2 *>(a + (long)q * TILE2);
+        if (o) {
+          const sv2 v = *reinterpret_cast<const sv2 *>(dead + (long)q * TILE2);
           o[2 * q] = (double)v.x;
           o[2 * q + 1] = (double)v.y;
         }
+        *reinterpret_cast<sv2 *>(b + (long)q * TILE2) = live;
       }
-      if (t == 0) {
+    }
+    // gains pieces
+    {
+      const int g0 = (u0 > nt ? u0 : nt) - nt, g1 = (u1 < nt + ng ? u1 : nt + ng) - nt;
+      if (g0 < g1) copy_pieces<S>((const S *)st.gains + knot_base<true>(src, n, 52), (S *)st.gains + knot_base<true>(dst, n, 52), TILE2, g0, g1);
+    }
+    if (nr) {
+      const RecLayout &L = st.layout;
+      const int r0 = (u0 > nt + ng ? u0 : nt + ng) - nt - ng, r1 = u1 - nt - ng;
+      if (r0 < r1) copy_pieces<S>((const S *)st.lin[cs] + rec_base(L, src, n), (S *)st.lin[cs] + rec_base(L, dst, n), L.tiled ? TILE2 : 2, r0, r1);
+    }
+    if (c == 0 && t == 0) {
+      if (row >= 0) {
         if (out.cost) out.cost[row] = st.cost[dst];
         if (out.status) out.status[row] = st.status[dst];
         if (out.iters) out.iters[row] = st.iters[dst];
         if (out.n_bwd) out.n_bwd[row] = st.n_bwd[dst];
         if (out.n_fwd) out.n_fwd[row] = st.n_fwd[dst];
       }
-    }
-    __syncthreads();  // (the hole's current trajectory may sit in the buffer the copy writes)
-    // 2. the live trajectory moves in
-    copy_pieces<S>((const S *)st.traj[cs] + knot_base<true>(src, n, 18), (S *)st.traj[cs] + knot_base<true>(dst, n, 18), TILE2, 0, n * 9);
-    if (t == 0) {
       st.cur[dst] = cs;
       st.cost[dst] = st.cost[src];
       st.prev_cost[dst] = st.prev_cost[src];
@@ -2667,12 +2707,12 @@ __global__ __launch_bounds__(256) void k_compact_move(BatchState st, int B, int 
       st.n_fwd[dst] = st.n_fwd[src];
       st.orig[dst] = st.orig[src];
       st.flags[dst] = st.flags[src];
-      st.flags[src] = 0;  // nothing runs in the slot it left, and k_gather passes it by (the other parts of the pair read
-      st.orig[src] = -1;  // the source's selector, gains and records, none of which changes here)
+      st.flags[src] = 0;  // nothing runs in the slot it left, and k_gather passes it by
+      st.orig[src] = -1;
     }
-    __syncthreads();
   }
 }
+
 // ILQRDebug on the device (ilqr.hh:78-80: one entry per completed forward pass, the accepted trajectory and its cost) for the
 // single-problem solve: launched behind every round's backward pass (whose settle step is where an iteration completes), one
 // block; when trajectory 0 has completed an iteration since the last look, its current trajectory -- in the buffer the next
