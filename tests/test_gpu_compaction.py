@@ -93,6 +93,19 @@ def test_the_solver_is_reusable_at_other_batch_sizes():
     np.testing.assert_array_equal(solve_device(s, cfg["init"])["traj"], full["traj"])
 
 
+@pytest.mark.parametrize("B,N,opts", [(1, 20, {}), (5, 3, {}), (130, 2, {}), (64, 30, dict(max_iters=1)), (200, 25, dict(max_iters=0)),
+                                      (300, 30, dict(ls_max_iters=0)), (257, 30, dict(rtol=1e-2, atol=1e-2))])
+def test_edge_shapes_and_options(B, N, opts):
+    """one problem, a ragged tile, two knots, a single iteration, none at all, no trial allowed (every problem leaves in the same
+    round: nothing to move), loose thresholds (most leave at once)"""
+    cfg = pb.config2(B=B, N=N, seed=13)
+    cfg["options"] = dict(cfg["options"], **opts)
+    on, off = capi.from_config(cfg, compaction=1), capi.from_config(cfg, compaction=-1)
+    a, b = solve_device(on, cfg["init"]), solve_device(off, cfg["init"])
+    assert_same(a, b, f"B={B} N={N} {opts}")
+    assert np.isfinite(a["traj"]).all()
+
+
 def test_full_size_shard_with_and_without():
     """BASELINE.json configs[3], the shard of one GPU (B = 8192, N = 100): the automatic setting compacts; same bits as never."""
     cfg = pb.config2(B=8192, N=100, seed=4)
