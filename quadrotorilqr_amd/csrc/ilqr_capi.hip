@@ -506,7 +506,8 @@ int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
 // k_backward_rollout (ilqr_kernels.h): the backward pass and the rollout of a round in one launch, when every block of four
 // trajectories has a CU to itself (the rollout's register budget allows one block per CU) and the round's kernels are the
 // fused k_backward4 and k_rollout16 anyway.  QILQR_FUSE_BACKWARD_ROLLOUT=0 in the environment keeps them apart (A/B).
-bool fuse_backward_rollout(const qilqr_solver *s, long B) {
+// (the kernels of the round are the two the combined launch stands for: everything but the room on the chip)
+bool fuse_kinds(const qilqr_solver *s, long B) {
   static const bool off = [] {
     const char *e = std::getenv("QILQR_FUSE_BACKWARD_ROLLOUT");
     return e && e[0] == '0';
@@ -515,7 +516,10 @@ bool fuse_backward_rollout(const qilqr_solver *s, long B) {
   if (off || s->integrator != 0 || !s->symmetric || !s->st.layout.tiled) return false;
   if (!(s->dev.force_general == 0 || s->dev.force_general == 5) || backward_kind(s, load_B) != BW_FUSED) return false;
   if (!(s->dev.single_wave_rollout == 0 || s->dev.single_wave_rollout == 3) || load_B > R16_MAX_B) return false;
-  return cdiv(load_B, 4) <= (unsigned)s->num_cus;
+  return true;
+}
+bool fuse_backward_rollout(const qilqr_solver *s, long B) {
+  return fuse_kinds(s, B) && cdiv(std::max(B, s->total_B), 4) <= (unsigned)s->num_cus;
 }
 // Batch solves in flight on a device, over all the handles of the process.  The combined kernel takes a whole CU per block of
 // four trajectories (the rollout's register budget): alone on the chip that is +3 to +4 % of a solve, beside other solves'
@@ -574,6 +578,26 @@ int launch_compact(qilqr_solver *s, long B, long n) {
   else
     launch(s, K_OTHER, k_compact_move<double>, dim3(grid), dim3(256), s->st, (int)B, (int)n, s->compact_out, with_records);
   return QILQR_OK;
+}
+
+// A batch of 1025 ... 4096 trajectories runs the same two kernels apart, with the compaction between them; once the running
+// trajectories fit the combined launch -- `slots` of them for this (sub-)batch: a block of four per CU over all the sub-batches --
+// the compaction has nothing left to give (a block per CU whatever the slots) and the rounds change over to the one launch.
+struct TailFuse {
+  bool kinds = false;  // the round's kernels are the fused k_backward4 and k_rollout16
+  long slots = 0;      // slots in use at or below which this (sub-)batch's rounds are one launch
+  unsigned stop = 0;   // the compaction runs while more trajectories than this are running
+};
+TailFuse tail_fuse(const qilqr_solver *s, long B, int nparts) {
+  TailFuse t;
+  t.stop = compact_stop(s);
+  if (!s->compact || s->dev.compaction == 1) return t;  // (forced: the compaction runs to the last trajectory)
+  t.kinds = fuse_kinds(s, B);
+  if (t.kinds) {
+    t.slots = std::max<long>(64, 4L * s->num_cus / nparts / 64 * 64);
+    t.stop = std::max<unsigned>(t.stop, (unsigned)t.slots);
+  }
+  return t;
 }
 
 int read_active(qilqr_solver *s, int *n_active) {
@@ -709,15 +733,18 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
     for (int k = 0; k < 8; ++k) s->h_active[k] = 0;
     const InFlight in_flight(s->device);
     const bool can_fuse = fuse_backward_rollout(s, B) && !s->compact;  // (compaction works between the two halves)
+    const TailFuse tf = tail_fuse(s, B, 1);
     if (s->compact) s->plan_heads.push_back(0);
     unsigned seen_active = (unsigned)B;  // the last count the host has read (the count only falls)
     long used = B;                       // slots the round's kernels are launched over (slots_in_use)
     for (long round = 0; round < max_rounds; ++round) {
-      if (can_fuse && in_flight.alone()) {
-        if ((rc = launch_backward_rollout(s, B, n))) return rc;
+      // (one more compaction behind the last count above the threshold brings the slots in use under it)
+      const bool compacting = s->compact && (seen_active > tf.stop || (tf.kinds && used > tf.slots));
+      if ((can_fuse || (tf.kinds && !compacting && used <= tf.slots)) && in_flight.alone()) {
+        if ((rc = launch_backward_rollout(s, used, n))) return rc;
       } else {
         if ((rc = launch_backward(s, used, n, 0))) return rc;
-        if (s->compact && seen_active > compact_stop(s)) {
+        if (compacting) {
           if ((rc = launch_compact(s, used, n))) return rc;
           used = slots_in_use(used, seen_active);
         }
@@ -894,12 +921,20 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
         (std::fmin(s->params.max_iters, 1e7) + 1.0) * ((double)std::max(s->params.ls_max_iters, 1) + 1.0) * (1.0 + max_restarts(s->params));
     const long max_rounds = (long)std::fmin(bound, 2e9);
     const int lag = std::max(1, std::min(s->dev.sync_every, 6));
+    const InFlight in_flight(s->device);
+    const TailFuse tf = tail_fuse(s, B, nparts);
     for (long round = 0; round < max_rounds && remaining > 0; ++round) {
       for (auto &part : parts) {
         if (part.done) continue;
         PartScope scope(s, part);
+        const bool compacting = s->compact && (part.seen_active > tf.stop || (tf.kinds && part.used > tf.slots));
+        if (tf.kinds && !compacting && part.used <= tf.slots && in_flight.alone()) {
+          if ((rc = launch_backward_rollout(s, part.used, n))) return rc;
+          if ((rc = launch_linearize(s, part.used, n, 1, F_SEARCH, (int)(round & 0x3fffffff)))) return rc;
+          continue;
+        }
         if ((rc = launch_backward(s, part.used, n, 0))) return rc;
-        if (s->compact && part.seen_active > compact_stop(s)) {
+        if (compacting) {
           if ((rc = launch_compact(s, part.used, n))) return rc;
           part.used = slots_in_use(part.used, part.seen_active);
         }
