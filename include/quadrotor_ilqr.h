@@ -331,10 +331,12 @@ int qilqr_solve_batch_sharded_device(qilqr_sharded *h, const double *init, const
 int qilqr_gather_schedule(int32_t B, int32_t n, const int32_t *devices, int32_t n_shards, int32_t root, uint32_t arrays,
                           int64_t *out, int32_t cap);
 
-/* ABI version of this header */
 /* trajectories moved by the compaction (qilqr_device_config.compaction) in the last batch solve of this handle; 0 when it was
  * off for that call.  Waits for the handle's stream. */
 int qilqr_compaction_moves(qilqr_solver *s, int64_t *moves);
+
+/* ABI version of this header: 6 (qilqr_device_config grew by `compaction`: a caller built against version 5 passes a shorter
+ * structure -- check the version before qilqr_create) */
 int qilqr_abi_version(void);
 
 #ifdef __cplusplus
