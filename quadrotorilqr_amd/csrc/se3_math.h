@@ -37,6 +37,14 @@
 #define QILQR_PIN(x) do { } while (0)
 #endif
 
+// Fused multiply-adds are formed where the SOURCE says a * b + c in one expression and nowhere else (hipcc's default, "fast", also
+// fuses across statements, and what it finds depends on the kernel a function is inlined into: the same linearisation inlined into two
+// kernels gave records that differed in their last bits -- DESIGN.md section 4, k_round).  With this every function of this file
+// computes the same bits in every kernel that uses it; the rest of the translation unit goes back to the default below.
+#if defined(__clang__)
+#pragma clang fp contract(on)
+#endif
+
 namespace qilqr {
 
 template <typename T>
@@ -1374,3 +1382,7 @@ QILQR_HD void rollout_problem(const ModelConsts<T> &c, const T *traj, const T *g
 }
 
 }  // namespace qilqr
+
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
