@@ -234,7 +234,8 @@ def main():
     ap.add_argument("--backward", type=int, default=0, help="diagnostic: backward kernel (qilqr_device_config.force_general: 0 automatic, 1 general, 2 one wavefront per trajectory, 3 k_backward2 (diagnostics build), 4 k_backward4 six wavefronts, 5 fused, 6 fused with block barriers)")
     ap.add_argument("--persistent", type=int, default=0, help="qilqr_device_config.persistent: 0 / 2 rounds of three launches (the product), 1 the solve as one launch (k_solve4: loads the diagnostics build of the library)")
     ap.add_argument("--streams", type=int, default=0, help="sub-batches on their own streams (qilqr_device_config.streams; 0 automatic)")
-    ap.add_argument("--event-stride", type=int, default=4, help="time every k-th launch of the dominant kernel in the timed region (a timed dispatch costs the stream about 6 us)")
+    ap.add_argument("--event-stride", type=int, default=16, help="time every k-th launch of the dominant kernel in the timed region (a timed dispatch costs the stream about 6 us: "
+                    "with every 4th timed `value` reads 1.4 %% low, with every 16th 0.2 %% -- profiles/r04_event_stride.txt)")
     ap.add_argument("--settle-ms", type=float, default=300.0, help="untimed solves before the warm-up steps (clocks out of idle)")
     ap.add_argument("--no-serving", action="store_true", help="skip the extra several-batches-in-flight measurement (never part of value)")
     ap.add_argument("--serving-batches", type=int, default=18)
