@@ -179,66 +179,4 @@ QILQR_HD void ldlt4_pivoted_solve(const double (&Quu)[16], const double (&rhs)[4
   for (int e = 0; e < 4; ++e) x[e] = y[e];
 }
 
-// ---- the 4x4 solve of the fused backward wavefront, stated lane by lane (round 4) --------------------------------------------
-// x = -Q_uu^-1 r for the sixteen columns a row of 16 lanes holds: lane j < 12 has column j of Q_ux, lanes 12..15 the columns of
-// Q_uu itself, lane 12's RIGHT-HAND SIDE is Q_u (so its solution is the feed-forward k, ilqr.hh:128) while its matrix column
-// still serves as pivot column.  Elimination WITHOUT divisions (Bareiss without the exact division: every step multiplies the
-// trailing rows by the pivot instead of dividing the pivot row), so that the four reciprocals do not sit in series on the
-// per-knot chain as they do in ldlt4_factor: with z = L^-1 r of the unpivoted LDL^T,
-//     b_i = q0 r_i - q_i r_0 = q0 z_i',  c_i = B1 b_i - B_i b_1,  e = C2 c_3 - C3 c_2 = q0 B1 C2 z_3
-// where q = column 0 of Q_uu (lane 12), B = (b_1, b_2, b_3) of lane 13, C = (c_2, c_3) of lane 14, E = e of lane 15, and
-//     d_0 = q0, d_1 = B1 / q0, d_2 = C2 / (q0 B1), d_3 = E / (q0 B1 C2):
-// the scale factors cancel in D^-1 z, which is (r_0 / q0, b_1 / B1, c_2 / C2, e / E), and the back substitution runs with
-// l_10.. = q_i / q0, l_21, l_31 = B_i / B1, l_32 = C3 / C2.  Same factorisation as ldlt4_factor in exact arithmetic; rounding
-// differs.  On the device a lane reads another lane's value inside v_fmac_f64_dpp row_newbcast (ilqr_kernels.h, ff4_solve_neg:
-// one asm block, this statement instruction for instruction); here the pivot lanes' values are passed in.  rcp(x) is the
-// hardware's estimate on the device, 1 / x here: the two Newton steps bring either to the last bits.
-struct Ff4Pivots {
-  double q[4];  // col_i of lane 12
-  double B[4];  // b_i of lane 13 (B[0] unused)
-  double C[4];  // c_i of lane 14 (C[0], C[1] unused)
-  double E;     // e of lane 15
-};
-QILQR_HD double ff4_rcp_nr(double x, double est) {
-  double r = est;
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  return r;
-}
-// forward part of one lane: r (its right-hand side) -> b[1..3], c[2..3], e, given the pivot lanes' values so far
-QILQR_HD void ff4_lane_b(const double (&q)[4], const double (&r)[4], double (&b)[4]) {
-  for (int i = 1; i < 4; ++i) b[i] = __builtin_fma(-q[i], r[0], __builtin_fma(q[0], r[i], 0.0));
-}
-QILQR_HD void ff4_lane_c(const double (&B)[4], const double (&b)[4], double (&c)[4]) {
-  for (int i = 2; i < 4; ++i) c[i] = __builtin_fma(-B[i], b[1], __builtin_fma(B[1], b[i], 0.0));
-}
-QILQR_HD double ff4_lane_e(const double (&C)[4], const double (&c)[4]) {
-  return __builtin_fma(-C[3], c[2], __builtin_fma(C[2], c[3], 0.0));
-}
-// the whole row: col[i][j] = H[12 + i][j] (j = 0..15), qu = Q_u; x[a][j] = -(Q_uu^-1 column j)[a], x[a][12] = k[a]
-QILQR_HD void ff4_row_solve_neg(const double (&col)[4][16], const double (&qu)[4], double (&x)[4][16]) {
-  double r[16][4], b[16][4], c[16][4], e[16];
-  for (int j = 0; j < 16; ++j)
-    for (int i = 0; i < 4; ++i) r[j][i] = (j == 12) ? qu[i] : col[i][j];
-  Ff4Pivots P;
-  for (int i = 0; i < 4; ++i) P.q[i] = col[i][12];
-  for (int j = 0; j < 16; ++j) ff4_lane_b(P.q, r[j], b[j]);
-  for (int i = 0; i < 4; ++i) P.B[i] = b[13][i];
-  for (int j = 0; j < 16; ++j) ff4_lane_c(P.B, b[j], c[j]);
-  for (int i = 0; i < 4; ++i) P.C[i] = c[14][i];
-  for (int j = 0; j < 16; ++j) e[j] = ff4_lane_e(P.C, c[j]);
-  P.E = e[15];
-  const double R0 = ff4_rcp_nr(P.q[0], 1.0 / P.q[0]), R1 = ff4_rcp_nr(P.B[1], 1.0 / P.B[1]);
-  const double R2 = ff4_rcp_nr(P.C[2], 1.0 / P.C[2]), R3 = ff4_rcp_nr(P.E, 1.0 / P.E);
-  const double u1 = P.q[1] * R0, u2 = P.q[2] * R0, u3 = P.q[3] * R0, v2 = P.B[2] * R1, v3 = P.B[3] * R1, w3 = P.C[3] * R2;
-  for (int j = 0; j < 16; ++j) {
-    const double y0 = __builtin_fma(-R0, r[j][0], 0.0), y1 = __builtin_fma(-R1, b[j][1], 0.0), y2 = __builtin_fma(-R2, c[j][2], 0.0);
-    const double x3 = __builtin_fma(-R3, e[j], 0.0);
-    const double x2 = __builtin_fma(-w3, x3, y2);
-    const double x1 = __builtin_fma(-v2, x2, __builtin_fma(-v3, x3, y1));
-    const double x0 = __builtin_fma(-u1, x1, __builtin_fma(-u2, x2, __builtin_fma(-u3, x3, y0)));
-    x[0][j] = x0; x[1][j] = x1; x[2][j] = x2; x[3][j] = x3;
-  }
-}
-
 }  // namespace qilqr

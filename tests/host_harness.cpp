@@ -334,20 +334,6 @@ void hh_ldlt4_pivoted_solve(const double *A, const double *b, double *x) {
   for (int e = 0; e < 4; ++e) x[e] = xv[e];
 }
 
-// the fused backward wavefront's division-free 4x4 solve, as stated lane by lane in backward_layout.h (ff4_row_solve_neg; on the
-// device one asm block of v_fmac_f64_dpp, ilqr_kernels.h ff4_solve_neg): H4 = rows 12..15 of H (4 x 16, row-major), qu = Q_u;
-// x = 4 x 16: column j < 12 of -Q_uu^-1 Q_ux, column 12 = k
-void hh_ff4_row_solve(const double *H4, const double *qu, double *x) {
-  double col[4][16], q[4], xs[4][16];
-  for (int i = 0; i < 4; ++i) {
-    q[i] = qu[i];
-    for (int j = 0; j < 16; ++j) col[i][j] = H4[i * 16 + j];
-  }
-  ff4_row_solve_neg(col, q, xs);
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 16; ++j) x[i * 16 + j] = xs[i][j];
-}
-
 // k_backward re-enacted lane by lane (same statements, loops over the 64 lanes between the
 // points where the kernel exchanges data).  sym = 1: the SYM = true instantiation (accumulator tile
 // reused as A operand, V_x / V_xx / k^T Quu k in their Q_xu forms), sym = 0: the general one.

@@ -548,38 +548,6 @@ def test_pivoted_ldlt_of_the_general_kernel_is_eigens(hh):
         assert np.abs(x - du).max() < 1e-13
 
 
-def test_division_free_solve_of_the_fused_backward_wavefront(hh):
-    """ff4_row_solve_neg (backward_layout.h): the 4x4 solve of the fused backward wavefront -- elimination without divisions,
-    one reciprocal on the chain, pivot values read from lanes 12..15 -- against the oracle's LDL^T solve (the restated
-    Eigen LDLT of ilqr.hh:126-128) for the twelve columns of Q_ux and for Q_u (lane 12), over well- and ill-conditioned
-    positive definite Q_uu, Q_uu with entries of very different magnitude, and the reference's 2 R + J_u^T V J_u shape."""
-    r = np.random.default_rng(11)
-    for trial in range(300):
-        kind = trial % 4
-        if kind == 0:
-            A = r.uniform(-1, 1, (4, 4)); Quu = A @ A.T + 0.5 * np.eye(4)
-        elif kind == 1:   # cond ~ 1e6
-            U, _ = np.linalg.qr(r.normal(size=(4, 4))); Quu = U @ np.diag(10.0 ** r.uniform(-3, 3, 4)) @ U.T
-        elif kind == 2:   # badly scaled rows / columns
-            A = r.uniform(-1, 1, (4, 4)); D = np.diag(10.0 ** r.uniform(-4, 4, 4)); Quu = D @ (A @ A.T + np.eye(4)) @ D
-        else:             # 2 R + J_u^T V J_u
-            J = r.normal(size=(12, 4)) * 0.1; W = r.normal(size=(12, 12)); Quu = 2 * np.eye(4) + J.T @ (W @ W.T * 50) @ J
-        Quu = 0.5 * (Quu + Quu.T)
-        # the device tile is symmetric only to rounding: perturb the upper triangle by an ulp or two
-        Quu_t = Quu * (1 + np.triu(r.integers(-2, 3, (4, 4)), 1) * 2.2e-16)
-        Qux = r.uniform(-3, 3, (4, 12)) * 10.0 ** r.uniform(-2, 2)
-        qu = r.uniform(-3, 3, 4)
-        H4 = np.ascontiguousarray(np.concatenate([Qux, Quu_t], axis=1))
-        x = np.zeros((4, 16))
-        hh.hh_ff4_row_solve(P(H4), P(np.ascontiguousarray(qu)), P(x))
-        cond = np.linalg.cond(Quu)
-        for j in range(12):
-            ref = -np.asarray(orc.ldlt4_solve(np.ascontiguousarray(Quu), np.ascontiguousarray(Qux[:, j]))).reshape(4)
-            assert np.abs(x[:, j] - ref).max() <= 4e-16 * cond * max(np.abs(ref).max(), 1e-300) * 8, (trial, j, cond)
-        ref = -np.asarray(orc.ldlt4_solve(np.ascontiguousarray(Quu), np.ascontiguousarray(qu))).reshape(4)
-        assert np.abs(x[:, 12] - ref).max() <= 4e-16 * cond * np.abs(ref).max() * 8, (trial, cond)
-
-
 def test_diagonal_weights_instantiation_gives_the_block_diagonal_one_bit_for_bit(hh):
     """linearize_cost<3> (round 3: Q exactly diagonal -- the reference's demo and tests -- so J^T Q is a row scaling) against
     linearize_cost<2> (Q symmetric with zero pose x velocity blocks) on the same diagonal Q: the sums of <2> add products with
