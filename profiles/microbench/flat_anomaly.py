@@ -5,6 +5,9 @@ oracle's path on 3 of 60 restart seeds.  Two builds side by side in one process:
 functions) and -DQILQR_BODY_AS_FUNCTION; the randomised restart problems of tests/test_gpu_parity.py, force_general = 4.
 For every seed on which a build's counts differ from the oracle's: the comparison of the oracle's path that explains it
 (tests/exit_paths.py) with its margin; and whether ONE backward pass of the two builds on the same trajectory gives the same bits.
+(The build switch -DQILQR_BODY_AS_FUNCTION -- k_backward4's body as a __device__ function, QILQR_BODY_REF_MASK choosing which argument
+structures it takes by reference -- was in csrc/ilqr_kernels.h until the cause was found and fixed at the source (commit "Root cause of the
+flat-pointer anomaly ..."): it is gone with the reason for it; this script documents how the nine deviating seeds were found.)
 usage (repository root, GPU box; the variant: make -C quadrotorilqr_amd/csrc variant NAME=bodyfn DEFS=-DQILQR_BODY_AS_FUNCTION):
     PYTHONPATH=. python3 profiles/microbench/flat_anomaly.py [first_seed [n_seeds]]"""
 import importlib.util

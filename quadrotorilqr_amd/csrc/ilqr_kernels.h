@@ -1689,34 +1689,16 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
 // 404 000 -> 412 000 solves/s; nothing at 4096, -0.5 % at 1024)
 // FUSED: five wavefronts per block -- MG_0..MG_3 (matrix and gradient recursion of a trajectory in one wavefront, bw4_fused_wave)
 // and the loader L -- instead of six (M_0..M_3, G, L).
-#ifdef QILQR_BODY_AS_FUNCTION
-#ifndef QILQR_BODY_REF_MASK
-#define QILQR_BODY_REF_MASK 7  // which of the three argument structures arrive by const reference: 1 c, 2 p, 4 st
-#endif
-template <typename T, bool REF> struct BodyArg { typedef T type; };
-template <typename T> struct BodyArg<T, true> { typedef const T &type; };
-template <typename S, int WAVES, bool FUSED, bool FREE>
-__device__ __forceinline__ void backward4_block_fn(typename BodyArg<ModelConsts<double>, (QILQR_BODY_REF_MASK & 1) != 0>::type c,
-                                                   typename BodyArg<SolveParams, (QILQR_BODY_REF_MASK & 2) != 0>::type p,
-                                                   typename BodyArg<BatchState, (QILQR_BODY_REF_MASK & 4) != 0>::type st, int B, int n, int force) {
-#define BW4_RETURN return
-#include "backward4_body.inc"
-#undef BW4_RETURN
-}
-#endif
 template <typename S, int WAVES, bool FUSED = false, bool FREE = false>
 __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_backward4(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n,
                                                    int force) {
   // (the body lives in a file of its own because k_backward_rollout contains it too, as statements of the kernel function:
   // called as a device function it loses what the compiler knows about pointers that come from kernel arguments -- every
-  // global access became a flat one -- and the six-wavefront form's results changed)
-#ifdef QILQR_BODY_AS_FUNCTION  // diagnosis only (round 3's anomaly): the body as a __device__ function
-  backward4_block_fn<S, WAVES, FUSED, FREE>(c, p, st, B, n, force);
-#else
+  // global access becomes a flat one.  Round 3 saw the six-wavefront form's results change that way; the cause was a merged
+  // conditional store the compiler got wrong with the workspace pointers in scratch: store_settled / arm_line_search above)
 #define BW4_RETURN return
 #include "backward4_body.inc"
 #undef BW4_RETURN
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
