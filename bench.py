@@ -53,7 +53,7 @@ BYTES_BWD_KNOT, BYTES_FWD_KNOT, BYTES_IO_KNOT = 86 * 8.0, 103 * 8.0, 53 * 8.0
 # The PMC summary `roofline.traffic` is read from: named explicitly, and only used when its tag is this round's
 # (profiles/run_rocprof.sh <tag> writes profiles/<tag>_rocprof_summary.json from the same bench command).
 ROUND_TAG = "r04"
-TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r04c_rocprof_summary.json")
+TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r04e_rocprof_summary.json")
 
 
 def kernel_table(prof, n_bwd_knots, n_fwd_knots):
@@ -66,7 +66,10 @@ def kernel_table(prof, n_bwd_knots, n_fwd_knots):
     if prof.get("rollout_launches", 0) == 0 and prof.get("backward_launches", 0) > 0:
         # k_backward_rollout: the backward pass and the rollout of a round in one launch (one block of four trajectories per CU:
         # up to 1024 trajectories) -- its work is both passes' knots, its time both serial chains
-        return {"k_backward_rollout": dict(ms=prof["backward_ms"], launches=prof["backward_launches"], seen=prof["backward_seen"],
+        # k_round (round 4): the same launch with the linearisation of the block's candidates behind the rollout -- then k_linearize
+        # is launched once per solve (the initial trajectory), not once per round
+        name = "k_round" if 4 * prof.get("linearize_seen", 0) < prof["backward_seen"] else "k_backward_rollout"
+        return {name: dict(ms=prof["backward_ms"], launches=prof["backward_launches"], seen=prof["backward_seen"],
                                            flops=FLOP_BWD_KNOT * n_bwd_knots + FLOP_FWD_KNOT * n_fwd_knots,
                                            bytes=BYTES_BWD_KNOT * n_bwd_knots + BYTES_FWD_KNOT * n_fwd_knots)}
     return {
@@ -202,7 +205,7 @@ def reference_faithful_leg(cfg, dev, default_cost, args):
             for b in range(8):
                 go, to = ref_o.backwards_pass(c["init"][b])
                 dg = max(dg, float(np.max(np.abs(g[b] - go)) / np.max(np.abs(go))))
-                dt_ = max(dt_, float(np.max(np.abs(tm[b] - to) / np.abs(to))))
+                dt_ = max(dt_, float(np.max(np.abs(tm[b] - to)) / max(float(np.max(np.abs(to))), 1e-300)))  # (over the larger term: one of the two can be 0)
             out[key]["one_backward_pass_vs_oracle"] = {"problems": 8, "max_gain_diff_over_largest_gain": dg, "max_rel_diff_of_cost_reduction_terms": dt_}
             out[key]["oracle_status_counts_on_sample"] = np.bincount(ref["status"], minlength=4).tolist()
             out[key]["status_counts_on_sample"] = np.bincount(st[:sample], minlength=4).tolist()
@@ -476,7 +479,7 @@ def main():
             traffic, traffic_src = read_traffic(dom, B, N)
             # k_backward (and the persistent solve, which contains it) is matrix-core work (fp64 MFMA); k_rollout has none:
             # its bound is the bytes it moves
-            if dom in ("k_backward", "k_backward_rollout", "k_solve4"):
+            if dom in ("k_backward", "k_backward_rollout", "k_round", "k_solve4"):
                 bound = dict(bound="mfma", achieved=tflops, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=tflops / FP64_PEAK_TFLOPS)
             else:
                 bound = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
@@ -494,6 +497,15 @@ def main():
                             "profiles/r03f_rocprof_summary.txt; 67.2 us with one live wavefront per block since round 4's pipelined knot, "
                             "profiles/r04_knot_anatomy.txt) and the rollout at 51.8 us.  The numerator is the reference's dense-as-written 30 kflop "
                             "per backward knot; the kernel issues 7 x 2048 flop of MFMA + ~68 fp64 vector instructions per knot"} if dom == "k_backward_rollout" else {}),
+                **({"note": "k_round = a whole round in one launch (up to 1024 trajectories, a block of four per CU): the block's backward pass, the "
+                            "rollout of its four trajectories and the linearisation of the candidates, three serial chains one after the other "
+                            "(about 66 + 52 + 9 us with one running trajectory per block).  Its work is the backward and forward knots' algorithmic "
+                            "flops -- the reference's backward knot, 30 kflop dense-as-written, calls the dynamics and cost differentials itself (ilqr.hh:110-116), which "
+                            "until round 4 ran in a launch of its own outside this denominator: the fraction fell from 0.129 (k_backward_rollout, "
+                            "114 us per launch) for that reason while `value` rose 2 %.  The backward kernel alone ran at 20.6 % of the fp64 peak in "
+                            "round 3 (68.9 us per launch; 67.2 us with one live wavefront per block since the pipelined knot, "
+                            "profiles/r04_knot_anatomy.txt); the kernel issues 7 x 2048 flop of MFMA + ~68 fp64 vector instructions per knot"}
+                   if dom == "k_round" else {}),
                 "kernels_ms": {k: round(v["ms"], 3) for k, v in kern.items()}
                               | {"k_linearize": round(prof["linearize_ms"], 3), "other": round(prof["other_ms"], 3)},
                 "warmup_avg_launch_us": {k: round(calib[k + "_ms"] * 1e3 / max(calib[k + "_launches"], 1), 2)

@@ -20,7 +20,8 @@ def short(name):
     """kernel class: the variants of one pass (k_backward / k_backward2 / k_backward4, k_rollout / k_rollout3 / k_rollout16) share a
     row -- one run uses one variant of each (run_rocprof.sh switches off bench.py's legs at other batch sizes); the
     variants seen are listed beside the row"""
-    for k in ("k_solve4", "k_backward_rollout", "k_backward", "k_rollout", "k_linearize", "k_accept", "k_init", "k_gather", "k_retile", "k_begin", "k_seed_search"):
+    for k in ("k_solve4", "k_round", "k_backward_rollout", "k_backward", "k_rollout", "k_linearize", "k_compact_plan", "k_compact_move", "k_publish_active",
+              "k_debug_capture", "k_accept", "k_init", "k_gather", "k_retile", "k_begin", "k_seed_search"):
         if k in name:
             return k
     return name[:60]

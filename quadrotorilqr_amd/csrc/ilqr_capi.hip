@@ -81,7 +81,7 @@ struct qilqr_solver {
   hipStream_t part_stream[MAX_PARTS] = {};
   hipEvent_t part_done[MAX_PARTS] = {};
   hipEvent_t main_ready = nullptr;
-  int *d_part_counters = nullptr;  // [MAX_PARTS][COUNT_WORDS]
+  int *d_part_counters = nullptr;  // [MAX_PARTS][2][COUNT_WORDS]
   long total_B = 0;                // trajectories in flight on the device in this call (kernel choices go by it)
   double *io_aos = nullptr;         // device scratch in the plain [B][n][W] layout (W <= 52), for host I/O (lazy)
   size_t io_cap = 0;                // its capacity in doubles
@@ -239,7 +239,7 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
   if ((rc = dalloc(s, &st.iters, cB))) return rc;
   if ((rc = dalloc(s, &st.n_bwd, cB))) return rc;
   if ((rc = dalloc(s, &st.n_fwd, cB))) return rc;
-  if ((rc = dalloc(s, &st.counters, COUNT_WORDS))) return rc;
+  if ((rc = dalloc(s, &st.counters, 2 * COUNT_WORDS))) return rc;  // (two sets: k_round alternates between them)
   if ((rc = dalloc_s(s, &st.dump, 4 * cB))) return rc;
   if ((rc = dalloc(s, &st.orig, cB))) return rc;
   if ((rc = dalloc(s, &st.plan, (size_t)PLAN_HEAD * (qilqr_solver::MAX_PARTS + 2) + 4 * (size_t)cB))) return rc;  // (a part: head, B holes, B live slots, B / 2 pairs x 4)
@@ -536,6 +536,31 @@ struct InFlight {
   ~InFlight() { n.fetch_sub(1, std::memory_order_relaxed); }
   bool alone() const { return n.load(std::memory_order_relaxed) == 1; }
 };
+// k_round (ilqr_kernels.h): the combined launch and the linearisation of its candidates in one.  fp64 storage only (the mixed mode keeps
+// the two launches).  The round's counts go into the counter set of its parity; the launch publishes the round before it.
+bool round_kernel_ok(const qilqr_solver *s) {
+  static const bool off = [] {
+    const char *e = std::getenv("QILQR_ROUND_KERNEL");
+    return e && e[0] == '0';
+  }();
+  return !off && !s->f32;
+}
+int launch_round(qilqr_solver *s, long B, long n, long round, bool publish_prev) {
+  const ModelConsts<double> *cp = (const ModelConsts<double> *)s->d_consts;
+  const dim3 grid(cdiv(B, 4)), block(320);
+  BatchState st = s->st;
+  int *base = s->st.counters;
+  st.counters = base + (round & 1) * COUNT_WORDS;
+  int *prev = base + ((round + 1) & 1) * COUNT_WORDS;
+  const int prev_round = publish_prev ? (int)((round - 1) & 0x3fffffff) : -1;
+  if (s->q_diag && layout_kind(s->layout) == 2)
+    launch(s, K_BACKWARD, k_round<3>, grid, block, s->consts, cp, s->params, st, (int)B, (int)n, prev, prev_round);
+  else if (layout_kind(s->layout) == 2)
+    launch(s, K_BACKWARD, k_round<2>, grid, block, s->consts, cp, s->params, st, (int)B, (int)n, prev, prev_round);
+  else
+    launch(s, K_BACKWARD, k_round<1>, grid, block, s->consts, cp, s->params, st, (int)B, (int)n, prev, prev_round);
+  return QILQR_OK;
+}
 int launch_backward_rollout(qilqr_solver *s, long B, long n) {
   if (s->f32)
     launch(s, K_BACKWARD, k_backward_rollout<float>, dim3(cdiv(B, 4)), dim3(320), s->consts, s->params, s->st, (int)B, (int)n);
@@ -737,10 +762,39 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
     if (s->compact) s->plan_heads.push_back(0);
     unsigned seen_active = (unsigned)B;  // the last count the host has read (the count only falls)
     long used = B;                       // slots the round's kernels are launched over (slots_in_use)
+    bool pending_publish = false;        // the round before was a k_round: the next launch publishes its count
+    bool two_sets = false;               // a k_round has run in this solve: rounds count into the counter set of their parity
     for (long round = 0; round < max_rounds; ++round) {
       // (one more compaction behind the last count above the threshold brings the slots in use under it)
       const bool compacting = s->compact && (seen_active > tf.stop || (tf.kinds && used > tf.slots));
-      if ((can_fuse || (tf.kinds && !compacting && used <= tf.slots)) && in_flight.alone()) {
+      const bool fuse_now = (can_fuse || (tf.kinds && !compacting && used <= tf.slots)) && in_flight.alone();
+      // the counter set of this round's parity (k_round publishes a round's count from the NEXT launch; the other kernels of a
+      // round count and publish within it, in the same set)
+      struct CounterSet {
+        qilqr_solver *s;
+        int *base;
+        CounterSet(qilqr_solver *s_, long round, bool two) : s(s_), base(s_->st.counters) { if (two) s->st.counters = base + (round & 1) * COUNT_WORDS; }
+        ~CounterSet() { s->st.counters = base; }
+      };
+      // k_round linearises a block's candidates with the block's own five wavefronts: as fast as k_linearize when a block has one
+      // candidate (the tail of every solve) or when the chip is full anyway, 2.5 times slower with four candidates per block and
+      // idle CUs beside it (B = 64 ... 512 in their first rounds: -0.3 to -1.2 % of a solve if taken there)
+      const bool blocks_full = (long)seen_active > 2L * cdiv(used, 4);  // (more than two candidates per block)
+      if (fuse_now && round_kernel_ok(s) && (!blocks_full || used >= 768)) {
+        if ((rc = launch_round(s, used, n, round, pending_publish))) return rc;
+        pending_publish = true;
+        two_sets = true;
+        if ((rc = on_round())) return rc;
+        goto round_enqueued;
+      }
+      if (pending_publish) {  // the round before was a k_round: its count has no launch left to publish it
+        launch(s, K_OTHER, k_publish_active, dim3(1), dim3(64), s->st.counters + ((round + 1) & 1) * COUNT_WORDS, s->st.host_active,
+               (int)((round - 1) & 0x3fffffff));
+        pending_publish = false;
+      }
+      {
+      const CounterSet counter_set(s, round, two_sets);
+      if (fuse_now) {
         if ((rc = launch_backward_rollout(s, used, n))) return rc;
       } else {
         if ((rc = launch_backward(s, used, n, 0))) return rc;
@@ -752,6 +806,8 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
       }
       if ((rc = on_round())) return rc;  // (debug capture of the single solve: one more launch, nothing waited for)
       if ((rc = launch_linearize(s, used, n, 1, F_SEARCH, (int)(round & 0x3fffffff)))) return rc;
+      }
+    round_enqueued:
       if (round >= lag) {
         const long old = round - lag;
         const unsigned tag = (unsigned)((old & 0x3fffffff) + 1);
@@ -826,7 +882,7 @@ BatchState slice_state(const qilqr_solver *s, long b0, long n, int part) {
   v.cur = w.cur + b0; v.cost = w.cost + b0; v.prev_cost = w.prev_cost + b0; v.terms = w.terms + 2 * b0;
   v.alpha = w.alpha + b0; v.mu = w.mu + b0; v.trial = w.trial + b0; v.flags = w.flags + b0; v.status = w.status + b0;
   v.iters = w.iters + b0; v.n_bwd = w.n_bwd + b0; v.n_fwd = w.n_fwd + b0;
-  v.counters = s->d_part_counters + COUNT_WORDS * part;
+  v.counters = s->d_part_counters + 2 * COUNT_WORDS * part;  // (two sets: k_init zeroes both, k_round alternates)
   v.host_active = s->d_active + 8 * (1 + part);
   if (w.cost_hist) v.cost_hist = w.cost_hist + b0 * w.hist_cap;
   v.dump = adv(w.dump, 4 * b0);
@@ -1242,7 +1298,7 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
     s->st.host_active = s->d_active;
     s->st.host_error = s->d_active + 8 * (1 + qilqr_solver::MAX_PARTS);
   }
-  if (e == hipSuccess) e = hipMalloc((void **)&s->d_part_counters, sizeof(int) * COUNT_WORDS * qilqr_solver::MAX_PARTS);
+  if (e == hipSuccess) e = hipMalloc((void **)&s->d_part_counters, sizeof(int) * 2 * COUNT_WORDS * qilqr_solver::MAX_PARTS);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&s->main_ready, hipEventDisableTiming);
   // (the streams and events of sub-batches are created when a solve first uses them: ensure_parts)
   if (e == hipSuccess) e = hipMalloc(&s->d_consts, s->f32 ? sizeof(ModelConsts<float>) : sizeof(ModelConsts<double>));
