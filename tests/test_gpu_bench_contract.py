@@ -30,7 +30,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     r = j["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and r["kernel"] in ("k_backward", "k_rollout", "k_backward_rollout")
+    assert r["bound"] in ("hbm", "mfma") and r["kernel"] in ("k_backward", "k_rollout", "k_backward_rollout", "k_round")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["launches"] >= r["timed_launches"] > 0 and r["avg_launch_us"] > 1.0
     c = j["cpu_baseline"]
