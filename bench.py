@@ -53,10 +53,10 @@ BYTES_BWD_KNOT, BYTES_FWD_KNOT, BYTES_IO_KNOT = 86 * 8.0, 103 * 8.0, 53 * 8.0
 # The PMC summary `roofline.traffic` is read from: named explicitly, and only used when its tag is this round's
 # (profiles/run_rocprof.sh <tag> writes profiles/<tag>_rocprof_summary.json from the same bench command).
 ROUND_TAG = "r04"
-TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r04e_rocprof_summary.json")
+TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r04f_rocprof_summary.json")
 
 
-def kernel_table(prof, n_bwd_knots, n_fwd_knots):
+def kernel_table(prof, n_bwd_knots, n_fwd_knots, solves=None):
     """per-kernel work and time of the timed region (HIP events attached to the dispatches).  With the persistent solve
     (k_solve4: the whole solve is one launch) there is one kernel, and its work is all the backward and forward knots."""
     if prof.get("solve_launches", 0) > 0:
@@ -67,8 +67,9 @@ def kernel_table(prof, n_bwd_knots, n_fwd_knots):
         # k_backward_rollout: the backward pass and the rollout of a round in one launch (one block of four trajectories per CU:
         # up to 1024 trajectories) -- its work is both passes' knots, its time both serial chains
         # k_round (round 4): the same launch with the linearisation of the block's candidates behind the rollout -- then k_linearize
-        # is launched once per solve (the initial trajectory), not once per round
-        name = "k_round" if 4 * prof.get("linearize_seen", 0) < prof["backward_seen"] else "k_backward_rollout"
+        # is launched once per solve (the initial trajectory), not once per round; a k_round launch holds up to four rounds
+        lin = prof.get("linearize_seen", 0)
+        name = "k_round" if (lin <= solves if solves else 4 * lin < prof["backward_seen"]) else "k_backward_rollout"
         return {name: dict(ms=prof["backward_ms"], launches=prof["backward_launches"], seen=prof["backward_seen"],
                                            flops=FLOP_BWD_KNOT * n_bwd_knots + FLOP_FWD_KNOT * n_fwd_knots,
                                            bytes=BYTES_BWD_KNOT * n_bwd_knots + BYTES_FWD_KNOT * n_fwd_knots)}
@@ -237,8 +238,9 @@ def main():
     ap.add_argument("--backward", type=int, default=0, help="diagnostic: backward kernel (qilqr_device_config.force_general: 0 automatic, 1 general, 2 one wavefront per trajectory, 3 k_backward2 (diagnostics build), 4 k_backward4 six wavefronts, 5 fused, 6 fused with block barriers)")
     ap.add_argument("--persistent", type=int, default=0, help="qilqr_device_config.persistent: 0 / 2 rounds of three launches (the product), 1 the solve as one launch (k_solve4: loads the diagnostics build of the library)")
     ap.add_argument("--streams", type=int, default=0, help="sub-batches on their own streams (qilqr_device_config.streams; 0 automatic)")
-    ap.add_argument("--event-stride", type=int, default=16, help="time every k-th launch of the dominant kernel in the timed region (a timed dispatch costs the stream about 6 us: "
-                    "with every 4th timed `value` reads 1.4 %% low, with every 16th 0.2 %% -- profiles/r04_event_stride.txt)")
+    ap.add_argument("--event-stride", type=int, default=0, help="time every k-th launch of the dominant kernel in the timed region (a timed dispatch costs the stream about 6 us: "
+                    "with every 4th launch of ~115 us timed `value` reads 1.4 %% low, with every 16th 0.2 %% -- profiles/r04_event_stride.txt); 0 = by the "
+                    "launch time seen in the warm-up: every 5th when a launch holds several rounds (> 300 us), every 16th otherwise")
     ap.add_argument("--settle-ms", type=float, default=300.0, help="untimed solves before the warm-up steps (clocks out of idle)")
     ap.add_argument("--no-serving", action="store_true", help="skip the extra several-batches-in-flight measurement (never part of value)")
     ap.add_argument("--serving-batches", type=int, default=18)
@@ -385,7 +387,11 @@ def main():
     # perturbation of the rounds being measured).
     calib = solver.profile_get()
     if not args.no_profile and not args.profile_all and args.warmup > 0:
-        solver.profile_mode((3 if calib["backward_ms"] >= calib["rollout_ms"] else 4) | (args.event_stride << 8))  # (k_solve4 is timed in every mode)
+        dom_ms, dom_n = max((calib["backward_ms"], calib["backward_launches"]), (calib["rollout_ms"], calib["rollout_launches"]))
+        # (strides that share no factor with the launches of a solve -- 37 of one round, 12 or 13 of four -- so that the sample covers every
+        # position of a solve: with every 4th of 12 timed, always the same three launches, the average read 440 us for rocprofv3's 382)
+        stride = args.event_stride or (5 if dom_ms * 1e3 / max(dom_n, 1) > 300.0 else 16)
+        solver.profile_mode((3 if calib["backward_ms"] >= calib["rollout_ms"] else 4) | (stride << 8))  # (k_solve4 is timed in every mode)
     solver.profile_reset()
     count_passes[0] = True
     t0 = time.perf_counter()
@@ -472,7 +478,7 @@ def main():
         # ---- roofline of the dominant kernel (this rank's launches, timed region only)
         roofline = None
         if not args.no_profile:
-            kern = kernel_table(prof, knots_bwd, knots_fwd)
+            kern = kernel_table(prof, knots_bwd, knots_fwd, solves=args.steps)
             dom = max(kern, key=lambda k: kern[k]["ms"])
             kd = kern[dom]
             tflops, gbs = rates(kd)
@@ -499,7 +505,8 @@ def main():
                             "per backward knot; the kernel issues 7 x 2048 flop of MFMA + ~68 fp64 vector instructions per knot"} if dom == "k_backward_rollout" else {}),
                 **({"note": "k_round = a whole round in one launch (up to 1024 trajectories, a block of four per CU): the block's backward pass, the "
                             "rollout of its four trajectories and the linearisation of the candidates, three serial chains one after the other "
-                            "(about 66 + 52 + 9 us with one running trajectory per block).  Its work is the backward and forward knots' algorithmic "
+                            "(about 66 + 52 + 9 us with one running trajectory per block), and up to FOUR such rounds per launch (avg_launch_us is a "
+                            "launch of four).  Its work is the backward and forward knots' algorithmic "
                             "flops -- the reference's backward knot, 30 kflop dense-as-written, calls the dynamics and cost differentials itself (ilqr.hh:110-116), which "
                             "until round 4 ran in a launch of its own outside this denominator: the fraction fell from 0.129 (k_backward_rollout, "
                             "114 us per launch) for that reason while `value` rose 2 %.  The backward kernel alone ran at 20.6 % of the fp64 peak in "

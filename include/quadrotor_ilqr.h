@@ -90,7 +90,7 @@ typedef struct {
                             every block of four trajectories has a CU to itself (B <= 4 x the device's CUs: 1024 on
                             MI355X), the two are ONE launch (k_backward_rollout: the block's backward pass, a block
                             barrier, the rollout of its own four trajectories; same arithmetic, same bits) -- in fp64 together with
-                            the linearisation of the block's candidates (k_round: the whole round in one launch, same bits again).
+                            the linearisation of the block's candidates, four rounds to a launch (k_round: same bits again).
                             WHICH ARITHMETIC A CALLER GETS.  The general kernel evaluates ilqr.hh:118-140 in the
                             reference's own forms: Q_uu factored by Eigen's diagonally pivoted LDL^T (largest |d_ii| of
                             the trailing block, first on ties), V_x = Q_x - K^T Q_uu k, V_xx = Q_xx - K^T Q_uu K, not

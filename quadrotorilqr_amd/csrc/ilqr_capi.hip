@@ -545,7 +545,16 @@ bool round_kernel_ok(const qilqr_solver *s) {
   }();
   return !off && !s->f32;
 }
-int launch_round(qilqr_solver *s, long B, long n, long round, bool publish_prev) {
+// rounds per launch of k_round where a launch may hold several (QILQR_ROUNDS_PER_LAUNCH = 1, 2 or 4 in the environment: A/B)
+int rounds_per_launch() {
+  static const int r = [] {
+    const char *e = std::getenv("QILQR_ROUNDS_PER_LAUNCH");
+    const int v = e ? std::atoi(e) : 4;
+    return (v == 1 || v == 2) ? v : 4;
+  }();
+  return r;
+}
+int launch_round(qilqr_solver *s, long B, long n, long round, bool publish_prev, int rounds) {
   const ModelConsts<double> *cp = (const ModelConsts<double> *)s->d_consts;
   const dim3 grid(cdiv(B, 4)), block(320);
   BatchState st = s->st;
@@ -553,12 +562,22 @@ int launch_round(qilqr_solver *s, long B, long n, long round, bool publish_prev)
   st.counters = base + (round & 1) * COUNT_WORDS;
   int *prev = base + ((round + 1) & 1) * COUNT_WORDS;
   const int prev_round = publish_prev ? (int)((round - 1) & 0x3fffffff) : -1;
-  if (s->q_diag && layout_kind(s->layout) == 2)
-    launch(s, K_BACKWARD, k_round<3>, grid, block, s->consts, cp, s->params, st, (int)B, (int)n, prev, prev_round);
-  else if (layout_kind(s->layout) == 2)
-    launch(s, K_BACKWARD, k_round<2>, grid, block, s->consts, cp, s->params, st, (int)B, (int)n, prev, prev_round);
-  else
-    launch(s, K_BACKWARD, k_round<1>, grid, block, s->consts, cp, s->params, st, (int)B, (int)n, prev, prev_round);
+  const int lk = (s->q_diag && layout_kind(s->layout) == 2) ? 3 : (layout_kind(s->layout) == 2 ? 2 : 1);
+#define QILQR_LAUNCH_ROUND(LK, R) launch(s, K_BACKWARD, (k_round<LK, R>), grid, block, s->consts, cp, s->params, st, (int)B, (int)n, prev, prev_round)
+  if (rounds == 4) {
+    if (lk == 3) QILQR_LAUNCH_ROUND(3, 4);
+    else if (lk == 2) QILQR_LAUNCH_ROUND(2, 4);
+    else QILQR_LAUNCH_ROUND(1, 4);
+  } else if (rounds == 2) {
+    if (lk == 3) QILQR_LAUNCH_ROUND(3, 2);
+    else if (lk == 2) QILQR_LAUNCH_ROUND(2, 2);
+    else QILQR_LAUNCH_ROUND(1, 2);
+  } else {
+    if (lk == 3) QILQR_LAUNCH_ROUND(3, 1);
+    else if (lk == 2) QILQR_LAUNCH_ROUND(2, 1);
+    else QILQR_LAUNCH_ROUND(1, 1);
+  }
+#undef QILQR_LAUNCH_ROUND
   return QILQR_OK;
 }
 int launch_backward_rollout(qilqr_solver *s, long B, long n) {
@@ -720,9 +739,10 @@ int fire_early_out(qilqr_solver *s, long B, long n, EarlyOut *eo, unsigned activ
 // drain = false: return as soon as the host knows that no trajectory is active; the caller enqueues
 // its own work behind the rounds still in flight and waits for the stream itself.
 // on_count (optional): called with the count of running trajectories each time the free-running loop learns one.
+// double_ok: the caller does not look at the solve round by round (on_round does nothing): launches may hold two rounds
 template <typename F>
 int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool drain = true,
-              const std::function<int(unsigned)> *on_count = nullptr) {
+              const std::function<int(unsigned)> *on_count = nullptr, bool double_ok = false) {
   int rc;
   if ((rc = launch_linearize(s, B, n, 0, 0))) return rc;
   {
@@ -763,6 +783,8 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
     unsigned seen_active = (unsigned)B;  // the last count the host has read (the count only falls)
     long used = B;                       // slots the round's kernels are launched over (slots_in_use)
     bool pending_publish = false;        // the round before was a k_round: the next launch publishes its count
+    unsigned launched_rounds[8] = {1, 1, 1, 1, 1, 1, 1, 1};  // rounds in launch `round & 7` (its count is the sum of theirs)
+    unsigned seen_rounds = 1;            // ... and of the launch the last count the host has read came from
     bool two_sets = false;               // a k_round has run in this solve: rounds count into the counter set of their parity
     for (long round = 0; round < max_rounds; ++round) {
       // (one more compaction behind the last count above the threshold brings the slots in use under it)
@@ -779,9 +801,14 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
       // k_round linearises a block's candidates with the block's own five wavefronts: as fast as k_linearize when a block has one
       // candidate (the tail of every solve) or when the chip is full anyway, 2.5 times slower with four candidates per block and
       // idle CUs beside it (B = 64 ... 512 in their first rounds: -0.3 to -1.2 % of a solve if taken there)
-      const bool blocks_full = (long)seen_active > 2L * cdiv(used, 4);  // (more than two candidates per block)
+      // (a launch of several rounds reports the sum of their counts: at most so many times the last one's)
+      const bool blocks_full = (long)((seen_active + seen_rounds - 1) / seen_rounds) > 2L * cdiv(used, 4);  // (more than two candidates per block)
       if (fuse_now && round_kernel_ok(s) && (!blocks_full || used >= 768)) {
-        if ((rc = launch_round(s, used, n, round, pending_publish))) return rc;
+        // two rounds per launch where the rounds are this kernel from the first (no compaction, whose thresholds go by the count) and
+        // the caller does not look at a solve round by round (the single solve's debug capture)
+        const int rounds = (can_fuse && double_ok) ? rounds_per_launch() : 1;
+        if ((rc = launch_round(s, used, n, round, pending_publish, rounds))) return rc;
+        launched_rounds[round & 7] = rounds;
         pending_publish = true;
         two_sets = true;
         if ((rc = on_round())) return rc;
@@ -792,6 +819,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
                (int)((round - 1) & 0x3fffffff));
         pending_publish = false;
       }
+      launched_rounds[round & 7] = 1;
       {
       const CounterSet counter_set(s, round, two_sets);
       if (fuse_now) {
@@ -828,6 +856,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
         }
         if ((unsigned)v == 0) break;
         seen_active = (unsigned)v;
+        seen_rounds = launched_rounds[old & 7];
         // a block that gave up a hand-off (BatchState::host_error) voids the call: stop enqueuing rounds on void gains -- each
         // could burn a full bounded spin -- let what is in flight finish, and report
         if (__atomic_load_n(s->h_active + 8 * (1 + qilqr_solver::MAX_PARTS), __ATOMIC_ACQUIRE)) {
@@ -1124,7 +1153,7 @@ int solve_batch_device_impl(qilqr_solver *s, const double *d_init, const double 
       if (eo->fired || active > eo->threshold) return QILQR_OK;
       return fire_early_out(s, B, n, eo, active);
     };
-    if ((rc = run_solve(s, B, n, s->dev.sync_every, [] { return QILQR_OK; }, false, eo ? &hook : nullptr))) return rc;
+    if ((rc = run_solve(s, B, n, s->dev.sync_every, [] { return QILQR_OK; }, false, eo ? &hook : nullptr, /*double_ok=*/true))) return rc;
     if (eo && eo->fired) {
       // the late finishers into the compact block, one copy to the pinned host block; qilqr_solve_batch puts them in place
       const LateLayout L = *eo->layout;

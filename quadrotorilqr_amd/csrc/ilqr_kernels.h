@@ -1691,6 +1691,16 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
 // 404 000 -> 412 000 solves/s; nothing at 4096, -0.5 % at 1024)
 // FUSED: five wavefronts per block -- MG_0..MG_3 (matrix and gradient recursion of a trajectory in one wavefront, bw4_fused_wave)
 // and the loader L -- instead of six (M_0..M_3, G, L).
+// the LDS of a block of k_backward4 (backward4_body.inc declares it unless the including kernel has: BW4_LDS_DECLARED).  ring: four slots
+// per trajectory -- in interval i the matrix wave reads slot (i-1) & 3 and writes slot (i-2) & 3 while G reads slot (i+1) & 3
+#define BW4_DECLARE_LDS                                                  \
+  __shared__ int s_run[4], s_cur[4], s_iters[4], s_act[4];               \
+  __shared__ double s_cost[4];                                           \
+  __shared__ __attribute__((aligned(16))) double ring[4][4][BW2_BUF];    \
+  __shared__ double kf[4][2][80];                                        \
+  __shared__ int prog[24];
+#define QILQR_CAT_(a, b) a##b
+#define QILQR_CAT(a, b) QILQR_CAT_(a, b)
 template <typename S, int WAVES, bool FUSED = false, bool FREE = false>
 __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_backward4(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n,
                                                    int force) {
@@ -2468,33 +2478,43 @@ __device__ __forceinline__ void publish_active(int *counters, unsigned long long
 __global__ void k_publish_active(int *counters, unsigned long long *host_active, int round) {
   publish_active(counters, host_active, round, threadIdx.x & 63);
 }
-template <int LK>
+// ROUNDS > 1: several rounds per launch (a round's settle step finds the knot costs the block has just written): the launch
+// boundaries between them are gone too.  All of them count into the launch's counter set: the host reads the SUM of their counts of
+// running trajectories, an upper bound of the last one's and zero exactly when the first one's is.  The rounds share the block's LDS.
+template <int LK, int ROUNDS>
 __global__ __launch_bounds__(320) void k_round(ModelConsts<double> c, const ModelConsts<double> *__restrict__ cp, SolveParams p, BatchState st, int B,
                                                 int n, int *prev_counters, int prev_round) {
   typedef double S;
   __shared__ double qr_w[160];  // the weights of the cost half (k_linearize keeps a copy per wavefront: here the block's)
+  BW4_DECLARE_LDS
+  __shared__ R16Lds sh;
+#define BW4_LDS_DECLARED
+#define R16_LDS_DECLARED
   for (int k = threadIdx.x; k < 160; k += blockDim.x) qr_w[k] = (k < 144) ? cp->Q[k] : cp->R[k - 144];
-  {
-    constexpr int WAVES = 5;
-    constexpr bool FUSED = true, FREE = true;
-    const int force = 0;
-    (void)WAVES;
-#define BW4_RETURN goto backward_done
-#include "backward4_body.inc"
-#undef BW4_RETURN
-  }
-backward_done:
-  __syncthreads();  // (every wavefront comes out of the backward pass; its stores are visible to the block)
+  // (an idle wavefront of block 0 hands the host the count of the launch before this one while the others roll out)
+#define ROUND_BEHIND_BACKWARD \
   if (blockIdx.x == 0 && (threadIdx.x >> 6) == 4 && prev_round >= 0) publish_active(prev_counters, st.host_active, prev_round, threadIdx.x & 63);
-  {
-    const int need_flag = F_SEARCH;
-#define R16_RETURN goto rollout_done
-#include "rollout16_body.inc"
-#undef R16_RETURN
+#define ROUND_ID 0
+#include "round_body.inc"
+#undef ROUND_ID
+#undef ROUND_BEHIND_BACKWARD
+#define ROUND_BEHIND_BACKWARD
+  if constexpr (ROUNDS > 1) {
+#define ROUND_ID 1
+#include "round_body.inc"
+#undef ROUND_ID
   }
-rollout_done:
-  __syncthreads();
-  linearize_block<S, LK>(c, qr_w, st, (int)blockIdx.x * 4, B, n, 1, F_SEARCH);
+  if constexpr (ROUNDS > 2) {
+#define ROUND_ID 2
+#include "round_body.inc"
+#undef ROUND_ID
+#define ROUND_ID 3
+#include "round_body.inc"
+#undef ROUND_ID
+  }
+#undef ROUND_BEHIND_BACKWARD
+#undef BW4_LDS_DECLARED
+#undef R16_LDS_DECLARED
 }
 
 // ---------------------------------------------------------------------------------------------
