@@ -786,10 +786,14 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
     unsigned launched_rounds[8] = {1, 1, 1, 1, 1, 1, 1, 1};  // rounds in launch `round & 7` (its count is the sum of theirs)
     unsigned seen_rounds = 1;            // ... and of the launch the last count the host has read came from
     bool two_sets = false;               // a k_round has run in this solve: rounds count into the counter set of their parity
+    bool tail_started = false;           // a compacted batch has changed over to the combined launch for the rest of the solve
     for (long round = 0; round < max_rounds; ++round) {
       // (one more compaction behind the last count above the threshold brings the slots in use under it)
-      const bool compacting = s->compact && (seen_active > tf.stop || (tf.kinds && used > tf.slots));
-      const bool fuse_now = (can_fuse || (tf.kinds && !compacting && used <= tf.slots)) && in_flight.alone();
+      // (once the compaction has stopped for a batch that changes over to the combined launch it stays stopped: the launches may then hold
+      // several rounds, and the sums of counts they report say nothing against the threshold)
+      const bool compacting = s->compact && !tail_started && (seen_active > tf.stop || (tf.kinds && used > tf.slots));
+      if (s->compact && tf.kinds && !compacting && used <= tf.slots) tail_started = true;
+      const bool fuse_now = (can_fuse || tail_started) && in_flight.alone();
       // the counter set of this round's parity (k_round publishes a round's count from the NEXT launch; the other kernels of a
       // round count and publish within it, in the same set)
       struct CounterSet {
@@ -806,7 +810,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
       if (fuse_now && round_kernel_ok(s) && (!blocks_full || used >= 768)) {
         // two rounds per launch where the rounds are this kernel from the first (no compaction, whose thresholds go by the count) and
         // the caller does not look at a solve round by round (the single solve's debug capture)
-        const int rounds = (can_fuse && double_ok) ? rounds_per_launch() : 1;
+        const int rounds = ((can_fuse || tail_started) && double_ok) ? rounds_per_launch() : 1;
         if ((rc = launch_round(s, used, n, round, pending_publish, rounds))) return rc;
         launched_rounds[round & 7] = rounds;
         pending_publish = true;
