@@ -840,6 +840,8 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
       if ((rc = launch_linearize(s, used, n, 1, F_SEARCH, (int)(round & 0x3fffffff)))) return rc;
       }
     round_enqueued:
+      // (following launches of several rounds ONE launch back instead of two -- four rounds that find nothing to do at the end of a solve
+      // instead of eight -- measured no different: 4.71-4.73 ms either way)
       if (round >= lag) {
         const long old = round - lag;
         const unsigned tag = (unsigned)((old & 0x3fffffff) + 1);

@@ -2490,7 +2490,12 @@ __global__ __launch_bounds__(320) void k_round(ModelConsts<double> c, const Mode
   __shared__ R16Lds sh;
 #define BW4_LDS_DECLARED
 #define R16_LDS_DECLARED
+#define BW4_CTAB_FILLED
   for (int k = threadIdx.x; k < 160; k += blockDim.x) qr_w[k] = (k < 144) ? cp->Q[k] : cp->R[k - 144];
+  // the constant operand table behind the ring slots, once for all the rounds of the launch (a round whose block has nothing to run
+  // leaves before it would fill it, and a later round of the same launch may have something: so here, unconditionally; the records and
+  // the settle step's scratch use the slots' other words)
+  bw4_fill_ctab<S>(ring, st.ctab, 320);
   // (an idle wavefront of block 0 hands the host the count of the launch before this one while the others roll out)
 #define ROUND_BEHIND_BACKWARD \
   if (blockIdx.x == 0 && (threadIdx.x >> 6) == 4 && prev_round >= 0) publish_active(prev_counters, st.host_active, prev_round, threadIdx.x & 63);
@@ -2515,6 +2520,7 @@ __global__ __launch_bounds__(320) void k_round(ModelConsts<double> c, const Mode
 #undef ROUND_BEHIND_BACKWARD
 #undef BW4_LDS_DECLARED
 #undef R16_LDS_DECLARED
+#undef BW4_CTAB_FILLED
 }
 
 // ---------------------------------------------------------------------------------------------
