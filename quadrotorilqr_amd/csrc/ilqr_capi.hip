@@ -784,7 +784,6 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
     long used = B;                       // slots the round's kernels are launched over (slots_in_use)
     bool pending_publish = false;        // the round before was a k_round: the next launch publishes its count
     unsigned launched_rounds[8] = {1, 1, 1, 1, 1, 1, 1, 1};  // rounds in launch `round & 7` (its count is the sum of theirs)
-    unsigned seen_rounds = 1;            // ... and of the launch the last count the host has read came from
     bool two_sets = false;               // a k_round has run in this solve: rounds count into the counter set of their parity
     bool tail_started = false;           // a compacted batch has changed over to the combined launch for the rest of the solve
     for (long round = 0; round < max_rounds; ++round) {
@@ -805,8 +804,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
       // k_round linearises a block's candidates with the block's own five wavefronts: as fast as k_linearize when a block has one
       // candidate (the tail of every solve) or when the chip is full anyway, 2.5 times slower with four candidates per block and
       // idle CUs beside it (B = 64 ... 512 in their first rounds: -0.3 to -1.2 % of a solve if taken there)
-      // (a launch of several rounds reports the sum of their counts: at most so many times the last one's)
-      const bool blocks_full = (long)((seen_active + seen_rounds - 1) / seen_rounds) > 2L * cdiv(used, 4);  // (more than two candidates per block)
+      const bool blocks_full = (long)seen_active > 2L * cdiv(used, 4);  // (more than two candidates per block)
       if (fuse_now && round_kernel_ok(s) && (!blocks_full || used >= 768)) {
         // two rounds per launch where the rounds are this kernel from the first (no compaction, whose thresholds go by the count) and
         // the caller does not look at a solve round by round (the single solve's debug capture)
@@ -861,8 +859,10 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
           __builtin_ia32_pause();
         }
         if ((unsigned)v == 0) break;
-        seen_active = (unsigned)v;
-        seen_rounds = launched_rounds[old & 7];
+        // a launch of several rounds reports the SUM of their counts; counts only fall, so the mean over the launch's rounds is an upper
+        // bound of the last round's -- of the count now
+        const unsigned now_at_most = ((unsigned)v + launched_rounds[old & 7] - 1) / launched_rounds[old & 7];
+        seen_active = now_at_most;
         // a block that gave up a hand-off (BatchState::host_error) voids the call: stop enqueuing rounds on void gains -- each
         // could burn a full bounded spin -- let what is in flight finish, and report
         if (__atomic_load_n(s->h_active + 8 * (1 + qilqr_solver::MAX_PARTS), __ATOMIC_ACQUIRE)) {
@@ -870,7 +870,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
           if (s->early_stream) (void)hipStreamSynchronize(s->early_stream);
           return device_error(s);
         }
-        if (on_count && (rc = (*on_count)((unsigned)v))) return rc;
+        if (on_count && (rc = (*on_count)(now_at_most))) return rc;
         // (Round 3 tried following the device ONE round behind in the tail, where a round takes well over 100 us and the host
         // needs about 15 to enqueue the next: one round of three empty launches fewer after the last trajectory has finished --
         // 36 rounds instead of 37 -- and no measurable difference, 5.223 against 5.221 ms per solve.  `lag` stays fixed.)
