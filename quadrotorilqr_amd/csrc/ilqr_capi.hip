@@ -1642,7 +1642,8 @@ int qilqr_solve(qilqr_solver *s, const double *init, int32_t n, double *out_traj
       launch(s, K_OTHER, k_debug_capture<double>, dim3(1), dim3(256), s->st, (int)n, debug_trajs ? s->dbg_trajs : nullptr, s->dbg_cost, s->dbg_seen, (int)debug_cap);
     return QILQR_OK;
   };
-  if ((rc = run_solve(s, 1, n, s->dev.sync_every, capture))) return rc;
+  // (without debug entries nobody looks at the solve round by round: the launches may hold several rounds)
+  if ((rc = run_solve(s, 1, n, s->dev.sync_every, capture, true, nullptr, /*double_ok=*/!want_debug))) return rc;
   int status = 0, iters = 0, seen = 0;
   double cost = 0;
   HIP_TRY(hipMemcpy(&status, s->st.status, sizeof(int), hipMemcpyDeviceToHost));
