@@ -37,7 +37,7 @@ for si, sv in enumerate(solves[-int(os.environ.get('TIMELINE_SOLVES', '3')):]):
     print(f"solve {si}: span {(t1 - t0) / 1e3:.1f} us, kernels {len(sv)}, idle between kernels {idle:.1f} us")
     for n in sorted(busy, key=lambda k: -busy[k]):
         print(f"    {n:16s} n={cnt[n]:4d} sum={busy[n]:8.1f} us mean={busy[n] / cnt[n]:7.2f}")
-    bw = [i for i, r in enumerate(sv) if r[2].startswith("k_backward")]
+    bw = [i for i, r in enumerate(sv) if r[2].startswith("k_backward") or r[2] == "k_round"]
     print(f"    before first k_backward: {(sv[bw[0]][0] - t0) / 1e3:.1f} us; after last k_backward start: {(t1 - sv[bw[-1]][0]) / 1e3:.1f} us")
     per = []
     for a, b in zip(bw, bw[1:]):
