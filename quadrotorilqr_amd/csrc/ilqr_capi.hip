@@ -775,6 +775,14 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
     // the host looks at the count `lag` rounds late, i.e. keeps the stream `lag` rounds ahead of the
     // device, so the GPU never waits for a host round trip.  Rounds enqueued past the end find nothing
     // to do.
+    // the counter set of a round's parity (k_round publishes a round's count from the NEXT launch; the other kernels of a round
+    // count and publish within it, in the same set)
+    struct CounterSet {
+      qilqr_solver *s;
+      int *base;
+      CounterSet(qilqr_solver *s_, long round, bool two) : s(s_), base(s_->st.counters) { if (two) s->st.counters = base + (round & 1) * COUNT_WORDS; }
+      ~CounterSet() { s->st.counters = base; }
+    };
     for (int k = 0; k < 8; ++k) s->h_active[k] = 0;
     const InFlight in_flight(s->device);
     const bool can_fuse = fuse_backward_rollout(s, B) && !s->compact;  // (compaction works between the two halves)
@@ -793,21 +801,13 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
       const bool compacting = s->compact && !tail_started && (seen_active > tf.stop || (tf.kinds && used > tf.slots));
       if (s->compact && tf.kinds && !compacting && used <= tf.slots) tail_started = true;
       const bool fuse_now = (can_fuse || tail_started) && in_flight.alone();
-      // the counter set of this round's parity (k_round publishes a round's count from the NEXT launch; the other kernels of a
-      // round count and publish within it, in the same set)
-      struct CounterSet {
-        qilqr_solver *s;
-        int *base;
-        CounterSet(qilqr_solver *s_, long round, bool two) : s(s_), base(s_->st.counters) { if (two) s->st.counters = base + (round & 1) * COUNT_WORDS; }
-        ~CounterSet() { s->st.counters = base; }
-      };
       // k_round linearises a block's candidates with the block's own five wavefronts: as fast as k_linearize when a block has one
       // candidate (the tail of every solve) or when the chip is full anyway, 2.5 times slower with four candidates per block and
       // idle CUs beside it (B = 64 ... 512 in their first rounds: -0.3 to -1.2 % of a solve if taken there)
       const bool blocks_full = (long)seen_active > 2L * cdiv(used, 4);  // (more than two candidates per block)
       if (fuse_now && round_kernel_ok(s) && (!blocks_full || used >= 768)) {
-        // two rounds per launch where the rounds are this kernel from the first (no compaction, whose thresholds go by the count) and
-        // the caller does not look at a solve round by round (the single solve's debug capture)
+        // several rounds per launch where the rounds are this kernel for the rest of the solve (no compaction any more, whose
+        // thresholds go by the count) and the caller does not look at a solve round by round (the single solve's debug capture)
         const int rounds = ((can_fuse || tail_started) && double_ok) ? rounds_per_launch() : 1;
         if ((rc = launch_round(s, used, n, round, pending_publish, rounds))) return rc;
         launched_rounds[round & 7] = rounds;
