@@ -534,7 +534,13 @@ struct InFlight {
   std::atomic<int> &n;
   explicit InFlight(int device) : n(g_solves_in_flight[(unsigned)device % MAX_TRACKED_DEVICES]) { n.fetch_add(1, std::memory_order_relaxed); }
   ~InFlight() { n.fetch_sub(1, std::memory_order_relaxed); }
-  bool alone() const { return n.load(std::memory_order_relaxed) == 1; }
+  bool alone() const {
+    static const bool always = [] {  // (diagnostic: QILQR_FUSE_IN_FLIGHT=1 keeps the combined launches beside other solves)
+      const char *e = std::getenv("QILQR_FUSE_IN_FLIGHT");
+      return e && e[0] == '1';
+    }();
+    return always || n.load(std::memory_order_relaxed) == 1;
+  }
 };
 // k_round (ilqr_kernels.h): the combined launch and the linearisation of its candidates in one.  fp64 storage only (the mixed mode keeps
 // the two launches).  The round's counts go into the counter set of its parity; the launch publishes the round before it.
