@@ -55,16 +55,17 @@ def test_compacted_solve_matches_the_oracle():
     np.testing.assert_allclose(out["traj"], ref["traj"], atol=1e-6)
 
 
-@pytest.mark.parametrize("seed", [100, 101, 103, 106])
-def test_compaction_with_restarts_moves_the_knot_records(seed):
-    """Levenberg-Marquardt restarts run the recursion again on the CURRENT records of a trajectory: they move with it."""
+@pytest.mark.parametrize("seed,precision", [(100, "f64"), (101, "f64"), (103, "f64"), (106, "f64"), (101, "f32"), (106, "f32")])
+def test_compaction_with_restarts_moves_the_knot_records(seed, precision):
+    """Levenberg-Marquardt restarts run the recursion again on the CURRENT records of a trajectory: they move with it (in the mixed
+    mode as fp32 pairs)."""
     cfg, reg = randomised_cfg(seed, restarts=True)
     # the randomised batches are small (1..40 problems): tile them so that slots really change
     reps = 8
     init = np.concatenate([cfg["init"]] * reps)
     r = np.random.default_rng(seed)
     init = init[r.permutation(len(init))]
-    on, off = capi.from_config(cfg, compaction=1), capi.from_config(cfg, compaction=-1)
+    on, off = capi.from_config(cfg, compaction=1, precision=precision), capi.from_config(cfg, compaction=-1, precision=precision)
     for s in (on, off):
         s.set_regularisation(*reg)
     assert_same(solve_device(on, init), solve_device(off, init), f"seed {seed}")
