@@ -835,6 +835,9 @@ struct orc_solver {
   double mu_init, mu_factor, mu_max;
   /* integrator of the discrete dynamics: 0 = explicit Euler (the reference), 1 = Runge-Kutta (extension, see discrete_dynamics_rk4) */
   int integrator;
+  /* form of the value recursion: 0 = ilqr.hh:132-133 as written (the reference), 1 = the substituted, symmetrised form (EXTENSION, see
+   * orc_set_recursion) */
+  int recursion;
 };
 
 int orc_solver_create(const orc_model_params *mp, const double Q[144], const double R[16],
@@ -940,6 +943,22 @@ int orc_set_integrator(orc_solver *s, int integrator) {
   s->integrator = integrator;
   return ORC_OK;
 }
+/* EXTENSION (default 0 = the reference).  mode 1 evaluates the value update of ilqr.hh:132-133 and the term of :139 with
+ * K = -Q_uu^-1 Q_ux and k = -Q_uu^-1 Q_u substituted (exact for the exact solve with symmetric Q_uu) and symmetrises V_xx:
+ *     V_x  = Q_x  + K^T Q_u            (= Q_x  - K^T Q_uu k)
+ *     V_xx = Q_xx + Q_xu K             (= Q_xx - K^T Q_uu K),   then V_xx <- (V_xx + V_xx^T) / 2
+ *     k^T Q_uu k = -(Q_u^T k)
+ * Everything else (Q assembly :118-124, the pivoted LDL^T solves :126-128, Q_u^T k :138) is the reference's.  Why it exists: the
+ * reference's unsymmetrised V_xx amplifies its rounding asymmetry from knot to knot and is noise beyond about 150 knots (DESIGN.md
+ * section 4, finding), so at the horizons of BASELINE.json configs[2] (200 knots) and configs[4] (500 knots) the reference recursion
+ * has no usable answer; this form is the one the symmetric-weight device kernels document, stated independently of them in dense
+ * scalar C so that those configurations have a comparand outside the library.  tests/test_oracle_recursion.py holds it to the
+ * reference form (gains 1e-10 relative) wherever that one is stable. */
+int orc_set_recursion(orc_solver *s, int mode) {
+  if (!s || (mode != 0 && mode != 1)) return ORC_ERR_INVALID;
+  s->recursion = mode;
+  return ORC_OK;
+}
 int orc_backwards_pass(const orc_solver *s, const double *traj, int n, double *gains,
                        double terms[2]) {
   return orc_backwards_pass_reg(s, traj, n, 0.0, gains, terms);
@@ -994,6 +1013,21 @@ int orc_backwards_pass_reg(const orc_solver *s, const double *traj, int n, doubl
     for (int c = 0; c < 12; ++c)
       for (int a = 0; a < 4; ++a) g[4 + c * 4 + a] = K[a * 12 + c];
 
+    double quk = 0;
+    for (int a = 0; a < 4; ++a) quk += Qu[a] * k[a];
+    if (s->recursion == 1) {
+      /* EXTENSION (orc_set_recursion): v_x = Qx + K^T Qu ; v_xx = sym(Qxx + Qxu K) ; k^T Quu k = -Qu^T k */
+      double t12b[12], T2[144];
+      mat_tmul(K, Qu, t12b, 4, 12, 1);
+      for (int a = 0; a < 12; ++a) v_x[a] = Qx[a] + t12b[a];
+      mat_mul(Qxu, K, T2, 12, 4, 12);
+      for (int a = 0; a < 144; ++a) T2[a] = Qxx[a] + T2[a];
+      for (int a = 0; a < 12; ++a)
+        for (int b = 0; b < 12; ++b) v_xx[a * 12 + b] = 0.5 * (T2[a * 12 + b] + T2[b * 12 + a]);
+      terms[0] += quk;
+      terms[1] += -quk;
+      continue;
+    }
     /* :132-133 v_x = Qx - (K^T Quu) k ; v_xx = Qxx - (K^T Quu) K */
     double KtQ[48], t12b[12], T2[144];
     mat_tmul(K, Quu, KtQ, 4, 12, 4);
@@ -1003,8 +1037,6 @@ int orc_backwards_pass_reg(const orc_solver *s, const double *traj, int n, doubl
     for (int a = 0; a < 144; ++a) v_xx[a] = Qxx[a] - T2[a];
 
     /* :136-140 */
-    double quk = 0;
-    for (int a = 0; a < 4; ++a) quk += Qu[a] * k[a];
     terms[0] += quk;
     double kq[4], kqk = 0;
     mat_tmul(k, Quu, kq, 4, 1, 4);

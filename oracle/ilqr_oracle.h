@@ -138,6 +138,12 @@ int orc_backwards_pass_reg(const orc_solver *s, const double *traj, int n, doubl
 int orc_set_regularisation(orc_solver *s, double mu_init, double mu_factor, double mu_max);
 /* EXTENSION: integrator of every pass of this solver, 0 (default, the reference) or 1 */
 int orc_set_integrator(orc_solver *s, int integrator);
+/* EXTENSION: form of the value recursion of every backward pass of this solver.  0 (default) = ilqr.hh:132-133 as the reference
+ * writes it; 1 = the same update with K = -Q_uu^-1 Q_ux, k = -Q_uu^-1 Q_u substituted and V_xx symmetrised (V_x = Q_x + K^T Q_u,
+ * V_xx = sym(Q_xx + Q_xu K), k^T Q_uu k = -Q_u^T k): algebraically the reference's, numerically stable at the 200- and 500-knot
+ * horizons where the reference's own form is rounding noise.  The comparand of the full-size tests of BASELINE.json configs[2],
+ * configs[4]; see the definition in ilqr_oracle.c. */
+int orc_set_recursion(orc_solver *s, int mode);
 
 int orc_forward_sim(const orc_solver *s, const double *traj, int n, const double *gains,
                     double alpha, double *out_traj);

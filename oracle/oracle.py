@@ -323,6 +323,12 @@ class OracleSolver:
         """Extension (not in the reference's executed code): 1 = the Runge-Kutta step of quadrotor_model.cc:51-63."""
         self._check(lib().orc_set_integrator(self._h, C.c_int(integrator)))
 
+    def set_recursion(self, mode):
+        """Extension (orc_set_recursion): 0 = ilqr.hh:132-133 as written (default), 1 = the substituted, symmetrised form
+        V_x = Q_x + K^T Q_u, V_xx = sym(Q_xx + Q_xu K), k^T Q_uu k = -Q_u^T k -- stable at 200 / 500 knots, where the reference's own
+        form is rounding noise; the comparand of the full-size tests of BASELINE.json configs[2] and configs[4]."""
+        self._check(lib().orc_set_recursion(self._h, C.c_int(mode)))
+
     def forward_sim(self, traj, gains, alpha=1.0):
         traj = _d(traj).reshape(-1, 18)
         gains = _d(gains).reshape(-1, 52)

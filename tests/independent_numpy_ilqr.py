@@ -177,7 +177,9 @@ def cost_knot(Q, R, T, v, u, Td, vd, ud, diffs=False):
 class ILQR:
     """ILQR<QuadrotorModel> (ilqr.hh:25-206) on (n, 18) knot arrays"""
 
-    def __init__(self, model, Q, R, desired, dt, options, integrator=0):
+    def __init__(self, model, Q, R, desired, dt, options, integrator=0, recursion=0):
+        # recursion 1: the substituted, symmetrised value update (the extension orc_set_recursion of the oracle states)
+        self.recursion = recursion
         self.model, self.Q, self.R, self.dt, self.o = model, np.asarray(Q, float), np.asarray(R, float), dt, options
         self.step = model.step_rk4 if integrator == 1 else model.step  # 1: the Runge-Kutta extension
         self.des = [(pose_from_knot(p), p[8:14].copy(), p[14:18].copy()) for p in np.asarray(desired)]
@@ -209,9 +211,15 @@ class ILQR:
             K = -np.linalg.solve(Quu, Qxu.T)
             k = -np.linalg.solve(Quu, Qu)
             ks[i], Ks[i] = k, K
+            QuTk += Qu @ k
+            if self.recursion == 1:           # EXTENSION: K = -Quu^-1 Qux, k = -Quu^-1 Qu substituted, V_xx symmetrised
+                vx = Qx + K.T @ Qu
+                vxx = Qxx + Qxu @ K
+                vxx = 0.5 * (vxx + vxx.T)
+                kTQuuk += -(Qu @ k)
+                continue
             vx = Qx - K.T @ Quu @ k
             vxx = Qxx - K.T @ Quu @ K       # not symmetrised, as the reference
-            QuTk += Qu @ k
             kTQuuk += k @ Quu @ k
         return ks, Ks, (QuTk, kTQuuk)
 
