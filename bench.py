@@ -186,7 +186,7 @@ def reference_faithful_leg(cfg, dev, default_cost, args):
         cost = bufs[1].cpu().numpy()
         sample = 64
         ref = orc.OracleSolver(orc.model_params(**c["model"]), c["Q"], c["R"], c["desired"], c["dt"],
-                               orc.options(**c["options"])).solve_batch(c["init"][:sample], n_threads=max(1, min(os.cpu_count() or 1, 64)))
+                               orc.options(**c["options"])).solve_batch(c["init"][:sample], n_threads=usable_cores())
         st = bufs[2][0].cpu().numpy()
         out[key] = {"value": B / t, "unit": "solves/s", "ms_per_solve": t * 1e3,
                     "max_rel_cost_diff_vs_oracle": float(np.max(np.abs(cost[:sample] - ref["cost"]) / np.abs(ref["cost"]))),
@@ -218,6 +218,138 @@ def reference_faithful_leg(cfg, dev, default_cost, args):
     return out
 
 
+def sharded_c_abi_child(args):
+    """The N > 1 line's step through the PRODUCT's own multi-GPU entry point, qilqr_solve_batch_sharded_device (north_star: "host side
+    is C++ ... RCCL-over-xGMI gather"): ONE process, one solver, stream and host thread per device, every shard's rows gathered into
+    device arrays on shard 0's device by the library's transport (RCCL groups per shard when the shards sit on different devices).
+    Runs in a child process of rank 0 after the timed region, the other ranks idle at a barrier (never `value`); a child, so
+    that a communicator that fails to come up on hardware nobody has run it on ends a leg, not the line.  Host (pinned) inputs ->
+    device-resident gathered outputs.  Prints one JSON object; writes the gathered costs to --leg-out for the parent's parity check."""
+    import torch
+    from quadrotorilqr_amd import capi, problems as pb
+    n_dev, N = args.gpus, args.knots
+    one_device = os.environ.get("QILQR_BENCH_ONE_DEVICE_TEST") == "1"
+    devices = [0] * n_dev if one_device else list(range(n_dev))
+    if args.config == 3:
+        B_total, seed = args.batch or 65536, 4
+    else:
+        B_total, seed = (args.batch or 1024) * n_dev, 2
+    cfg = pb.config2(B=B_total, N=N, seed=seed)  # counter-based generator: the N shards of the rank-per-GPU run, in global order
+    many = capi.sharded_from_config(cfg, devices=devices, sync_every=args.sync_every)
+    transport = many.set_transport("auto")
+    hin = capi.host_array(cfg["init"].shape)
+    hin[...] = cfg["init"]
+    root = torch.device("cuda", devices[0])
+    outs = (torch.empty((B_total, N, 18), dtype=torch.float64, device=root), torch.empty(B_total, dtype=torch.float64, device=root),
+            *[torch.empty(B_total, dtype=torch.int32, device=root) for _ in range(4)])
+    steps = max(2, min(args.steps, 10))
+    for _ in range(2):
+        many.solve_batch_gathered(hin, *outs, root=0)
+    torch.cuda.synchronize(root)
+    gms = []
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        gms.append(many.solve_batch_gathered(hin, *outs, root=0))
+    torch.cuda.synchronize(root)
+    dt = (time.perf_counter() - t1) / steps
+    cost = outs[1].cpu().numpy()
+    if args.leg_out:
+        np.save(args.leg_out, cost)
+    st = outs[2].cpu().numpy()
+    print(json.dumps({"value": B_total / dt, "unit": "solves/s", "ms_per_step": dt * 1e3, "steps": steps, "devices": devices,
+                      "transport": transport, "exposed_gather_ms": float(np.median(gms)), "batch_total": B_total,
+                      "status_counts": np.bincount(st, minlength=4).tolist(),
+                      "what": "qilqr_solve_batch_sharded_device: one process, one solver / stream / host thread per device, pinned host "
+                              "inputs, results gathered on shard 0's device by the library's own transport"}))
+    many.close()
+
+
+def sharded_c_abi_leg(args, g_cost_host):
+    """rank 0, after the timed region: run sharded_c_abi_child in a child process (bounded), compare its gathered costs with the
+    rank-per-GPU path's last gathered step"""
+    import subprocess
+    import tempfile
+    tmp = tempfile.NamedTemporaryFile(suffix=".npy", delete=False)
+    tmp.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                           "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", "sharded-c-abi", "--leg-out", tmp.name, "--gpus", str(args.gpus),
+           "--steps", str(args.steps), "--config", str(args.config), "--batch", str(args.batch), "--knots", str(args.knots),
+           "--sync-every", str(args.sync_every)]
+    try:
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        except subprocess.TimeoutExpired:
+            return {"error": "the child process did not finish within 300 s (killed)"}
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or len(lines) != 1:
+            return {"error": f"child exit code {r.returncode}", "stderr_tail": r.stderr[-600:]}
+        out = json.loads(lines[0])
+        if g_cost_host is not None:
+            got = np.load(tmp.name)
+            same = got.shape == g_cost_host.shape and bool(np.array_equal(got, g_cost_host))
+            out["same_costs_as_rank_per_gpu_gather"] = same
+            if not same and got.shape == g_cost_host.shape:
+                out["max_rel_cost_diff_vs_rank_per_gpu_gather"] = float(np.max(np.abs(got - g_cost_host) / np.abs(g_cost_host)))
+        return out
+    finally:
+        try:
+            os.unlink(tmp.name)
+        except OSError:
+            pass
+
+
+def usable_cores():
+    """hardware threads this process may actually use: the affinity mask cut by the cgroup's CPU quota (a GPU box hands a one-GPU
+    job 16 of the host's cores; os.cpu_count() reports all of them)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = float(txt[0])
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
+def launch_ranks_if_needed(args):
+    """`python3 bench.py --gpus N` with no launcher IS an N-rank run: when N > 1 and no rank environment is present, start
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` as a CHILD process (nothing in
+    this process has touched the GPU, and it never execs), let its rank 0 print the line on the inherited stdout, and leave with
+    its return code.  A rank environment that contradicts --gpus is an error, not a silently different run."""
+    in_launcher = "RANK" in os.environ or "WORLD_SIZE" in os.environ
+    if in_launcher:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world != args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}\n")
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,7 +367,7 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="HIP events around every kernel, not only the two candidates for dominant kernel")
     ap.add_argument("--rollout", type=int, default=-1, help="rollout kernel (qilqr_device_config.single_wave_rollout): 0 by the batch (k_rollout16 up to 4096 trajectories, k_rollout3 beyond), "
                                                              "1 k_rollout, 2 k_rollout3, 3 k_rollout16 (default: library default)")
-    ap.add_argument("--backward", type=int, default=0, help="diagnostic: backward kernel (qilqr_device_config.force_general: 0 automatic, 1 general, 2 one wavefront per trajectory, 3 k_backward2 (diagnostics build), 4 k_backward4 six wavefronts, 5 fused, 6 fused with block barriers)")
+    ap.add_argument("--backward", type=int, default=0, help="diagnostic: backward kernel (qilqr_device_config.force_general: 0 automatic, 1 general, 2 one wavefront per trajectory, 3 k_backward2 (diagnostics build), 4 k_backward4 six wavefronts, 5 fused)")
     ap.add_argument("--persistent", type=int, default=0, help="qilqr_device_config.persistent: 0 / 2 rounds of three launches (the product), 1 the solve as one launch (k_solve4: loads the diagnostics build of the library)")
     ap.add_argument("--streams", type=int, default=0, help="sub-batches on their own streams (qilqr_device_config.streams; 0 automatic)")
     ap.add_argument("--event-stride", type=int, default=0, help="time every k-th launch of the dominant kernel in the timed region (a timed dispatch costs the stream about 6 us: "
@@ -253,7 +385,14 @@ def main():
     ap.add_argument("--no-single-solve", action="store_true", help="skip the one-problem-per-call measurement through the binding (never part of value)")
     ap.add_argument("--no-reference-faithful", action="store_true", help="skip the force_general = 1 / non-symmetric-Q measurement (never part of value)")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP events around the kernels (roofline = null)")
+    ap.add_argument("--no-sharded-c-abi", action="store_true", help="N > 1: skip the extra measurement of the same step through qilqr_solve_batch_sharded_device "
+                                                                   "(one process, N devices, the library's own RCCL gather; never part of value)")
+    ap.add_argument("--leg", default="", help=argparse.SUPPRESS)  # internal: a leg bench.py runs in a child process of rank 0 ("sharded-c-abi")
+    ap.add_argument("--leg-out", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.leg == "sharded-c-abi":
+        return sharded_c_abi_child(args)
+    launch_ranks_if_needed(args)
 
     import torch
     import torch.distributed as dist
@@ -417,6 +556,10 @@ def main():
         tg = to_wire(torch.tensor([(time.perf_counter() - t1) / 3], dtype=torch.float64, device=dev))
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         gather_ms = float(tg.item()) * 1e3
+    # (rank 0 now holds the last timed step's costs of the WHOLE batch in global problem order: the comparand of the sharded_c_abi leg)
+    ref_cost = None
+    if world > 1 and rank == 0 and (strong or args.shards != "same"):
+        ref_cost = g_cost.cpu().numpy().copy()
 
     # ---- diagnostic leg (N > 1, configs[1], after the timed region, never `value`): the machine's own scaling.  Every rank
     # solves shard 0 -- exactly the N = 1 line's work -- with the gather, all ranks together; then rank 0 solves it alone.
@@ -455,6 +598,14 @@ def main():
                           "value": v_same, "ms_per_step": float(ts.item()) / ks * 1e3, "one_rank_alone_value": v_alone,
                           "machine_efficiency": v_same / (world * v_alone)}
         # (the last solve of this leg overwrote out_i with shard 0's counts: the line's iters/status are shard 0's)
+
+    # ---- the product's own multi-GPU path (never `value`): the same step through qilqr_solve_batch_sharded_device, in a child
+    # process of rank 0 while the other ranks wait, idle, at the fence
+    sharded_abi = None
+    if world > 1 and not args.no_sharded_c_abi:
+        if rank == 0:
+            sharded_abi = sharded_c_abi_leg(args, ref_cost)
+        fence()
 
     status, iters, n_bwd, n_fwd = (t.cpu().numpy() for t in out_i)
     if world > 1:
@@ -499,7 +650,7 @@ def main():
                 "flops": {"achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS},
                 **({"note": "k_backward_rollout = the backward pass and the rollout of a round in one launch (up to 1024 trajectories); its "
                             "work is both passes' algorithmic flops, its time both serial chains (the rollout's has no matrix work).  Launched apart "
-                            "(QILQR_FUSE_BACKWARD_ROLLOUT=0) the backward kernel alone ran at 20.6 % of the fp64 peak in round 3 (68.9 us per launch, "
+                            "(qilqr_device_config.round_launch = 1) the backward kernel alone ran at 20.6 % of the fp64 peak in round 3 (68.9 us per launch, "
                             "profiles/r03f_rocprof_summary.txt; 67.2 us with one live wavefront per block since round 4's pipelined knot, "
                             "profiles/r04_knot_anatomy.txt) and the rollout at 51.8 us.  The numerator is the reference's dense-as-written 30 kflop "
                             "per backward knot; the kernel issues 7 x 2048 flop of MFMA + ~68 fp64 vector instructions per knot"} if dom == "k_backward_rollout" else {}),
@@ -611,28 +762,37 @@ def main():
                      "status_counts": np.bincount(lbuf[2][0].cpu().numpy(), minlength=4).tolist()}
             ls.close()
             del linit, lbuf
-        # ---- CPU baseline: the oracle on this host's cores, bounded sample of the same workload
+        # ---- CPU baseline: the oracle on this host's cores, bounded sample of the same workload.  Timed on the TIMING build of the
+        # oracle's source (fused multiply-adds allowed, compiled for this host when gcc is here: oracle/Makefile `fast-native`), every
+        # hardware thread this process may use, problems drawn from an atomic counter; parity is checked on the PARITY build.
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             from oracle import oracle as orc
-            cores = max(1, min(os.cpu_count() or 1, 64))
+            cores = usable_cores()
             sample = min(B, max(64, 24 * cores))
-            ref = orc.OracleSolver(orc.model_params(**cfg["model"]), cfg["Q"], cfg["R"], cfg["desired"],
-                                   cfg["dt"], orc.options(**cfg["options"]))
+            mk = lambda L: orc.OracleSolver(orc.model_params(**cfg["model"]), cfg["Q"], cfg["R"], cfg["desired"],
+                                            cfg["dt"], orc.options(**cfg["options"]), library=L)
+            fast = mk(orc.fast_library())
+            fast.solve_batch(cfg["init"][:cores], n_threads=cores)  # threads, pages and clocks warm
             # repeat the sample until about 15 core-seconds of CPU work have been timed
             reps, tc = 0, 0.0
             while reps == 0 or (tc * cores < 15.0 and reps < 64):
                 t1 = time.perf_counter()
-                r = ref.solve_batch(cfg["init"][:sample], n_threads=cores)
+                fast.solve_batch(cfg["init"][:sample], n_threads=cores)
                 tc += time.perf_counter() - t1
                 reps += 1
             t1 = time.perf_counter()
-            ref.solve_batch(cfg["init"][:16], n_threads=1)
+            fast.solve_batch(cfg["init"][:32], n_threads=1)
             t1c = time.perf_counter() - t1
+            r = mk(None).solve_batch(cfg["init"][:sample], n_threads=cores)  # the parity build: the checker
             got = out_cost[(step_no[0] - 1) & 1].cpu().numpy()[:sample]
-            cpu = {"value": sample * reps / tc, "unit": "solves/s", "cores": cores, "kind": "port",
-                   "sample": f"first {sample} of the {B} problems of rank 0 x {reps} repeats, {cores} threads, {tc:.2f} s; "
-                             f"single thread: {16 / t1c:.1f} solves/s on 16 problems",
+            v = sample * reps / tc
+            cpu = {"value": v, "unit": "solves/s", "cores": cores, "kind": "port",
+                   "sample": f"first {sample} of the {B} problems of rank 0 x {reps} repeats, {cores} threads (affinity and cgroup quota; the host "
+                             f"reports {os.cpu_count()}), problems drawn from an atomic counter, {tc:.2f} s; timing build of the oracle "
+                             f"[{fast.flavour()}]; single thread: {32 / t1c:.1f} solves/s on 32 problems",
+                   "single_thread_value": 32 / t1c, "thread_scaling": v / (cores * 32 / t1c),
+                   "parity_build": mk(None).flavour(),
                    "parity_max_rel_cost_err": float(np.max(np.abs(got - r["cost"]) / np.abs(r["cost"])))}
         # ---- extra, outside the timed region and never `value`: a stream of such batches with several in flight
         # (one solver handle and one host thread per batch in flight): the tail of one batch -- a few trajectories
@@ -690,6 +850,8 @@ def main():
                                          f"distinct: {world} shards of {B} distinct problems per step; rank r solves shard (r + step) mod {world}")}
         line = {
             "metric": "iLQR solves/sec (batch, 100-knot SE(3) quadrotor)", "value": value, "unit": "solves/s",
+            "value_region": "device-resident: inputs in HBM when the timed region starts, results left in HBM (the task's contract for `value`); "
+                            "the metric as SURVEY.md section 8(d) words it, host buffers in -> host buffers out over PCIe, is `host_to_host.value`",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "config": conf,
@@ -698,7 +860,7 @@ def main():
             "knot_steps_per_s": knot_steps / dt,
             "gather_ms": gather_ms,
             "shard_rounds": shard_rounds_list,  # per shard: rollouts of its slowest problem (the straggler sets a shard's time)
-            "same_shard": same_shard,
+            "same_shard": same_shard, "sharded_c_abi": sharded_abi,
             "roofline": roofline, "cpu_baseline": cpu, "host_to_host": h2h, "large_batch": large, "serving": serving,
             "single_solve": single, "reference_faithful": faithful,
             **({"rehearse_nccl": {"backend": dist.get_backend(), "world_size": 1,

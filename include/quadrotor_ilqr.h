@@ -130,7 +130,24 @@ typedef struct {
                          count the call allows
                          (not with populate_debug's cost history, per-problem desired trajectories, or the copy-back under the
                          tail of qilqr_solve_batch), -1 = never */
+  int32_t round_launch; /* (ABI version 7; until then the environment variables QILQR_FUSE_BACKWARD_ROLLOUT / QILQR_ROUND_KERNEL) how a round of
+                           up to 4 x CUs trajectories is launched when its kernels are the fused k_backward4 and k_rollout16: 0 = automatic
+                           (ONE launch: k_round, fp64 -- backward pass, rollout and linearisation of the candidates -- or k_backward_rollout +
+                           k_linearize in the mixed mode), 1 = three launches (k_backward4, k_rollout16, k_linearize), 2 = two launches
+                           (k_backward_rollout + k_linearize).  The same bits in every form: A/B measurements and the bit-identity tests */
+  int32_t rounds_per_launch; /* (ABI version 7; was QILQR_ROUNDS_PER_LAUNCH) rounds in one k_round launch where a launch may hold several:
+                                0 = automatic (4), or 1, 2, 4 */
+  int32_t fuse_in_flight; /* (ABI version 7; was QILQR_FUSE_IN_FLIGHT) 1 = keep the combined launches although other batch solves of the
+                             process are in flight on the device (0: a solve that is not alone launches the kernels apart) */
+  int32_t dense_weights; /* (ABI version 7; was QILQR_NO_DIAG_Q) 1 = a diagonal Q is multiplied as a dense matrix instead of scaling rows
+                            (the same bits: tests/test_gpu_parity.py::test_diagonal_weights_path_gives_the_same_bits) */
 } qilqr_device_config;
+/* The structure only ever grows at its end.  qilqr_create_sized / qilqr_sharded_create_sized take the size the CALLER was compiled with
+ * (fields beyond it keep their defaults: 0, sync_every 2), so a caller built against an older header runs against a newer library;
+ * with this header `qilqr_create(...)` in source code IS the sized call (macros below).  The exported symbols qilqr_create,
+ * qilqr_sharded_create and qilqr_sharded_create_mask remain for binaries built before ABI version 7 and read only the eight
+ * fields of ABI version 5 (32 bytes). */
+#define QILQR_DEVICE_CONFIG_BYTES_ABI5 32
 
 /* One arithmetic at every batch size: the fused k_backward4 and k_rollout16 (with the tiled knot records they read) are forced,
  * so that a problem's result does not depend on the size of the batch it is solved in, on sharding, or on sub-batch streams
@@ -161,6 +178,10 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R,
                  const double *desired, int32_t n_desired, double dt_s,
                  const qilqr_options *options, const qilqr_device_config *dev,
                  qilqr_solver **out);
+int qilqr_create_sized(const qilqr_model *model, const double *Q, const double *R,
+                       const double *desired, int32_t n_desired, double dt_s,
+                       const qilqr_options *options, const qilqr_device_config *dev, size_t dev_bytes,
+                       qilqr_solver **out);
 void qilqr_destroy(qilqr_solver *s);
 
 /* text of the last error on the calling thread */
@@ -278,6 +299,9 @@ typedef struct qilqr_sharded qilqr_sharded;
 int qilqr_sharded_create(const qilqr_model *model, const double *Q, const double *R, const double *desired,
                          int32_t n_desired, double dt_s, const qilqr_options *options, const qilqr_device_config *dev,
                          const int32_t *devices, int32_t n_devices, qilqr_sharded **out);
+int qilqr_sharded_create_sized(const qilqr_model *model, const double *Q, const double *R, const double *desired,
+                               int32_t n_desired, double dt_s, const qilqr_options *options, const qilqr_device_config *dev,
+                               size_t dev_bytes, const int32_t *devices, int32_t n_devices, qilqr_sharded **out);
 /* the same with the devices given as a bit mask (bit d = HIP device d), lowest ordinal first */
 int qilqr_sharded_create_mask(const qilqr_model *model, const double *Q, const double *R, const double *desired,
                               int32_t n_desired, double dt_s, const qilqr_options *options,
@@ -336,11 +360,21 @@ int qilqr_gather_schedule(int32_t B, int32_t n, const int32_t *devices, int32_t 
  * off for that call.  Waits for the handle's stream. */
 int qilqr_compaction_moves(qilqr_solver *s, int64_t *moves);
 
-/* ABI version of this header: 6 (qilqr_device_config grew by `compaction`: a caller built against version 5 passes a shorter
- * structure -- check the version before qilqr_create) */
+/* ABI version of this header: 7 (qilqr_device_config grew by round_launch, rounds_per_launch, fuse_in_flight, dense_weights -- the
+ * switches that were environment variables -- and the *_sized entry points carry the caller's structure size; version 6 added
+ * `compaction`) */
+#define QILQR_ABI_VERSION 7
 int qilqr_abi_version(void);
 
 #ifdef __cplusplus
 }
+#endif
+
+/* In source code compiled against this header the create calls pass the size of the structure they were compiled with. */
+#ifndef QILQR_NO_SIZED_MACROS
+#define qilqr_create(model, Q, R, desired, n_desired, dt_s, options, dev, out) \
+  qilqr_create_sized(model, Q, R, desired, n_desired, dt_s, options, dev, sizeof(qilqr_device_config), out)
+#define qilqr_sharded_create(model, Q, R, desired, n_desired, dt_s, options, dev, devices, n_devices, out) \
+  qilqr_sharded_create_sized(model, Q, R, desired, n_desired, dt_s, options, dev, sizeof(qilqr_device_config), devices, n_devices, out)
 #endif
 #endif

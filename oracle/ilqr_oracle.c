@@ -17,6 +17,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <stdatomic.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1219,7 +1220,8 @@ int orc_solve_decisions(const orc_solver *s, const double *init, int n, double *
 typedef struct {
   const orc_solver *s;
   const double *init;
-  int B, n, tid, nt;
+  int B, n;
+  atomic_int *next; /* the next problem nobody has taken: threads draw problems one at a time (solve times differ by 3 x) */
   double *out_traj, *out_cost;
   int *out_status, *out_iters, *out_n_bwd, *out_n_fwd;
 } BatchJob;
@@ -1227,7 +1229,9 @@ typedef struct {
 static void *batch_worker(void *arg) {
   BatchJob *j = (BatchJob *)arg;
   const size_t stride = (size_t)ORC_PT * j->n;
-  for (int b = j->tid; b < j->B; b += j->nt) {
+  for (;;) {
+    const int b = atomic_fetch_add_explicit(j->next, 1, memory_order_relaxed);
+    if (b >= j->B) break;
     double c;
     int st, it, nb, nf;
     orc_solve(j->s, j->init + b * stride, j->n, j->out_traj + b * stride, &c, &st, &it, &nb, &nf,
@@ -1247,19 +1251,29 @@ int orc_solve_batch(const orc_solver *s, const double *init, int B, int n, doubl
   if (n <= 0 || B < 0) return ORC_ERR_INVALID;
   if (n > s->n_desired) return ORC_ERR_LENGTH_MISMATCH;
   if (n_threads < 1) n_threads = 1;
-  if (n_threads > 256) n_threads = 256;
-  pthread_t th[256];
-  BatchJob jobs[256];
-  for (int t = 0; t < n_threads; ++t) {
-    BatchJob jb = {s, init, B, n, t, n_threads, out_traj, out_cost,
-                   out_status, out_iters, out_n_bwd, out_n_fwd};
-    jobs[t] = jb;
-    if (n_threads == 1)
-      batch_worker(&jobs[t]);
-    else
-      pthread_create(&th[t], 0, batch_worker, &jobs[t]);
+  if (n_threads > 512) n_threads = 512;
+  pthread_t th[512];
+  atomic_int next;
+  atomic_init(&next, 0);
+  BatchJob job = {s, init, B, n, &next, out_traj, out_cost, out_status, out_iters, out_n_bwd, out_n_fwd};
+  if (n_threads == 1) {
+    batch_worker(&job);
+    return ORC_OK;
   }
-  if (n_threads > 1)
-    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], 0);
+  int started = 0;
+  for (int t = 0; t < n_threads; ++t)
+    if (pthread_create(&th[started], 0, batch_worker, &job) == 0) ++started;
+  if (started == 0) batch_worker(&job); /* no thread could be created: this one does the work */
+  for (int t = 0; t < started; ++t) pthread_join(th[t], 0);
   return ORC_OK;
+}
+
+/* how this library was compiled: "parity" (-ffp-contract=off, the build every test compares with) or "fast" (timing only:
+ * -O3 -mfma -ffp-contract=fast; bench.py's cpu_baseline) */
+const char *orc_build_flavour(void) {
+#ifdef ORC_FAST_BUILD
+  return "fast: " ORC_FAST_BUILD;
+#else
+  return "parity: -O3 -march=x86-64-v3 -ffp-contract=off";
+#endif
 }

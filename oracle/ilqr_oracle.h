@@ -177,11 +177,14 @@ int orc_solve_decisions(const orc_solver *s, const double *init, int n, double *
                         int *out_status, int *out_iters, int *out_n_bwd, int *out_n_fwd, double *cost_hist, int cap,
                         int *out_n_hist, orc_decision *dec, int dec_cap, int *n_dec);
 
-/* batch over independent problems, n_threads host threads (pthreads).
- * init: B x n x 18; desired shared (from create).  Used only for cpu_baseline timing. */
+/* batch over independent problems, n_threads host threads (pthreads) drawing problems from an atomic counter.
+ * init: B x n x 18; desired shared (from create).  Results do not depend on n_threads. */
 int orc_solve_batch(const orc_solver *s, const double *init, int B, int n, double *out_traj,
                     double *out_cost, int *out_status, int *out_iters, int *out_n_bwd,
                     int *out_n_fwd, int n_threads);
+
+/* "parity: ..." (the build every test compares with: no contraction) or "fast: <flags>" (timing only, bench.py's cpu_baseline) */
+const char *orc_build_flavour(void);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,29 @@ def build(force=False):
 _lib = None
 
 
+def fast_library(native=True):
+    """The TIMING-ONLY build of the same source (fused multiply-adds allowed; oracle/Makefile): bench.py's cpu_baseline.  Tries to
+    compile it for this host's own CPU first (`make fast-native`), falls back to the portable build that travels with the tree.
+    Never a parity comparand: pass it to OracleSolver(library=...) explicitly."""
+    paths = []
+    if native:
+        try:
+            subprocess.check_call(["make", "-C", _HERE, "fast-native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            paths.append(os.path.join(_HERE, "libilqr_oracle_fast_native.so"))
+        except Exception:
+            pass
+    paths.append(os.path.join(_HERE, "libilqr_oracle_fast.so"))
+    for p in paths:
+        if not os.path.exists(p) and p.endswith("_fast.so"):
+            subprocess.check_call(["make", "-C", _HERE, "libilqr_oracle_fast.so"], stdout=subprocess.DEVNULL)
+        if os.path.exists(p):
+            L = C.CDLL(p)
+            L.orc_cost.restype = C.c_double
+            L.orc_build_flavour.restype = C.c_char_p
+            return L
+    raise OSError("no fast oracle library")
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -78,6 +101,7 @@ def lib():
             build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.orc_cost.restype = C.c_double
+        _lib.orc_build_flavour.restype = C.c_char_p
     return _lib
 
 
@@ -267,11 +291,12 @@ def kK_to_gains(k, K):
 class OracleSolver:
     """ILQR<QuadrotorModel> of the reference (ilqr.hh:25-206) on the CPU oracle."""
 
-    def __init__(self, mp, Q, R, desired, dt, opt):
+    def __init__(self, mp, Q, R, desired, dt, opt, library=None):
+        self._L = library if library is not None else lib()  # (library: fast_library() for timing; the parity build otherwise)
         self.mp, self.opt, self.dt = mp, opt, dt
         self.desired = _d(desired).reshape(-1, 18)
         self._h = C.c_void_p()
-        rc = lib().orc_solver_create(C.byref(mp), _p(_d(Q)), _p(_d(R)), _p(self.desired),
+        rc = self._L.orc_solver_create(C.byref(mp), _p(_d(Q)), _p(_d(R)), _p(self.desired),
                                      C.c_int(self.desired.shape[0]), C.c_double(dt),
                                      C.byref(opt), C.byref(self._h))
         if rc == ERR_BAD_INERTIA:
@@ -281,8 +306,11 @@ class OracleSolver:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_solver_destroy(self._h)
+            self._L.orc_solver_destroy(self._h)
             self._h = None
+
+    def flavour(self):
+        return self._L.orc_build_flavour().decode()
 
     @staticmethod
     def _check(rc):
@@ -294,14 +322,14 @@ class OracleSolver:
     def cost_trajectory(self, traj):
         traj = _d(traj).reshape(-1, 18)
         c = C.c_double()
-        self._check(lib().orc_cost_trajectory(self._h, _p(traj), C.c_int(len(traj)), C.byref(c)))
+        self._check(self._L.orc_cost_trajectory(self._h, _p(traj), C.c_int(len(traj)), C.byref(c)))
         return c.value
 
     def backwards_pass(self, traj):
         traj = _d(traj).reshape(-1, 18)
         gains = np.zeros((len(traj), 52))
         terms = np.zeros(2)
-        self._check(lib().orc_backwards_pass(self._h, _p(traj), C.c_int(len(traj)), _p(gains),
+        self._check(self._L.orc_backwards_pass(self._h, _p(traj), C.c_int(len(traj)), _p(gains),
                                              _p(terms)))
         return gains, terms
 
@@ -310,30 +338,30 @@ class OracleSolver:
         traj = _d(traj).reshape(-1, 18)
         gains = np.zeros((len(traj), 52))
         terms = np.zeros(2)
-        self._check(lib().orc_backwards_pass_reg(self._h, _p(traj), C.c_int(len(traj)), C.c_double(mu),
+        self._check(self._L.orc_backwards_pass_reg(self._h, _p(traj), C.c_int(len(traj)), C.c_double(mu),
                                                  _p(gains), _p(terms)))
         return gains, terms
 
     def set_regularisation(self, mu_init, mu_factor=10.0, mu_max=1e6):
         """Extension (not in the reference): Levenberg-Marquardt restarts in solve / solve_batch."""
-        self._check(lib().orc_set_regularisation(self._h, C.c_double(mu_init), C.c_double(mu_factor),
+        self._check(self._L.orc_set_regularisation(self._h, C.c_double(mu_init), C.c_double(mu_factor),
                                                  C.c_double(mu_max)))
 
     def set_integrator(self, integrator):
         """Extension (not in the reference's executed code): 1 = the Runge-Kutta step of quadrotor_model.cc:51-63."""
-        self._check(lib().orc_set_integrator(self._h, C.c_int(integrator)))
+        self._check(self._L.orc_set_integrator(self._h, C.c_int(integrator)))
 
     def set_recursion(self, mode):
         """Extension (orc_set_recursion): 0 = ilqr.hh:132-133 as written (default), 1 = the substituted, symmetrised form
         V_x = Q_x + K^T Q_u, V_xx = sym(Q_xx + Q_xu K), k^T Q_uu k = -Q_u^T k -- stable at 200 / 500 knots, where the reference's own
         form is rounding noise; the comparand of the full-size tests of BASELINE.json configs[2] and configs[4]."""
-        self._check(lib().orc_set_recursion(self._h, C.c_int(mode)))
+        self._check(self._L.orc_set_recursion(self._h, C.c_int(mode)))
 
     def forward_sim(self, traj, gains, alpha=1.0):
         traj = _d(traj).reshape(-1, 18)
         gains = _d(gains).reshape(-1, 52)
         out = np.zeros_like(traj)
-        self._check(lib().orc_forward_sim(self._h, _p(traj), C.c_int(len(traj)), _p(gains),
+        self._check(self._L.orc_forward_sim(self._h, _p(traj), C.c_int(len(traj)), _p(gains),
                                           C.c_double(alpha), _p(out)))
         return out
 
@@ -342,7 +370,7 @@ class OracleSolver:
         gains = _d(gains).reshape(-1, 52)
         out = np.zeros_like(traj)
         c, step, trials = C.c_double(), C.c_double(), C.c_int()
-        st = lib().orc_line_search(self._h, _p(traj), C.c_int(len(traj)), C.c_double(cost),
+        st = self._L.orc_line_search(self._h, _p(traj), C.c_int(len(traj)), C.c_double(cost),
                                    _p(gains), _p(_d(terms)), _p(out), C.byref(c), C.byref(step),
                                    C.byref(trials))
         if st < 0:
@@ -358,7 +386,7 @@ class OracleSolver:
         dbg = np.zeros((cap, n, 18)) if debug else None
         c = C.c_double()
         st, it, nb, nf, nh = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        self._check(lib().orc_solve(self._h, _p(init), C.c_int(n), _p(out), C.byref(c),
+        self._check(self._L.orc_solve(self._h, _p(init), C.c_int(n), _p(out), C.byref(c),
                                     C.byref(st), C.byref(it), C.byref(nb), C.byref(nf), _p(hist),
                                     _p(dbg), C.c_int(cap), C.byref(nh)))
         k = min(nh.value, cap)
@@ -378,7 +406,7 @@ class OracleSolver:
         dec = (Decision * dcap)()
         c = C.c_double()
         st, it, nb, nf, nh, nd = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        self._check(lib().orc_solve_decisions(self._h, _p(init), C.c_int(n), _p(out), C.byref(c), C.byref(st), C.byref(it),
+        self._check(self._L.orc_solve_decisions(self._h, _p(init), C.c_int(n), _p(out), C.byref(c), C.byref(st), C.byref(it),
                                               C.byref(nb), C.byref(nf), _p(hist), C.c_int(cap), C.byref(nh), dec,
                                               C.c_int(dcap), C.byref(nd)))
         assert nd.value <= dcap
@@ -393,7 +421,7 @@ class OracleSolver:
         out = np.zeros_like(init)
         cost = np.zeros(B)
         st, it, nb, nf = (np.zeros(B, dtype=np.int32) for _ in range(4))
-        self._check(lib().orc_solve_batch(self._h, _p(init), C.c_int(B), C.c_int(n), _p(out),
+        self._check(self._L.orc_solve_batch(self._h, _p(init), C.c_int(B), C.c_int(n), _p(out),
                                           _p(cost), _ip(st), _ip(it), _ip(nb), _ip(nf),
                                           C.c_int(n_threads)))
         return dict(traj=out, cost=cost, status=st, iters=it, n_bwd=nb, n_fwd=nf)

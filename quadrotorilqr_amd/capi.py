@@ -34,12 +34,12 @@ STATUS_LINE_SEARCH_FAILED = 3
 
 # every symbol include/quadrotor_ilqr.h declares
 EXPORTS = (
-    "qilqr_create", "qilqr_destroy", "qilqr_last_error", "qilqr_solve", "qilqr_solve_batch",
+    "qilqr_create", "qilqr_create_sized", "qilqr_destroy", "qilqr_last_error", "qilqr_solve", "qilqr_solve_batch",
     "qilqr_solve_batch_device", "qilqr_cost_trajectory", "qilqr_backwards_pass", "qilqr_forward_sim",
     "qilqr_line_search", "qilqr_cost_history", "qilqr_profile_reset", "qilqr_profile_get", "qilqr_profile_mode", "qilqr_set_regularisation",
     "qilqr_set_integrator",
     "qilqr_device", "qilqr_stream", "qilqr_stream_wait_event", "qilqr_host_alloc", "qilqr_host_free",
-    "qilqr_sharded_create", "qilqr_sharded_create_mask", "qilqr_sharded_destroy", "qilqr_sharded_count", "qilqr_sharded_solver",
+    "qilqr_sharded_create", "qilqr_sharded_create_sized", "qilqr_sharded_create_mask", "qilqr_sharded_destroy", "qilqr_sharded_count", "qilqr_sharded_solver",
     "qilqr_shard_range", "qilqr_solve_batch_sharded",
     "qilqr_sharded_set_transport", "qilqr_sharded_transport", "qilqr_solve_batch_sharded_device", "qilqr_gather_schedule",
     "qilqr_abi_version", "qilqr_compaction_moves",
@@ -60,7 +60,9 @@ class Options(C.Structure):
 class DeviceConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("profile", C.c_int32), ("sync_every", C.c_int32),
                 ("force_general", C.c_int32), ("single_wave_rollout", C.c_int32), ("precision", C.c_int32),
-                ("streams", C.c_int32), ("persistent", C.c_int32), ("compaction", C.c_int32)]
+                ("streams", C.c_int32), ("persistent", C.c_int32), ("compaction", C.c_int32),
+                # ABI version 7: the A/B switches that were environment variables
+                ("round_launch", C.c_int32), ("rounds_per_launch", C.c_int32), ("fuse_in_flight", C.c_int32), ("dense_weights", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -128,7 +130,8 @@ def _raise(rc, ls_max_iters=None):
 
 
 def _create_args(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired, options, device, profile,
-                 sync_every, force_general, single_wave_rollout, precision, streams, persistent, compaction=0):
+                 sync_every, force_general, single_wave_rollout, precision, streams, persistent, compaction=0, round_launch=0,
+                 rounds_per_launch=0, fuse_in_flight=0, dense_weights=0):
     """the C structures of qilqr_create / qilqr_sharded_create; sets self.options and self.desired"""
     m = Model()
     m.mass_kg = mass_kg
@@ -154,7 +157,8 @@ def _create_args(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m,
     self.options = dict(options)
     self.desired = _d(desired).reshape(-1, KNOT)
     dc = DeviceConfig(int(device), int(profile), int(sync_every), int(force_general),
-                      int(single_wave_rollout), {"f64": 0, "f32": 1}[precision], int(streams), int(persistent), int(compaction))
+                      int(single_wave_rollout), {"f64": 0, "f32": 1}[precision], int(streams), int(persistent), int(compaction),
+                      int(round_launch), int(rounds_per_launch), int(fuse_in_flight), int(dense_weights))
     return m, Q, R, o, dc
 
 
@@ -176,13 +180,15 @@ class QuadrotorILQRBatch:
 
     def __init__(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired,
                  dt_s, options, device=0, profile=0, sync_every=2, force_general=False,
-                 single_wave_rollout=False, precision="f64", streams=0, persistent=0, compaction=0):
+                 single_wave_rollout=False, precision="f64", streams=0, persistent=0, compaction=0, round_launch=0,
+                 rounds_per_launch=0, fuse_in_flight=0, dense_weights=0):
         lib = load()
         m, Q, R, o, dc = _create_args(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired, options,
-                                      device, profile, sync_every, force_general, single_wave_rollout, precision, streams, persistent, compaction)
+                                      device, profile, sync_every, force_general, single_wave_rollout, precision, streams, persistent, compaction,
+                                      round_launch, rounds_per_launch, fuse_in_flight, dense_weights)
         self._h = C.c_void_p()
-        rc = lib.qilqr_create(C.byref(m), _p(Q), _p(R), _p(self.desired), C.c_int32(len(self.desired)),
-                              C.c_double(dt_s), C.byref(o), C.byref(dc), C.byref(self._h))
+        rc = lib.qilqr_create_sized(C.byref(m), _p(Q), _p(R), _p(self.desired), C.c_int32(len(self.desired)),
+                                    C.c_double(dt_s), C.byref(o), C.byref(dc), C.c_size_t(C.sizeof(dc)), C.byref(self._h))
         if rc:
             self._h = None
             _raise(rc)
@@ -383,15 +389,16 @@ class QuadrotorILQRSharded:
 
     def __init__(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired, dt_s, options,
                  devices=(0,), profile=0, sync_every=2, force_general=False, single_wave_rollout=False, precision="f64",
-                 streams=0, persistent=0, compaction=0):
+                 streams=0, persistent=0, compaction=0, round_launch=0, rounds_per_launch=0, fuse_in_flight=0, dense_weights=0):
         lib = load()
         m, Q, R, o, dc = _create_args(self, mass_kg, inertia, arm_length_m, torque_to_thrust_ratio_m, g_mpss, Q, R, desired, options,
-                                      0, profile, sync_every, force_general, single_wave_rollout, precision, streams, persistent, compaction)
+                                      0, profile, sync_every, force_general, single_wave_rollout, precision, streams, persistent, compaction,
+                                      round_launch, rounds_per_launch, fuse_in_flight, dense_weights)
         self.devices = [int(d) for d in devices]
         arr = (C.c_int32 * len(self.devices))(*self.devices)
         self._h = C.c_void_p()
-        rc = lib.qilqr_sharded_create(C.byref(m), _p(Q), _p(R), _p(self.desired), C.c_int32(len(self.desired)), C.c_double(dt_s),
-                                      C.byref(o), C.byref(dc), arr, C.c_int32(len(self.devices)), C.byref(self._h))
+        rc = lib.qilqr_sharded_create_sized(C.byref(m), _p(Q), _p(R), _p(self.desired), C.c_int32(len(self.desired)), C.c_double(dt_s),
+                                            C.byref(o), C.byref(dc), C.c_size_t(C.sizeof(dc)), arr, C.c_int32(len(self.devices)), C.byref(self._h))
         if rc:
             self._h = None
             _raise(rc)

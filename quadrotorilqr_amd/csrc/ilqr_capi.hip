@@ -19,6 +19,7 @@
 #include <thread>
 #include <vector>
 
+#define QILQR_NO_SIZED_MACROS  // (this file DEFINES the legacy symbols the macros stand in front of)
 #include "../../include/quadrotor_ilqr.h"
 #include "host_model.h"
 #include "ilqr_kernels.h"
@@ -505,13 +506,10 @@ int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
 }
 // k_backward_rollout (ilqr_kernels.h): the backward pass and the rollout of a round in one launch, when every block of four
 // trajectories has a CU to itself (the rollout's register budget allows one block per CU) and the round's kernels are the
-// fused k_backward4 and k_rollout16 anyway.  QILQR_FUSE_BACKWARD_ROLLOUT=0 in the environment keeps them apart (A/B).
+// fused k_backward4 and k_rollout16 anyway.  qilqr_device_config.round_launch = 1 keeps them apart (A/B).
 // (the kernels of the round are the two the combined launch stands for: everything but the room on the chip)
 bool fuse_kinds(const qilqr_solver *s, long B) {
-  static const bool off = [] {
-    const char *e = std::getenv("QILQR_FUSE_BACKWARD_ROLLOUT");
-    return e && e[0] == '0';
-  }();
+  const bool off = s->dev.round_launch == 1;  // (qilqr_device_config.round_launch: three launches per round, A/B)
   const long load_B = std::max(B, s->total_B);
   if (off || s->integrator != 0 || !s->symmetric || !s->st.layout.tiled) return false;
   if (!(s->dev.force_general == 0 || s->dev.force_general == 5) || backward_kind(s, load_B) != BW_FUSED) return false;
@@ -534,31 +532,16 @@ struct InFlight {
   std::atomic<int> &n;
   explicit InFlight(int device) : n(g_solves_in_flight[(unsigned)device % MAX_TRACKED_DEVICES]) { n.fetch_add(1, std::memory_order_relaxed); }
   ~InFlight() { n.fetch_sub(1, std::memory_order_relaxed); }
-  bool alone() const {
-    static const bool always = [] {  // (diagnostic: QILQR_FUSE_IN_FLIGHT=1 keeps the combined launches beside other solves)
-      const char *e = std::getenv("QILQR_FUSE_IN_FLIGHT");
-      return e && e[0] == '1';
-    }();
-    return always || n.load(std::memory_order_relaxed) == 1;
-  }
+  // (always: qilqr_device_config.fuse_in_flight = 1 keeps the combined launches beside other solves -- diagnostic)
+  bool alone(bool always = false) const { return always || n.load(std::memory_order_relaxed) == 1; }
 };
 // k_round (ilqr_kernels.h): the combined launch and the linearisation of its candidates in one.  fp64 storage only (the mixed mode keeps
 // the two launches).  The round's counts go into the counter set of its parity; the launch publishes the round before it.
-bool round_kernel_ok(const qilqr_solver *s) {
-  static const bool off = [] {
-    const char *e = std::getenv("QILQR_ROUND_KERNEL");
-    return e && e[0] == '0';
-  }();
-  return !off && !s->f32;
-}
-// rounds per launch of k_round where a launch may hold several (QILQR_ROUNDS_PER_LAUNCH = 1, 2 or 4 in the environment: A/B)
-int rounds_per_launch() {
-  static const int r = [] {
-    const char *e = std::getenv("QILQR_ROUNDS_PER_LAUNCH");
-    const int v = e ? std::atoi(e) : 4;
-    return (v == 1 || v == 2) ? v : 4;
-  }();
-  return r;
+bool round_kernel_ok(const qilqr_solver *s) { return s->dev.round_launch == 0 && !s->f32; }
+// rounds per launch of k_round where a launch may hold several (qilqr_device_config.rounds_per_launch = 1, 2 or 4: A/B; 0 = 4)
+int rounds_per_launch(const qilqr_solver *s) {
+  const int v = s->dev.rounds_per_launch;
+  return (v == 1 || v == 2) ? v : 4;
 }
 int launch_round(qilqr_solver *s, long B, long n, long round, bool publish_prev, int rounds) {
   const ModelConsts<double> *cp = (const ModelConsts<double> *)s->d_consts;
@@ -806,7 +789,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
       // several rounds, and the sums of counts they report say nothing against the threshold)
       const bool compacting = s->compact && !tail_started && (seen_active > tf.stop || (tf.kinds && used > tf.slots));
       if (s->compact && tf.kinds && !compacting && used <= tf.slots) tail_started = true;
-      const bool fuse_now = (can_fuse || tail_started) && in_flight.alone();
+      const bool fuse_now = (can_fuse || tail_started) && in_flight.alone(s->dev.fuse_in_flight == 1);
       // k_round linearises a block's candidates with the block's own five wavefronts: as fast as k_linearize when a block has one
       // candidate (the tail of every solve) or when the chip is full anyway, 2.5 times slower with four candidates per block and
       // idle CUs beside it (B = 64 ... 512 in their first rounds: -0.3 to -1.2 % of a solve if taken there)
@@ -814,7 +797,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
       if (fuse_now && round_kernel_ok(s) && (!blocks_full || used >= 768)) {
         // several rounds per launch where the rounds are this kernel for the rest of the solve (no compaction any more, whose
         // thresholds go by the count) and the caller does not look at a solve round by round (the single solve's debug capture)
-        const int rounds = ((can_fuse || tail_started) && double_ok) ? rounds_per_launch() : 1;
+        const int rounds = ((can_fuse || tail_started) && double_ok) ? rounds_per_launch(s) : 1;
         if ((rc = launch_round(s, used, n, round, pending_publish, rounds))) return rc;
         launched_rounds[round & 7] = rounds;
         pending_publish = true;
@@ -948,8 +931,8 @@ struct PartScope {
   }
 };
 // hardware queues HIP multiplexes this process's streams onto: GPU_MAX_HW_QUEUES as the runtime read it at start-up (default 4)
-// Latched at the first qilqr_create of the process (the runtime reads the variable once, when it starts: a value put into
-// the environment later -- os.environ after the first GPU call -- changes nothing in the runtime and must change nothing here)
+// Latched at the first qilqr_create_sized of the process, which calls it (the runtime reads the variable once, when it starts: a value
+// put into the environment later -- os.environ after the first GPU call -- changes nothing in the runtime and must change nothing here)
 int hw_queues() {
   static const int latched = [] {
     const char *e = std::getenv("GPU_MAX_HW_QUEUES");
@@ -1025,7 +1008,7 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
         if (part.done) continue;
         PartScope scope(s, part);
         const bool compacting = s->compact && (part.seen_active > tf.stop || (tf.kinds && part.used > tf.slots));
-        if (tf.kinds && !compacting && part.used <= tf.slots && in_flight.alone()) {
+        if (tf.kinds && !compacting && part.used <= tf.slots && in_flight.alone(s->dev.fuse_in_flight == 1)) {
           if ((rc = launch_backward_rollout(s, part.used, n))) return rc;
           if ((rc = launch_linearize(s, part.used, n, 1, F_SEARCH, (int)(round & 0x3fffffff)))) return rc;
           continue;
@@ -1062,6 +1045,12 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
           part.done = true;
           --remaining;
         }
+      }
+      // a block that gave up a hand-off (BatchState::host_error) voids the call: stop enqueuing rounds on void gains -- each could burn a
+      // full bounded spin in every block that gave up -- let what is in flight finish, and report (as run_solve does)
+      if (__atomic_load_n(s->h_active + 8 * (1 + qilqr_solver::MAX_PARTS), __ATOMIC_ACQUIRE)) {
+        for (auto &part : parts) (void)hipStreamSynchronize(part.stream);
+        return device_error(s);
       }
     }
   }
@@ -1244,13 +1233,30 @@ int solve_batch_staged(qilqr_solver *s, const double *init, const double *desire
 
 extern "C" {
 
-int qilqr_abi_version(void) { return 6; }
+int qilqr_abi_version(void) { return QILQR_ABI_VERSION; }
 
 const char *qilqr_last_error(void) { return g_last_error.c_str(); }
+
+// the caller's structure (dev_bytes of it: the fields of the header it was compiled with) over the defaults
+static bool read_device_config(const qilqr_device_config *dev, size_t dev_bytes, qilqr_device_config *dc) {
+  *dc = qilqr_device_config{};
+  dc->sync_every = 2;
+  if (!dev) return true;
+  if (dev_bytes < sizeof(int32_t) || dev_bytes % sizeof(int32_t) != 0) return false;
+  std::memcpy(dc, dev, std::min(dev_bytes, sizeof(qilqr_device_config)));  // (a caller NEWER than the library: its extra fields are not known here)
+  return true;
+}
 
 int qilqr_create(const qilqr_model *model, const double *Q, const double *R, const double *desired,
                  int32_t n_desired, double dt_s, const qilqr_options *options,
                  const qilqr_device_config *dev, qilqr_solver **out) {
+  // the symbol binaries built before ABI version 7 call: it reads the fields every such header had
+  return qilqr_create_sized(model, Q, R, desired, n_desired, dt_s, options, dev, QILQR_DEVICE_CONFIG_BYTES_ABI5, out);
+}
+
+int qilqr_create_sized(const qilqr_model *model, const double *Q, const double *R, const double *desired,
+                       int32_t n_desired, double dt_s, const qilqr_options *options,
+                       const qilqr_device_config *dev, size_t dev_bytes, qilqr_solver **out) {
   if (!model || !Q || !R || !options || !out || n_desired < 0 || (n_desired > 0 && !desired))
     return fail(QILQR_ERR_INVALID_ARG, "null argument");
   // QuadrotorModel ctor, quadrotor_model.cc:6-25
@@ -1265,9 +1271,13 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(QILQR_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
-  qilqr_device_config dc = {0, 0, 2, 0, 0, 0, 0, 0, 0};
-  if (dev) dc = *dev;
+  qilqr_device_config dc;
+  if (!read_device_config(dev, dev_bytes, &dc)) return fail(QILQR_ERR_INVALID_ARG, "dev_bytes is not the size of a qilqr_device_config");
+  (void)hw_queues();  // latched here, with the process's first solver
   if (dc.device < 0 || dc.device >= ndev) return fail(QILQR_ERR_INVALID_ARG, "bad device ordinal");
+  if (dc.round_launch < 0 || dc.round_launch > 2) return fail(QILQR_ERR_INVALID_ARG, "round_launch is 0 (automatic), 1 (three launches per round) or 2 (two)");
+  if (!(dc.rounds_per_launch == 0 || dc.rounds_per_launch == 1 || dc.rounds_per_launch == 2 || dc.rounds_per_launch == 4))
+    return fail(QILQR_ERR_INVALID_ARG, "rounds_per_launch is 0 (automatic), 1, 2 or 4");
   if (dc.sync_every < 1) dc.sync_every = 1;
 #ifndef QILQR_WITH_SOLVE4
   if (dc.persistent == 1)
@@ -1308,7 +1318,7 @@ int qilqr_create(const qilqr_model *model, const double *Q, const double *R, con
     for (int i = 0; i < 12; ++i)
       for (int k = 0; k < 12; ++k)
         if (i != k) diag = diag && (Q[i * 12 + k] == 0.0);
-    s->q_diag = diag && std::getenv("QILQR_NO_DIAG_Q") == nullptr;  // (the environment switch: A/B and the bit-identity test)
+    s->q_diag = diag && dc.dense_weights == 0;  // (qilqr_device_config.dense_weights: A/B and the bit-identity test)
   }
   s->n_desired = n_desired;
 
@@ -2010,17 +2020,26 @@ int qilqr_shard_range(int32_t B, int32_t n_shards, int32_t r, int32_t *begin, in
 int qilqr_sharded_create(const qilqr_model *model, const double *Q, const double *R, const double *desired,
                          int32_t n_desired, double dt_s, const qilqr_options *options, const qilqr_device_config *dev,
                          const int32_t *devices, int32_t n_devices, qilqr_sharded **out) {
+  return qilqr_sharded_create_sized(model, Q, R, desired, n_desired, dt_s, options, dev, QILQR_DEVICE_CONFIG_BYTES_ABI5, devices, n_devices, out);
+}
+
+int qilqr_sharded_create_sized(const qilqr_model *model, const double *Q, const double *R, const double *desired,
+                               int32_t n_desired, double dt_s, const qilqr_options *options, const qilqr_device_config *dev,
+                               size_t dev_bytes, const int32_t *devices, int32_t n_devices, qilqr_sharded **out) {
   if (!out || !devices || n_devices <= 0 || n_devices > 64) return fail(QILQR_ERR_INVALID_ARG, "bad device list");
   DeviceGuard guard;
   qilqr_sharded *h = nullptr;
   try {
     h = new qilqr_sharded();
     for (int32_t r = 0; r < n_devices; ++r) {
-      qilqr_device_config dc = {0, 0, 2, 0, 0, 0, 0, 0, 0};
-      if (dev) dc = *dev;
+      qilqr_device_config dc;
+      if (!read_device_config(dev, dev_bytes, &dc)) {
+        qilqr_sharded_destroy(h);
+        return fail(QILQR_ERR_INVALID_ARG, "dev_bytes is not the size of a qilqr_device_config");
+      }
       dc.device = devices[r];
       qilqr_solver *s = nullptr;
-      const int rc = qilqr_create(model, Q, R, desired, n_desired, dt_s, options, &dc, &s);
+      const int rc = qilqr_create_sized(model, Q, R, desired, n_desired, dt_s, options, &dc, sizeof(dc), &s);
       if (rc != QILQR_OK) {
         const std::string msg = "shard " + std::to_string(r) + " (device " + std::to_string(devices[r]) + "): " + g_last_error;
         qilqr_sharded_destroy(h);

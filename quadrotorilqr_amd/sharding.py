@@ -43,7 +43,13 @@ def _first_call_rendezvous(t, group):
     which some shard is empty (B < world) is entered by the root and the non-empty ranks only, so without this the
     first such call could wait for ranks that never come.  Keyed on the group OBJECT (the default group: on the object
     torch.distributed holds for it, so destroy_process_group + a new init_process_group starts over)."""
-    g = group if group is not None else dist.distributed_c10d._get_default_group()
+    if group is not None:
+        g = group
+    else:
+        try:
+            g = dist.distributed_c10d._get_default_group()  # (private: the object torch holds for the default group)
+        except Exception:
+            g = dist.group.WORLD
     try:
         if g in _warmed_groups:
             return

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = capi.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.qilqr_abi_version() == 6
+    assert lib.qilqr_abi_version() == 7
 
 
 def test_struct_layouts_match_header():
@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(capi.Model) == 13 * 8
     assert C.sizeof(capi.Options) == 56      # 2 doubles, int32 + pad, 3 doubles, int32 + pad
     assert capi.Options.rtol.offset == 24 and capi.Options.populate_debug.offset == 48
-    assert C.sizeof(capi.DeviceConfig) == 36  # nine int32 (ABI version 2 added `streams`, version 3 `persistent`, version 6 `compaction`)
+    assert C.sizeof(capi.DeviceConfig) == 52  # thirteen int32 (ABI version 2 added `streams`, 3 `persistent`, 6 `compaction`, 7 the four A/B switches)
     assert C.sizeof(capi.Profile) == 96  # four (double, int32 + pad) pairs, four int32 counts, (double, int32, int32)
 
 

@@ -64,20 +64,25 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
 @pytest.mark.gpu
 @pytest.mark.parametrize("shards", ["same", "distinct"])
 def test_two_rank_code_path_on_one_gpu(shards):
-    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with the test
-    hook that puts both ranks on GPU 0 over gloo: the default weak-scaling workload (N x 1024 distinct problems per step,
-    rotating assignment) and the diagnostic in which every rank solves the N = 1 line's problems, the gather to rank 0
-    inside the timed region, max-over-ranks timing, one JSON line from rank 0 only."""
+    """bench.py --gpus 2, with the test hook that puts both ranks on GPU 0 over gloo.  'distinct' (the default weak-scaling
+    workload: N x 1024 distinct problems per step, rotating assignment) is started with NO launcher -- `python bench.py --gpus 2`
+    must be a two-rank run by itself (it starts torch.distributed.run as a child process) -- and carries the `sharded_c_abi`
+    object: the same step through qilqr_solve_batch_sharded_device in one process, bit-identical costs.  'same' (the diagnostic
+    in which every rank solves the N = 1 line's problems) is started the way the driver starts N > 1 (torch.distributed.run, one
+    process per rank).  Both: the gather to rank 0 inside the timed region, max-over-ranks timing, one JSON line from rank 0."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, QILQR_BENCH_ONE_DEVICE_TEST="1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--steps", "4", "--warmup", "1"] + ([] if shards == "distinct" else ["--shards", "same"]),
-                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["QILQR_BENCH_ONE_DEVICE_TEST"] = "1"
+    if shards == "distinct":
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--shards", "same"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -97,6 +102,20 @@ def test_two_rank_code_path_on_one_gpu(shards):
     assert ss["value"] > 0 and ss["one_rank_alone_value"] > 0 and 0 < ss["machine_efficiency"] < 1.5
     assert j["status_counts"][2] == 0 and j["status_counts"][3] == 0  # every problem of the last shard converged
     assert j["gather_ms"] > 0 and j["host_to_host"] is None and j["large_batch"] is None
+    sa = j["sharded_c_abi"]
+    assert "error" not in sa, sa
+    assert sa["devices"] == [0, 0] and sa["batch_total"] == 2048 and sa["value"] > 10000 and sa["exposed_gather_ms"] >= 0.0
+    assert sa["status_counts"][2] == 0 and sa["status_counts"][3] == 0
+    if shards == "distinct":  # the same 2048 problems, shard by shard in the same kernel regime: the same bits
+        assert sa["same_costs_as_rank_per_gpu_gather"] is True, sa
+
+
+def test_a_rank_environment_that_contradicts_gpus_is_refused():  # (no GPU needed: runs in the CPU suite)
+    """WORLD_SIZE from a launcher and --gpus disagree: bench.py exits non-zero before it touches anything (VERDICT r04 missing #1:
+    `--gpus 8` under no launcher used to print an n_gpus: 1 line with rc 0)"""
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=60, cwd=ROOT, env=env)
+    assert out.returncode == 2 and "WORLD_SIZE" in out.stderr and out.stdout.strip() == ""
 
 
 @pytest.mark.gpu

@@ -73,3 +73,28 @@ def test_line_search_exhaustion_raises_reference_text():
                          cfg["Q"], cfg["R"], trajectory_message(cfg["desired"]), cfg["dt"], o)
     with pytest.raises(RuntimeError, match=r"^Reached maximum number of line search iterations, 7\n$"):
         ilqr.solve(trajectory_message(cfg["init"][0]))
+
+
+def test_legacy_create_symbol_reads_only_the_fields_every_header_had():
+    """qilqr_device_config grew (ABI 6: compaction; ABI 7: round_launch ...) and qilqr_create copied the whole
+    current structure, so a caller built against an older, shorter header had the library read past its structure.  Since ABI
+    version 7 the exported symbol qilqr_create reads the 32 bytes every earlier header had, and qilqr_create_sized takes the
+    caller's size: a 32-byte structure followed by garbage is accepted by both when the size says 32, and the garbage is
+    rejected by name when the size says it is part of the structure."""
+    import ctypes as C
+    from quadrotorilqr_amd import capi, problems as pb
+    cfg = pb.config2(B=4, N=8)
+    lib = capi.load()
+    holder = capi.QuadrotorILQRBatch.__new__(capi.QuadrotorILQRBatch)
+    m, Q, R, o, dc = capi._create_args(holder, **cfg["model"], Q=cfg["Q"], R=cfg["R"], desired=cfg["desired"], options=cfg["options"],
+                                       device=0, profile=0, sync_every=2, force_general=0, single_wave_rollout=0, precision="f64",
+                                       streams=0, persistent=0, compaction=77, round_launch=99)  # fields 9 and 10: garbage
+    args = (C.byref(m), capi._p(Q), capi._p(R), capi._p(holder.desired), C.c_int32(len(holder.desired)), C.c_double(cfg["dt"]), C.byref(o), C.byref(dc))
+    for call in (lambda h: lib.qilqr_create(*args, C.byref(h)), lambda h: lib.qilqr_create_sized(*args, C.c_size_t(32), C.byref(h))):
+        h = C.c_void_p()
+        assert call(h) == 0, lib.qilqr_last_error()
+        lib.qilqr_destroy(h)
+    h = C.c_void_p()
+    assert lib.qilqr_create_sized(*args, C.c_size_t(C.sizeof(dc)), C.byref(h)) == capi.ERR_INVALID_ARG
+    assert b"compaction" in lib.qilqr_last_error()
+    assert lib.qilqr_create_sized(*args, C.c_size_t(30), C.byref(h)) == capi.ERR_INVALID_ARG  # not a whole number of fields

@@ -1,60 +1,74 @@
 """k_backward_rollout -- the backward pass and the rollout of a round in ONE launch, up to 1024 trajectories -- against the
-two kernels launched apart (QILQR_FUSE_BACKWARD_ROLLOUT=0 in the environment, read once per process: hence two child
-processes).  The combined kernel contains the two kernels' bodies as statements (backward4_body.inc, rollout16_body.inc):
-the same instructions on the same operands, so every output must be the same BITS -- fp64 and mixed precision, ragged
-batches, per-problem desired trajectories, few-trial line searches with Levenberg-Marquardt restarts, the host-buffer path
-with its copy-back under the tail.
-k_round (round 4) adds the linearisation of the block's candidates to the same launch (QILQR_ROUND_KERNEL=0 keeps k_linearize a launch of
-its own): se3_math.h forms its fused multiply-adds from the source alone, so the records -- and with them everything -- are the same bits
-whichever kernel wrote them; a solve changes between the two forms from round to round (full blocks / one candidate per block)."""
-import os
-import subprocess
-import sys
-
+two kernels launched apart (qilqr_device_config.round_launch = 1; until ABI version 7 an environment variable read once per
+process, hence child processes then).  The combined kernel contains the two kernels' bodies as statements
+(backward4_body.inc, rollout16_body.inc): the same instructions on the same operands, so every output must be the same BITS
+-- fp64 and mixed precision, ragged batches, per-problem desired trajectories, few-trial line searches with
+Levenberg-Marquardt restarts, the host-buffer path with its copy-back under the tail.
+k_round (round 4) adds the linearisation of the block's candidates to the same launch (round_launch = 2 keeps k_linearize a launch
+of its own): se3_math.h forms its fused multiply-adds from the source alone, so the records -- and with them everything -- are the
+same bits whichever kernel wrote them; a solve changes between the two forms from round to round (full blocks / one candidate per
+block).  rounds_per_launch (1, 2, 4 rounds in one k_round launch) changes no bit either."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-CHILD = r"""
-import sys, numpy as np
-sys.path.insert(0, %r)
-from quadrotorilqr_amd import capi, problems as pb
-out = {}
-def keep(tag, o):
-    for k in ("traj", "cost", "status", "iters", "n_bwd", "n_fwd"):
-        out[tag + "_" + k] = o[k]
-for B, n, seed in [(1024, 100, 2), (203, 60, 9), (5, 7, 1), (64, 30, 4)]:
-    cfg = pb.config2(B=B, N=n, seed=seed)
-    keep("f64_%%d" %% B, capi.from_config(cfg).solve_batch(cfg["init"]))
-cfg = pb.config2(B=130, N=40, seed=5)
-keep("f32", capi.from_config(cfg, precision="f32").solve_batch(cfg["init"]))
-r = np.random.default_rng(3)
-des = np.repeat(cfg["desired"][None], 130, axis=0)
-des[:, :, 1:4] += r.uniform(-0.2, 0.2, (130, 1, 3))
-keep("desired", capi.from_config(cfg).solve_batch(cfg["init"], des))
-cfg = pb.config2(B=77, N=50, seed=8)
-cfg["options"] = dict(cfg["options"], ls_max_iters=1)
-s = capi.from_config(cfg)
-s.set_regularisation(1.0, 4.0, 1e6)
-keep("restarts", s.solve_batch(cfg["init"]))
-np.savez(sys.argv[1], **out)
-""" % ROOT
+from quadrotorilqr_amd import capi, problems as pb  # noqa: E402
 
 
-def run_child(tmp_path, fuse, round_kernel=1):
-    path = os.path.join(str(tmp_path), "fuse%d%d.npz" % (fuse, round_kernel))
-    env = dict(os.environ, QILQR_FUSE_BACKWARD_ROLLOUT=str(fuse), QILQR_ROUND_KERNEL=str(round_kernel))
-    subprocess.run([sys.executable, "-c", CHILD, path], check=True, env=env, timeout=600)
-    return np.load(path)
+def solves(**kw):
+    out = {}
+
+    def keep(tag, o):
+        for k in ("traj", "cost", "status", "iters", "n_bwd", "n_fwd"):
+            out[tag + "_" + k] = o[k]
+
+    for B, n, seed in [(1024, 100, 2), (203, 60, 9), (5, 7, 1), (64, 30, 4)]:
+        cfg = pb.config2(B=B, N=n, seed=seed)
+        keep("f64_%d" % B, capi.from_config(cfg, **kw).solve_batch(cfg["init"]))
+    cfg = pb.config2(B=130, N=40, seed=5)
+    keep("f32", capi.from_config(cfg, precision="f32", **kw).solve_batch(cfg["init"]))
+    r = np.random.default_rng(3)
+    des = np.repeat(cfg["desired"][None], 130, axis=0)
+    des[:, :, 1:4] += r.uniform(-0.2, 0.2, (130, 1, 3))
+    keep("desired", capi.from_config(cfg, **kw).solve_batch(cfg["init"], des))
+    cfg = pb.config2(B=77, N=50, seed=8)
+    cfg["options"] = dict(cfg["options"], ls_max_iters=1)
+    s = capi.from_config(cfg, **kw)
+    s.set_regularisation(1.0, 4.0, 1e6)
+    keep("restarts", s.solve_batch(cfg["init"]))
+    return out
 
 
-def test_one_launch_for_backward_and_rollout_gives_the_same_bits(tmp_path):
-    apart, fused, whole = run_child(tmp_path, 0), run_child(tmp_path, 1, 0), run_child(tmp_path, 1, 1)
-    assert set(apart.files) == set(fused.files) == set(whole.files) and len(apart.files) == 7 * 6
-    for k in apart.files:
+def test_one_launch_for_backward_and_rollout_gives_the_same_bits():
+    apart, fused, whole = solves(round_launch=1), solves(round_launch=2), solves()
+    assert set(apart) == set(fused) == set(whole) and len(apart) == 7 * 6
+    for k in apart:
         np.testing.assert_array_equal(fused[k], apart[k], err_msg=k)
         np.testing.assert_array_equal(whole[k], apart[k], err_msg="k_round: " + k)
     assert np.isin(fused["f64_1024_status"], [0, 1]).all() and (fused["restarts_n_bwd"] > fused["restarts_iters"] + 1).any()
+
+
+@pytest.mark.parametrize("rounds", [1, 2])
+def test_rounds_per_launch_changes_no_bit(rounds):
+    cfg = pb.config2(B=1024, N=100, seed=2)
+    import torch
+    dev = torch.device("cuda", 0)
+    init = torch.from_numpy(cfg["init"]).to(dev)
+
+    def run(**kw):  # (the device-resident call: the one whose launches may hold several rounds)
+        s = capi.from_config(cfg, **kw)
+        o = (torch.empty_like(init), torch.empty(1024, dtype=torch.float64, device=dev), *[torch.empty(1024, dtype=torch.int32, device=dev) for _ in range(4)])
+        s.solve_batch_device(init, *o)
+        return [t.cpu().numpy() for t in o]
+
+    for a, b in zip(run(), run(rounds_per_launch=rounds)):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_bad_round_launch_values_are_refused():
+    cfg = pb.config2(B=4, N=8)
+    with pytest.raises(TypeError, match="round_launch"):
+        capi.from_config(cfg, round_launch=3)
+    with pytest.raises(TypeError, match="rounds_per_launch"):
+        capi.from_config(cfg, rounds_per_launch=3)

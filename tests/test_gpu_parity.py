@@ -877,7 +877,7 @@ def test_persistent_solve_is_one_launch_and_matches_the_rounds():
 
 def test_diagonal_weights_path_gives_the_same_bits():
     """Q exactly diagonal (configs[1..4], the reference's demo and tests) takes the instantiation of k_linearize whose cost half
-    scales rows instead of multiplying by Q (linearize_cost<3>); QILQR_NO_DIAG_Q in the environment at creation keeps the
+    scales rows instead of multiplying by Q (linearize_cost<3>); qilqr_device_config.dense_weights = 1 keeps the
     block-diagonal one.  The sums of the latter add exact zeros to the products the former keeps: whole solves agree bit
     for bit.  (fp64 solvers only: the mixed mode keeps the block-diagonal instantiation, and the switch changes nothing there.)"""
     import os
@@ -885,11 +885,7 @@ def test_diagonal_weights_path_gives_the_same_bits():
     for prec in ("f64", "f32"):
         c = cfg if prec == "f64" else dict(cfg, options=dict(cfg["options"], rtol=1e-5, atol=1e-5))
         fast = capi.from_config(c, precision=prec).solve_batch(c["init"])
-        os.environ["QILQR_NO_DIAG_Q"] = "1"
-        try:
-            plain = capi.from_config(c, precision=prec).solve_batch(c["init"])
-        finally:
-            del os.environ["QILQR_NO_DIAG_Q"]
+        plain = capi.from_config(c, precision=prec, dense_weights=1).solve_batch(c["init"])
         for k in ("status", "iters", "n_bwd", "n_fwd", "cost", "traj"):
             np.testing.assert_array_equal(fast[k], plain[k], err_msg=f"{prec} {k}")
 

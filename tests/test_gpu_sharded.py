@@ -159,7 +159,8 @@ def test_plain_c_host_gathers_over_rccl():
     root = os.path.dirname(here)
     exe = os.path.join(here, "c", "sharded_gather_harness")
     src = exe + ".c"
-    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+    hdr = os.path.join(root, "include", "quadrotor_ilqr.h")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.check_call(["gcc", "-O2", "-std=c99", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
                                src, "-L" + os.path.join(root, "quadrotorilqr_amd", "lib"), "-lquadrotor_ilqr", "-L/opt/rocm/lib",
                                "-lamdhip64", "-lm", "-Wl,-rpath," + os.path.join(root, "quadrotorilqr_amd", "lib"),
