@@ -51,19 +51,12 @@ def test_one_launch_for_backward_and_rollout_gives_the_same_bits():
 
 @pytest.mark.parametrize("rounds", [1, 2])
 def test_rounds_per_launch_changes_no_bit(rounds):
+    """(qilqr_solve_batch from pageable arrays: staging, then the device-resident solve whose launches may hold several rounds)"""
     cfg = pb.config2(B=1024, N=100, seed=2)
-    import torch
-    dev = torch.device("cuda", 0)
-    init = torch.from_numpy(cfg["init"]).to(dev)
-
-    def run(**kw):  # (the device-resident call: the one whose launches may hold several rounds)
-        s = capi.from_config(cfg, **kw)
-        o = (torch.empty_like(init), torch.empty(1024, dtype=torch.float64, device=dev), *[torch.empty(1024, dtype=torch.int32, device=dev) for _ in range(4)])
-        s.solve_batch_device(init, *o)
-        return [t.cpu().numpy() for t in o]
-
-    for a, b in zip(run(), run(rounds_per_launch=rounds)):
-        np.testing.assert_array_equal(a, b)
+    a = capi.from_config(cfg).solve_batch(cfg["init"])
+    b = capi.from_config(cfg, rounds_per_launch=rounds).solve_batch(cfg["init"])
+    for k in ("traj", "cost", "status", "iters", "n_bwd", "n_fwd"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
 def test_bad_round_launch_values_are_refused():
