@@ -95,9 +95,59 @@ QILQR_HD int cxx_source_tab(const RecLayout &L, int row, int col) {
 // possible values), so the 4x4 stays in registers.  Used by the general kernel (k_backward<false>: non-symmetric weights,
 // or force_general = 1), where faithfulness to the reference is the point; the symmetric-weight kernels factor without
 // pivoting (identical in exact arithmetic when Q_uu is positive definite).
+// a / b for the quotients of the factorisation.  The sequence the compiler emits for an IEEE `/` on gfx950 is ~ 40 dependent fp64
+// instructions (v_div_scale, v_rcp, four refinements, v_div_fmas, v_div_fixup), and a knot has ten of them: half of the general kernel's
+// instructions.  On the device the divisions by one pivot share ONE reciprocal (hardware estimate + two Newton steps: within an ulp of
+// 1 / b) and every quotient gets one correction step, q = a r, q <- q + r (a - b q) with the residual exact in a fused multiply-add: the
+// correctly rounded quotient except for rare ties of the last correction (then the neighbouring double), i.e. Eigen's division to the
+// last bit or the one beside it.  Pivots of magnitude below ~ 1e-292 (the reciprocal overflows) are beyond it; Eigen's own threshold
+// for a zero pivot is 2.2e-308, and such a Q_uu has no usable gains in the reference either.  The host (tests/host_harness.cpp, where
+// the oracle's pivoted LDL^T is compared bit for bit) divides.
+struct PivotRcp {
+  double b, r;
+};
+QILQR_HD PivotRcp pivot_rcp(double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(b);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  return PivotRcp{b, r};
+#else
+  return PivotRcp{b, 0.0};
+#endif
+}
+QILQR_HD double div_by(double a, const PivotRcp &p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double q = a * p.r;
+  return __builtin_fma(__builtin_fma(-p.b, q, a), p.r, q);
+#else
+  return a / p.b;
+#endif
+}
+// y[k] <-> y[big] (big in k..3, wave-uniform).  Three `if (big == B) swap(y[k], y[B])` in a row -- and every way of writing the same
+// with selections -- are merged by the compiler into ONE access y[big] with a run-time index, which keeps the whole array in scratch
+// memory: the right-hand side's six trips there sat on the knot's dependent chain until round 5.  On the device the three exchanges are
+// therefore kept apart by empty asm statements that claim the four values in vector registers.
+QILQR_HD void ldlt4_swap_rhs(double (&y)[4], int k, int big) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define QILQR_PIN_Y() asm volatile("" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]))
+#else
+#define QILQR_PIN_Y() do { } while (0)
+#endif
+  if (big != k) {
+    QILQR_PIN_Y();
+    if (big == 1) { const double t = y[k]; y[k] = y[1]; y[1] = t; }
+    QILQR_PIN_Y();
+    if (big == 2) { const double t = y[k]; y[k] = y[2]; y[2] = t; }
+    QILQR_PIN_Y();
+    if (big == 3) { const double t = y[k]; y[k] = y[3]; y[3] = t; }
+    QILQR_PIN_Y();
+  }
+#undef QILQR_PIN_Y
+}
 template <int K, int BIG>
-QILQR_HD void ldlt4_swap(double (&m)[16], double (&y)[4]) {
-  // symmetric exchange of rows / columns K and BIG restricted to the lower triangle, and of the right-hand side's entries
+QILQR_HD void ldlt4_swap(double (&m)[16]) {
+  // symmetric exchange of rows / columns K and BIG restricted to the lower triangle (the right-hand side: ldlt4_swap_rhs)
 #pragma unroll
   for (int jj = 0; jj < K; ++jj) { const double t = m[K * 4 + jj]; m[K * 4 + jj] = m[BIG * 4 + jj]; m[BIG * 4 + jj] = t; }
 #pragma unroll
@@ -105,18 +155,24 @@ QILQR_HD void ldlt4_swap(double (&m)[16], double (&y)[4]) {
   { const double t = m[K * 4 + K]; m[K * 4 + K] = m[BIG * 4 + BIG]; m[BIG * 4 + BIG] = t; }
 #pragma unroll
   for (int ii = K + 1; ii < BIG; ++ii) { const double t = m[ii * 4 + K]; m[ii * 4 + K] = m[BIG * 4 + ii]; m[BIG * 4 + ii] = t; }
-  { const double t = y[K]; y[K] = y[BIG]; y[BIG] = t; }
 }
 template <int K>
 QILQR_HD int ldlt4_pivot_step(double (&m)[16], double (&y)[4]) {
-  int big = K;
+  int bigv = K;
   double best = fabs(m[K * 4 + K]);
 #pragma unroll
   for (int ii = K + 1; ii < 4; ++ii)
-    if (fabs(m[ii * 4 + ii]) > best) { best = fabs(m[ii * 4 + ii]); big = ii; }
-  if constexpr (K < 1) { if (big == 1) ldlt4_swap<K, 1>(m, y); }
-  if constexpr (K < 2) { if (big == 2) ldlt4_swap<K, 2>(m, y); }
-  if constexpr (K < 3) { if (big == 3) ldlt4_swap<K, 3>(m, y); }
+    if (fabs(m[ii * 4 + ii]) > best) { best = fabs(m[ii * 4 + ii]); bigv = ii; }
+  int big = bigv;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // every lane factors the same Q_uu: the pivot is wave-uniform, and with it in a scalar register the exchange of rows and columns is
+  // behind scalar branches
+  big = __builtin_amdgcn_readfirstlane(bigv);
+#endif
+  if constexpr (K < 1) { if (big == 1) ldlt4_swap<K, 1>(m); }
+  if constexpr (K < 2) { if (big == 2) ldlt4_swap<K, 2>(m); }
+  if constexpr (K < 3) { if (big == 3) ldlt4_swap<K, 3>(m); }
+  if constexpr (K < 3) ldlt4_swap_rhs(y, K, big);
   if constexpr (K > 0) {
     double temp[K > 0 ? K : 1];
 #pragma unroll
@@ -135,8 +191,9 @@ QILQR_HD int ldlt4_pivot_step(double (&m)[16], double (&y)[4]) {
   }
   const double akk = m[K * 4 + K];
   if (fabs(akk) > 0.0) {
+    const PivotRcp pr = pivot_rcp(akk);
 #pragma unroll
-    for (int ii = K + 1; ii < 4; ++ii) m[ii * 4 + K] /= akk;
+    for (int ii = K + 1; ii < 4; ++ii) m[ii * 4 + K] = div_by(m[ii * 4 + K], pr);
   }
   return big;
 }
@@ -158,23 +215,15 @@ QILQR_HD void ldlt4_pivoted_solve(const double (&Quu)[16], const double (&rhs)[4
     for (int jj = 0; jj < ii; ++jj) y[ii] -= m[ii * 4 + jj] * y[jj];
   const double tol = 2.2250738585072014e-308;  // numeric_limits<double>::min(), Eigen's threshold for a zero pivot
 #pragma unroll
-  for (int ii = 0; ii < 4; ++ii) y[ii] = (fabs(m[ii * 4 + ii]) > tol) ? y[ii] / m[ii * 4 + ii] : 0.0;
+  for (int ii = 0; ii < 4; ++ii) y[ii] = (fabs(m[ii * 4 + ii]) > tol) ? div_by(y[ii], pivot_rcp(m[ii * 4 + ii])) : 0.0;
 #pragma unroll
   for (int ii = 3; ii >= 0; --ii)
 #pragma unroll
     for (int jj = ii + 1; jj < 4; ++jj) y[ii] -= m[jj * 4 + ii] * y[jj];
   // P^T: the transpositions in reverse order
-  auto unswap = [&](int k, int big) {
-    double a = y[k];
-    const double b = (big == 1) ? y[1] : ((big == 2) ? y[2] : y[3]);
-    if (big != k) {
-      y[k] = b;
-      if (big == 1) y[1] = a; else if (big == 2) y[2] = a; else y[3] = a;
-    }
-  };
-  unswap(2, t2);
-  unswap(1, t1);
-  unswap(0, t0);
+  ldlt4_swap_rhs(y, 2, t2);
+  ldlt4_swap_rhs(y, 1, t1);
+  ldlt4_swap_rhs(y, 0, t0);
 #pragma unroll
   for (int e = 0; e < 4; ++e) x[e] = y[e];
 }
