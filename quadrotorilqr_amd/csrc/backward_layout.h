@@ -91,8 +91,8 @@ QILQR_HD int cxx_source_tab(const RecLayout &L, int row, int col) {
 
 // Eigen 3.4.0 LDLT<Matrix4d, Lower> as the reference uses it (ilqr.hh:126-128: Q_uu.ldlt().solve(rhs)): in place on the
 // lower triangle, DIAGONAL PIVOTING (the largest |d_ii| of the trailing block, the first one on ties), x = P^T L^-T D^-1
-// L^-1 P b with IEEE divisions.  Every index is a compile-time constant (the pivot position is dispatched over its three
-// possible values), so the 4x4 stays in registers.  Used by the general kernel (k_backward<false>: non-symmetric weights,
+// L^-1 P b.  Every index is a compile-time constant (the sequence of transpositions is dispatched over its 24 possible
+// values), so the 4x4 stays in registers.  Used by the general kernel (k_backward<false>: non-symmetric weights,
 // or force_general = 1), where faithfulness to the reference is the point; the symmetric-weight kernels factor without
 // pivoting (identical in exact arithmetic when Q_uu is positive definite).
 // a / b for the quotients of the factorisation.  The sequence the compiler emits for an IEEE `/` on gfx950 is ~ 40 dependent fp64
@@ -124,91 +124,76 @@ QILQR_HD double div_by(double a, const PivotRcp &p) {
   return a / p.b;
 #endif
 }
-// y[k] <-> y[big] (big in k..3, wave-uniform).  Three `if (big == B) swap(y[k], y[B])` in a row -- and every way of writing the same
-// with selections -- are merged by the compiler into ONE access y[big] with a run-time index, which keeps the whole array in scratch
-// memory: the right-hand side's six trips there sat on the knot's dependent chain until round 5.  On the device the three exchanges are
-// therefore kept apart by empty asm statements that claim the four values in vector registers.
-QILQR_HD void ldlt4_swap_rhs(double (&y)[4], int k, int big) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#define QILQR_PIN_Y() asm volatile("" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]))
-#else
-#define QILQR_PIN_Y() do { } while (0)
-#endif
-  if (big != k) {
-    QILQR_PIN_Y();
-    if (big == 1) { const double t = y[k]; y[k] = y[1]; y[1] = t; }
-    QILQR_PIN_Y();
-    if (big == 2) { const double t = y[k]; y[k] = y[2]; y[2] = t; }
-    QILQR_PIN_Y();
-    if (big == 3) { const double t = y[k]; y[k] = y[3]; y[3] = t; }
-    QILQR_PIN_Y();
-  }
-#undef QILQR_PIN_Y
+// Eigen's pivot search looks at mat.diagonal().tail(size - k) BEFORE column k is updated, and its left-looking update touches only column
+// k: the diagonal entries it compares are the ORIGINAL ones (exchanged along with the rows).  The transpositions are therefore known
+// from the four |d_ii| alone -- a selection sort with Eigen's tie rule (the first of equal magnitudes, in the arrangement the earlier
+// exchanges left) -- before any arithmetic: b0 in 0..3, b1 in 1..3, b2 in 2..3.
+QILQR_HD void ldlt4_pivot_order(const double (&A)[16], int &b0, int &b1, int &b2) {
+  double d0 = fabs(A[0]), d1 = fabs(A[5]), d2 = fabs(A[10]), d3 = fabs(A[15]);
+  b0 = 0;
+  double best = d0;
+  if (d1 > best) { best = d1; b0 = 1; }
+  if (d2 > best) { best = d2; b0 = 2; }
+  if (d3 > best) { best = d3; b0 = 3; }
+  const double o0 = d0;  // rows / columns 0 and b0 change places: so do their diagonal entries
+  d1 = (b0 == 1) ? o0 : d1; d2 = (b0 == 2) ? o0 : d2; d3 = (b0 == 3) ? o0 : d3;
+  b1 = 1;
+  best = d1;
+  if (d2 > best) { best = d2; b1 = 2; }
+  if (d3 > best) { best = d3; b1 = 3; }
+  const double o1 = d1;
+  d2 = (b1 == 2) ? o1 : d2; d3 = (b1 == 3) ? o1 : d3;
+  b2 = (d3 > d2) ? 3 : 2;
 }
-template <int K, int BIG>
-QILQR_HD void ldlt4_swap(double (&m)[16]) {
-  // symmetric exchange of rows / columns K and BIG restricted to the lower triangle (the right-hand side: ldlt4_swap_rhs)
-#pragma unroll
-  for (int jj = 0; jj < K; ++jj) { const double t = m[K * 4 + jj]; m[K * 4 + jj] = m[BIG * 4 + jj]; m[BIG * 4 + jj] = t; }
-#pragma unroll
-  for (int ii = BIG + 1; ii < 4; ++ii) { const double t = m[ii * 4 + K]; m[ii * 4 + K] = m[ii * 4 + BIG]; m[ii * 4 + BIG] = t; }
-  { const double t = m[K * 4 + K]; m[K * 4 + K] = m[BIG * 4 + BIG]; m[BIG * 4 + BIG] = t; }
-#pragma unroll
-  for (int ii = K + 1; ii < BIG; ++ii) { const double t = m[ii * 4 + K]; m[ii * 4 + K] = m[BIG * 4 + ii]; m[BIG * 4 + ii] = t; }
+// position i of the permuted matrix holds row / column ldlt4_perm_at(b0, b1, b2, i) of the original: the transpositions (0 b0)(1 b1)(2 b2)
+// applied in that order to the identity
+constexpr int ldlt4_perm_at(int b0, int b1, int b2, int i) {
+  int p[4] = {0, 1, 2, 3};
+  int t = p[0]; p[0] = p[b0]; p[b0] = t;
+  t = p[1]; p[1] = p[b1]; p[b1] = t;
+  t = p[2]; p[2] = p[b2]; p[b2] = t;
+  return p[i];
 }
-template <int K>
-QILQR_HD int ldlt4_pivot_step(double (&m)[16], double (&y)[4]) {
-  int bigv = K;
-  double best = fabs(m[K * 4 + K]);
-#pragma unroll
-  for (int ii = K + 1; ii < 4; ++ii)
-    if (fabs(m[ii * 4 + ii]) > best) { best = fabs(m[ii * 4 + ii]); bigv = ii; }
-  int big = bigv;
-#if defined(__HIP_DEVICE_COMPILE__)
-  // every lane factors the same Q_uu: the pivot is wave-uniform, and with it in a scalar register the exchange of rows and columns is
-  // behind scalar branches
-  big = __builtin_amdgcn_readfirstlane(bigv);
-#endif
-  if constexpr (K < 1) { if (big == 1) ldlt4_swap<K, 1>(m); }
-  if constexpr (K < 2) { if (big == 2) ldlt4_swap<K, 2>(m); }
-  if constexpr (K < 3) { if (big == 3) ldlt4_swap<K, 3>(m); }
-  if constexpr (K < 3) ldlt4_swap_rhs(y, K, big);
-  if constexpr (K > 0) {
-    double temp[K > 0 ? K : 1];
-#pragma unroll
-    for (int jj = 0; jj < K; ++jj) temp[jj] = m[jj * 4 + jj] * m[K * 4 + jj];
-    double sacc = 0.0;
-#pragma unroll
-    for (int jj = 0; jj < K; ++jj) sacc += m[K * 4 + jj] * temp[jj];
-    m[K * 4 + K] -= sacc;
-#pragma unroll
-    for (int ii = K + 1; ii < 4; ++ii) {
-      double r = 0.0;
-#pragma unroll
-      for (int jj = 0; jj < K; ++jj) r += m[ii * 4 + jj] * temp[jj];
-      m[ii * 4 + K] -= r;
-    }
-  }
-  const double akk = m[K * 4 + K];
-  if (fabs(akk) > 0.0) {
-    const PivotRcp pr = pivot_rcp(akk);
-#pragma unroll
-    for (int ii = K + 1; ii < 4; ++ii) m[ii * 4 + K] = div_by(m[ii * 4 + K], pr);
-  }
-  return big;
-}
-// x = Q_uu^-1 rhs.  (The permutation is applied to the right-hand side as the factorisation finds it: the same
-// transpositions, in the same order, that Eigen applies to b before the triangular solves.)
-QILQR_HD void ldlt4_pivoted_solve(const double (&Quu)[16], const double (&rhs)[4], double (&x)[4]) {
+// The factorisation and the solves for ONE sequence of transpositions, known at compile time: the exchanges of rows, columns and
+// right-hand side entries are a renaming of registers (until round 5 they were ~ 100 moves behind data-dependent branches per knot, and the
+// right-hand side lived in scratch memory).  Element (i, j), i >= j, of the exchanged lower triangle is element (max, min) of the original
+// one at the permuted indices -- what Eigen's exchanges restricted to the lower triangle produce.  The arithmetic is Eigen's, operation by
+// operation: for every column k the products with the earlier columns (temp = D(0..k) A10^T; a_kk -= A10 temp; A21 -= A20 temp), then
+// A21 /= a_kk if a_kk != 0; L y = P b; y_i /= d_i (0 where |d_i| <= numeric_limits::min()); L^T z = y; x = P^T z.
+template <int B0, int B1, int B2>
+QILQR_HD void ldlt4_solve_permuted(const double (&A)[16], const double (&rhs)[4], double (&x)[4]) {
+  constexpr int P[4] = {ldlt4_perm_at(B0, B1, B2, 0), ldlt4_perm_at(B0, B1, B2, 1), ldlt4_perm_at(B0, B1, B2, 2), ldlt4_perm_at(B0, B1, B2, 3)};
   double m[16], y[4];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) m[e] = Quu[e];
+  for (int i = 0; i < 4; ++i) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) y[e] = rhs[e];
-  const int t0 = ldlt4_pivot_step<0>(m, y);
-  const int t1 = ldlt4_pivot_step<1>(m, y);
-  const int t2 = ldlt4_pivot_step<2>(m, y);
-  (void)ldlt4_pivot_step<3>(m, y);
+    for (int j = 0; j <= i; ++j) m[i * 4 + j] = A[(P[i] > P[j] ? P[i] : P[j]) * 4 + (P[i] > P[j] ? P[j] : P[i])];
+    y[i] = rhs[P[i]];
+  }
+#pragma unroll
+  for (int K = 0; K < 4; ++K) {
+    if (K > 0) {
+      double temp[3];
+#pragma unroll
+      for (int jj = 0; jj < K; ++jj) temp[jj] = m[jj * 4 + jj] * m[K * 4 + jj];
+      double sacc = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < K; ++jj) sacc += m[K * 4 + jj] * temp[jj];
+      m[K * 4 + K] -= sacc;
+#pragma unroll
+      for (int ii = K + 1; ii < 4; ++ii) {
+        double r = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < K; ++jj) r += m[ii * 4 + jj] * temp[jj];
+        m[ii * 4 + K] -= r;
+      }
+    }
+    const double akk = m[K * 4 + K];
+    const bool valid = fabs(akk) > 0.0;  // (Eigen: `if (rs > 0 && pivot_is_valid) A21 /= realAkk`; a selection here, not a branch)
+    const PivotRcp pr = pivot_rcp(akk);
+#pragma unroll
+    for (int ii = K + 1; ii < 4; ++ii) m[ii * 4 + K] = valid ? div_by(m[ii * 4 + K], pr) : m[ii * 4 + K];
+  }
 #pragma unroll
   for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
@@ -220,12 +205,38 @@ QILQR_HD void ldlt4_pivoted_solve(const double (&Quu)[16], const double (&rhs)[4
   for (int ii = 3; ii >= 0; --ii)
 #pragma unroll
     for (int jj = ii + 1; jj < 4; ++jj) y[ii] -= m[jj * 4 + ii] * y[jj];
-  // P^T: the transpositions in reverse order
-  ldlt4_swap_rhs(y, 2, t2);
-  ldlt4_swap_rhs(y, 1, t1);
-  ldlt4_swap_rhs(y, 0, t0);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) x[e] = y[e];
+  for (int i = 0; i < 4; ++i) x[P[i]] = y[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (the four results in vector registers before the 24 instances meet: their stores x[P[i]] = y[i] would otherwise be merged into one
+  // store through a run-time index, and x would live in scratch memory)
+  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+#endif
+}
+template <int B0, int B1>
+QILQR_HD void ldlt4_dispatch2(int b2, const double (&A)[16], const double (&rhs)[4], double (&x)[4]) {
+  if (b2 == 2) ldlt4_solve_permuted<B0, B1, 2>(A, rhs, x);
+  else ldlt4_solve_permuted<B0, B1, 3>(A, rhs, x);
+}
+template <int B0>
+QILQR_HD void ldlt4_dispatch1(int b1, int b2, const double (&A)[16], const double (&rhs)[4], double (&x)[4]) {
+  if (b1 == 1) ldlt4_dispatch2<B0, 1>(b2, A, rhs, x);
+  else if (b1 == 2) ldlt4_dispatch2<B0, 2>(b2, A, rhs, x);
+  else ldlt4_dispatch2<B0, 3>(b2, A, rhs, x);
+}
+// x = Q_uu^-1 rhs as Eigen's LDLT<Matrix4d, Lower> computes it.  Q_uu must be the same in every lane of the wavefront (the right-hand
+// sides may differ): the pivot order is then wave-uniform and the dispatch over its 24 values a few scalar branches.
+QILQR_HD void ldlt4_pivoted_solve(const double (&Quu)[16], const double (&rhs)[4], double (&x)[4]) {
+  int b0, b1, b2;
+  ldlt4_pivot_order(Quu, b0, b1, b2);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int code = __builtin_amdgcn_readfirstlane(b0 | (b1 << 2) | (b2 << 4));
+  b0 = code & 3; b1 = (code >> 2) & 3; b2 = code >> 4;
+#endif
+  if (b0 == 0) ldlt4_dispatch1<0>(b1, b2, Quu, rhs, x);
+  else if (b0 == 1) ldlt4_dispatch1<1>(b1, b2, Quu, rhs, x);
+  else if (b0 == 2) ldlt4_dispatch1<2>(b1, b2, Quu, rhs, x);
+  else ldlt4_dispatch1<3>(b1, b2, Quu, rhs, x);
 }
 
 }  // namespace qilqr

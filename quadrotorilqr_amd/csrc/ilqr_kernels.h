@@ -575,8 +575,6 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   constexpr int LD = 17;  // padded leading dimension: column reads of a row-major tile
   __shared__ double Vs[SYM ? 1 : 12 * LD];
   __shared__ double Hs[SYM ? 1 : 16 * LD];
-  __shared__ double gs[SYM ? 1 : 16];
-  __shared__ double vxs[SYM ? 1 : 12];
 
   // Seven operands per lane and knot: three elements of M = [J_x | J_u] (rows kk, 4+kk, 8+kk of
   // column j), three of C_xx (accumulator layout: register r <-> row 4 r + kk, column j) and one of
@@ -666,17 +664,28 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
       // lane 12: feed-forward.  Lanes 13..15 solve against a column of Q_uu itself; nobody reads them.
       for (int a = 0; a < 4; ++a) rhs[a] = (j == 12) ? Qu[a] : col[a];
     } else {
+      // Q_xu[j][a] = H[j][12 + a] sits in the accumulator's COLUMNS 12..15 (lane (12 + a, j & 3), register j >> 2): the right-hand sides
+      // cross the tile through LDS -- columns 12..15 of rows 0..11 only.  Q_uu (all sixteen entries: K^T Q_uu below is not symmetric
+      // arithmetic) and Q_u come from registers while that round trip is in flight: rows 12..15 of H are register 3, gathered and
+      // broadcast as in the symmetric kernels (until round 5 all twenty went through LDS behind the barrier).
+      if (j >= 12) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Hs[(4 * r + kk) * LD + j] = H[r];
-      if (kk == 0) gs[j] = ghat;
+        for (int r = 0; r < 3; ++r) Hs[(4 * r + kk) * LD + j] = H[r];
+      }
       __syncthreads();
+      double xr[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) xr[a] = Hs[(j < 12 ? j : 0) * LD + 12 + a];
+      double col[4];
+      gather_rows(H[3], col);  // col[a] in lane j = H[12 + a][j]
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) Quu[a * 4 + bb] = Hs[(12 + a) * LD + 12 + bb];
-        Qu[a] = gs[12 + a];
-        rhs[a] = (j < 12) ? Hs[j * LD + 12 + a] : ((j == 12) ? gs[12 + a] : 0.0);  // lane 12: feed-forward
+        Quu[a * 4 + 0] = row_bcast<12>(col[a]); Quu[a * 4 + 1] = row_bcast<13>(col[a]);
+        Quu[a * 4 + 2] = row_bcast<14>(col[a]); Quu[a * 4 + 3] = row_bcast<15>(col[a]);
       }
+      Qu[0] = row_bcast<12>(ghat); Qu[1] = row_bcast<13>(ghat); Qu[2] = row_bcast<14>(ghat); Qu[3] = row_bcast<15>(ghat);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) rhs[a] = (j < 12) ? xr[a] : ((j == 12) ? Qu[a] : 0.0);  // lane 12: feed-forward
     }
     QKEEP(Quu[15]); QKEEP(Quu[0]); QKEEP(Qu[3]); QKEEP(rhs[3]); QKEEP(rhs[0]);
     QSTAMP(4);  // broadcast of Q_uu, Q_u, right-hand sides
@@ -756,14 +765,12 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
       if (j < 12) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) Vs[(4 * r + kk) * LD + j] = H[r];
-        if (kk == 0) vxs[j] = vx;
       }
+#pragma unroll
+      for (int kc = 0; kc < 3; ++kc) vxl[kc] = __shfl(vx, 4 * kc + kk);  // V_x[r] lives in lanes with j == r
       __syncthreads();
 #pragma unroll
-      for (int kc = 0; kc < 3; ++kc) {
-        va[kc] = (j < 12) ? Vs[j * LD + 4 * kc + kk] : 0.0;
-        vxl[kc] = vxs[4 * kc + kk];
-      }
+      for (int kc = 0; kc < 3; ++kc) va[kc] = (j < 12) ? Vs[j * LD + 4 * kc + kk] : 0.0;
     }
     m[0] = (double)m_s0; m[1] = (double)m_s1; m[2] = (double)m_s2;
     cx[0] = (double)cx_s0; cx[1] = (double)cx_s1; cx[2] = (double)cx_s2;

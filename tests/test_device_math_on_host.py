@@ -526,6 +526,13 @@ def test_pivoted_ldlt_of_the_general_kernel_is_eigens(hh):
         cases.append(R)                                                 # tiny (or zero) leading entry: the pivot moves
     T = np.full((4, 4), 0.25) + np.diag([2.0, 2.0, 2.0, 2.0])
     cases.append(T)                                                     # ties on the diagonal: the first one wins
+    # ties where Eigen's exchanges are NOT a stable sort of the diagonal: |d| = (2, 1, 2, 3) ends as rows (3, 2, 0, 1) -- the exchange of
+    # rows 0 and 3 moves the first 2 behind the second one (round 5: the order is found from the diagonal alone, ldlt4_pivot_order)
+    for dg in ([2.0, 1.0, 2.0, 3.0], [1.0, 3.0, 3.0, 1.0], [2.0, 2.0, 1.0, 2.0], [-2.0, 2.0, 1.0, -2.0], [1.0, 1.0, 2.0, 2.0]):
+        S = r.uniform(-0.3, 0.3, (4, 4))
+        S = (S + S.T) / 2
+        np.fill_diagonal(S, dg)
+        cases.append(S)
     cases.append(np.diag([0.0, 3.0, 0.0, 1.0]))                         # zero pivots: Eigen's solve puts 0 there
     U = r.uniform(-1, 1, (4, 4))
     U[np.triu_indices(4, 1)] = 777.0                                    # garbage above the diagonal is never read
@@ -537,6 +544,7 @@ def test_pivoted_ldlt_of_the_general_kernel_is_eigens(hh):
         hh.hh_ldlt4_pivoted_solve(P(A), P(b), P(x))
         ref = orc.ldlt4_solve(A, b)
         np.testing.assert_allclose(x, np.asarray(ref).reshape(4), rtol=1e-13, atol=1e-13 * max(1.0, np.abs(ref).max()))
+        np.testing.assert_array_equal(x, np.asarray(ref).reshape(4))  # (the host build divides as the oracle does: the same operations, the same bits)
     # the documented case (tests/test_gpu_robustness.py): k = -du to rounding whatever the leading entry
     for p in (1e-4, 1e-8, 1e-12):
         R = np.eye(4)
