@@ -1,0 +1,649 @@
+// backward4_kernel.h -- k_backward4: the backward pass over FOUR trajectories per block -- the roles (gradient, loader, matrix, fused matrix + gradient
+// wavefronts), the block's LDS, the kernel; its body is backward4_body.inc (k_backward_rollout and k_round contain it too).
+// Part of the device code of libquadrotor_ilqr.so (gfx950 only); ilqr_kernels.h includes every part.
+#pragma once
+
+#include "backward_common.h"
+
+namespace qilqr {
+
+// ---------------------------------------------------------------------------------------------
+// k_backward4: k_backward2 with ONE gradient wavefront and ONE loader wavefront for FOUR trajectories
+// (block = 384: matrix waves M0..M3, gradient wave G, loader wave L).  With a gradient wave per trajectory, 1024
+// trajectories are 2048 wavefronts on 1024 SIMDs and every matrix wave shares its SIMD (the kernel takes 84 us
+// against 64 us for 512 trajectories).  G gives a row of 16 lanes to each trajectory: lane (g, j) holds column j
+// of M = [J_x | J_u] and V_x[j]; the products M^T V_x take the 12 entries of V_x by DPP row broadcasts (no
+// shuffles, no butterflies), Q_u is broadcast the same way, and V_x = Q_x + K^T Q_u lands in the lane that owns
+// it.  L streams the knot records of the block's four trajectories into their LDS rings (record i-3 requested in
+// interval i, written in interval i-1): the matrix waves are left with the recursion and their gain stores (their
+// own record loads shared the in-order memory counter with those stores: 78.7 -> 73.7 us).  Everything else as
+// k_backward2.
+// ---------------------------------------------------------------------------------------------
+// acc += m * (vx of lane R of the caller's row of 16): one v_fmac_f64_dpp (the compiler keeps broadcast and
+// multiply-add apart).  vx must have been written at least two instructions earlier (DPP read hazard): it is
+// the previous knot's result here.
+template <int R>
+__device__ __forceinline__ double bw4_dot_step(double acc, double m, double vx) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(vx), "v"(m), "n"(R));
+  return acc;
+}
+// ---- the three roles of the backward pass over FOUR trajectories per block (k_backward4 and the persistent k_solve4).
+// LDS: ring[trajectory][slot] = knot record followed by the constant operand table; kf[trajectory][parity] = K and the
+// LDL^T factors handed from a matrix wave to the gradient wave.  Every role executes exactly 1 + n block barriers.
+template <typename S>
+__device__ __forceinline__ void bw4_fill_ctab(double (&ring)[4][4][BW2_BUF], const void *ctab, int nthreads) {
+  // constant operand table behind every ring slot
+  for (int t = threadIdx.x; t < CTAB_SIZE; t += nthreads) {
+    const double v = (double)((const S *)ctab)[t];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      ring[g][0][BW2_REC + t] = v;
+      ring[g][1][BW2_REC + t] = v;
+      ring[g][2][BW2_REC + t] = v;
+      ring[g][3][BW2_REC + t] = v;
+    }
+  }
+}
+// G: gradients of four trajectories, one row of 16 lanes each (lane = 16 g + j).  gains / dump4: the gains of the row's
+// trajectory (tiled) and its four-element dump slot; grun: the row's trajectory is being solved.  Returns Q_u^T k summed
+// over the knots (every lane of the row holds it).
+template <typename S>
+__device__ __forceinline__ double bw4_gradient_wave(double (&ring)[4][4][BW2_BUF], double (&kf)[4][2][80], const RecLayout &L,
+                                                    S *gains, S *dump4, bool grun, int n, int lane) {
+  typedef typename GA<S>::v2 sv2;
+  typedef typename GA<S>::ptr2 gptr2;
+  const int g = lane >> 4, j = lane & 15;
+  // operand addresses of lane (g, j) in ring slot 0: column j of M (12 rows) and entry j of [C_x ; C_u]
+  // (the slot is a compile-time constant in gradient_step, so it folds into the ds_read offset field)
+  const double *mp[12];
+#pragma unroll
+  for (int r = 0; r < 12; ++r) {
+    const int src = m_source_tab(r, j);
+    mp[r] = &ring[g][0][(src >= 0) ? src : BW2_REC + (-1 - src)];
+  }
+  const double *gp = &ring[g][0][L.off_g + j];
+  const bool kowner = grun && (j == 0);
+  gptr2 kdst0 = (gptr2)(kowner ? gains + knot_elem<true>(n - 1, 0, 52) : dump4);
+  gptr2 kdst1 = (gptr2)(kowner ? gains + knot_elem<true>(n - 1, 2, 52) : dump4 + 2);
+  const long kst = kowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
+  double vx = 0.0;  // V_x[j] (lanes j < 12)
+  double QuTk = 0.0;
+  __syncthreads();
+  auto gradient_slot = [&](int q, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const double *f = kf[g][q & 1];
+    // every LDS read of the step first, in the order of use (LDS returns in order): one exposed round trip
+    double m[12];
+#pragma unroll
+    for (int r = 0; r < 12; ++r) m[r] = mp[r][SLOT * BW2_BUF];
+    const double gcj = gp[SLOT * BW2_BUF];
+    asm volatile("" ::: "memory");
+    // (K row-major from the sixteen lanes kk == 0 only -- 128 contiguous bytes per row, no bank conflicts, a quarter of the
+    // bytes -- measures the same: 70.6 against 70.3 us per launch, profiles/r03_ab_backward.txt)
+    const double c0 = f[4 * j], c1 = f[4 * j + 1], c2 = f[4 * j + 2], c3 = f[4 * j + 3];  // K[:, j]
+    const double l10 = f[64], l20 = f[65], l30 = f[66], l21 = f[67], l31 = f[68], l32 = f[69], i0 = f[70],
+                 i1 = f[71], i2 = f[72], i3 = f[73];
+    asm volatile("" ::: "memory");
+    // [Q_x ; Q_u][j] = [C_x ; C_u][j] + sum_r M[r][j] V_x[r], three partial sums of four rows.  (Not the
+    // summation order of k_backward / k_backward2 -- rows kk, 4 + kk, 8 + kk chained, then a butterfly: that
+    // order was tried here for bit-identical results across batch sizes, costs 3% and still differs in the
+    // last bit elsewhere.  Results agree to ~1e-15 relative; the tests state it.)
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+    p0 = bw4_dot_step<0>(p0, m[0], vx); p1 = bw4_dot_step<4>(p1, m[4], vx); p2 = bw4_dot_step<8>(p2, m[8], vx);
+    p0 = bw4_dot_step<1>(p0, m[1], vx); p1 = bw4_dot_step<5>(p1, m[5], vx); p2 = bw4_dot_step<9>(p2, m[9], vx);
+    p0 = bw4_dot_step<2>(p0, m[2], vx); p1 = bw4_dot_step<6>(p1, m[6], vx); p2 = bw4_dot_step<10>(p2, m[10], vx);
+    p0 = bw4_dot_step<3>(p0, m[3], vx); p1 = bw4_dot_step<7>(p1, m[7], vx); p2 = bw4_dot_step<11>(p2, m[11], vx);
+    const double ghat = gcj + ((p0 + p1) + p2);
+    const double Qu0 = row_bcast<12>(ghat), Qu1 = row_bcast<13>(ghat), Qu2 = row_bcast<14>(ghat),
+                 Qu3 = row_bcast<15>(ghat);
+    vx = ghat + ((c0 * Qu0 + c1 * Qu1) + (c2 * Qu2 + c3 * Qu3));  // V_x = Q_x + K^T Q_u: the recurrence ends here
+    double kff[4];
+    ldlt4_solve_neg(Ldlt4{l10, l20, l30, l21, l31, l32, i0, i1, i2, i3}, Qu0, Qu1, Qu2, Qu3, kff);
+    const double k0 = kff[0], k1 = kff[1], k2 = kff[2], k3 = kff[3];  // feed-forward (ilqr.hh:128)
+    const sv2 w0 = {(S)k0, (S)k1}, w1 = {(S)k2, (S)k3};
+    *kdst0 = w0;
+    *kdst1 = w1;
+    kdst0 -= kst;
+    kdst1 -= kst;
+    QuTk += Qu0 * k0 + Qu1 * k1 + Qu2 * k2 + Qu3 * k3;
+  };
+  auto gradient_step = [&](int q) {
+    switch (q & 3) {
+      case 0: gradient_slot(q, std::integral_constant<int, 0>()); break;
+      case 1: gradient_slot(q, std::integral_constant<int, 1>()); break;
+      case 2: gradient_slot(q, std::integral_constant<int, 2>()); break;
+      default: gradient_slot(q, std::integral_constant<int, 3>()); break;
+    }
+  };
+  // interval i: issue the loads of record i-3 (set B), gradient step of knot i+1, record i-2 (set A, loaded
+  // one interval ago) into the ring; the two sets swap roles every interval
+  for (int i = n - 1; i >= 0; --i) {
+    if (i + 1 <= n - 1) gradient_step(i + 1);
+    __syncthreads();
+  }
+  gradient_step(0);
+  return QuTk;
+}
+// L: streams the knot records of the block's four trajectories (rec0..rec3: their record bases, TILED placement) into the
+// rings.  A record is stride / 2 entry pairs TILE2 elements apart, and with tiles of four the block's trajectories are the
+// four slots of one tile: lane l takes trajectory g = l & 3 and entry pairs l / 4 + 16 j (j = 0..3), so that one load
+// instruction covers sixteen pairs of all four trajectories -- a contiguous kilobyte when they use the same record buffer
+// (each trajectory has its own current buffer, hence a base per lane) -- and the lane writes its sixteen bytes to ring
+// entries 2 pair, 2 pair + 1 of ring g.  Pairs beyond the record are clamped to its last pair and land in entries nobody
+// reads.
+//
+// FREE (the fused form's product path): no block barrier inside the knot loop.  The five wavefronts of a block meet through
+// 24 words of LDS instead (prog[]):
+//   prog[w], w = 0..3   MG_w holds the operands of this many records in registers or is done with them (1 after its prologue,
+//                       k + 2 after the knot of record k): the slots of those records may be overwritten
+//   prog[4]             records the loader has placed (diagnostic)
+//   prog[5]             somebody's bounded wait ran out: the block's results are void, the host is told (BatchState::host_error)
+//   prog[8 + 4 g + slot] tag of ring g's slot: the ordinal t of the record it holds (record t is knot n - 1 - t), -1 before
+// L writes a record's pairs, then the four tags (LDS operations of one wavefront execute in order); MG_w reads the tag of the
+// slot it is about to take its next operands from and only then the operands.  L overwrites a slot once every live MG wave
+// has finished the knot that read it.  With the barrier, every wavefront of the block waited for the slowest at every knot
+// (1 live wave: 66.9 us per launch at N = 100, 4 live: 73.8); without it each matrix wave runs at its own pace: 68.1 with
+// four live, 78.6 against 83.7 at B = 1024 (profiles/r03_ab_backward.txt).  All waits are bounded spins.
+constexpr int BW4_SPIN_MAX = 1 << 22;
+#ifdef QILQR_DIAG
+// diagnostics build: the record ordinal whose tags the loader withholds (-1: none), so that the matrix wavefronts' bounded
+// waits run out (tests/test_gpu_robustness.py)
+__device__ int g_bw4_stall_rec = -1;
+#endif
+__device__ __forceinline__ int bw4_prog_read(int *prog, int k) { return __hip_atomic_load(&prog[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void bw4_prog_post(int *prog, int k, int v, int lane) {
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_store(&prog[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <typename S, bool FREE = false>
+__device__ __forceinline__ void bw4_loader_wave(double (&ring)[4][4][BW2_BUF], const RecLayout &L, const S *rec0, const S *rec1,
+                                                const S *rec2, const S *rec3, int n, int lane, int *prog = nullptr, int live = 0) {
+  static_assert(BW2_BUF % 2 == 0 && BW2_REC == 128, "ring entries are written in aligned pairs, 64 of them per record slot");
+  typedef typename GA<S>::v2 rv2;
+  typedef typename GA<S>::cptr2 rptr2;
+  typedef double dv2 __attribute__((ext_vector_type(2)));
+  const int g = lane & 3, npairs = L.stride / 2;
+  const S *lp = (g & 2) ? ((g & 1) ? rec3 : rec2) : ((g & 1) ? rec1 : rec0);
+  int poff[4];   // element offset of the lane's j-th pair inside a knot
+  double *dst[4];  // its ring entries in slot 0
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int pu = (lane >> 2) + 16 * j, pc = pu < npairs ? pu : npairs - 1;
+    poff[j] = (int)rec_elem(L, 0, 2 * pc);
+    dst[j] = &ring[g][0][2 * pu];
+  }
+  const long knot_step = rec_elem(L, 1, 0);
+  auto rec_pair = [&](int j, int i) -> rv2 { return *(rptr2)(lp + (long)i * knot_step + poff[j]); };
+  auto put = [&](int j, int i, rv2 v) {
+    const dv2 d = {(double)v.x, (double)v.y};
+    *reinterpret_cast<dv2 *>(dst[j] + (i & 3) * BW2_BUF) = d;
+  };
+  rv2 q[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {  // (trajectories with nothing to do are streamed too: no branches in this wave)
+    const rv2 a = rec_pair(j, n - 1);
+    rv2 b_ = {0, 0};
+    if (n >= 2) b_ = rec_pair(j, n - 2);
+    if (n >= 3) q[j] = rec_pair(j, n - 3);
+    put(j, n - 1, a);
+    if (n >= 2) put(j, n - 2, b_);
+  }
+  if constexpr (FREE) {
+    if (lane == 0) prog[4] = n >= 2 ? 2 : 1;
+  }
+  __syncthreads();  // rings and constant tables are filled
+  if constexpr (FREE) {
+    auto wait_slot = [&](int t) -> bool {
+      if (t < 4) return true;
+      int spins = 0;
+      for (;;) {
+        int lo = 1 << 30;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+          if ((live >> w) & 1) {
+            const int c = bw4_prog_read(prog, w);
+            lo = c < lo ? c : lo;
+          }
+        if (lo >= t - 3) break;
+        if (bw4_prog_read(prog, 5) || ++spins > BW4_SPIN_MAX) {
+          bw4_prog_post(prog, 5, 1, lane);
+          return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      asm volatile("" ::: "memory");
+      return true;
+    };
+    for (int t = 2; t < n; ++t) {
+      const int i = n - 1 - t;
+      if (!wait_slot(t)) return;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) put(j, i, q[j]);
+      asm volatile("" ::: "memory");
+#ifdef QILQR_DIAG
+      if (t != g_bw4_stall_rec)  // fault injection (qilqr_debug_set_backward_stall)
+#endif
+      if (lane < 4) __hip_atomic_store(&prog[8 + 4 * lane + (i & 3)], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (t + 1 < n) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = rec_pair(j, i - 1);
+      }
+      bw4_prog_post(prog, 4, t + 1, lane);
+    }
+    return;
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    // first the four pieces requested one interval ago, then the next four requests: the wait in front of
+    // the LDS writes is for loads that are all older than anything in flight
+    if (i - 2 >= 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) put(j, i - 2, q[j]);
+    }
+    if (i - 3 >= 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        q[j] = rec_pair(j, i - 3);
+      }
+    }
+    __syncthreads();
+  }
+}
+// M_w: the matrix recursion of one trajectory (ring / kf row w).  cuu: the lane's entry of C_uu = 2 R (+ mu on the diagonal,
+// lm_restart) in accumulator register 3 (row 12 + kk, column j >= 12), zero elsewhere.
+template <typename S, bool UNROLL = false>
+__device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], double (&kf)[4][2][80], const RecLayout &L, int w,
+                                                bool run, S *gains, S *dump4, double cuu, int n, int lane,
+                                                unsigned long long *stamps_out) {
+  typedef typename GA<S>::v2 sv2;
+  typedef typename GA<S>::ptr2 gptr2;
+  // the matrix waves are the block's critical chain: issue them ahead of the gradient / loader wave (and of other blocks'
+  // helper waves) on their SIMD.  Nothing at one block per CU (83.1 us either way), +1.5 % of a solve at four blocks per CU
+  __builtin_amdgcn_s_setprio(3);
+  const int j = lane & 15, kk = lane >> 4;
+  int off[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int src;
+    if (k < 3) src = m_source_tab(4 * k + kk, j);
+    else src = (j < 12) ? cxx_source_tab(L, 4 * (k - 3) + kk, j) : -1 - CTAB_ZERO;
+    off[k] = (src >= 0) ? src : BW2_REC + (-1 - src);
+  }
+  const bool gowner = run && (kk == 0 && j < 12);
+  const int ge0 = 4 + 4 * j;
+  gptr2 gdst0 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0, 52) : dump4);
+  gptr2 gdst1 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0 + 2, 52) : dump4 + 2);
+  const long gstep = gowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
+  double va[3] = {0.0, 0.0, 0.0};  // V_xx[j][4 kc + kk]  (A operand)
+  __syncthreads();  // rings and constant tables are filled
+  if (!run) {
+    // this trajectory has nothing to do in this round: keep the block's barriers company
+    for (int i = n - 1; i >= 0; --i) __syncthreads();
+    return;
+  }
+  double m[3], cx[3];
+  {
+    const double *buf = ring[w][(n - 1) & 3];
+    m[0] = buf[off[0]]; m[1] = buf[off[1]]; m[2] = buf[off[2]];
+    cx[0] = buf[off[3]]; cx[1] = buf[off[4]]; cx[2] = buf[off[5]];
+  }
+  // The knot loop is sensitive to where its instruction stream sits: the same code shifted by 4 bytes (mod 8) runs 7 %
+  // slower (71.5 -> 77 us per launch at B = 1024; MI355X_MICROARCH.md, "code-placement sensitivity").  Pin it to a
+  // 64-byte boundary.
+  asm volatile(".p2align 6");  // (the loop is sensitive to where it sits; phase 0 behind a 64-byte boundary measured fastest of 0..7 in round 3: profiles/r03_ab_backward.txt)
+#ifdef QILQR_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev, real0;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real0)::"memory");
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+  // One knot.  (mc, cc): its operands, in registers; (mn, cn): the operands of the next knot (i - 1), requested here from ring
+  // slot `ns` (filled during the previous interval); par: i & 1, the hand-off buffer.  ns and par are ints in the rolled loop
+  // and compile-time constants in the unrolled one (immediate offsets of the LDS instructions).
+  const double *rp[6];  // the lane's six operand addresses in ring slot 0
+#pragma unroll
+  for (int k = 0; k < 6; ++k) rp[k] = &ring[w][0][off[k]];
+  double *const kfw = &kf[w][0][0];
+  auto knot = [&](auto ns, auto par, double (&mc)[3], double (&cc)[3], double (&mn)[3], double (&cn)[3]) {
+    const int so = (int)ns * BW2_BUF;
+    mn[0] = rp[0][so]; mn[1] = rp[1][so]; mn[2] = rp[2][so];
+    cn[0] = rp[3][so]; cn[1] = rp[4][so]; cn[2] = rp[5][so];
+    const d4 T = bw_tile_T(va, mc);
+    QKEEP(T[0]); QKEEP(T[3]);
+    QSTAMP(0);  // ring reads issued, T = V M
+    d4 H = bw_tile_H(mc, T, cc, cuu);
+    QKEEP(H[0]); QKEEP(H[3]);
+    QSTAMP(1);  // H = C + M^T T
+    double Quu[16], Qu_unused[4], col[4];
+    gather_rows(H[3], col);
+    bcast_quu_row<0>(col, 0.0, Quu, Qu_unused);
+    bcast_quu_row<1>(col, 0.0, Quu, Qu_unused);
+    bcast_quu_row<2>(col, 0.0, Quu, Qu_unused);
+    bcast_quu_row<3>(col, 0.0, Quu, Qu_unused);
+    QKEEP(Quu[0]); QKEEP(Quu[15]); QKEEP(col[3]);
+    QSTAMP(2);  // gather + Q_uu broadcast
+    const Ldlt4 f4 = ldlt4_factor(Quu);  // (ilqr.hh:126; unpivoted: see ldlt4_factor)
+    double kcol[4];
+    ldlt4_solve_neg(f4, col[0], col[1], col[2], col[3], kcol);  // K[:, j] (ilqr.hh:127)
+    QKEEP(kcol[0]); QKEEP(kcol[3]);
+    QSTAMP(4);  // LDL^T + solve
+    {
+      const sv2 w0 = {(S)kcol[0], (S)kcol[1]}, w1 = {(S)kcol[2], (S)kcol[3]};
+      *gdst0 = w0;
+      *gdst1 = w1;
+      gdst0 -= gstep;
+      gdst1 -= gstep;
+    }
+    // hand K and the factors to G (the four lanes of a column hold the same K[:, j]: same address, same data)
+    double *f = kfw + (int)par * 80;
+    f[4 * j] = kcol[0]; f[4 * j + 1] = kcol[1]; f[4 * j + 2] = kcol[2]; f[4 * j + 3] = kcol[3];
+    if (lane == 0) {
+      f[64] = f4.l10; f[65] = f4.l20; f[66] = f4.l30; f[67] = f4.l21; f[68] = f4.l31; f[69] = f4.l32;
+      f[70] = f4.i0; f[71] = f4.i1; f[72] = f4.i2; f[73] = f4.i3;
+    }
+    QSTAMP(5);  // gain stores, hand-off to G
+    // V_xx = Q_xx + Q_xu K: A[j][kk] = Q_xu[j][kk] = H[12 + kk][j] is accumulator register 3
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(H[3], sel4(kcol, kk), H, 0, 0, 0);
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
+    QKEEP(va[0]); QKEEP(mn[2]);
+    QSTAMP(6);  // V_xx MFMA, next operands
+    __syncthreads();
+    QSTAMP(7);  // barrier
+  };
+  // Two forms of the loop.  Rolled: 147 instructions per knot.  Unrolled by four -- ring slot and hand-off parity as immediate
+  // offsets, the two operand register sets alternating: no copies, no address arithmetic, 124 instructions per knot.  Which
+  // is faster depends on what bounds the wave (profiles/r03_ab_backward.txt).  With one block per CU (B = 1024) a matrix wave
+  // is alone on its SIMD and bound by the LATENCIES between its instructions -- seven dependent matrix instructions, the
+  // reciprocal chains of the factorisation, the cross-lane gathers --, 23 fewer instructions return nothing and the four
+  // times longer loop body costs instruction fetch: 71.4 us per launch unrolled against 70.2 rolled, every code phase tried.
+  // With four blocks per CU (B > 4096) the SIMD interleaves four matrix waves and is bound by what they ISSUE: there the
+  // unrolled loop is the faster one.  The instantiation decides (UNROLL = the many-blocks build of k_backward4).
+  double mn[3], cn[3];
+  int i = n - 1;
+  if constexpr (UNROLL) {
+    // the first n mod 4 knots, until the knot index is 3 mod 4
+    for (; i >= 0 && (i & 3) != 3; --i) {
+      knot((i > 0 ? i - 1 : 0) & 3, i & 1, m, cx, mn, cn);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { m[k] = mn[k]; cx[k] = cn[k]; }
+    }
+    typedef std::integral_constant<int, 0> C0;
+    typedef std::integral_constant<int, 1> C1;
+    typedef std::integral_constant<int, 2> C2;
+    typedef std::integral_constant<int, 3> C3;
+    for (; i >= 3; i -= 4) {
+      knot(C2(), C1(), m, cx, mn, cn);    // knot 4 q + 3 (slot 3); next operands from slot 2
+      knot(C1(), C0(), mn, cn, m, cx);    // knot 4 q + 2
+      knot(C0(), C1(), m, cx, mn, cn);    // knot 4 q + 1
+      knot(C3(), C0(), mn, cn, m, cx);    // knot 4 q; the next pass starts in slot 3 (after knot 0: read and never used)
+    }
+  } else {
+    // (the rolled loop is written out, not built from `knot`: the same statements through the lambda schedule 1.3 us per
+    // launch slower -- this loop is that sensitive to the order the compiler picks)
+    for (; i >= 0; --i) {
+      // operands of knot i-1, for the next iteration (the slot was filled during the previous interval)
+      const double *nb = ring[w][(i > 0 ? i - 1 : 0) & 3];
+      const double m_n0 = nb[off[0]], m_n1 = nb[off[1]], m_n2 = nb[off[2]], cx_n0 = nb[off[3]], cx_n1 = nb[off[4]],
+                   cx_n2 = nb[off[5]];
+      const d4 T = bw_tile_T(va, m);
+      QKEEP(T[0]); QKEEP(T[3]);
+      QSTAMP(0);  // ring reads issued, T = V M
+      d4 H = bw_tile_H(m, T, cx, cuu);
+      QKEEP(H[0]); QKEEP(H[3]);
+      QSTAMP(1);  // H = C + M^T T
+      double Quu[16], Qu_unused[4], col[4];
+      gather_rows(H[3], col);
+      bcast_quu_row<0>(col, 0.0, Quu, Qu_unused);
+      bcast_quu_row<1>(col, 0.0, Quu, Qu_unused);
+      bcast_quu_row<2>(col, 0.0, Quu, Qu_unused);
+      bcast_quu_row<3>(col, 0.0, Quu, Qu_unused);
+      QKEEP(Quu[0]); QKEEP(Quu[15]); QKEEP(col[3]);
+      QSTAMP(2);  // gather + Q_uu broadcast
+      const Ldlt4 f4 = ldlt4_factor(Quu);  // (ilqr.hh:126; unpivoted: see ldlt4_factor)
+      double kcol[4];
+      ldlt4_solve_neg(f4, col[0], col[1], col[2], col[3], kcol);  // K[:, j] (ilqr.hh:127)
+      QKEEP(kcol[0]); QKEEP(kcol[3]);
+      QSTAMP(4);  // LDL^T + solve
+      {
+        const sv2 w0 = {(S)kcol[0], (S)kcol[1]}, w1 = {(S)kcol[2], (S)kcol[3]};
+        *gdst0 = w0;
+        *gdst1 = w1;
+        gdst0 -= gstep;
+        gdst1 -= gstep;
+      }
+      // hand K and the factors to G (the four lanes of a column hold the same K[:, j]: same address, same data)
+      double *f = kf[w][i & 1];
+      f[4 * j] = kcol[0]; f[4 * j + 1] = kcol[1]; f[4 * j + 2] = kcol[2]; f[4 * j + 3] = kcol[3];
+      if (lane == 0) {
+        f[64] = f4.l10; f[65] = f4.l20; f[66] = f4.l30; f[67] = f4.l21; f[68] = f4.l31; f[69] = f4.l32;
+        f[70] = f4.i0; f[71] = f4.i1; f[72] = f4.i2; f[73] = f4.i3;
+      }
+      QSTAMP(5);  // gain stores, hand-off to G
+      // V_xx = Q_xx + Q_xu K: A[j][kk] = Q_xu[j][kk] = H[12 + kk][j] is accumulator register 3
+      H = __builtin_amdgcn_mfma_f64_16x16x4f64(H[3], sel4(kcol, kk), H, 0, 0, 0);
+#pragma unroll
+      for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
+      m[0] = m_n0; m[1] = m_n1; m[2] = m_n2;
+      cx[0] = cx_n0; cx[1] = cx_n1; cx[2] = cx_n2;
+      QKEEP(va[0]); QKEEP(m[2]);
+      QSTAMP(6);  // V_xx MFMA, next operands
+      __syncthreads();
+      QSTAMP(7);  // barrier
+    }
+  }
+#ifdef QILQR_STAMPS
+  {
+    // slot 3 (no section of wave M uses it): the loop's duration on the constant 100 MHz clock, so that
+    // cycles / time gives the shader clock the loop ran at
+    unsigned long long real1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real1)::"memory");
+    stamp_sum[3] = (real1 - real0) & 0xfffffull;
+  }
+  if (lane == 0 && stamps_out)
+    for (int k = 0; k < 8; ++k) stamps_out[k] = stamp_sum[k];
+#endif
+}
+
+// MG_w: matrix AND gradient recursion of one trajectory in one wavefront (k_backward4<.., FUSED = true>): the arithmetic of the
+// one-wavefront kernel k_backward<true> -- gradient by three multiply-adds and two permlane butterflies, k solved in lane 12
+// with the lane's own factors, V_x = Q_x + K^T Q_u -- with its seven operands from the LDS ring the loader wave fills
+// (ring row w; no gradient wavefront, no hand-off of K and the factors; no block barrier in the knot loop: the loader tags
+// every ring slot it fills, the wave looks at the tag of its next record's slot before it reads the operands, every wait a
+// bounded spin).  Returns Q_u^T k summed over the knots.
+// The knot is SOFTWARE-PIPELINED around the six matrix instructions (round 4).  A lone wavefront issues in
+// order, and what profiles/r04_knot_anatomy.txt shows is a knot whose pieces simply add up (1640 cycles: 6 + 1 MFMA 500, the
+// 4x4 solve 300, tag check and operand reads 280, gather and broadcasts 140, stores / Q_u^T k / V_x / shuffles 140, ...): the
+// compiler issues T's three products back to back, then everything else.  But a chained v_mfma_f64_16x16x4_f64 cannot issue
+// before its predecessor has finished (64 cycles, mfma_chain.hip), and in between the wavefront is free to issue anything
+// that does not touch the tile -- so everything that is NOT on the chain V_xx -> T -> H -> gather -> solve -> V_xx is issued
+// in those gaps, one group behind each product, the groups held in place by scheduling barriers:
+//     T1 | V_x of the PREVIOUS knot (its K and Q_u are carried over)     T2 | its shuffles, Q_u^T k
+//     T3 | the previous knot's gain stores, H's start values             H1 | M^T V_x, three multiply-adds
+//     H2 | the two butterflies, Q_x / Q_u                                H3 | tag check, next operands from the ring, progress
+// then the chain's own part: row gather, Q_uu broadcasts, LDL^T, solve, operand select, V_xx.  The first knot carries zeros in
+// (V_x = 0, a store to the dump slot); the last knot's tail runs behind the loop.  Same arithmetic, same order of operations
+// per value as the round-3 loop.  (Measured, profiles/microbench/mfma_shadow.hip: between two chained products a wavefront's own
+// integer / move / DPP / permlane instructions cost 1.5-3 cycles each instead of 4-5; fp64 instructions hide nothing -- they
+// share the double-precision units with the products.)
+template <typename S>
+__device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], const RecLayout &L, int w, bool run, S *gains, S *dump4,
+                                                          double cuu, int n, int lane, int *prog, unsigned long long *stamps_out = nullptr) {
+  typedef typename GA<S>::v2 sv2;
+  typedef typename GA<S>::ptr2 gptr2;
+  __builtin_amdgcn_s_setprio(3);
+  const int j = lane & 15, kk = lane >> 4;
+  int off[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    int src;
+    if (k < 3) src = m_source_tab(4 * k + kk, j);
+    else if (k < 6) src = (j < 12) ? cxx_source_tab(L, 4 * (k - 3) + kk, j) : -1 - CTAB_ZERO;
+    else src = L.off_g + j;
+    off[k] = (src >= 0) ? src : BW2_REC + (-1 - src);
+  }
+  const bool gowner = run && (kk == 0 && j <= 12);
+  const int ge0 = (j < 12) ? 4 + 4 * j : 0;
+  // the gains of a knot are stored one iteration late: st* = where the carried gains go (the dump slot in front of the first knot)
+  gptr2 st0 = (gptr2)dump4, st1 = (gptr2)(dump4 + 2);
+  gptr2 nx0 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0, 52) : dump4);
+  gptr2 nx1 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0 + 2, 52) : dump4 + 2);
+  const long gstep = gowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
+  double va[3] = {0.0, 0.0, 0.0};   // V_xx[j][4 kc + kk]  (A operand)
+  double vxl[3] = {0.0, 0.0, 0.0};  // V_x[4 kc + kk]
+  double QuTk = 0.0;
+  __syncthreads();  // rings and constant tables are filled
+  if (!run) return 0.0;
+  double m[3], cx[3], gcj;
+  {
+    const double *buf = ring[w][(n - 1) & 3];
+    m[0] = buf[off[0]]; m[1] = buf[off[1]]; m[2] = buf[off[2]];
+    cx[0] = buf[off[3]]; cx[1] = buf[off[4]]; cx[2] = buf[off[5]];
+    gcj = buf[off[6]];
+  }
+  bw4_prog_post(prog, w, 1, lane);  // record 0 is in registers (the loader may reuse its slot)
+  double kp[4] = {0.0, 0.0, 0.0, 0.0}, Qup[4] = {0.0, 0.0, 0.0, 0.0}, ghp = 0.0;  // the previous knot's K column, Q_u, Q_x
+#define QSB() __builtin_amdgcn_sched_barrier(0)
+  asm volatile(".p2align 6");
+  bool dead = false;
+#ifdef QILQR_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+  for (int i = n - 1; i >= 0; --i) {
+    const double *nb = ring[w][(i > 0 ? i - 1 : 0) & 3];
+    const int slot_word = 8 + 4 * w + ((i > 0 ? i - 1 : 0) & 3), want = n - 1 - i + 1;
+    const unsigned tag_addr = (unsigned)(size_t)(__attribute__((address_space(3))) int *)&prog[slot_word];
+    int tag = bw4_prog_read(prog, slot_word);  // an ordinary load: the compiler keeps count of it
+    QSB();
+    d4 T = {0.0, 0.0, 0.0, 0.0};
+    d4 H;
+    double Quu[16], Qu[4], col[4], rhs[4], ghat, h3;
+    double m_n0, m_n1, m_n2, cx_n0, cx_n1, cx_n2, g_n;
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0], m[0], T, 0, 0, 0);
+    QSB();
+    // K^T Q_u of the previous knot: V_x = Q_x + K^T Q_u in every lane, and in lane 12 -- whose column is k and whose right-hand
+    // side was Q_u -- the same sum is Q_u^T k (one sum for both; nobody reads the other lanes' Q_u^T k)
+    const double ktq = kp[0] * Qup[0] + kp[1] * Qup[1] + kp[2] * Qup[2] + kp[3] * Qup[3];
+    const double vx = ghp + ktq;
+    QSB();
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1], m[1], T, 0, 0, 0);
+    QSB();
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) vxl[kc] = __shfl(vx, 4 * kc + kk);  // V_x[r] lives in lanes with j == r
+    QuTk += ktq;  // (lane 12's is Q_u^T k)
+    QSB();
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[2], m[2], T, 0, 0, 0);
+    QSB();
+    {
+      const sv2 w0 = {(S)kp[0], (S)kp[1]}, w1 = {(S)kp[2], (S)kp[3]};
+      *st0 = w0;
+      *st1 = w1;
+      st0 = nx0; st1 = nx1;
+      nx0 -= gstep; nx1 -= gstep;
+    }
+    H = d4{cx[0], cx[1], cx[2], cuu};
+    QKEEP(T[0]); QKEEP(vxl[0]); QKEEP(vxl[2]); QKEEP(QuTk);
+    QSTAMP(0);  // T (3 MFMA) with the previous knot's V_x, shuffles, Q_u^T k, stores in the gaps
+    QSB();
+    // (the kc = 2 product first: rows 12..15 of H -- result register 3 -- receive nothing from the other two, J_u being zero in
+    // rows 0..7, so the register is final one product early; the order is part of the arithmetic: every build adds in it)
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
+    QSB();
+    double part = m[0] * vxl[0] + m[1] * vxl[1] + m[2] * vxl[2];  // [Q_x ; Q_u] = [C_x ; C_u] + M^T V_x
+    QSB();
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
+    QSB();
+    part = xor16_sum(part);
+    part = xor32_sum(part);
+    ghat = gcj + part;
+    QSB();
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
+    QKEEP(H[3]); QKEEP(ghat);
+    QSTAMP(1);  // H (3 MFMA) with M^T V_x and the butterflies in the gaps
+    QSB();
+    {
+      int tag_s = __builtin_amdgcn_readfirstlane(tag);
+      if (__builtin_expect(i > 0 && want >= 2 && !dead && tag_s != want, 0)) {
+        int spins = 0;
+        do {
+          asm volatile("ds_read_b32 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, %0" : "=&v"(tag), "=s"(tag_s) : "v"(tag_addr) : "memory");
+          if (++spins > BW4_SPIN_MAX) dead = true;
+        } while (tag_s != want && !dead);
+      }
+      asm volatile("" ::: "memory");
+      m_n0 = nb[off[0]]; m_n1 = nb[off[1]]; m_n2 = nb[off[2]]; cx_n0 = nb[off[3]]; cx_n1 = nb[off[4]]; cx_n2 = nb[off[5]]; g_n = nb[off[6]];
+      bw4_prog_post(prog, w, n - 1 - i + 2, lane);  // (the LDS executes a wavefront's operations in order: behind the reads)
+    }
+    QKEEP(m_n0); QKEEP(g_n);
+    QSTAMP(2);  // tag check, next operands, progress
+    QSB();
+    gather_rows(H[3], col);
+    h3 = H[3];
+    bcast_quu_row<0>(col, ghat, Quu, Qu);
+    bcast_quu_row<1>(col, ghat, Quu, Qu);
+    bcast_quu_row<2>(col, ghat, Quu, Qu);
+    bcast_quu_row<3>(col, ghat, Quu, Qu);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) rhs[a] = (j == 12) ? Qu[a] : col[a];  // lane 12: feed-forward
+    QKEEP(rhs[0]); QKEEP(rhs[3]); QKEEP(Quu[15]);
+    QSTAMP(3);  // row gather, Q_uu / Q_u broadcasts, right-hand sides
+    const Ldlt4 f4 = ldlt4_factor(Quu);
+    double kcol[4];
+    ldlt4_solve_neg(f4, rhs[0], rhs[1], rhs[2], rhs[3], kcol);  // K[:, j] (ilqr.hh:127); k in lane 12 (:128)
+    QKEEP(kcol[0]); QKEEP(kcol[3]);
+    QSTAMP(4);  // LDL^T and solve
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(h3, sel4(kcol, kk), H, 0, 0, 0);  // V_xx = Q_xx + Q_xu K (A = rows 12..15 of H)
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
+    QKEEP(va[0]); QKEEP(va[2]);
+    QSTAMP(5);  // operand select, V_xx MFMA
+    m[0] = m_n0; m[1] = m_n1; m[2] = m_n2;
+    cx[0] = cx_n0; cx[1] = cx_n1; cx[2] = cx_n2;
+    gcj = g_n;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { kp[a] = kcol[a]; Qup[a] = Qu[a]; }
+    ghp = ghat;
+  }
+#undef QSB
+  {  // the last knot's tail
+    const sv2 w0 = {(S)kp[0], (S)kp[1]}, w1 = {(S)kp[2], (S)kp[3]};
+    *st0 = w0;
+    *st1 = w1;
+    QuTk += kp[0] * Qup[0] + kp[1] * Qup[1] + kp[2] * Qup[2] + kp[3] * Qup[3];
+  }
+#ifdef QILQR_STAMPS
+  if (lane == 0 && stamps_out)
+    for (int k = 0; k < 8; ++k) stamps_out[k] = stamp_sum[k];
+#endif
+  if (dead) bw4_prog_post(prog, 5, 1, lane);
+  return bcast_lane(QuTk, 12);
+}
+
+// WAVES: register budget in waves per SIMD.  5 (90 registers, nothing spilled): three blocks per CU, the fastest single
+// block; 6 (80 registers, four of them spilled outside the knot loop): four blocks per CU -- with 33 KB of LDS per block the
+// registers are what decides -- for the launches that have more than three blocks per CU to run (B = 8192 in two parts:
+// 404 000 -> 412 000 solves/s; nothing at 4096, -0.5 % at 1024)
+// FUSED: five wavefronts per block -- MG_0..MG_3 (matrix and gradient recursion of a trajectory in one wavefront, bw4_fused_wave)
+// and the loader L -- instead of six (M_0..M_3, G, L).
+// the LDS of a block of k_backward4 (backward4_body.inc declares it unless the including kernel has: BW4_LDS_DECLARED).  ring: four slots
+// per trajectory -- in interval i the matrix wave reads slot (i-1) & 3 and writes slot (i-2) & 3 while G reads slot (i+1) & 3
+#define BW4_DECLARE_LDS                                                  \
+  __shared__ int s_run[4], s_cur[4], s_iters[4], s_act[4];               \
+  __shared__ double s_cost[4];                                           \
+  __shared__ __attribute__((aligned(16))) double ring[4][4][BW2_BUF];    \
+  __shared__ double kf[4][2][80];                                        \
+  __shared__ int prog[24];
+#define QILQR_CAT_(a, b) a##b
+#define QILQR_CAT(a, b) QILQR_CAT_(a, b)
+template <typename S, int WAVES, bool FUSED = false, bool FREE = false>
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_backward4(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n,
+                                                   int force) {
+  // (the body lives in a file of its own because k_backward_rollout contains it too, as statements of the kernel function:
+  // called as a device function it loses what the compiler knows about pointers that come from kernel arguments -- every
+  // global access becomes a flat one.  Round 3 saw the six-wavefront form's results change that way; the cause was a merged
+  // conditional store the compiler got wrong with the workspace pointers in scratch: store_settled / arm_line_search above)
+#define BW4_RETURN return
+#include "backward4_body.inc"
+#undef BW4_RETURN
+}
+
+}  // namespace qilqr

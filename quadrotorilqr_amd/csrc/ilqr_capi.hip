@@ -264,7 +264,7 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
 
 inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
 constexpr long R16_MAX_B = 4096;  // k_rollout16 up to this many trajectories (launch_rollout)
-// largest number of consecutive restarts lm_restart (ilqr_kernels.h) can grant one iteration
+// largest number of consecutive restarts lm_restart (kernels_common.h) can grant one iteration
 inline double max_restarts(const SolveParams &p) {
   if (!(p.mu_init > 0.0) || !(p.mu_init <= p.mu_max)) return 0.0;
   return 1.0 + std::floor(std::log(p.mu_max / p.mu_init) / std::log(p.mu_factor));
@@ -504,7 +504,7 @@ int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
   }
   return QILQR_OK;
 }
-// k_backward_rollout (ilqr_kernels.h): the backward pass and the rollout of a round in one launch, when every block of four
+// k_backward_rollout (round_kernels.h): the backward pass and the rollout of a round in one launch, when every block of four
 // trajectories has a CU to itself (the rollout's register budget allows one block per CU) and the round's kernels are the
 // fused k_backward4 and k_rollout16 anyway.  qilqr_device_config.round_launch = 1 keeps them apart (A/B).
 // (the kernels of the round are the two the combined launch stands for: everything but the room on the chip)
@@ -535,7 +535,7 @@ struct InFlight {
   // (always: qilqr_device_config.fuse_in_flight = 1 keeps the combined launches beside other solves -- diagnostic)
   bool alone(bool always = false) const { return always || n.load(std::memory_order_relaxed) == 1; }
 };
-// k_round (ilqr_kernels.h): the combined launch and the linearisation of its candidates in one.  fp64 storage only (the mixed mode keeps
+// k_round (round_kernels.h): the combined launch and the linearisation of its candidates in one.  fp64 storage only (the mixed mode keeps
 // the two launches).  The round's counts go into the counter set of its parity; the launch publishes the round before it.
 bool round_kernel_ok(const qilqr_solver *s) { return s->dev.round_launch == 0 && !s->f32; }
 // rounds per launch of k_round where a launch may hold several (qilqr_device_config.rounds_per_launch = 1, 2 or 4: A/B; 0 = 4)
@@ -582,7 +582,7 @@ int launch_accept(qilqr_solver *s, long B, long n, int ls_only) {
   return QILQR_OK;
 }
 
-// ---- compaction of the live trajectories (ilqr_kernels.h, k_compact_plan): between a round's backward pass and its rollout.
+// ---- compaction of the live trajectories (bookkeeping_kernels.h, k_compact_plan): between a round's backward pass and its rollout.
 // Worth its two launches while the live trajectories fill more blocks than the device runs side by side; below
 // COMPACT_STOP running trajectories every kernel of a round is a lone dependent chain whatever the slots are.
 #ifndef QILQR_COMPACT_STOP

@@ -129,7 +129,7 @@ QILQR_HD typename W::V cross_rot(typename W::V ap, typename W::V app, typename W
   return W::fma(ap, bpp, -(app * bp));
 }
 
-// One step of the rollout for four trajectories, as the pieces the device code composes (ilqr_kernels.h, r16_wave_X; the
+// One step of the rollout for four trajectories, as the pieces the device code composes (rollout16_kernel.h, r16_wave_X; the
 // host harness composes them the same way).  The recurrence has a two-knot period -- the pose of knot i + 2 needs v_{i+1},
 // which needs u_i, which needs the pose of knot i:  Log_i -> u_i -> v_{i+1} -> Exp(dt v_{i+1}) -> T_{i+2} -> Log_{i+2} -- and the
 // step of knot i is

@@ -1,0 +1,149 @@
+// round_kernels.h -- the combined launches of batches of up to 4 x CUs trajectories: k_backward_rollout (backward pass + rollout) and k_round
+// (+ the linearisation of the block's candidates, up to four rounds per launch); bodies: backward4_body.inc, rollout16_body.inc, round_body.inc.
+// Part of the device code of libquadrotor_ilqr.so (gfx950 only); ilqr_kernels.h includes every part.
+#pragma once
+
+#include "backward4_kernel.h"
+#include "rollout16_kernel.h"
+#include "linearize_kernels.h"
+
+namespace qilqr {
+
+// k_backward_rollout: the two in ONE launch for batches whose blocks of four trajectories all fit the chip at once (one block
+// per CU: the rollout's 214 registers): the block's backward pass (fused, barrier-free form), a block barrier, then the
+// rollout of its own four trajectories by wavefronts 0..2 -- gains, flags, step sizes written and read by the same CU.  One
+// launch boundary and one kernel start fewer per round.
+template <typename S>
+__global__ __launch_bounds__(320) void k_backward_rollout(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n) {
+  {
+    constexpr int WAVES = 5;
+    constexpr bool FUSED = true, FREE = true;
+    const int force = 0;
+    (void)WAVES;
+#define BW4_RETURN goto backward_done
+#include "backward4_body.inc"
+#undef BW4_RETURN
+  }
+backward_done:
+  __syncthreads();  // (every wavefront comes out of the backward pass; its stores are visible to the block)
+  if (threadIdx.x >= 192) return;
+  {
+    const int need_flag = F_SEARCH;
+#define R16_RETURN return
+#include "rollout16_body.inc"
+#undef R16_RETURN
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_round: a whole round in ONE launch, where k_backward_rollout is allowed (a block per CU) -- its backward pass and rollout, then the
+// linearisation of the block's own candidates by all five wavefronts (k_linearize's arithmetic: se3_math.h forms its fused
+// multiply-adds from the source alone, so the records are the same bits whichever kernel writes them).  One launch boundary and one
+// kernel start and end fewer per round than k_backward_rollout + k_linearize.  The count of running trajectories is complete only
+// when every block has settled, so a launch hands the host the count of the round BEFORE it (prev_counters, prev_round): the host
+// alternates between two sets of counters, and an idle wavefront of block 0 publishes while the others roll out.
+// ---------------------------------------------------------------------------------------------
+// k_linearize's work for the trajectories of one block: lane-tasks (knot, live trajectory) of the cost half first -- the longer
+// chain -- then of the dynamics half, sixty-four to a wavefront, wavefront w of the block taking tasks w, w + nwaves, ...
+template <typename S, int LK>
+__device__ __forceinline__ void linearize_block(const ModelConsts<S> &c, const S *qr, const BatchState &st, int b0, int B, int n, int which,
+                                                int need_flag) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = (int)(blockDim.x >> 6);
+  int l0 = 0, l1 = 0, l2 = 0, l3 = 0, u0 = 0, u1 = 0, u2 = 0, u3 = 0, nl = 0;  // slots and buffers of the trajectories that take part
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int b = b0 + g;
+    if (b >= B) continue;
+    const int fl = st.flags[b], buf = st.cur[b] ^ which;
+    if (need_flag && !(fl & need_flag)) continue;
+    if (nl == 0) { l0 = b; u0 = buf; } else if (nl == 1) { l1 = b; u1 = buf; } else if (nl == 2) { l2 = b; u2 = buf; } else { l3 = b; u3 = buf; }
+    ++nl;
+  }
+  if (nl == 0) return;
+  const int per = nl * n, wt = (per + 63) >> 6;
+  for (int t = wave; t < 2 * wt; t += nwaves) {
+    const bool cost_half = t < wt;  // wave-uniform
+    const int r = (cost_half ? t : t - wt) * 64 + lane;
+    if (r >= per) continue;
+    const int i = (nl == 1) ? r : (nl == 2) ? (r >> 1) : (nl == 3) ? r / 3 : (r >> 2);
+    const int g = r - i * nl;
+    const int b = (g == 0) ? l0 : (g == 1) ? l1 : (g == 2) ? l2 : l3;
+    const int buf = (g == 0) ? u0 : (g == 1) ? u1 : (g == 2) ? u2 : u3;
+    S pt[18];
+    load_knot<true>((const S *)st.traj[buf] + knot_base<true>(b, n, 18), i, 18, pt);
+    S *rec = (S *)st.lin[buf] + rec_base(st.layout, b, n) + rec_elem(st.layout, i, 0);
+    if (!cost_half) {
+      const TiledRecWriter<S> wd{rec};
+      linearize_dynamics(c, pt, wd);
+      wd.flush();
+    } else {
+      const TiledRecWriter<S> w{rec};
+      S pd[18];
+      if (st.desired_tiled) load_knot<true>((const S *)st.desired + knot_base<true>(b, n, 18), i, 18, pd);
+      else load_knot<false>((const S *)st.desired, i, 18, pd);
+      const S cost = linearize_cost<LK>(qr, qr + 144, pt, pd, w);
+      w.flush();
+      st.knot_cost[buf][cost_index(b, i, n)] = (double)cost;
+    }
+  }
+}
+// the count of running trajectories of a finished round to the host (k_linearize's first wavefront does the same for its own round)
+__device__ __forceinline__ void publish_active(int *counters, unsigned long long *host_active, int round, int lane) {
+  int act = counters[COUNT_BASE + lane];
+  counters[COUNT_BASE + lane] = 0;  // (the round after next counts into these words again)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) act += __shfl_xor(act, off);
+  if (lane == 0)
+    __hip_atomic_store(&host_active[round & 7], ((unsigned long long)(unsigned)(round + 1) << 32) | (unsigned)act, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_publish_active(int *counters, unsigned long long *host_active, int round) {
+  publish_active(counters, host_active, round, threadIdx.x & 63);
+}
+// ROUNDS > 1: several rounds per launch (a round's settle step finds the knot costs the block has just written): the launch
+// boundaries between them are gone too.  All of them count into the launch's counter set: the host reads the SUM of their counts of
+// running trajectories, an upper bound of the last one's and zero exactly when the first one's is.  The rounds share the block's LDS.
+template <int LK, int ROUNDS>
+__global__ __launch_bounds__(320) void k_round(ModelConsts<double> c, const ModelConsts<double> *__restrict__ cp, SolveParams p, BatchState st, int B,
+                                                int n, int *prev_counters, int prev_round) {
+  typedef double S;
+  __shared__ double qr_w[160];  // the weights of the cost half (k_linearize keeps a copy per wavefront: here the block's)
+  BW4_DECLARE_LDS
+  __shared__ R16Lds sh;
+#define BW4_LDS_DECLARED
+#define R16_LDS_DECLARED
+#define BW4_CTAB_FILLED
+  for (int k = threadIdx.x; k < 160; k += blockDim.x) qr_w[k] = (k < 144) ? cp->Q[k] : cp->R[k - 144];
+  // the constant operand table behind the ring slots, once for all the rounds of the launch (a round whose block has nothing to run
+  // leaves before it would fill it, and a later round of the same launch may have something: so here, unconditionally; the records and
+  // the settle step's scratch use the slots' other words)
+  bw4_fill_ctab<S>(ring, st.ctab, 320);
+  // (an idle wavefront of block 0 hands the host the count of the launch before this one while the others roll out)
+#define ROUND_BEHIND_BACKWARD \
+  if (blockIdx.x == 0 && (threadIdx.x >> 6) == 4 && prev_round >= 0) publish_active(prev_counters, st.host_active, prev_round, threadIdx.x & 63);
+#define ROUND_ID 0
+#include "round_body.inc"
+#undef ROUND_ID
+#undef ROUND_BEHIND_BACKWARD
+#define ROUND_BEHIND_BACKWARD
+  if constexpr (ROUNDS > 1) {
+#define ROUND_ID 1
+#include "round_body.inc"
+#undef ROUND_ID
+  }
+  if constexpr (ROUNDS > 2) {
+#define ROUND_ID 2
+#include "round_body.inc"
+#undef ROUND_ID
+#define ROUND_ID 3
+#include "round_body.inc"
+#undef ROUND_ID
+  }
+#undef ROUND_BEHIND_BACKWARD
+#undef BW4_LDS_DECLARED
+#undef R16_LDS_DECLARED
+#undef BW4_CTAB_FILLED
+}
+
+}  // namespace qilqr
