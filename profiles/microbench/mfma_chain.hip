@@ -52,8 +52,15 @@ void run(const char *name, int tpb, double *out, long long *cyc, long long *rt) 
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long hc, hr; hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost); hipMemcpy(&hr, rt, 8, hipMemcpyDeviceToHost);
-    if (rep) printf("%d wave%s per SIMD  %-44s: %7.1f shader cycles per MFMA and wave (%5.1f ns; per SIMD one MFMA every %6.1f cycles; %.2f GHz)\n", tpb / 256 ? tpb / 256 : 1,
-                    tpb > 256 ? "s" : " ", name, (double)hc / (24.0 * iters), ms * 1e6 / (24.0 * iters), (double)hc / (24.0 * iters) / (tpb / 256 ? tpb / 256 : 1), (double)hc / ((double)hr * 10.0));
+    // Two clocks: wavefront 0's own loop on the shader clock (clock64 around ITS loop), and the whole launch (HIP events).  With several
+    // MFMA-bound wavefronts on a SIMD the oldest one issues its chain back to back and the others wait their turn: wavefront 0's loop takes
+    // what it takes alone while the launch takes `waves` times as long.  The per-SIMD rate therefore comes from the LAUNCH's duration
+    // (round 4 printed wavefront 0's cycles divided by the waves per SIMD there: "one MFMA every 16 cycles" at four waves -- four times the
+    // matrix pipe's peak).
+    const int waves = tpb / 256 ? tpb / 256 : 1;
+    const double ghz = (double)hc / ((double)hr * 10.0), ns_launch = ms * 1e6 / (24.0 * iters);
+    if (rep) printf("%d wave%s per SIMD  %-44s: wavefront 0's own loop %6.1f shader cycles per MFMA; the launch %6.1f ns per MFMA and wave = per SIMD one MFMA every %6.1f cycles (%.2f GHz)\n",
+                    waves, tpb > 256 ? "s" : " ", name, (double)hc / (24.0 * iters), ns_launch, ns_launch * ghz / waves, ghz);
   }
 }
 int main() {
