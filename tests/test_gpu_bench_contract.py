@@ -52,7 +52,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert abs(ss["final_cost"] - ss["cpu_oracle_one_core"]["final_cost"]) / ss["final_cost"] < 1e-3   # (configs[0] is chaotic: DESIGN.md section 2)
     f1 = rf["symmetric_weights_force_general_1"]
     assert f1["max_rel_cost_diff_vs_oracle"] < 1e-9 and f1["same_status_iters_as_oracle"] == f1["oracle_sample"]
-    assert f1["value"] * 3.0 > j["value"]                              # (not more than 3 x slower than the default kernels)
+    assert f1["value"] * 2.2 > j["value"]                              # (round 5: 1.9 x behind the default kernels; 2.6 x in round 4)
     assert rf["non_symmetric_Q"]["one_backward_pass_vs_oracle"]["max_gain_diff_over_largest_gain"] < 1e-9
     # the saturated machine: B = 8192 in the same run, per-kernel launch times and roofline fractions
     lb = j["large_batch"]
