@@ -84,6 +84,18 @@ def test_debug_encode():
                                               for t, c in zip(trajs, costs)])
     assert msg == ref and msg.SerializeToString() == ref.SerializeToString()
     assert len(_encode_debug(np.zeros((0, 4, 18)), np.zeros(0)).iter_debugs) == 0
+    # the size of ILQRDebug's real use (100 knots: three-byte lengths), with all-zero knots (every sub-message empty but present), zero
+    # vectors and -0.0 among the values: the two-pass encoder (sizes, then bytes into one buffer) against python-protobuf, byte for byte
+    trajs, costs = r.standard_normal((3, 100, 18)), np.array([-0.0, 2.5, 0.0])
+    trajs[0, 7] = 0.0
+    trajs[1, 3, 1:4] = 0.0
+    trajs[1, 4, 8:14] = 0.0
+    trajs[2, :, 0] = 0.0
+    trajs[2, 50, 4] = -0.0
+    msg = _encode_debug(trajs, costs)
+    ref = dbg.QuadrotorILQRDebug(iter_debugs=[dbg.QuadrotorILQRIterDebug(trajectory=trajectory_message(t), cost=c)
+                                              for t, c in zip(trajs, costs)])
+    assert msg.SerializeToString() == ref.SerializeToString()
 
 
 def test_constructor_signature_and_errors():
