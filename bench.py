@@ -281,9 +281,9 @@ def sharded_c_abi_leg(args, g_cost_host):
            "--sync-every", str(args.sync_every)]
     try:
         try:
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
         except subprocess.TimeoutExpired:
-            return {"error": "the child process did not finish within 300 s (killed)"}
+            return {"error": "the child process did not finish within 150 s (killed)"}
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or len(lines) != 1:
             return {"error": f"child exit code {r.returncode}", "stderr_tail": r.stderr[-600:]}
