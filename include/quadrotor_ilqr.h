@@ -322,9 +322,10 @@ int qilqr_solve_batch_sharded(qilqr_sharded *h, const double *init, const double
  * `root` (devices[root]), B x n x 18 doubles / B doubles / B int32, any of them may be NULL.  Every shard's rows travel from
  * its solver's staging buffers straight into their place in the root's arrays -- ragged shards, no padding, no second
  * copy -- as soon as that shard has finished, by the handle's transport:
- *   QILQR_TRANSPORT_RCCL       ncclSend on the shard's device / ncclRecv on the root's, ONE GROUP PER SHARD, enqueued by that
- *                              shard's own host thread the moment its solve is enqueued (behind an event on its stream: a
- *                              shard's rows travel while slower shards still solve), over one communicator per distinct
+ *   QILQR_TRANSPORT_RCCL       ncclSend on the shard's device / ncclRecv on the root's, ONE GROUP PER SHARD, issued by that
+ *                              shard's own host thread when its solve has finished (a communicator executes in issue order:
+ *                              the groups reach the root's in the order the shards finish, so a shard's rows travel while
+ *                              slower shards still solve), over one communicator per distinct
  *                              device (ncclCommInitAll: all in this process); librccl.so.1 is loaded when the first
  *                              communicator is needed.  Exercised with ONE rank so far (every shard on the one GPU of the
  *                              test box: self send / receive); the multi-rank path has not run on hardware -- its schedule

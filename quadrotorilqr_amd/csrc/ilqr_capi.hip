@@ -2152,6 +2152,15 @@ int enqueue_shard_gather(qilqr_sharded *h, const ShardCall &c, int32_t r) {
   hipStream_t gs = h->gstream[h->rank_of[r]], rs = h->gstream[rr];
   void *dst_base[6] = {c.out_traj, c.out_cost, c.out_status, c.out_iters, c.out_n_bwd, c.out_n_fwd};
   const void *src_base[6] = {s->stage_traj, s->stage_cost, s->stage_int, s->stage_int, s->stage_int, s->stage_int};
+  if (h->resolved == QILQR_TRANSPORT_RCCL) {
+    // A communicator executes its operations in the order they were issued, and every shard's receives are operations of the ROOT's
+    // communicator: issued when the solves are enqueued, the group of a slow shard would hold back the receives of every faster shard
+    // issued behind it.  The shard's host thread therefore waits for its own solve first and issues its group then: the
+    // groups reach the root's communicator in the order the shards finish.  (Peer copies run on a stream per source device and need no
+    // such care.)
+    HIP_TRY(hipSetDevice(h->device[r]));
+    HIP_TRY(hipEventSynchronize(h->done[r]));
+  }
   std::lock_guard<std::mutex> lock(h->gather_mutex);
   HIP_TRY(hipSetDevice(h->device[r]));
   HIP_TRY(hipStreamWaitEvent(gs, h->done[r], 0));
