@@ -361,6 +361,12 @@ int qilqr_gather_schedule(int32_t B, int32_t n, const int32_t *devices, int32_t 
  * off for that call.  Waits for the handle's stream. */
 int qilqr_compaction_moves(qilqr_solver *s, int64_t *moves);
 
+/* In words, which arithmetic and which kernels a batch solve of B problems on this handle uses: the reference's own forms or the
+ * symmetric-weight forms (the choice is made by whether Q and R are bit-exactly symmetric and by force_general: see
+ * qilqr_device_config.force_general), the integrator, the precision, the backward and rollout kernels, how a round is launched,
+ * sub-batch streams, compaction.  buf receives a NUL-terminated text of at most cap - 1 characters. */
+int qilqr_describe(qilqr_solver *s, int32_t B, char *buf, size_t cap);
+
 /* ABI version of this header: 7 (qilqr_device_config grew by round_launch, rounds_per_launch, fuse_in_flight, dense_weights -- the
  * switches that were environment variables -- and the *_sized entry points carry the caller's structure size; version 6 added
  * `compaction`) */

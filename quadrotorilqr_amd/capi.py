@@ -42,7 +42,7 @@ EXPORTS = (
     "qilqr_sharded_create", "qilqr_sharded_create_sized", "qilqr_sharded_create_mask", "qilqr_sharded_destroy", "qilqr_sharded_count", "qilqr_sharded_solver",
     "qilqr_shard_range", "qilqr_solve_batch_sharded",
     "qilqr_sharded_set_transport", "qilqr_sharded_transport", "qilqr_solve_batch_sharded_device", "qilqr_gather_schedule",
-    "qilqr_abi_version", "qilqr_compaction_moves",
+    "qilqr_abi_version", "qilqr_compaction_moves", "qilqr_describe",
 )
 
 
@@ -349,6 +349,14 @@ class QuadrotorILQRBatch:
         rc = load().qilqr_profile_mode(self._h, C.c_int32(int(mode)))
         if rc:
             _raise(rc)
+
+    def describe(self, B):
+        """qilqr_describe: in words, the arithmetic and the kernels a batch solve of B problems on this handle uses"""
+        buf = C.create_string_buffer(2048)
+        rc = load().qilqr_describe(self._h, C.c_int32(int(B)), buf, C.c_size_t(len(buf)))
+        if rc:
+            _raise(rc)
+        return buf.value.decode()
 
     def compaction_moves(self):
         """trajectories the compaction moved in the last batch solve (qilqr_compaction_moves)"""

@@ -2287,6 +2287,49 @@ int qilqr_solve_batch_sharded_device(qilqr_sharded *h, const double *init, const
   }
 }
 
+// In words: which arithmetic and which kernels a batch solve of B problems on this handle uses (the choice between the
+// reference's own forms and the symmetric-weight kernels is made by whether Q and R are bit-exactly symmetric, and was silent).
+int qilqr_describe(qilqr_solver *s, int32_t B, char *buf, size_t cap) {
+  if (!s || !buf || cap == 0 || B <= 0) return fail(QILQR_ERR_INVALID_ARG, "bad argument");
+  const long load_B = B;
+  std::string t;
+  const bool persistent = use_persistent(s, B);
+  const BackwardKind kind = persistent ? BW_FOUR : backward_kind(s, load_B);
+  if (kind == BW_ONE && !s->symmetric)
+    t += "arithmetic: the reference's own forms (ilqr.hh:126-133: Eigen's diagonally pivoted LDL^T, V_x = Q_x - K^T Q_uu k, V_xx = Q_xx - K^T Q_uu K, "
+         "not symmetrised)";
+  else
+    t += "arithmetic: symmetric-weight forms (Q == Q^T and R == R^T exactly: unpivoted LDL^T, V_x = Q_x + K^T Q_u, V_xx = Q_xx + Q_xu K on a symmetric "
+         "accumulator; force_general = 1 selects the reference's own forms)";
+  t += s->integrator == 1 ? "; Runge-Kutta step (extension)" : "; explicit Euler step (the reference's)";
+  t += s->f32 ? "; mixed precision (fp32 storage and lane-local arithmetic, fp64 recursion and cost sums)" : "; fp64";
+  t += "; backward: ";
+  t += persistent ? "k_solve4 (one launch per solve)" : kind == BW_FUSED ? "k_backward4, fused matrix + gradient wavefronts" : kind == BW_FOUR ? "k_backward4, six wavefronts"
+       : kind == BW_TWO ? "k_backward2" : (s->symmetric ? "k_backward<true>, one wavefront per trajectory" : "k_backward<false>, one wavefront per trajectory (general kernel)");
+  if (!persistent) {
+    const int choice = s->dev.single_wave_rollout;
+    t += "; rollout: ";
+    t += (s->integrator == 1 || choice == 1) ? "k_rollout" : (choice == 3 || (choice == 0 && load_B <= R16_MAX_B)) ? "k_rollout16" : "k_rollout3";
+    const qilqr_solver *cs = s;
+    const long saved_total = s->total_B;
+    s->total_B = B;  // (the launch helpers go by the batch a call has in flight)
+    const bool fused = fuse_backward_rollout(cs, B) && s->dev.sync_every > 1;
+    const int parts = s->dev.sync_every > 1 ? auto_parts(cs, B) : 1;
+    s->total_B = saved_total;
+    if (fused && parts == 1)
+      t += round_kernel_ok(cs) ? "; round: one launch (k_round), " + std::to_string(rounds_per_launch(cs)) + " rounds per launch, while no other batch solve of the process is in flight on the device"
+                                : std::string("; round: k_backward_rollout + k_linearize");
+    else
+      t += "; round: three launches";
+    t += "; sub-batch streams: " + std::to_string(parts);
+    const bool compact = s->dev.compaction >= 0 && s->dev.sync_every > 1 &&
+                         (s->dev.compaction == 1 || (!(fused && parts == 1) && kind != BW_ONE));
+    t += compact ? "; compaction of the running trajectories: on (device-resident calls)" : "; compaction: off";
+  }
+  std::snprintf(buf, cap, "%s", t.c_str());
+  return QILQR_OK;
+}
+
 // trajectories k_compact_move moved in the last batch solve of this handle (0: compaction was off, or nothing finished early)
 int qilqr_compaction_moves(qilqr_solver *s, int64_t *moves) {
   if (!s || !moves) return fail(QILQR_ERR_INVALID_ARG, "null argument");
