@@ -606,8 +606,20 @@ def main():
     # process of rank 0 while the other ranks wait, idle, at the fence
     sharded_abi = None
     if world > 1 and not args.no_sharded_c_abi:
+        # the other ranks wait on the HOST (a key of the rendezvous store), not in a collective: an RCCL barrier is a kernel that spins on
+        # every waiting GPU, and the child process is about to measure a solve on exactly those GPUs
+        fence()
+        store = None
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:
+            store = None
         if rank == 0:
             sharded_abi = sharded_c_abi_leg(args, ref_cost)
+            if store is not None:
+                store.set("qilqr_sharded_c_abi_done", "1")
+        elif store is not None:
+            store.wait(["qilqr_sharded_c_abi_done"])
         fence()
 
     status, iters, n_bwd, n_fwd = (t.cpu().numpy() for t in out_i)
