@@ -2312,10 +2312,13 @@ int qilqr_describe(qilqr_solver *s, int32_t B, char *buf, size_t cap) {
     t += (s->integrator == 1 || choice == 1) ? "k_rollout" : (choice == 3 || (choice == 0 && load_B <= R16_MAX_B)) ? "k_rollout16" : "k_rollout3";
     const qilqr_solver *cs = s;
     const long saved_total = s->total_B;
-    s->total_B = B;  // (the launch helpers go by the batch a call has in flight)
+    const int saved_tiled = s->st.layout.tiled;
+    s->total_B = B;  // (the launch helpers go by the batch a call has in flight and by the record placement begin_batch chooses for it)
+    s->st.layout.tiled = records_tiled(s, B, persistent) ? 1 : 0;
     const bool fused = fuse_backward_rollout(cs, B) && s->dev.sync_every > 1;
     const int parts = s->dev.sync_every > 1 ? auto_parts(cs, B) : 1;
     s->total_B = saved_total;
+    s->st.layout.tiled = saved_tiled;
     if (fused && parts == 1)
       t += round_kernel_ok(cs) ? "; round: one launch (k_round), " + std::to_string(rounds_per_launch(cs)) + " rounds per launch, while no other batch solve of the process is in flight on the device"
                                 : std::string("; round: k_backward_rollout + k_linearize");

@@ -107,7 +107,7 @@ def test_describe_says_which_arithmetic_a_handle_uses():
     d = capi.from_config(cfg).describe(1024)
     assert "symmetric-weight forms" in d and "k_backward4, fused" in d and "k_rollout16" in d and "k_round" in d and "4 rounds per launch" in d
     d = capi.from_config(cfg).describe(8192)
-    assert "six wavefronts" in d and "k_rollout3" in d and "sub-batch streams: " in d and "compaction of the running trajectories: on" in d
+    assert "six wavefronts" in d and "k_rollout3" in d and "three launches" in d and "sub-batch streams: " in d and "compaction of the running trajectories: on" in d
     d = capi.from_config(cfg, force_general=1).describe(1024)
     assert "the reference's own forms" in d and "general kernel" in d and "three launches" in d
     Q = cfg["Q"].copy()
