@@ -96,7 +96,8 @@ typedef struct {
                             the trailing block, first on ties), V_x = Q_x - K^T Q_uu k, V_xx = Q_xx - K^T Q_uu K, not
                             symmetrised -- force_general = 1 REPRODUCES THE REFERENCE, including its loss of accuracy
                             beyond about 150 knots (the unsymmetrised recursion amplifies rounding asymmetry until the
-                            gains are noise: DESIGN.md section 4).  The symmetric-weight kernels (selected silently
+                            gains are noise -- in the reference, the oracle and this kernel alike, of different magnitudes:
+                            DESIGN.md section 4).  The symmetric-weight kernels (selected silently
                             whenever Q == Q^T and R == R^T exactly, i.e. for every weight the reference's demo and tests
                             use) DELIBERATELY DIFFER: unpivoted LDL^T (same result in exact arithmetic for positive
                             definite Q_uu; loses eps / p for an indefinite Q_uu with a tiny leading entry p) and the

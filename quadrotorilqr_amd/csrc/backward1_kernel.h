@@ -105,8 +105,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   S *gains = (S *)st.gains + knot_base<true>(b, n, 52);
 
   constexpr int LD = 17;  // padded leading dimension: column reads of a row-major tile
-  __shared__ double Vs[SYM ? 1 : 12 * LD];
-  __shared__ double Hs[SYM ? 1 : 16 * LD];
+  __shared__ double Hs[SYM ? 1 : 16 * LD];  // (general kernel: the right-hand sides of every other knot cross the tile here)
 
   // Seven operands per lane and knot: three elements of M = [J_x | J_u] (rows kk, 4+kk, 8+kk of
   // column j), three of C_xx (accumulator layout: register r <-> row 4 r + kk, column j) and one of
@@ -126,6 +125,19 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
       step[k] = (src >= 0) ? knot_step : 0;
     }
   }
+  // The general kernel alternates between two kinds of knot (round 5; below): the odd kind takes C TRANSPOSED -- entry [j][4 r + kk] where the
+  // even kind takes [4 r + kk][j] (the same entry when the record stores a symmetric C_xx).
+  typename GA<S>::cptr opt[3];
+  long stept[3];
+  if constexpr (!SYM) {
+    const long knot_step = rec_elem(L, 1, 0) - rec_elem(L, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int src = (j < 12) ? cxx_source_tab(L, j, 4 * k + kk) : -1 - CTAB_ZERO;
+      opt[k] = (typename GA<S>::cptr)((src >= 0) ? lin + rec_elem(L, n - 1, src) : (const S *)st.ctab + (-1 - src));
+      stept[k] = (src >= 0) ? knot_step : 0;
+    }
+  }
   // gain slots of this lane for knot n-1, walked back one knot per iteration (tiled layout: one
   // 16-byte slot per element pair); lanes that own nothing point at the dump slot with step 0
   const bool gowner = (kk == 0 && j <= 12);
@@ -137,6 +149,7 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   const long gstep = gowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
   // register 3 <-> row 12 + kk: C_uu = 2 R (cost.hh:55) in columns 12..15
   const double cuu = (j >= 12) ? 2.0 * c.R[kk * 4 + (j - 12)] + ((j - 12 == kk) ? mu : 0.0) : 0.0;
+  const double cuut = (j >= 12) ? 2.0 * c.R[(j - 12) * 4 + kk] + ((j - 12 == kk) ? mu : 0.0) : 0.0;  // C_uu^T (general kernel, odd knots)
 
   double va[3] = {0.0, 0.0, 0.0};   // V_xx[j][4 kc + kk]  (A operand)
   double vxl[3] = {0.0, 0.0, 0.0};  // V_x[4 kc + kk]
@@ -145,26 +158,46 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   // software pipeline: the operands of knot i-1 are requested before the chain of knot i starts
   double m[3], cx[3], gcj;
   m[0] = (double)*op[0]; m[1] = (double)*op[1]; m[2] = (double)*op[2];
-  cx[0] = (double)*op[3]; cx[1] = (double)*op[4]; cx[2] = (double)*op[5];
+  if constexpr (SYM) {
+    cx[0] = (double)*op[3]; cx[1] = (double)*op[4]; cx[2] = (double)*op[5];
+  } else {
+    cx[0] = (double)*opt[0]; cx[1] = (double)*opt[1]; cx[2] = (double)*opt[2];
+  }
   gcj = (double)*op[6];
 
 #ifdef QILQR_STAMPS
   unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
-  for (int i = n - 1; i >= 0; --i) {
+  // KIND 0: the symmetric recursion.  KIND 1 / 2: the general kernel's two kinds of knot (round 5).  An accumulator tile X used as the A
+  // operand of the next product IS X^T.  The symmetric recursion lives on that (V = V^T to rounding); a non-symmetric V_xx needed a real
+  // transpose through LDS every knot -- until the two kinds alternate:
+  //   kind 1: the accumulator holds V.  A = V^T, so the products give T' = V^T M and, started from C^T, H' = C^T + M^T V^T M = H^T.  Rows 12..15
+  //           of H^T are the COLUMNS 12..15 of H: register 3 of lane (j, a) is H[j][12 + a] = Q_xu[j][a] -- the right-hand sides, in place --
+  //           and Q_uu[b][a] sits in lane (12 + b, a).  The update is formed transposed as well: V_new^T = Q_xx^T - K^T (Q_uu^T K), one matrix
+  //           instruction with A[i][kk] = K[kk][i], B[kk][j] = -(K^T Q_uu)[j][kk] -- the same products and sums as the plain form.
+  //   kind 2: the accumulator holds V^T.  A = V: T = V M, H = C + M^T T as written (ilqr.hh:118-124); Q_xu[j][a] = H[j][12 + a] is then a
+  //           column of the tile and crosses it through LDS; V_new = Q_xx - (K^T Q_uu) K in place (ilqr.hh:133) -- and the next knot is kind 1.
+  // No transpose of V_xx anywhere, one trip through LDS every other knot.  Same operations per value as before (the reference's forms).
+  auto knot = [&](int i, auto kind_tag) {
+    constexpr int KIND = decltype(kind_tag)::value;
     if (i > 0) {
 #pragma unroll
       for (int k = 0; k < 7; ++k) op[k] -= step[k];
+      if constexpr (!SYM) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) opt[k] -= stept[k];
+      }
     }
     // (loaded in storage precision, converted where first used, so that the conversion does not wait
-    // on the load at the top of the loop)
-    const S m_s0 = *op[0], m_s1 = *op[1], m_s2 = *op[2], cx_s0 = *op[3], cx_s1 = *op[4], cx_s2 = *op[5], g_s = *op[6];
+    // on the load at the top of the loop; the next knot of the general kernel is of the other kind: C transposed behind a kind-2 knot)
+    const S m_s0 = *op[0], m_s1 = *op[1], m_s2 = *op[2], g_s = *op[6];
+    const S cx_s0 = (KIND == 2) ? *opt[0] : *op[3], cx_s1 = (KIND == 2) ? *opt[1] : *op[4], cx_s2 = (KIND == 2) ? *opt[2] : *op[5];
     QSTAMP(0);  // prefetch issue
     const d4 T = bw_tile_T(va, m);
     QKEEP(T[0]); QKEEP(T[3]);
     QSTAMP(1);  // T = V M (3 MFMA) complete
-    d4 H = bw_tile_H(m, T, cx, cuu);
+    d4 H = bw_tile_H(m, T, cx, (KIND == 1) ? cuut : cuu);
     QKEEP(H[0]); QKEEP(H[3]);
     QSTAMP(2);  // H (3 MFMA) complete
     // [Q_x ; Q_u] = [C_x ; C_u] + M^T V_x
@@ -196,28 +229,41 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
       // lane 12: feed-forward.  Lanes 13..15 solve against a column of Q_uu itself; nobody reads them.
       for (int a = 0; a < 4; ++a) rhs[a] = (j == 12) ? Qu[a] : col[a];
     } else {
-      // Q_xu[j][a] = H[j][12 + a] sits in the accumulator's COLUMNS 12..15 (lane (12 + a, j & 3), register j >> 2): the right-hand sides
-      // cross the tile through LDS -- columns 12..15 of rows 0..11 only.  Q_uu (all sixteen entries: K^T Q_uu below is not symmetric
-      // arithmetic) and Q_u come from registers while that round trip is in flight: rows 12..15 of H are register 3, gathered and
-      // broadcast as in the symmetric kernels (until round 5 all twenty went through LDS behind the barrier).
-      if (j >= 12) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) Hs[(4 * r + kk) * LD + j] = H[r];
-      }
-      __syncthreads();
-      double xr[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) xr[a] = Hs[(j < 12 ? j : 0) * LD + 12 + a];
       double col[4];
-      gather_rows(H[3], col);  // col[a] in lane j = H[12 + a][j]
+      if constexpr (KIND == 1) {
+        // H^T in the accumulator: col[a] in lane j = H^T[12 + a][j] = H[j][12 + a] -- Q_xu[j][a] for j < 12, Q_uu[j - 12][a] for j >= 12
+        gather_rows(H[3], col);
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        Quu[a * 4 + 0] = row_bcast<12>(col[a]); Quu[a * 4 + 1] = row_bcast<13>(col[a]);
-        Quu[a * 4 + 2] = row_bcast<14>(col[a]); Quu[a * 4 + 3] = row_bcast<15>(col[a]);
+        for (int bb = 0; bb < 4; ++bb) {
+          Quu[0 * 4 + bb] = row_bcast<12>(col[bb]); Quu[1 * 4 + bb] = row_bcast<13>(col[bb]);
+          Quu[2 * 4 + bb] = row_bcast<14>(col[bb]); Quu[3 * 4 + bb] = row_bcast<15>(col[bb]);
+        }
+        Qu[0] = row_bcast<12>(ghat); Qu[1] = row_bcast<13>(ghat); Qu[2] = row_bcast<14>(ghat); Qu[3] = row_bcast<15>(ghat);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) rhs[a] = (j < 12) ? col[a] : ((j == 12) ? Qu[a] : 0.0);  // lane 12: feed-forward
+      } else {
+        // H in the accumulator: Q_xu[j][a] = H[j][12 + a] sits in its COLUMNS 12..15 (lane (12 + a, j & 3), register j >> 2): the right-hand
+        // sides cross the tile through LDS -- columns 12..15 of rows 0..11 only.  Q_uu (all sixteen entries: K^T Q_uu below is not symmetric
+        // arithmetic) and Q_u come from registers while that round trip is in flight: rows 12..15 of H are register 3, gathered and broadcast
+        // as in the symmetric kernels.
+        if (j >= 12) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) Hs[(4 * r + kk) * LD + j] = H[r];
+        }
+        __syncthreads();
+        double xr[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) xr[a] = Hs[(j < 12 ? j : 0) * LD + 12 + a];
+        gather_rows(H[3], col);  // col[a] in lane j = H[12 + a][j]
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          Quu[a * 4 + 0] = row_bcast<12>(col[a]); Quu[a * 4 + 1] = row_bcast<13>(col[a]);
+          Quu[a * 4 + 2] = row_bcast<14>(col[a]); Quu[a * 4 + 3] = row_bcast<15>(col[a]);
+        }
+        Qu[0] = row_bcast<12>(ghat); Qu[1] = row_bcast<13>(ghat); Qu[2] = row_bcast<14>(ghat); Qu[3] = row_bcast<15>(ghat);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) rhs[a] = (j < 12) ? xr[a] : ((j == 12) ? Qu[a] : 0.0);  // lane 12: feed-forward
       }
-      Qu[0] = row_bcast<12>(ghat); Qu[1] = row_bcast<13>(ghat); Qu[2] = row_bcast<14>(ghat); Qu[3] = row_bcast<15>(ghat);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) rhs[a] = (j < 12) ? xr[a] : ((j == 12) ? Qu[a] : 0.0);  // lane 12: feed-forward
     }
     QKEEP(Quu[15]); QKEEP(Quu[0]); QKEEP(Qu[3]); QKEEP(rhs[3]); QKEEP(rhs[0]);
     QSTAMP(4);  // broadcast of Q_uu, Q_u, right-hand sides
@@ -280,9 +326,10 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
       kTQuuk += mc[0] * kcol[0] + mc[1] * kcol[1] + mc[2] * kcol[2] + mc[3] * kcol[3];
       QKEEP(mc[3]); QKEEP(vx); QKEEP(QuTk); QKEEP(kTQuuk);
       QSTAMP(6);  // K^T Quu, V_x, reduction terms
-      // V_xx = Q_xx - (K^T Quu) K   (ilqr.hh:133): one more MFMA on the same accumulator,
-      // A[j][kk] = -(K^T Quu)[j][kk], B[kk][j] = K[kk][j]
-      H = __builtin_amdgcn_mfma_f64_16x16x4f64(-sel4(mc, kk), sel4(kcol, kk), H, 0, 0, 0);
+      // V_xx = Q_xx - (K^T Quu) K   (ilqr.hh:133): one more MFMA on the same accumulator, A[j][kk] = -(K^T Quu)[j][kk], B[kk][j] = K[kk][j]
+      // (kind 2); on H^T (kind 1) the transposed update V_new^T = Q_xx^T - K^T (Quu^T K): A[i][kk] = K[kk][i], B[kk][j] = -(K^T Quu)[j][kk]
+      if constexpr (KIND == 1) H = __builtin_amdgcn_mfma_f64_16x16x4f64(sel4(kcol, kk), -sel4(mc, kk), H, 0, 0, 0);
+      else H = __builtin_amdgcn_mfma_f64_16x16x4f64(-sel4(mc, kk), sel4(kcol, kk), H, 0, 0, 0);
     }
 
     // hand V_xx, V_x to the next knot
@@ -293,22 +340,26 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
 #pragma unroll
       for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
     } else {
-      // accumulator layout -> A-operand layout through LDS (a transpose)
-      if (j < 12) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) Vs[(4 * r + kk) * LD + j] = H[r];
-      }
+      // the accumulator (V or V^T) is the next A operand (V^T or V): what the next knot's kind expects; lanes j >= 12 hold leftovers that
+      // only reach rows 12..15 of T, which nobody reads (as in the symmetric kernels)
 #pragma unroll
       for (int kc = 0; kc < 3; ++kc) vxl[kc] = __shfl(vx, 4 * kc + kk);  // V_x[r] lives in lanes with j == r
-      __syncthreads();
 #pragma unroll
-      for (int kc = 0; kc < 3; ++kc) va[kc] = (j < 12) ? Vs[j * LD + 4 * kc + kk] : 0.0;
+      for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
     }
     m[0] = (double)m_s0; m[1] = (double)m_s1; m[2] = (double)m_s2;
     cx[0] = (double)cx_s0; cx[1] = (double)cx_s1; cx[2] = (double)cx_s2;
     gcj = (double)g_s;
     QKEEP(va[0]); QKEEP(vxl[2]);
     QSTAMP(7);  // V_xx MFMA, gain stores, hand-off
+  };
+  if constexpr (SYM) {
+    for (int i = n - 1; i >= 0; --i) knot(i, std::integral_constant<int, 0>());
+  } else {
+    for (int i = n - 1; i >= 0; i -= 2) {
+      knot(i, std::integral_constant<int, 1>());
+      if (i >= 1) knot(i - 1, std::integral_constant<int, 2>());
+    }
   }
 
 #ifdef QILQR_STAMPS

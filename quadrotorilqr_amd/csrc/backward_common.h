@@ -15,12 +15,22 @@ __device__ __forceinline__ double sel4(const double v[4], int kk) {
   const double lo = (kk & 1) ? v[1] : v[0], hi = (kk & 1) ? v[3] : v[2];
   return (kk & 2) ? hi : lo;
 }
-// 1/x to fp64 accuracy (not correctly rounded): hardware estimate + two Newton steps; half the
-// dependent depth of the IEEE division sequence, which matters on the per-knot serial chain
+// 1/x for the pivots of the unpivoted LDL^T: the hardware estimate (4.6e-8 relative) and two Newton steps (1.1e-16;
+// profiles/microbench/rcp_accuracy.hip): half the dependent depth of the IEEE division sequence.  ONE step (2.2e-15) was measured in round 5
+// (-DQILQR_RCP_NEWTON_STEPS=1): the second step is two dependent fp64 instructions behind each of a knot's four pivots, and without it a
+// launch takes 65.0 instead of 66.8 us per 100 knots, a configs[1] solve 4.66 instead of 4.75 ms (+ 1.8 %), with every solver-against-oracle
+// maximum of WHOLE solves unchanged (cost 1e-13, trajectory 1.7e-9 at 200 knots) -- but ONE backward pass at 200 knots lands 3.9e-9 of the
+// largest gain from the oracle's instead of 1e-9 (what a knot injects is carried to the pass's end almost undamped), past the bar
+// tests/test_gpu_parity.py holds that pass to.  Parity before 1.8 %: two steps stay.
+#ifndef QILQR_RCP_NEWTON_STEPS
+#define QILQR_RCP_NEWTON_STEPS 2
+#endif
 __device__ __forceinline__ double rcp_nr(double x) {
   double r = __builtin_amdgcn_rcp(x);
   r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+#if QILQR_RCP_NEWTON_STEPS >= 2
   r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+#endif
   return r;
 }
 // value of x in lane `src` (compile-time constant), broadcast to the wave
