@@ -1,7 +1,11 @@
 """Generates tests/golden/oracle_golden.npz from the CPU oracle (SELF-goldens).
 
-The reference cannot be built or imported in this image (Eigen/manif/protoc absent), so
-these vectors come from oracle/ilqr_oracle.c after it passed the reference's own
+Which goldens are what: oracle_golden.npz (this script) holds SELF-goldens -- the reference's C++ solver cannot be
+built in this image (Eigen / manif absent), so these vectors come from oracle/ilqr_oracle.c; reference_demo_inputs.npz
+(make_reference_fixture.py, beside this file) holds REFERENCE-DERIVED vectors -- computed by the reference's own Python,
+quadrotor_ilqr.py, imported in the build container (tests/test_reference_fixture.py).
+
+The vectors here come from oracle/ilqr_oracle.c after it passed the reference's own
 known-answer and finite-difference tests (tests/test_oracle_*.py) and the scipy
 expm/logm cross-checks.  They pin the oracle against regressions and give the GPU
 tests fixed inputs/outputs.  Run from the repo root:  python tests/golden/make_golden.py

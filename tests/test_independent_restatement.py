@@ -130,3 +130,40 @@ def test_rk4_solves_reproduce_the_oracle():
         assert out["n_bwd"] == ref["n_bwd"][b] and out["n_fwd"] == ref["n_fwd"][b]
         np.testing.assert_allclose(out["cost"], ref["cost"][b], rtol=1e-8)
         np.testing.assert_allclose(align_quaternion_signs(out["traj"], ref["traj"][b]), ref["traj"][b], atol=1e-6)
+
+
+def test_reference_recursion_drifts_at_long_horizons_in_the_second_restatement_too():
+    """ilqr.hh:132-133: V_xx = Q_xx - K^T Q_uu K is never symmetrised and amplifies its own rounding asymmetry knot by knot.
+    BASELINE.json configs[2] (200 knots) and configs[4] (500) are compared with the SYMMETRISED form of the same recursion
+    (orc_set_recursion) on the strength of that claim; it must not rest on the oracle alone.  Here the
+    second restatement (LU solves, no code shared with the oracle) runs one backward pass of the time-invariant hover problem
+    (model A, the configurations' weights and dt) in the reference form and in its own symmetrised form: the two agree to
+    1e-10 sixty knots from the horizon's end, part by > 1e-2 at 150 and by more than the gains' own size / 2 at 200, growing by a
+    steady factor per knot, while the symmetrised form has long settled at the stationary gain (|K| ~ 20)."""
+    m = pb.MODEL_A
+    N = 200
+    des = pb.hover_desired(N, pb.DT_DEMO, pb.hover_thrust(m))
+    K = {}
+    for rec in (0, 1):
+        s = ind.ILQR(ind.Model(m["mass_kg"], m["inertia"], m["arm_length_m"], m["torque_to_thrust_ratio_m"], m["g_mpss"]),
+                     pb.Q_DEMO, pb.R_DEMO, des, pb.DT_DEMO, dict(pb.OPTIONS_DEMO), recursion=rec)
+        K[rec] = np.array(s.backwards_pass(s.unpack(des))[1])
+    d = lambda back: np.abs(K[0][N - back] - K[1][N - back]).max()
+    assert d(50) < 1e-10 and d(60) < 1e-10, (d(50), d(60))
+    assert 1e-8 < d(100) < 1e-4, d(100)
+    assert d(150) > 1e-2, d(150)
+    assert d(200) > 1.0, d(200)
+    rate = (d(150) / d(60)) ** (1.0 / 90.0)
+    assert 1.15 < rate < 1.45, rate                      # ~1.3 per knot
+    stationary = np.abs(K[1][N - 100]).max()
+    assert 15.0 < stationary < 25.0
+    assert np.abs(K[1][0] - K[1][N - 100]).max() < 1e-6   # the symmetrised form has settled; the reference form has not:
+    assert np.abs(K[0][0] - K[1][N - 100]).max() > 1.0
+    # and the oracle's two forms tell the same story on the same pass
+    o = orc.OracleSolver(orc.model_params(**m), pb.Q_DEMO, pb.R_DEMO, des, pb.DT_DEMO, orc.options(**pb.OPTIONS_DEMO))
+    g0 = o.backwards_pass(des)[0]
+    o.set_recursion(1)
+    g1 = o.backwards_pass(des)[0]
+    assert np.abs(g0[N - 60] - g1[N - 60]).max() < 1e-10 and np.abs(g0[0] - g1[0]).max() > 1.0
+    K1 = g1[:, 4:].reshape(N, 12, 4).transpose(0, 2, 1)  # [k(4) | K 4x12 column-major] (ilqr.hh:43-46)
+    np.testing.assert_allclose(K1[0], K[1][0], atol=1e-8)
