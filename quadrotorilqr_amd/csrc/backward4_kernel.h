@@ -19,6 +19,15 @@ namespace qilqr {
 // own record loads shared the in-order memory counter with those stores: 78.7 -> 73.7 us).  Everything else as
 // k_backward2.
 // ---------------------------------------------------------------------------------------------
+// The two sums of the gradient recursion whose ORDER is part of the arithmetic, written with explicit fused multiply-adds (until round 6 they
+// were `a*b + c*d + ...` expressions and the order was the compiler's choice of contraction -- m[1] vxl[1] first, as it happened; the six-
+// wavefront form performs the same operations, bw4f_gradient_wave, and a backward pass no longer depends on the batch size).
+__device__ __forceinline__ double bw4_quarter_sum(const double (&m)[3], const double (&v)[3]) {  // rows kk, 4 + kk, 8 + kk of M^T V_x
+  return __builtin_fma(m[2], v[2], __builtin_fma(m[0], v[0], m[1] * v[1]));
+}
+__device__ __forceinline__ double bw4_chain4(const double (&a)[4], const double (&b)[4]) {  // K[:, j]^T Q_u; in lane 12: Q_u^T k
+  return __builtin_fma(a[3], b[3], __builtin_fma(a[2], b[2], __builtin_fma(a[1], b[1], a[0] * b[0])));
+}
 // acc += m * (vx of lane R of the caller's row of 16): one v_fmac_f64_dpp (the compiler keeps broadcast and
 // multiply-add apart).  vx must have been written at least two instructions earlier (DPP read hazard): it is
 // the previous knot's result here.
@@ -155,7 +164,7 @@ __device__ __forceinline__ void bw4_prog_post(int *prog, int k, int v, int lane)
   asm volatile("" ::: "memory");
   if (lane == 0) __hip_atomic_store(&prog[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-template <typename S, bool FREE = false>
+template <typename S, bool FREE = false, bool TWO = false>  // TWO: two block barriers per knot (the bw4f_* roles)
 __device__ __forceinline__ void bw4_loader_wave(double (&ring)[4][4][BW2_BUF], const RecLayout &L, const S *rec0, const S *rec1,
                                                 const S *rec2, const S *rec3, int n, int lane, int *prog = nullptr, int live = 0) {
   static_assert(BW2_BUF % 2 == 0 && BW2_REC == 128, "ring entries are written in aligned pairs, 64 of them per record slot");
@@ -246,6 +255,7 @@ __device__ __forceinline__ void bw4_loader_wave(double (&ring)[4][4][BW2_BUF], c
       }
     }
     __syncthreads();
+    if constexpr (TWO) __syncthreads();
   }
 }
 // M_w: the matrix recursion of one trajectory (ring / kf row w).  cuu: the lane's entry of C_uu = 2 R (+ mu on the diagonal,
@@ -522,7 +532,7 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
     QSB();
     // K^T Q_u of the previous knot: V_x = Q_x + K^T Q_u in every lane, and in lane 12 -- whose column is k and whose right-hand
     // side was Q_u -- the same sum is Q_u^T k (one sum for both; nobody reads the other lanes' Q_u^T k)
-    const double ktq = kp[0] * Qup[0] + kp[1] * Qup[1] + kp[2] * Qup[2] + kp[3] * Qup[3];
+    const double ktq = bw4_chain4(kp, Qup);
     const double vx = ghp + ktq;
     QSB();
     T = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1], m[1], T, 0, 0, 0);
@@ -548,7 +558,7 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
     // rows 0..7, so the register is final one product early; the order is part of the arithmetic: every build adds in it)
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
     QSB();
-    double part = m[0] * vxl[0] + m[1] * vxl[1] + m[2] * vxl[2];  // [Q_x ; Q_u] = [C_x ; C_u] + M^T V_x
+    double part = bw4_quarter_sum(m, vxl);  // [Q_x ; Q_u] = [C_x ; C_u] + M^T V_x
     QSB();
     H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
     QSB();
@@ -608,7 +618,7 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
     const sv2 w0 = {(S)kp[0], (S)kp[1]}, w1 = {(S)kp[2], (S)kp[3]};
     *st0 = w0;
     *st1 = w1;
-    QuTk += kp[0] * Qup[0] + kp[1] * Qup[1] + kp[2] * Qup[2] + kp[3] * Qup[3];
+    QuTk += bw4_chain4(kp, Qup);
   }
 #ifdef QILQR_STAMPS
   if (lane == 0 && stamps_out)
@@ -616,6 +626,272 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
 #endif
   if (dead) bw4_prog_post(prog, 5, 1, lane);
   return bcast_lane(QuTk, 12);
+}
+
+// ---- Round 6: the six-wavefront form with the FACTORISATION IN THE GRADIENT WAVEFRONT (bw4f_*; what k_backward4<S, WAVES, false>
+// runs; the roles above stay for the diagnostics build's k_solve4).
+// In the form above every one of a matrix wavefront's 64 lanes computes the same LDL^T of Q_uu -- 37 of its 52 fp64 vector instructions
+// and ten broadcasts per knot, four times per block -- and beyond 4096 trajectories, with four blocks on a CU, a SIMD is bound by what
+// its wavefronts ISSUE.  Q_uu = C_uu + J_u^T V_xx J_u needs nothing of the knot but the previous knot's V_xx, and of that only the
+// 4 x 4 block of rows and columns 8..11 (J_u is zero above row 8): the matrix wavefront leaves that block in LDS behind its V_xx product
+// (kw), the gradient wavefront -- a row of 16 lanes per trajectory, lane 4 a + b of a row for Q_uu[a][b] -- forms Q_uu by 20 multiply-adds,
+// factors all four trajectories' in one instruction stream and hands ten numbers back (behind K in kf), while the matrix wavefronts are in their
+// T and H products; they wait for it at a second block barrier per knot, in front of the substitution.
+// SAME BITS as the accumulator tile's rows 12..15: v_mfma_f64_16x16x4_f64 is, per element, the chain of four fused multiply-adds
+// k = 0..3 on the accumulator (profiles/microbench/mfma_arith.hip: 0 of 2^20 elements differ, against 45 % for any other order), the
+// products with J_u's zero rows add exact zeros, so Q_uu[a][b] = fma-chain_r(J_u[8+r][a], T[8+r][12+b]; C_uu[a][b]) with
+// T[8+r][12+b] = fma-chain_s(V[8+s][8+r], J_u[8+s][b]; 0) is what the tile holds, to the last bit (a V_xx with infinities aside: 0 x inf
+// in the rows the chain skips).  And the same bits as the FUSED form (bw4_fused_wave, up to 4096 trajectories): H is accumulated in
+// its order (kc = 2, 0, 1), M^T V_x as its three multiply-adds per quarter and (p0 + p1) + (p2 + p3), K^T Q_u as its chain -- a
+// backward pass no longer depends on the batch size (tests/test_gpu_parity.py::test_backward_pass_bits_do_not_depend_on_the_batch_size).
+// Every role executes exactly 1 + 2 n block barriers: interval i = [A_i: W(i+1) and K(i+1) are in LDS | G factors Q_uu(i); M forms T, H,
+// gathers | B_i: the factors are in LDS | M substitutes, stores, V_xx(i), W(i); G's gradient step of knot i+1 | A_(i-1)].
+// m * (vx of lane R of the caller's row): the first term of a chain.  gfx950 has no DPP form of v_mul_f64; a multiply-add onto -0.0 is the
+// product to the last bit, the sign of a zero product included (x + -0.0 = x for every x, and -0.0 + -0.0 = -0.0).
+template <int R>
+__device__ __forceinline__ double bw4_mul_step(double m, double vx) { return bw4_dot_step<R>(-0.0, m, vx); }
+template <typename S>
+__device__ __forceinline__ double bw4f_gradient_wave(double (&ring)[4][4][BW2_BUF], double (&kf)[4][2][80], double (&kw)[4][16],
+                                                     const RecLayout &L, S *gains, S *dump4, bool grun,
+                                                     double cuu_ab, int n, int lane) {
+  typedef typename GA<S>::v2 sv2;
+  typedef typename GA<S>::ptr2 gptr2;
+  const int g = lane >> 4, j = lane & 15;
+  const double *mp[12];
+#pragma unroll
+  for (int r = 0; r < 12; ++r) {
+    const int src = m_source_tab(r, j);
+    mp[r] = &ring[g][0][(src >= 0) ? src : BW2_REC + (-1 - src)];
+  }
+  const double *gp = &ring[g][0][L.off_g + j];
+  const bool kowner = grun && (j == 0);
+  // (one pointer, the second pair's distance and the knot stride as 32-bit lane values: three registers fewer than two pointers and a
+  // 64-bit stride, in a wavefront that has 80)
+  gptr2 kdst = (gptr2)(kowner ? gains + knot_elem<true>(n - 1, 0, 52) : dump4);
+  const int kd1 = kowner ? (int)((knot_elem<true>(0, 2, 52) - knot_elem<true>(0, 0, 52)) / 2) : 1;
+  const int kst = kowner ? (int)((knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2) : 0;
+  double vx = 0.0;  // V_x[j] (lanes j < 12)
+  double QuTk = 0.0;
+  __syncthreads();                               // rings, constant tables, W = 0
+  // J_u's rows 8..11 as this lane needs them: column b for T, column a for Q_uu (the constant table behind ring slot 0; read again at
+  // every knot -- eight registers that stay are eight the gradient step does not have: 80 per lane at four blocks per CU)
+  const int qa = j >> 2, qb = j & 3;
+  const double *bpb = &ring[g][0][BW2_REC + CTAB_BU + 8 * 4 + qb], *bpa = &ring[g][0][BW2_REC + CTAB_BU + 8 * 4 + qa];
+  const double *wq = &kw[g][0];
+  // the factors go where the matrix wavefront used to leave them: behind K in the hand-off buffer of the knot's parity
+  auto factor_step = [&](int par) {
+    double wv[16], bub[4], bua[4];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) wv[e] = wq[e];   // [4 r + s] = V[8 + s][8 + r], the row's sixteen lanes read the same words
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bub[r] = bpb[4 * r]; bua[r] = bpa[4 * r]; }
+    double q = cuu_ab;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double t = 0.0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) t = __builtin_fma(wv[4 * r + s], bub[s], t);  // T[8 + r][12 + b]: the kc = 2 product of T = V M
+      q = __builtin_fma(bua[r], t, q);                                         // H[12 + a][12 + b]: the kc = 2 product of H
+    }
+    double Quu[16];
+    Quu[0] = row_bcast<0>(q);
+    Quu[4] = row_bcast<4>(q); Quu[5] = row_bcast<5>(q);
+    Quu[8] = row_bcast<8>(q); Quu[9] = row_bcast<9>(q); Quu[10] = row_bcast<10>(q);
+    Quu[12] = row_bcast<12>(q); Quu[13] = row_bcast<13>(q); Quu[14] = row_bcast<14>(q); Quu[15] = row_bcast<15>(q);
+    Quu[1] = Quu[2] = Quu[3] = Quu[6] = Quu[7] = Quu[11] = 0.0;
+    const Ldlt4 f = ldlt4_factor(Quu);  // (ilqr.hh:126; unpivoted: see ldlt4_factor)
+    if (j == 0) {
+      typedef double dv2 __attribute__((ext_vector_type(2)));
+      dv2 *o = reinterpret_cast<dv2 *>(&kf[g][par][64]);
+      o[0] = dv2{f.l10, f.l20}; o[1] = dv2{f.l30, f.l21}; o[2] = dv2{f.l31, f.l32}; o[3] = dv2{f.i0, f.i1}; o[4] = dv2{f.i2, f.i3};
+    }
+  };
+  auto gradient_slot = [&](int q, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const double *f = kf[g][q & 1];
+    double m[12];
+#pragma unroll
+    for (int r = 0; r < 12; ++r) m[r] = mp[r][SLOT * BW2_BUF];
+    const double gcj = gp[SLOT * BW2_BUF];
+    asm volatile("" ::: "memory");
+    const double c0 = f[4 * j], c1 = f[4 * j + 1], c2 = f[4 * j + 2], c3 = f[4 * j + 3];  // K[:, j]
+    const Ldlt4 f4 = {f[64], f[65], f[66], f[67], f[68], f[69], f[70], f[71], f[72], f[73]};  // (this wavefront's own, of one interval ago)
+    asm volatile("" ::: "memory");
+    // [Q_x ; Q_u][j] = [C_x ; C_u][j] + sum_r M[r][j] V_x[r] in the fused form's order: the quarter kk sums its three rows as one lane of
+    // bw4_fused_wave does -- the product of row 4 + kk, then multiply-adds of rows kk and 8 + kk (bw4_quarter_sum) --, then its two
+    // butterflies: (p0 + p1) + (p2 + p3)
+    double p0 = bw4_mul_step<4>(m[4], vx), p1 = bw4_mul_step<5>(m[5], vx), p2 = bw4_mul_step<6>(m[6], vx), p3 = bw4_mul_step<7>(m[7], vx);
+    p0 = bw4_dot_step<0>(p0, m[0], vx); p1 = bw4_dot_step<1>(p1, m[1], vx); p2 = bw4_dot_step<2>(p2, m[2], vx); p3 = bw4_dot_step<3>(p3, m[3], vx);
+    p0 = bw4_dot_step<8>(p0, m[8], vx); p1 = bw4_dot_step<9>(p1, m[9], vx); p2 = bw4_dot_step<10>(p2, m[10], vx); p3 = bw4_dot_step<11>(p3, m[11], vx);
+    const double ghat = gcj + ((p0 + p1) + (p2 + p3));
+    const double Qu0 = row_bcast<12>(ghat), Qu1 = row_bcast<13>(ghat), Qu2 = row_bcast<14>(ghat),
+                 Qu3 = row_bcast<15>(ghat);
+    // V_x = Q_x + K^T Q_u, the sum as the fused form's chain: k0 Q0, then three multiply-adds
+    const double ktq = __builtin_fma(c3, Qu3, __builtin_fma(c2, Qu2, __builtin_fma(c1, Qu1, c0 * Qu0)));
+    vx = ghat + ktq;  // the recurrence ends here
+    double kff[4];
+    ldlt4_solve_neg(f4, Qu0, Qu1, Qu2, Qu3, kff);
+    const double k0 = kff[0], k1 = kff[1], k2 = kff[2], k3 = kff[3];  // feed-forward (ilqr.hh:128)
+    const sv2 w0 = {(S)k0, (S)k1}, w1 = {(S)k2, (S)k3};
+    kdst[0] = w0;
+    kdst[kd1] = w1;
+    kdst -= kst;
+    QuTk += __builtin_fma(k3, Qu3, __builtin_fma(k2, Qu2, __builtin_fma(k1, Qu1, k0 * Qu0)));  // (lane 12's sum in the fused form)
+  };
+  auto gradient_step = [&](int q) {
+    switch (q & 3) {
+      case 0: gradient_slot(q, std::integral_constant<int, 0>()); break;
+      case 1: gradient_slot(q, std::integral_constant<int, 1>()); break;
+      case 2: gradient_slot(q, std::integral_constant<int, 2>()); break;
+      default: gradient_slot(q, std::integral_constant<int, 3>()); break;
+    }
+  };
+#ifndef QILQR_BW4F_GPRIO
+#define QILQR_BW4F_GPRIO 0
+#endif
+  if (QILQR_BW4F_GPRIO == 1) __builtin_amdgcn_s_setprio(3);
+  for (int i = n - 1; i >= 0; --i) {
+    if (QILQR_BW4F_GPRIO == 2) __builtin_amdgcn_s_setprio(3);
+    factor_step(i & 1);   // Q_uu(i) from W(i + 1)
+    if (QILQR_BW4F_GPRIO == 2) __builtin_amdgcn_s_setprio(0);
+    __syncthreads();      // B_i: the matrix wavefronts take the factors
+    if (i + 1 <= n - 1) gradient_step(i + 1);
+    __syncthreads();      // A_(i-1)
+  }
+  gradient_step(0);
+  return QuTk;
+}
+// M_w in that form: T, H (accumulated in the fused form's order), the row gather; the factors from G; the substitution, the gain stores, K
+// for G, V_xx, and the block of V_xx that the next Q_uu is made of.
+template <typename S, bool UNROLL = false>
+__device__ __forceinline__ void bw4f_matrix_wave(double (&ring)[4][4][BW2_BUF], double (&kf)[4][2][80], double (&kw)[4][16],
+                                                 const RecLayout &L, int w, bool run, S *gains, S *dump4, double cuu,
+                                                 int n, int lane, unsigned long long *stamps_out) {
+  typedef typename GA<S>::v2 sv2;
+  typedef typename GA<S>::ptr2 gptr2;
+  typedef double dv2 __attribute__((ext_vector_type(2)));
+  __builtin_amdgcn_s_setprio(3);
+  const int j = lane & 15, kk = lane >> 4;
+  int off[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int src;
+    if (k < 3) src = m_source_tab(4 * k + kk, j);
+    else src = (j < 12) ? cxx_source_tab(L, 4 * (k - 3) + kk, j) : -1 - CTAB_ZERO;
+    off[k] = (src >= 0) ? src : BW2_REC + (-1 - src);
+  }
+  const bool gowner = run && (kk == 0 && j < 12);
+  const int ge0 = 4 + 4 * j;
+  gptr2 gdst0 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0, 52) : dump4);
+  gptr2 gdst1 = (gptr2)(gowner ? gains + knot_elem<true>(n - 1, ge0 + 2, 52) : dump4 + 2);
+  const long gstep = gowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
+  double va[3] = {0.0, 0.0, 0.0};  // V_xx[j][4 kc + kk]  (A operand)
+  // W = rows / columns 8..11 of the accumulator tile: lane (j = 8 + r, kk = s) holds V[8 + s][8 + r] in register 2 -> kw[w][4 r + s]
+  const bool wowner = (j >= 8 && j < 12);
+  double *const wdst = &kw[w][wowner ? 4 * (j - 8) + kk : 0];
+  if (wowner) *wdst = 0.0;         // V_xx = 0 behind the last knot: Q_uu(n - 1) = C_uu
+  __syncthreads();                 // rings and constant tables are filled
+  if (!run) {
+    for (int i = n - 1; i >= 0; --i) { __syncthreads(); __syncthreads(); }
+    return;
+  }
+  double m[3], cx[3];
+  {
+    const double *buf = ring[w][(n - 1) & 3];
+    m[0] = buf[off[0]]; m[1] = buf[off[1]]; m[2] = buf[off[2]];
+    cx[0] = buf[off[3]]; cx[1] = buf[off[4]]; cx[2] = buf[off[5]];
+  }
+  asm volatile(".p2align 6");
+#ifdef QILQR_STAMPS
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev, real0;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real0)::"memory");
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+  const double *rp[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) rp[k] = &ring[w][0][off[k]];
+  double *const kfw = &kf[w][0][0];
+  auto knot = [&](auto ns, auto par, double (&mc)[3], double (&cc)[3], double (&mn)[3], double (&cn)[3]) {
+    const int so = (int)ns * BW2_BUF;
+    mn[0] = rp[0][so]; mn[1] = rp[1][so]; mn[2] = rp[2][so];
+    cn[0] = rp[3][so]; cn[1] = rp[4][so]; cn[2] = rp[5][so];
+    const d4 T = bw_tile_T(va, mc);
+    QKEEP(T[0]); QKEEP(T[3]);
+    QSTAMP(0);  // ring reads issued, T = V M
+    d4 H = {cc[0], cc[1], cc[2], cuu};
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(mc[2], T[2], H, 0, 0, 0);  // (the fused form's order: part of the arithmetic)
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(mc[0], T[0], H, 0, 0, 0);
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(mc[1], T[1], H, 0, 0, 0);
+    QKEEP(H[0]); QKEEP(H[3]);
+    QSTAMP(1);  // H = C + M^T T
+    double col[4];
+    gather_rows(H[3], col);
+    QKEEP(col[0]); QKEEP(col[3]);
+    QSTAMP(2);  // row gather
+    double *f = kfw + (int)par * 80;
+    __syncthreads();  // B: G has left the factors of this knot's Q_uu behind K's place in the hand-off buffer
+    const dv2 *fq = reinterpret_cast<const dv2 *>(f + 64);
+    const dv2 f0 = fq[0], f1 = fq[1], f2 = fq[2], f3 = fq[3], f4v = fq[4];
+    const Ldlt4 f4 = {f0.x, f0.y, f1.x, f1.y, f2.x, f2.y, f3.x, f3.y, f4v.x, f4v.y};
+    QSTAMP(3);  // barrier, factors
+    double kcol[4];
+    ldlt4_solve_neg(f4, col[0], col[1], col[2], col[3], kcol);  // K[:, j] (ilqr.hh:127)
+    QKEEP(kcol[0]); QKEEP(kcol[3]);
+    QSTAMP(4);  // substitution
+    {
+      const sv2 w0 = {(S)kcol[0], (S)kcol[1]}, w1 = {(S)kcol[2], (S)kcol[3]};
+      *gdst0 = w0;
+      *gdst1 = w1;
+      gdst0 -= gstep;
+      gdst1 -= gstep;
+    }
+    // hand K to G (the four lanes of a column hold the same K[:, j]: same address, same data)
+    f[4 * j] = kcol[0]; f[4 * j + 1] = kcol[1]; f[4 * j + 2] = kcol[2]; f[4 * j + 3] = kcol[3];
+    QSTAMP(5);  // gain stores, hand-off to G
+    // V_xx = Q_xx + Q_xu K: A[j][kk] = Q_xu[j][kk] = H[12 + kk][j] is accumulator register 3
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(H[3], sel4(kcol, kk), H, 0, 0, 0);
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) va[kc] = H[kc];
+    if (wowner) *wdst = H[2];
+    QKEEP(va[0]); QKEEP(mn[2]);
+    QSTAMP(6);  // V_xx MFMA, W, next operands
+    __syncthreads();  // A
+    QSTAMP(7);  // barrier
+  };
+  double mn[3], cn[3];
+  int i = n - 1;
+  if constexpr (UNROLL) {
+    for (; i >= 0 && (i & 3) != 3; --i) {
+      knot((i > 0 ? i - 1 : 0) & 3, i & 1, m, cx, mn, cn);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { m[k] = mn[k]; cx[k] = cn[k]; }
+    }
+    typedef std::integral_constant<int, 0> C0;
+    typedef std::integral_constant<int, 1> C1;
+    typedef std::integral_constant<int, 2> C2;
+    typedef std::integral_constant<int, 3> C3;
+    for (; i >= 3; i -= 4) {
+      knot(C2(), C1(), m, cx, mn, cn);    // knot 4 q + 3 (slot 3); next operands from slot 2
+      knot(C1(), C0(), mn, cn, m, cx);    // knot 4 q + 2
+      knot(C0(), C1(), m, cx, mn, cn);    // knot 4 q + 1
+      knot(C3(), C0(), mn, cn, m, cx);    // knot 4 q; the next pass starts in slot 3 (after knot 0: read and never used)
+    }
+  } else {
+    for (; i >= 0; --i) {
+      knot((i > 0 ? i - 1 : 0) & 3, i & 1, m, cx, mn, cn);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { m[k] = mn[k]; cx[k] = cn[k]; }
+    }
+  }
+#ifdef QILQR_STAMPS
+  {
+    unsigned long long real1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(real1)::"memory");
+    stamp_sum[3] = (real1 - real0) & 0xfffffull;
+  }
+  if (lane == 0 && stamps_out)
+    for (int k = 0; k < 8; ++k) stamps_out[k] = stamp_sum[k];
+#endif
 }
 
 // WAVES: register budget in waves per SIMD.  5 (90 registers, nothing spilled): three blocks per CU, the fastest single
@@ -630,7 +906,9 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
   __shared__ int s_run[4], s_cur[4], s_iters[4], s_act[4];               \
   __shared__ double s_cost[4];                                           \
   __shared__ __attribute__((aligned(16))) double ring[4][4][BW2_BUF];    \
-  __shared__ double kf[4][2][80];                                        \
+  __shared__ __attribute__((aligned(16))) double kf[4][2][80];           \
+  __shared__ __attribute__((aligned(16))) double kw[4][16];              \
+  __shared__ double s_mu[4];                                             \
   __shared__ int prog[24];
 #define QILQR_CAT_(a, b) a##b
 #define QILQR_CAT(a, b) QILQR_CAT_(a, b)

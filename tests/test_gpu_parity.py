@@ -264,7 +264,11 @@ def test_two_wave_backward_matches_single_wave():
         four = capi.from_config(cfg, precision=prec, force_general=4)
         g4, t4 = four.backwards_pass(trajs)
         np.testing.assert_allclose(t4, t2, rtol=1e-11, atol=1e-300)
-        np.testing.assert_allclose(g4, g2, rtol=1e-10 if prec == "f64" else 1e-6, atol=(1e-12 if prec == "f64" else 1e-6) * max(np.abs(g2).max(), 1e-300))
+        # (since round 6 the six-wavefront form performs the FUSED form's arithmetic, not k_backward2's: equal to the fused form bit for
+        # bit, and as far from k_backward2 as the fused form is)
+        np.testing.assert_array_equal(g4, g5)
+        np.testing.assert_array_equal(t4, t5)
+        np.testing.assert_allclose(g4, g2, rtol=1e-9 if prec == "f64" else 1e-5, atol=(1e-11 if prec == "f64" else 1e-5) * max(np.abs(g2).max(), 1e-300))
         np.testing.assert_allclose(t4, t1, rtol=1e-11 if prec == "f64" else 1e-6, atol=1e-300)
         o4 = four.solve_batch(cfg["init"])
         if prec == "f64":
@@ -272,6 +276,51 @@ def test_two_wave_backward_matches_single_wave():
             np.testing.assert_array_equal(o4["iters"], o2["iters"])
             np.testing.assert_array_equal(o4["n_fwd"], o2["n_fwd"])
         np.testing.assert_allclose(o4["cost"], o2["cost"], rtol=1e-9 if prec == "f64" else 1e-4)
+
+
+def test_backward_pass_bits_do_not_depend_on_the_batch_size():
+    """Round 6: the six-wavefront k_backward4 (what a call with more than 4096 trajectories in flight takes; forced
+    here at every size with force_general = 4) and the fused form (up to 4096; force_general = 5) perform the SAME arithmetic: H accumulated
+    in one order, M^T V_x as three multiply-adds per quarter and (p0 + p1) + (p2 + p3), K^T Q_u as one chain, and Q_uu -- which the
+    gradient wavefront of the six-wavefront form now builds and factors itself from the previous knot's V_xx -- the very bits of the
+    accumulator tile's rows 12..15 (profiles/microbench/mfma_arith.hip).  Gains and expected-reduction terms are compared BIT FOR BIT:
+    both register budgets of the six-wavefront form (batches on either side of 4096), horizons 1..4 (ring start-up, loop remainders),
+    dense symmetric weights, the mixed mode, Levenberg-Marquardt mu on the diagonal of Q_uu, and whole solves on one rollout kernel."""
+    r = np.random.default_rng(21)
+    Qd = r.uniform(-1, 1, (12, 12)); Qd = Qd @ Qd.T + 12 * np.eye(12)
+    Rd = r.uniform(-0.3, 0.3, (4, 4)); Rd = Rd + Rd.T + 2 * np.eye(4)
+    for B, n, dense, prec in [(33, 60, False, "f64"), (5, 1, False, "f64"), (7, 2, False, "f64"), (9, 3, False, "f64"), (6, 4, True, "f64"),
+                              (20, 37, True, "f64"), (16, 50, False, "f32"), (4100, 21, False, "f64"), (4099, 10, True, "f64"),
+                              (64, 100, False, "f64"), (12, 150, False, "f64")]:
+        cfg = pb.config2(B=B, N=n, seed=3 + n)
+        if dense:
+            cfg["Q"], cfg["R"] = Qd, Rd
+        six = capi.from_config(cfg, precision=prec, force_general=4)
+        fused = capi.from_config(cfg, precision=prec, force_general=5)
+        trajs = six.forward_sim(cfg["init"], np.zeros((B, n, 52)), 1.0)
+        g6, t6 = six.backwards_pass(trajs)
+        g5, t5 = fused.backwards_pass(trajs)
+        assert np.isfinite(g6).all() and (n < 3 or np.abs(g6).max() > 0)  # (the last knot's gains are zero: V = 0 behind it)
+        np.testing.assert_array_equal(t6, t5, err_msg=f"terms B={B} n={n} dense={dense} {prec}")
+        np.testing.assert_array_equal(g6, g5, err_msg=f"gains B={B} n={n} dense={dense} {prec}")
+    # the automatic choice on either side of 4096: the first 64 of 4100 problems as part of that batch and alone
+    cfg = pb.config2(B=4100, N=30, seed=8)
+    trajs = capi.from_config(cfg).forward_sim(cfg["init"], np.zeros((4100, 30, 52)), 1.0)
+    gw, tw = capi.from_config(cfg).backwards_pass(trajs)
+    gs, ts = capi.from_config(cfg).backwards_pass(trajs[:64])
+    np.testing.assert_array_equal(gw[:64], gs)
+    np.testing.assert_array_equal(tw[:64], ts)
+    # whole solves, one rollout kernel (k_rollout16 forced: single_wave_rollout = 3), with restarts (mu on the diagonal of Q_uu)
+    cfg = pb.config2(B=96, N=40, seed=9)
+    cfg["options"] = dict(cfg["options"], ls_max_iters=1)
+    outs = []
+    for fg in (4, 5):
+        s = capi.from_config(cfg, force_general=fg, single_wave_rollout=3)
+        s.set_regularisation(1.0, 4.0, 1e6)
+        outs.append(s.solve_batch(cfg["init"]))
+    assert (outs[0]["n_bwd"] > outs[0]["iters"] + 1).any()  # some problem restarted
+    for k in ("traj", "cost", "status", "iters", "n_bwd", "n_fwd"):
+        np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
 
 
 def test_sub_batches_on_their_own_streams_give_identical_results():
