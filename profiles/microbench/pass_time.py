@@ -20,7 +20,10 @@ for name in sys.argv[2:]:
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     m.LIB_PATH = path
-    s = m.from_config(cfg, profile=2, force_general=4)
+    fg = {"gfac": 7, "mfac": 8, "fused": 5}.get(name, 4)
+    path = path if name not in ("gfac", "mfac", "fused") else os.path.join(ROOT, "quadrotorilqr_amd", "lib", "libquadrotor_ilqr.so")
+    m.LIB_PATH = path
+    s = m.from_config(cfg, profile=2, force_general=fg)
     for _ in range(2):
         s.backwards_pass(cfg["init"])
     s.profile_reset()

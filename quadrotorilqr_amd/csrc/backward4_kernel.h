@@ -36,6 +36,10 @@ __device__ __forceinline__ double bw4_dot_step(double acc, double m, double vx) 
   asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(vx), "v"(m), "n"(R));
   return acc;
 }
+// m * (vx of lane R of the caller's row): the first term of a chain.  gfx950 has no DPP form of v_mul_f64; a multiply-add onto -0.0 is the
+// product to the last bit, the sign of a zero product included (x + -0.0 = x for every x, and -0.0 + -0.0 = -0.0).
+template <int R>
+__device__ __forceinline__ double bw4_mul_step(double m, double vx) { return bw4_dot_step<R>(-0.0, m, vx); }
 // ---- the three roles of the backward pass over FOUR trajectories per block (k_backward4 and the persistent k_solve4).
 // LDS: ring[trajectory][slot] = knot record followed by the constant operand table; kf[trajectory][parity] = K and the
 // LDL^T factors handed from a matrix wave to the gradient wave.  Every role executes exactly 1 + n block barriers.
@@ -93,19 +97,19 @@ __device__ __forceinline__ double bw4_gradient_wave(double (&ring)[4][4][BW2_BUF
     const double l10 = f[64], l20 = f[65], l30 = f[66], l21 = f[67], l31 = f[68], l32 = f[69], i0 = f[70],
                  i1 = f[71], i2 = f[72], i3 = f[73];
     asm volatile("" ::: "memory");
-    // [Q_x ; Q_u][j] = [C_x ; C_u][j] + sum_r M[r][j] V_x[r], three partial sums of four rows.  (Not the
-    // summation order of k_backward / k_backward2 -- rows kk, 4 + kk, 8 + kk chained, then a butterfly: that
-    // order was tried here for bit-identical results across batch sizes, costs 3% and still differs in the
-    // last bit elsewhere.  Results agree to ~1e-15 relative; the tests state it.)
-    double p0 = 0.0, p1 = 0.0, p2 = 0.0;
-    p0 = bw4_dot_step<0>(p0, m[0], vx); p1 = bw4_dot_step<4>(p1, m[4], vx); p2 = bw4_dot_step<8>(p2, m[8], vx);
-    p0 = bw4_dot_step<1>(p0, m[1], vx); p1 = bw4_dot_step<5>(p1, m[5], vx); p2 = bw4_dot_step<9>(p2, m[9], vx);
-    p0 = bw4_dot_step<2>(p0, m[2], vx); p1 = bw4_dot_step<6>(p1, m[6], vx); p2 = bw4_dot_step<10>(p2, m[10], vx);
-    p0 = bw4_dot_step<3>(p0, m[3], vx); p1 = bw4_dot_step<7>(p1, m[7], vx); p2 = bw4_dot_step<11>(p2, m[11], vx);
-    const double ghat = gcj + ((p0 + p1) + p2);
+    // [Q_x ; Q_u][j] = [C_x ; C_u][j] + sum_r M[r][j] V_x[r] in the FUSED form's order (round 6: a backward pass's bits do not depend on
+    // the batch size): the quarter kk sums its three rows as one lane of bw4_fused_wave does -- the product of row 4 + kk, then
+    // multiply-adds of rows kk and 8 + kk (bw4_quarter_sum) --, then its two butterflies: (p0 + p1) + (p2 + p3).  (Until round 5: three
+    // chains of four rows; the fused order had been tried in round 3 and dropped because the forms still differed elsewhere -- in the
+    // order H is accumulated, as it turned out.)
+    double p0 = bw4_mul_step<4>(m[4], vx), p1 = bw4_mul_step<5>(m[5], vx), p2 = bw4_mul_step<6>(m[6], vx), p3 = bw4_mul_step<7>(m[7], vx);
+    p0 = bw4_dot_step<0>(p0, m[0], vx); p1 = bw4_dot_step<1>(p1, m[1], vx); p2 = bw4_dot_step<2>(p2, m[2], vx); p3 = bw4_dot_step<3>(p3, m[3], vx);
+    p0 = bw4_dot_step<8>(p0, m[8], vx); p1 = bw4_dot_step<9>(p1, m[9], vx); p2 = bw4_dot_step<10>(p2, m[10], vx); p3 = bw4_dot_step<11>(p3, m[11], vx);
+    const double ghat = gcj + ((p0 + p1) + (p2 + p3));
     const double Qu0 = row_bcast<12>(ghat), Qu1 = row_bcast<13>(ghat), Qu2 = row_bcast<14>(ghat),
                  Qu3 = row_bcast<15>(ghat);
-    vx = ghat + ((c0 * Qu0 + c1 * Qu1) + (c2 * Qu2 + c3 * Qu3));  // V_x = Q_x + K^T Q_u: the recurrence ends here
+    // V_x = Q_x + K^T Q_u, the sum as the fused form's chain (bw4_chain4): the recurrence ends here
+    vx = ghat + __builtin_fma(c3, Qu3, __builtin_fma(c2, Qu2, __builtin_fma(c1, Qu1, c0 * Qu0)));
     double kff[4];
     ldlt4_solve_neg(Ldlt4{l10, l20, l30, l21, l31, l32, i0, i1, i2, i3}, Qu0, Qu1, Qu2, Qu3, kff);
     const double k0 = kff[0], k1 = kff[1], k2 = kff[2], k3 = kff[3];  // feed-forward (ilqr.hh:128)
@@ -114,7 +118,7 @@ __device__ __forceinline__ double bw4_gradient_wave(double (&ring)[4][4][BW2_BUF
     *kdst1 = w1;
     kdst0 -= kst;
     kdst1 -= kst;
-    QuTk += Qu0 * k0 + Qu1 * k1 + Qu2 * k2 + Qu3 * k3;
+    QuTk += __builtin_fma(k3, Qu3, __builtin_fma(k2, Qu2, __builtin_fma(k1, Qu1, k0 * Qu0)));  // (lane 12's sum in the fused form)
   };
   auto gradient_step = [&](int q) {
     switch (q & 3) {
@@ -319,7 +323,7 @@ __device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], d
     const d4 T = bw_tile_T(va, mc);
     QKEEP(T[0]); QKEEP(T[3]);
     QSTAMP(0);  // ring reads issued, T = V M
-    d4 H = bw_tile_H(mc, T, cc, cuu);
+    d4 H = bw_tile_H201(mc, T, cc, cuu);
     QKEEP(H[0]); QKEEP(H[3]);
     QSTAMP(1);  // H = C + M^T T
     double Quu[16], Qu_unused[4], col[4];
@@ -397,7 +401,7 @@ __device__ __forceinline__ void bw4_matrix_wave(double (&ring)[4][4][BW2_BUF], d
       const d4 T = bw_tile_T(va, m);
       QKEEP(T[0]); QKEEP(T[3]);
       QSTAMP(0);  // ring reads issued, T = V M
-      d4 H = bw_tile_H(m, T, cx, cuu);
+      d4 H = bw_tile_H201(m, T, cx, cuu);
       QKEEP(H[0]); QKEEP(H[3]);
       QSTAMP(1);  // H = C + M^T T
       double Quu[16], Qu_unused[4], col[4];
@@ -646,10 +650,6 @@ __device__ __forceinline__ double bw4_fused_wave(double (&ring)[4][4][BW2_BUF], 
 // backward pass no longer depends on the batch size (tests/test_gpu_parity.py::test_backward_pass_bits_do_not_depend_on_the_batch_size).
 // Every role executes exactly 1 + 2 n block barriers: interval i = [A_i: W(i+1) and K(i+1) are in LDS | G factors Q_uu(i); M forms T, H,
 // gathers | B_i: the factors are in LDS | M substitutes, stores, V_xx(i), W(i); G's gradient step of knot i+1 | A_(i-1)].
-// m * (vx of lane R of the caller's row): the first term of a chain.  gfx950 has no DPP form of v_mul_f64; a multiply-add onto -0.0 is the
-// product to the last bit, the sign of a zero product included (x + -0.0 = x for every x, and -0.0 + -0.0 = -0.0).
-template <int R>
-__device__ __forceinline__ double bw4_mul_step(double m, double vx) { return bw4_dot_step<R>(-0.0, m, vx); }
 template <typename S>
 __device__ __forceinline__ double bw4f_gradient_wave(double (&ring)[4][4][BW2_BUF], double (&kf)[4][2][80], double (&kw)[4][16],
                                                      const RecLayout &L, S *gains, S *dump4, bool grun,
@@ -746,14 +746,12 @@ __device__ __forceinline__ double bw4f_gradient_wave(double (&ring)[4][4][BW2_BU
       default: gradient_slot(q, std::integral_constant<int, 3>()); break;
     }
   };
-#ifndef QILQR_BW4F_GPRIO
-#define QILQR_BW4F_GPRIO 0
-#endif
-  if (QILQR_BW4F_GPRIO == 1) __builtin_amdgcn_s_setprio(3);
+  // The gradient wavefront is on its block's critical path twice per knot (the matrix wavefronts wait for its factors, then for its gradient
+  // step): it issues at the matrix wavefronts' priority.  At the default priority it waits behind the matrix wavefronts of the OTHER blocks
+  // on its SIMD while its own block's sit at the barrier: 3615 against 3515 us per launch at B = 65536, 520 / 484 at 8192.
+  __builtin_amdgcn_s_setprio(3);
   for (int i = n - 1; i >= 0; --i) {
-    if (QILQR_BW4F_GPRIO == 2) __builtin_amdgcn_s_setprio(3);
     factor_step(i & 1);   // Q_uu(i) from W(i + 1)
-    if (QILQR_BW4F_GPRIO == 2) __builtin_amdgcn_s_setprio(0);
     __syncthreads();      // B_i: the matrix wavefronts take the factors
     if (i + 1 <= n - 1) gradient_step(i + 1);
     __syncthreads();      // A_(i-1)
@@ -818,10 +816,7 @@ __device__ __forceinline__ void bw4f_matrix_wave(double (&ring)[4][4][BW2_BUF], 
     const d4 T = bw_tile_T(va, mc);
     QKEEP(T[0]); QKEEP(T[3]);
     QSTAMP(0);  // ring reads issued, T = V M
-    d4 H = {cc[0], cc[1], cc[2], cuu};
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(mc[2], T[2], H, 0, 0, 0);  // (the fused form's order: part of the arithmetic)
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(mc[0], T[0], H, 0, 0, 0);
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(mc[1], T[1], H, 0, 0, 0);
+    d4 H = bw_tile_H201(mc, T, cc, cuu);  // (the fused form's order: part of the arithmetic)
     QKEEP(H[0]); QKEEP(H[3]);
     QSTAMP(1);  // H = C + M^T T
     double col[4];
@@ -912,7 +907,10 @@ __device__ __forceinline__ void bw4f_matrix_wave(double (&ring)[4][4][BW2_BUF], 
   __shared__ int prog[24];
 #define QILQR_CAT_(a, b) a##b
 #define QILQR_CAT(a, b) QILQR_CAT_(a, b)
-template <typename S, int WAVES, bool FUSED = false, bool FREE = false>
+// GFAC (six wavefronts only): the factorisation of Q_uu in the gradient wavefront (bw4f_* roles, two block barriers per knot) -- the form for
+// a saturated chip; without it the matrix wavefronts factor (one barrier per knot) -- the form for launches whose wavefronts are alone
+// on their SIMDs.  THE SAME BITS either way: the host picks by how many trajectories are running (launch_backward).
+template <typename S, int WAVES, bool FUSED = false, bool FREE = false, bool GFAC = false>
 __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_backward4(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n,
                                                    int force) {
   // (the body lives in a file of its own because k_backward_rollout contains it too, as statements of the kernel function:

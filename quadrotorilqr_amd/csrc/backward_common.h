@@ -107,6 +107,16 @@ __device__ __forceinline__ d4 bw_tile_H(const double (&m)[3], const d4 &T, const
   H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
   return H;
 }
+// the same with the products in the order kc = 2, 0, 1 -- the order of bw4_fused_wave (rows 12..15 of H receive nothing from the other two
+// products, so that register is final one product early there) and, since round 6, of every k_backward4 form: the order is part of the
+// arithmetic of rows 0..11
+__device__ __forceinline__ d4 bw_tile_H201(const double (&m)[3], const d4 &T, const double (&cx)[3], double cuu) {
+  d4 H = {cx[0], cx[1], cx[2], cuu};
+  H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[2], T[2], H, 0, 0, 0);
+  H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[0], T[0], H, 0, 0, 0);
+  H = __builtin_amdgcn_mfma_f64_16x16x4f64(m[1], T[1], H, 0, 0, 0);
+  return H;
+}
 // (Round 3 tried to take the factorisation off the matrix instructions' chain: rows 12..15 of H -- [Q_ux | Q_uu] -- are complete
 // after the kc = 2 product alone, because J_u is zero in rows 0..7, so the gather, the LDL^T and the solve could run while the
 // other two products execute.  It does not pay and cannot: v_mfma_f64 and the fp64 vector instructions use the SAME double-

@@ -84,6 +84,7 @@ struct qilqr_solver {
   hipEvent_t main_ready = nullptr;
   int *d_part_counters = nullptr;  // [MAX_PARTS][2][COUNT_WORDS]
   long total_B = 0;                // trajectories in flight on the device in this call (kernel choices go by it)
+  long live_hint = 0;              // trajectories known to be running in this call right now (0: unknown, take the batch): launch_backward
   double *io_aos = nullptr;         // device scratch in the plain [B][n][W] layout (W <= 52), for host I/O (lazy)
   size_t io_cap = 0;                // its capacity in doubles
   void *desired_tiled = nullptr;    // per-problem desired trajectories, tiled (allocated on first use)
@@ -313,6 +314,7 @@ int begin_batch(qilqr_solver *s, long B, long n, const double *d_desired_batch) 
     s->st.desired_tiled = 0;
   }
   s->total_B = B;
+  s->live_hint = 0;  // (nothing known yet: launch_backward takes the batch)
   s->st.layout.tiled = records_tiled(s, B, use_persistent(s, B)) ? 1 : 0;
   launch(s, K_OTHER, k_begin, dim3(cdiv(B, 256)), dim3(256), s->st, (int)B);
   return QILQR_OK;
@@ -410,6 +412,10 @@ int launch_linearize(qilqr_solver *s, long B, long n, int which, int need_flag, 
 // k_backward2 (a matrix and a gradient wavefront per trajectory) was the choice below 512 trajectories in rounds 1 and 2; it
 // wins nowhere by more than 2 % and lives in the diagnostics build (force_general = 3 there).
 // The Runge-Kutta extension and non-symmetric weights take the one-wavefront kernel at every size.
+#ifndef QILQR_GFAC_MIN_LIVE
+#define QILQR_GFAC_MIN_LIVE 3072
+#endif
+constexpr long GFAC_MIN_LIVE = QILQR_GFAC_MIN_LIVE;  // running trajectories from which the gradient wavefront factors Q_uu (launch_backward)
 enum BackwardKind { BW_FOUR, BW_TWO, BW_ONE, BW_FUSED };
 BackwardKind backward_kind(const qilqr_solver *s, long load_B) {
   if (s->integrator == 1 || !s->symmetric) return BW_ONE;
@@ -433,7 +439,13 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
   const long load_B = std::max(B, s->total_B);
   // (the records were linearised in the placement this choice reads: begin_batch sets st.layout.tiled from the same function;
   // the one-wavefront kernel addresses its operands through rec_elem and reads either)
-  const BackwardKind kind = s->st.layout.tiled ? backward_kind(s, load_B) : BW_ONE;
+  BackwardKind kind = s->st.layout.tiled ? backward_kind(s, load_B) : BW_ONE;
+  // `live` = the trajectories known to be running on the device in this call (every sub-batch stream's last count; the batch while nothing is known)
+  const long live = s->live_hint > 0 ? s->live_hint : load_B;
+  // Since round 6 the fused and the six-wavefront forms give the same bits, so a batch of up to 4096 trajectories takes the six-wavefront form
+  // (Q_uu factored by the gradient wavefront, four blocks per CU) for the launches in which most of it is still running -- every trajectory live,
+  // per launch: 4096: 248 against 293 us, 3072: 177 / 184, 2048: 123 / 127, 1024: 86 / 74 -- and the fused form from there on.
+  if (kind == BW_FUSED && s->dev.force_general == 0 && live >= GFAC_MIN_LIVE) kind = BW_FOUR;
   if (kind == BW_FUSED) {
     // four matrix-and-gradient wavefronts + one loader wavefront per four trajectories, no block barrier in the knot loop
     // (one register budget: the pipelined knot carries the previous knot's tail and does not fit 80 registers)
@@ -446,7 +458,17 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
     // four matrix wavefronts + one gradient wavefront + one loader wavefront per four trajectories
     // (register budget by how many blocks the chip has to hold: see k_backward4)
     const bool many = load_B > 4096;
-    if (s->f32 && many)
+    // Who factors Q_uu (round 6; the same bits either way, backward4_kernel.h): the gradient wavefront when the chip is saturated -- a SIMD
+    // is then bound by what its wavefronts issue, and one instruction stream factors four trajectories' Q_uu instead of four (a launch with
+    // every trajectory live, MI355X, N = 100: B = 65536 3807 -> 3515 us, 8192 509 -> 484) -- and the matrix wavefronts when a launch's
+    // wavefronts are alone on their SIMDs and its time is the chain of one knot's dependent instructions (B = 64: 75.3 against 85.3 us;
+    // level at 2048).
+    const bool gfac = s->dev.force_general == 7 || (s->dev.force_general != 8 && (many || s->dev.force_general == 0) && live >= GFAC_MIN_LIVE);
+    if (gfac && s->f32)
+      launch(s, K_BACKWARD, (k_backward4<float, 6, false, false, true>), dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
+    else if (gfac)
+      launch(s, K_BACKWARD, (k_backward4<double, 6, false, false, true>), dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
+    else if (s->f32 && many)
       launch(s, K_BACKWARD, (k_backward4<float, 6>), dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
     else if (s->f32)
       launch(s, K_BACKWARD, (k_backward4<float, 5>), dim3(cdiv(B, 4)), dim3(384), s->consts, s->params, s->st, (int)B, (int)n, force);
@@ -789,6 +811,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
       // several rounds, and the sums of counts they report say nothing against the threshold)
       const bool compacting = s->compact && !tail_started && (seen_active > tf.stop || (tf.kinds && used > tf.slots));
       if (s->compact && tf.kinds && !compacting && used <= tf.slots) tail_started = true;
+      s->live_hint = (long)seen_active;
       const bool fuse_now = (can_fuse || tail_started) && in_flight.alone(s->dev.fuse_in_flight == 1);
       // k_round linearises a block's candidates with the block's own five wavefronts: as fast as k_linearize when a block has one
       // candidate (the tail of every solve) or when the chip is full anyway, 2.5 times slower with four candidates per block and
@@ -1004,6 +1027,9 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
     const InFlight in_flight(s->device);
     const TailFuse tf = tail_fuse(s, B, nparts);
     for (long round = 0; round < max_rounds && remaining > 0; ++round) {
+      long live_all = 0;  // (every part's last count: what shares the chip with this part's kernels)
+      for (auto &part : parts) live_all += part.done ? 0 : (long)part.seen_active;
+      s->live_hint = std::max<long>(live_all, 1);
       for (auto &part : parts) {
         if (part.done) continue;
         PartScope scope(s, part);

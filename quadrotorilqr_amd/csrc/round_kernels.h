@@ -17,7 +17,8 @@ template <typename S>
 __global__ __launch_bounds__(320) void k_backward_rollout(ModelConsts<double> c, SolveParams p, BatchState st, int B, int n) {
   {
     constexpr int WAVES = 5;
-    constexpr bool FUSED = true, FREE = true;
+    constexpr bool FUSED = true, FREE = true, GFAC = false;
+    (void)GFAC;
     const int force = 0;
     (void)WAVES;
 #define BW4_RETURN goto backward_done

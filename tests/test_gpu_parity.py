@@ -295,14 +295,16 @@ def test_backward_pass_bits_do_not_depend_on_the_batch_size():
         cfg = pb.config2(B=B, N=n, seed=3 + n)
         if dense:
             cfg["Q"], cfg["R"] = Qd, Rd
-        six = capi.from_config(cfg, precision=prec, force_general=4)
         fused = capi.from_config(cfg, precision=prec, force_general=5)
-        trajs = six.forward_sim(cfg["init"], np.zeros((B, n, 52)), 1.0)
-        g6, t6 = six.backwards_pass(trajs)
+        trajs = fused.forward_sim(cfg["init"], np.zeros((B, n, 52)), 1.0)
         g5, t5 = fused.backwards_pass(trajs)
-        assert np.isfinite(g6).all() and (n < 3 or np.abs(g6).max() > 0)  # (the last knot's gains are zero: V = 0 behind it)
-        np.testing.assert_array_equal(t6, t5, err_msg=f"terms B={B} n={n} dense={dense} {prec}")
-        np.testing.assert_array_equal(g6, g5, err_msg=f"gains B={B} n={n} dense={dense} {prec}")
+        assert np.isfinite(g5).all() and (n < 3 or np.abs(g5).max() > 0)  # (the last knot's gains are zero: V = 0 behind it)
+        # 4: the six-wavefront form as a call takes it (who factors Q_uu goes by the running trajectories); 7: the gradient wavefront
+        # factors at every launch; 8: the matrix wavefronts do
+        for fg in (4, 7, 8):
+            g6, t6 = capi.from_config(cfg, precision=prec, force_general=fg).backwards_pass(trajs)
+            np.testing.assert_array_equal(t6, t5, err_msg=f"terms force_general={fg} B={B} n={n} dense={dense} {prec}")
+            np.testing.assert_array_equal(g6, g5, err_msg=f"gains force_general={fg} B={B} n={n} dense={dense} {prec}")
     # the automatic choice on either side of 4096: the first 64 of 4100 problems as part of that batch and alone
     cfg = pb.config2(B=4100, N=30, seed=8)
     trajs = capi.from_config(cfg).forward_sim(cfg["init"], np.zeros((4100, 30, 52)), 1.0)
@@ -314,13 +316,14 @@ def test_backward_pass_bits_do_not_depend_on_the_batch_size():
     cfg = pb.config2(B=96, N=40, seed=9)
     cfg["options"] = dict(cfg["options"], ls_max_iters=1)
     outs = []
-    for fg in (4, 5):
+    for fg in (5, 4, 7, 8):
         s = capi.from_config(cfg, force_general=fg, single_wave_rollout=3)
         s.set_regularisation(1.0, 4.0, 1e6)
         outs.append(s.solve_batch(cfg["init"]))
     assert (outs[0]["n_bwd"] > outs[0]["iters"] + 1).any()  # some problem restarted
-    for k in ("traj", "cost", "status", "iters", "n_bwd", "n_fwd"):
-        np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
+    for o in outs[1:]:
+        for k in ("traj", "cost", "status", "iters", "n_bwd", "n_fwd"):
+            np.testing.assert_array_equal(outs[0][k], o[k], err_msg=k)
 
 
 def test_sub_batches_on_their_own_streams_give_identical_results():
