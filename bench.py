@@ -334,14 +334,30 @@ def launch_ranks_if_needed(args):
     in_launcher = "RANK" in os.environ or "WORLD_SIZE" in os.environ
     if in_launcher:
         world = int(os.environ.get("WORLD_SIZE", "1"))
+        if args.gpus is None:  # `torchrun --nproc-per-node N bench.py` without --gpus: the launcher says how many
+            args.gpus = world
         if world != args.gpus:
             sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}\n")
             sys.exit(2)
         return
+    if args.gpus is None:
+        args.gpus = 1
     if args.gpus <= 1:
         return
     import socket
     import subprocess
+    # preflight: are there N devices?  Asked in a throw-away CHILD process -- this process must not touch the GPU (it
+    # starts the ranks and never execs) -- before N ranks are started that would each fail on their own with a stack trace.
+    if os.environ.get("QILQR_BENCH_ONE_DEVICE_TEST") != "1":
+        try:
+            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+            have = int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else -1
+        except Exception:
+            have = -1
+        if 0 <= have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but this machine shows {have} GPU(s) (torch.cuda.device_count() in a child process); "
+                             f"nothing was started\n")
+            sys.exit(2)
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
@@ -355,7 +371,7 @@ def launch_ranks_if_needed(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs = ranks of one node (default: the launcher's WORLD_SIZE when there is one, else 1)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--shards", choices=("same", "distinct"), default="distinct",
@@ -602,25 +618,7 @@ def main():
                           "machine_efficiency": v_same / (world * v_alone)}
         # (the last solve of this leg overwrote out_i with shard 0's counts: the line's iters/status are shard 0's)
 
-    # ---- the product's own multi-GPU path (never `value`): the same step through qilqr_solve_batch_sharded_device, in a child
-    # process of rank 0 while the other ranks wait, idle, at the fence
-    sharded_abi = None
-    if world > 1 and not args.no_sharded_c_abi:
-        # the other ranks wait on the HOST (a key of the rendezvous store), not in a collective: an RCCL barrier is a kernel that spins on
-        # every waiting GPU, and the child process is about to measure a solve on exactly those GPUs
-        fence()
-        store = None
-        try:
-            store = dist.distributed_c10d._get_default_store()
-        except Exception:
-            store = None
-        if rank == 0:
-            sharded_abi = sharded_c_abi_leg(args, ref_cost)
-            if store is not None:
-                store.set("qilqr_sharded_c_abi_done", "1")
-        elif store is not None:
-            store.wait(["qilqr_sharded_c_abi_done"])
-        fence()
+    sharded_abi = None  # (the product's own multi-GPU path runs LAST, behind the process group's teardown: below)
 
     status, iters, n_bwd, n_fwd = (t.cpu().numpy() for t in out_i)
     if world > 1:
@@ -882,13 +880,54 @@ def main():
                                   "what": "every step's trajectories and costs sent to rank 0 itself through gather_to_root (ncclSend + ncclRecv in one group)"}}
                if rehearse else {}),
         }
-        print(json.dumps(line))
     if rehearse and rank == 0:  # the rows that went through RCCL are the rows that were sent
         k = (step_no[0] - 1) & 1
         assert torch.equal(g_traj, out_traj[k]) and torch.equal(g_cost, out_cost[k]), "rehearsal: gathered rows differ from the solver's"
+    # ---- the product's own multi-GPU path (never `value`): the same step through qilqr_solve_batch_sharded_device, in a
+    # child process of rank 0, started only AFTER every rank has destroyed its process group (torch's RCCL communicators are gone), closed its
+    # solver and -- ranks other than 0 -- left: the child's ncclCommInitAll then finds devices nobody else holds a communicator on.  The other
+    # ranks report through the rendezvous store (kept alive by rank 0's reference) just before they return; a rank that cannot is waited for
+    # by time.  Whatever the leg does, the line is printed.
+    store = None
+    if world > 1 and not args.no_sharded_c_abi:
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:
+            store = None
     if world > 1 or rehearse:
         dist.barrier()
         dist.destroy_process_group()
+    if world > 1 and not args.no_sharded_c_abi:
+        try:
+            solver.close()
+        except Exception:
+            pass
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        if rank != 0:
+            try:
+                if store is not None:
+                    store.add("qilqr_rank_released", 1)
+            except Exception:
+                pass
+            return
+        released, t_wait = 0, time.perf_counter()
+        while released < world - 1 and time.perf_counter() - t_wait < 20.0:
+            try:
+                released = int(store.add("qilqr_rank_released", 0)) if store is not None else 0
+            except Exception:
+                released = 0
+            if released < world - 1:
+                time.sleep(0.05)
+        time.sleep(0.5)  # (a rank reports just before its interpreter exits: let the processes go)
+        try:
+            line["sharded_c_abi"] = sharded_c_abi_leg(args, ref_cost)
+        except Exception as e:  # (json, np.load, a missing file: the leg's failure is a field of the line, never a missing line)
+            line["sharded_c_abi"] = {"error": f"{type(e).__name__}: {e}"}
+        if isinstance(line["sharded_c_abi"], dict):
+            line["sharded_c_abi"]["ranks_released_before_start"] = released
+    if rank == 0:
+        print(json.dumps(line))
 
 
 if __name__ == "__main__":

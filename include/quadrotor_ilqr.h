@@ -83,7 +83,9 @@ typedef struct {
                             per trajectory took over above 8192: with the running trajectories compacted, see `compaction`, the blocks of
                             four are ahead at every size); non-symmetric Q or R: the general kernel); 1: the general kernel even when
                             Q, R are symmetric; 2: the one-wavefront kernel for symmetric weights (k_backward<true>);
-                            3: k_backward2 (diagnostics build only); 4: k_backward4, six wavefronts; 5: k_backward4, fused
+                            3: k_backward2 (diagnostics build only); 4: k_backward4, six wavefronts (Q_uu factored by the gradient
+                            wavefront in launches with 3072 or more running trajectories, by the matrix wavefronts otherwise; 7 / 8:
+                            the one / the other at every launch); 5: k_backward4, fused
                             (its wavefronts meet through tagged LDS slots, no block barrier in the knot loop: what 0
                             selects up to 4096 trajectories; forced, it is used at every size); 6: retired in round 4
                             (the fused form with a block barrier per knot: refused by name).  When the round's kernels are the fused k_backward4 and k_rollout16 and
@@ -91,10 +93,17 @@ typedef struct {
                             MI355X), the two are ONE launch (k_backward_rollout: the block's backward pass, a block
                             barrier, the rollout of its own four trajectories; same arithmetic, same bits) -- in fp64 together with
                             the linearisation of the block's candidates, four rounds to a launch (k_round: same bits again).
+                            Since ABI version 7 / round 6 every form of k_backward4 performs ONE arithmetic (H accumulated in one
+                            order, the gradient's sums in one order, Q_uu the same bits whoever factors it): a backward pass does not
+                            depend on the batch size, and 0 also takes the six-wavefront form for the launches of a batch of up to 4096
+                            in which 3072 or more trajectories still run.
                             WHICH ARITHMETIC A CALLER GETS.  The general kernel evaluates ilqr.hh:118-140 in the
                             reference's own forms: Q_uu factored by Eigen's diagonally pivoted LDL^T (largest |d_ii| of
                             the trailing block, first on ties), V_x = Q_x - K^T Q_uu k, V_xx = Q_xx - K^T Q_uu K, not
-                            symmetrised -- force_general = 1 REPRODUCES THE REFERENCE, including its loss of accuracy
+                            symmetrised -- force_general = 1 evaluates THE REFERENCE'S FORMULAS (the same products and sums; the
+                            grouping of M^T V M alternates with the knot's parity -- (M^T V) M at odd knots, M^T (V M) at even ones --
+                            because the accumulator tile is used transposed every other knot: not one fixed evaluation order of
+                            ilqr.hh:118-124, equal to it to rounding), including the reference's loss of accuracy
                             beyond about 150 knots (the unsymmetrised recursion amplifies rounding asymmetry until the
                             gains are noise -- in the reference, the oracle and this kernel alike, of different magnitudes:
                             DESIGN.md section 4).  The symmetric-weight kernels (selected silently
@@ -145,16 +154,18 @@ typedef struct {
 } qilqr_device_config;
 /* The structure only ever grows at its end.  qilqr_create_sized / qilqr_sharded_create_sized take the size the CALLER was compiled with
  * (fields beyond it keep their defaults: 0, sync_every 2), so a caller built against an older header runs against a newer library;
- * with this header `qilqr_create(...)` in source code IS the sized call (macros below).  The exported symbols qilqr_create,
- * qilqr_sharded_create and qilqr_sharded_create_mask remain for binaries built before ABI version 7 and read only the eight
- * fields of ABI version 5 (32 bytes). */
+ * with this header `qilqr_create(...)`, `qilqr_sharded_create(...)` and `qilqr_sharded_create_mask(...)` in source code ARE the sized calls
+ * (macros below).  The exported symbols of those three names remain for binaries built before ABI version 7 -- and for callers that bind
+ * symbols by name (dlsym, ctypes, function pointers: bind the *_sized names instead): they read ONLY the eight fields of ABI version 5
+ * (32 bytes) and IGNORE every field behind them, whatever the caller's structure holds -- `compaction` of ABI version 6 (36 bytes: a
+ * version-6 binary's value is not honoured through the raw symbols) and the four switches of version 7 keep their defaults there. */
 #define QILQR_DEVICE_CONFIG_BYTES_ABI5 32
 
-/* One arithmetic at every batch size: the fused k_backward4 and k_rollout16 (with the tiled knot records they read) are forced,
- * so that a problem's result does not depend on the size of the batch it is solved in, on sharding, or on sub-batch streams
- * (the reference is trivially batching-independent: it solves one problem per call).  Costs throughput above 4096 trajectories
- * per call, where the automatic choice takes kernels built for a full chip. */
-#define QILQR_PIN_ARITHMETIC(cfg) do { (cfg).force_general = 5; (cfg).single_wave_rollout = 3; } while (0)
+/* One arithmetic at every batch size: k_rollout16 is forced, so that a problem's result does not depend on the size of the batch it is
+ * solved in, on sharding, or on sub-batch streams (the reference is trivially batching-independent: it solves one problem per call).
+ * Since round 6 the backward pass needs no pinning (every form of k_backward4 performs the same arithmetic; the macro no longer forces
+ * the fused form, which cost throughput above 4096 trajectories per call); the sixteen-lane rollout still costs some there. */
+#define QILQR_PIN_ARITHMETIC(cfg) do { (cfg).single_wave_rollout = 3; } while (0)
 
 /* A handle owns its device workspace and stream: use it from one thread at a time (different handles are
  * independent; the reference's ILQR object is const and re-entrant). */
@@ -287,13 +298,15 @@ void qilqr_host_free(void *p);
  * thread of its own: its input slice goes to the device, its results come back into the caller's arrays at the shard's
  * offset (the "gather" is the copy back itself: ragged shards need no padding), the call returns when every shard has.
  * Arguments and results are those of qilqr_solve_batch.  Problem by problem they are bit-identical to a single-device solve
- * of the same batch WHEN SHARD AND WHOLE BATCH FALL IN THE SAME KERNEL REGIME: with the automatic choices (force_general = 0,
- * single_wave_rollout = 0) the kernels go by the number of trajectories a call has in flight on its device (up to 4096:
- * the fused k_backward4 and k_rollout16; beyond: the six-wavefront k_backward4 and k_rollout3), the two regimes sum M^T V_x and
- * evaluate the rollout in different orders, and the same problem then differs in the last bits (about 2e-15 relative per pass)
- * between, say, a batch of 8192 and its eight shards of 1024 (a batch of 65536 and its shards of 8192 are one regime) -- the exit path of a problem that sits within rounding of a
- * convergence threshold can differ with them.  QILQR_PIN_ARITHMETIC (below) makes every call use ONE kernel family whatever
- * the batch size: a problem's bits then do not depend on how the caller batches or shards it.  A shard that fails makes the call return its error (the lowest failing shard's; text through
+ * of the same batch WHEN SHARD AND WHOLE BATCH TAKE THE SAME ROLLOUT KERNEL.  The backward pass, the linearisation, the cost sums and
+ * every decision are one arithmetic at every batch size (since round 6: tests/test_gpu_parity.py::
+ * test_backward_pass_bits_do_not_depend_on_the_batch_size); what remains is the rollout: with single_wave_rollout = 0 a call with up to
+ * 4096 trajectories in flight on its device takes k_rollout16 (sixteen lanes per trajectory) and a larger one k_rollout3 (a lane per
+ * trajectory) -- chosen once per call, never changed inside a solve --, the two evaluate the same formulas in different orders, and the
+ * same problem differs by about 1e-10 relative in its trajectory between, say, a batch of 8192 and its eight shards of 1024 (a batch of
+ * 65536 and its shards of 8192 take the same kernel) -- the exit path of a problem that sits within rounding of a convergence threshold
+ * can differ with them.  Forcing one rollout kernel (single_wave_rollout = 2 or 3; QILQR_PIN_ARITHMETIC below) makes a problem's bits
+ * independent of how the caller batches or shards it.  A shard that fails makes the call return its error (the lowest failing shard's; text through
  * qilqr_last_error, prefixed with the shard and device); the other shards still complete. */
 typedef struct qilqr_sharded qilqr_sharded;
 /* dev: as for qilqr_create, its `device` field is ignored (NULL = defaults) */
@@ -304,6 +317,9 @@ int qilqr_sharded_create_sized(const qilqr_model *model, const double *Q, const 
                                int32_t n_desired, double dt_s, const qilqr_options *options, const qilqr_device_config *dev,
                                size_t dev_bytes, const int32_t *devices, int32_t n_devices, qilqr_sharded **out);
 /* the same with the devices given as a bit mask (bit d = HIP device d), lowest ordinal first */
+int qilqr_sharded_create_mask_sized(const qilqr_model *model, const double *Q, const double *R, const double *desired,
+                                    int32_t n_desired, double dt_s, const qilqr_options *options,
+                                    const qilqr_device_config *dev, size_t dev_bytes, uint64_t device_mask, qilqr_sharded **out);
 int qilqr_sharded_create_mask(const qilqr_model *model, const double *Q, const double *R, const double *desired,
                               int32_t n_desired, double dt_s, const qilqr_options *options,
                               const qilqr_device_config *dev, uint64_t device_mask, qilqr_sharded **out);
@@ -384,5 +400,7 @@ int qilqr_abi_version(void);
   qilqr_create_sized(model, Q, R, desired, n_desired, dt_s, options, dev, sizeof(qilqr_device_config), out)
 #define qilqr_sharded_create(model, Q, R, desired, n_desired, dt_s, options, dev, devices, n_devices, out) \
   qilqr_sharded_create_sized(model, Q, R, desired, n_desired, dt_s, options, dev, sizeof(qilqr_device_config), devices, n_devices, out)
+#define qilqr_sharded_create_mask(model, Q, R, desired, n_desired, dt_s, options, dev, device_mask, out) \
+  qilqr_sharded_create_mask_sized(model, Q, R, desired, n_desired, dt_s, options, dev, sizeof(qilqr_device_config), device_mask, out)
 #endif
 #endif

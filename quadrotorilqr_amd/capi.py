@@ -39,7 +39,7 @@ EXPORTS = (
     "qilqr_line_search", "qilqr_cost_history", "qilqr_profile_reset", "qilqr_profile_get", "qilqr_profile_mode", "qilqr_set_regularisation",
     "qilqr_set_integrator",
     "qilqr_device", "qilqr_stream", "qilqr_stream_wait_event", "qilqr_host_alloc", "qilqr_host_free",
-    "qilqr_sharded_create", "qilqr_sharded_create_sized", "qilqr_sharded_create_mask", "qilqr_sharded_destroy", "qilqr_sharded_count", "qilqr_sharded_solver",
+    "qilqr_sharded_create", "qilqr_sharded_create_sized", "qilqr_sharded_create_mask", "qilqr_sharded_create_mask_sized", "qilqr_sharded_destroy", "qilqr_sharded_count", "qilqr_sharded_solver",
     "qilqr_shard_range", "qilqr_solve_batch_sharded",
     "qilqr_sharded_set_transport", "qilqr_sharded_transport", "qilqr_solve_batch_sharded_device", "qilqr_gather_schedule",
     "qilqr_abi_version", "qilqr_compaction_moves", "qilqr_describe",
@@ -520,7 +520,7 @@ def host_array(shape, dtype=np.float64):
     return a
 
 
-PIN_ARITHMETIC = dict(force_general=5, single_wave_rollout=3)  # QILQR_PIN_ARITHMETIC of the header: one kernel family at every batch size
+PIN_ARITHMETIC = dict(single_wave_rollout=3)  # QILQR_PIN_ARITHMETIC of the header: one rollout kernel at every batch size (the backward pass needs no pinning since round 6)
 
 
 def from_config(cfg, **kw):

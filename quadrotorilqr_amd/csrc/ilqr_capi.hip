@@ -2090,15 +2090,22 @@ int qilqr_sharded_create_sized(const qilqr_model *model, const double *Q, const 
   return QILQR_OK;
 }
 
-int qilqr_sharded_create_mask(const qilqr_model *model, const double *Q, const double *R, const double *desired,
-                              int32_t n_desired, double dt_s, const qilqr_options *options,
-                              const qilqr_device_config *dev, uint64_t device_mask, qilqr_sharded **out) {
+int qilqr_sharded_create_mask_sized(const qilqr_model *model, const double *Q, const double *R, const double *desired,
+                                    int32_t n_desired, double dt_s, const qilqr_options *options,
+                                    const qilqr_device_config *dev, size_t dev_bytes, uint64_t device_mask, qilqr_sharded **out) {
   int32_t devices[64];
   int32_t k = 0;
   for (int32_t d = 0; d < 64; ++d)
     if (device_mask & (1ull << d)) devices[k++] = d;
   if (k == 0) return fail(QILQR_ERR_INVALID_ARG, "empty device mask");
-  return qilqr_sharded_create(model, Q, R, desired, n_desired, dt_s, options, dev, devices, k, out);
+  return qilqr_sharded_create_sized(model, Q, R, desired, n_desired, dt_s, options, dev, dev_bytes, devices, k, out);
+}
+// (the raw symbol, for binaries built before ABI version 7: the 32 bytes of ABI version 5 -- fields behind them, `compaction` of version 6
+// included, keep their defaults: the header says so)
+int qilqr_sharded_create_mask(const qilqr_model *model, const double *Q, const double *R, const double *desired,
+                              int32_t n_desired, double dt_s, const qilqr_options *options,
+                              const qilqr_device_config *dev, uint64_t device_mask, qilqr_sharded **out) {
+  return qilqr_sharded_create_mask_sized(model, Q, R, desired, n_desired, dt_s, options, dev, QILQR_DEVICE_CONFIG_BYTES_ABI5, device_mask, out);
 }
 
 void qilqr_sharded_destroy(qilqr_sharded *h) {

@@ -118,6 +118,33 @@ def test_a_rank_environment_that_contradicts_gpus_is_refused():  # (no GPU neede
     assert out.returncode == 2 and "WORLD_SIZE" in out.stderr and out.stdout.strip() == ""
 
 
+def test_preflight_refuses_more_ranks_than_devices_and_launcher_sets_gpus():  # (no GPU needed: runs in the CPU suite)
+    """`python bench.py --gpus N` asks a throw-away child process how many devices there are BEFORE it starts N ranks,
+    and says so in a sentence with exit code 2 when there are fewer (this container has none; the parent never touches the GPU).  ADVICE r05:
+    under a launcher `--gpus` defaults to the launcher's WORLD_SIZE."""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import torch
+    if torch.cuda.device_count() < 2:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "QILQR_BENCH_ONE_DEVICE_TEST")}
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert out.returncode == 2 and "nothing was started" in out.stderr and "--gpus 2" in out.stderr and out.stdout.strip() == "", out.stderr[-500:]
+    old = {k: os.environ.get(k) for k in ("RANK", "WORLD_SIZE")}
+    try:
+        os.environ["WORLD_SIZE"], os.environ["RANK"] = "3", "1"
+        a = types.SimpleNamespace(gpus=None)
+        assert bench.launch_ranks_if_needed(a) is None and a.gpus == 3
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 @pytest.mark.gpu
 def test_config3_strong_scaling_code_path_on_one_gpu():
     """bench.py --config 3 (BASELINE.json configs[3]: ONE batch cut into contiguous shards, strong scaling) with two

@@ -56,6 +56,25 @@ def test_sharded_create_by_mask_and_accessors():
     assert b"empty device mask" in lib.qilqr_last_error()
     assert lib.qilqr_sharded_create_mask(*args, C.c_uint64(1 << 63), C.byref(h)) != 0
     assert b"shard 0 (device 63)" in lib.qilqr_last_error()
+    # the mask form carries the caller's structure size too (qilqr_sharded_create_mask_sized; in C source the macro of the plain
+    # name).  compaction = -1 sits behind the 32 bytes of ABI version 5: honoured through the sized call, ignored -- as the header says --
+    # through the raw symbol that binaries built before version 7 bind
+    m, Q, R, o, dc = capi._create_args(probe, **cfg["model"], Q=cfg["Q"], R=cfg["R"], desired=cfg["desired"], options=cfg["options"],
+                                       device=0, profile=0, sync_every=2, force_general=False, single_wave_rollout=0,
+                                       precision="f64", streams=0, persistent=0, compaction=-1)
+    args = (C.byref(m), capi._p(Q), capi._p(R), capi._p(probe.desired), C.c_int32(len(probe.desired)), C.c_double(cfg["dt"]),
+            C.byref(o), C.byref(dc))
+    texts = {}
+    for name, call in (("sized", lambda: lib.qilqr_sharded_create_mask_sized(*args, C.c_size_t(C.sizeof(dc)), C.c_uint64(1), C.byref(h))),
+                       ("raw", lambda: lib.qilqr_sharded_create_mask(*args, C.c_uint64(1), C.byref(h)))):
+        assert call() == 0, lib.qilqr_last_error()
+        buf = C.create_string_buffer(2048)
+        assert lib.qilqr_describe(C.c_void_p(lib.qilqr_sharded_solver(h, 0)), C.c_int32(2048), buf, C.c_size_t(len(buf))) == 0
+        texts[name] = buf.value.decode()
+        lib.qilqr_sharded_destroy(h)
+    assert "compaction: off" in texts["sized"], texts["sized"]
+    assert "compaction of the running trajectories: on" in texts["raw"], texts["raw"]
+    assert lib.qilqr_sharded_create_mask_sized(*args, C.c_size_t(7), C.c_uint64(1), C.byref(h)) != 0  # not a structure size
 
 
 def test_a_failing_shard_reports_itself_and_the_others_complete():
@@ -177,24 +196,29 @@ def test_plain_c_host_gathers_over_rccl():
 
 
 def test_pinned_arithmetic_gives_batching_independent_bits():
-    """QILQR_PIN_ARITHMETIC (include/quadrotor_ilqr.h; capi.PIN_ARITHMETIC): with the fused k_backward4 and k_rollout16 forced,
-    a problem's result is the same bits whether it is solved in a batch of 4500 (beyond the 4096 at which the automatic
-    choice changes kernels), in slices of 1500, 300 or alone, through sub-batch streams, or sharded -- which the automatic
-    choice does not promise (the regimes differ in the last bits)."""
+    """A problem's bits and the size of its batch.  Since round 6 every form of k_backward4 performs one arithmetic,
+    so the BACKWARD PASS NEEDS NO PINNING: with nothing but the rollout kernel fixed -- QILQR_PIN_ARITHMETIC (include/quadrotor_ilqr.h;
+    capi.PIN_ARITHMETIC) = k_rollout16 at every size, or k_rollout3 at every size -- and the backward kernel left to the automatic choice
+    (fused up to 4096 trajectories per call, six wavefronts beyond and in the early rounds of a mid-size batch, Q_uu factored by the gradient
+    or by the matrix wavefronts as the running count goes), a problem's result is the same bits whether it is solved in a batch of 4500
+    (beyond the 4096 at which the automatic choice changes kernels), in slices of 1500, 300 or alone, through sub-batch streams, or
+    sharded.  What the automatic ROLLOUT choice does not promise is stated at the end."""
     cfg = pb.config2(B=4500, N=24, seed=12)
-    whole = capi.from_config(cfg, **capi.PIN_ARITHMETIC).solve_batch(cfg["init"])
-    assert np.isin(whole["status"], [0, 1]).all()
     keys = ("traj", "cost", "status", "iters", "n_bwd", "n_fwd")
-    for lo, hi in ((0, 1500), (1500, 3000), (3000, 4500), (4100, 4400), (17, 18), (4499, 4500)):
-        part = capi.from_config(cfg, **capi.PIN_ARITHMETIC).solve_batch(cfg["init"][lo:hi])
+    for pin in (capi.PIN_ARITHMETIC, dict(single_wave_rollout=2)):
+        whole = capi.from_config(cfg, **pin).solve_batch(cfg["init"])
+        assert np.isin(whole["status"], [0, 1]).all()
+        for lo, hi in ((0, 1500), (1500, 3000), (3000, 4500), (4100, 4400), (17, 18), (4499, 4500)):
+            part = capi.from_config(cfg, **pin).solve_batch(cfg["init"][lo:hi])
+            for k in keys:
+                np.testing.assert_array_equal(part[k], whole[k][lo:hi], err_msg=f"{pin} {k} [{lo}:{hi}]")
+        streams = capi.from_config(cfg, streams=3, **pin).solve_batch(cfg["init"])
+        sh = capi.sharded_from_config(cfg, devices=(0, 0, 0), **pin).solve_batch(cfg["init"])
         for k in keys:
-            np.testing.assert_array_equal(part[k], whole[k][lo:hi], err_msg=f"{k} [{lo}:{hi}]")
-    streams = capi.from_config(cfg, streams=3, **capi.PIN_ARITHMETIC).solve_batch(cfg["init"])
-    sh = capi.sharded_from_config(cfg, devices=(0, 0, 0), **capi.PIN_ARITHMETIC).solve_batch(cfg["init"])
-    for k in keys:
-        np.testing.assert_array_equal(streams[k], whole[k], err_msg=k)
-        np.testing.assert_array_equal(sh[k], whole[k], err_msg=k)
-    # and the automatic choice across the 4096 boundary is NOT bit-identical in general (same results to rounding)
+            np.testing.assert_array_equal(streams[k], whole[k], err_msg=k)
+            np.testing.assert_array_equal(sh[k], whole[k], err_msg=k)
+    # the automatic choice across the 4096 boundary changes the ROLLOUT kernel (k_rollout16 / k_rollout3, chosen once per call): not
+    # bit-identical in general, the same results to rounding
     auto_whole = capi.from_config(cfg).solve_batch(cfg["init"])
     auto_part = capi.from_config(cfg).solve_batch(cfg["init"][:1500])
     np.testing.assert_allclose(auto_part["cost"], auto_whole["cost"][:1500], rtol=1e-9)
