@@ -450,6 +450,72 @@ def test_dense_coupled_weights_solve():
     np.testing.assert_allclose(out["traj"], ref["traj"], atol=1e-6)
 
 
+def test_non_symmetric_weights_whole_solves():
+    """cost.hh:30-34 takes any dense Q, R; non-symmetric weights take the general kernel (k_backward<false>: the
+    reference's own forms, Eigen's pivoted LDL^T).  VERDICT r05 missing 3 / item 4.
+    (a) Where the iteration is well posed -- short horizons: ilqr.hh:133 amplifies Q's antisymmetric part by ~ 1.3 per knot
+        (tests/test_oracle_nonsymmetric.py), and through its first iterations every decision sits far from its threshold -- WHOLE SOLVES are
+        held to the oracle with the bars of the symmetric path: exit status, iteration, pass and rollout counts equal, cost history 1e-8,
+        final cost 1e-9, trajectory 1e-6.  Q and R both non-symmetric (5 %).
+    (b) At configs[1]'s horizon (bench.py's `reference_faithful.non_symmetric_Q` sample: 100 knots, Q + 0.05 triu) the reference algorithm
+        itself has no answer: the first backward pass's gains are the amplified antisymmetric part, the first UNCHECKED step (ilqr.hh:71-73)
+        takes the cost from 1e1..1e2 to 1e21..1e22, and every later decision is rounding of a rollout through those gains.  Held here to what
+        is arithmetic-independent: the blow-up (the cost after the first step agrees with the oracle's to the few per cent by which the
+        oracle's own two arithmetics differ), the final cost (nothing later moves it by more than a few per cent), and the exit classes -- never
+        the expected-reduction convergence of a well-posed solve; mostly the exhausted search, like the oracle's fused-multiply-add build, whose
+        arithmetic the device shares."""
+    r7, r8 = np.random.default_rng(7), np.random.default_rng(8)
+    U, Ur = np.triu(r7.uniform(-1, 1, (12, 12)), 1), np.triu(r8.uniform(-1, 1, (4, 4)), 1)
+    for N, max_iters in ((12, 3), (20, 3), (30, 5)):
+        cfg = pb.config2(B=24, N=N, seed=2)
+        cfg["Q"], cfg["R"] = cfg["Q"] + 0.05 * U, cfg["R"] + 0.05 * Ur
+        cfg["options"] = dict(cfg["options"], max_iters=max_iters, populate_debug=True)
+        s = capi.from_config(cfg)
+        assert "general" in s.describe(24)
+        out = s.solve_batch(cfg["init"])
+        o = oracle_for(cfg)
+        ref = o.solve_batch(cfg["init"])
+        for k in ("status", "iters", "n_bwd", "n_fwd"):
+            np.testing.assert_array_equal(out[k], ref[k], err_msg=f"N={N} {k}")
+        np.testing.assert_allclose(out["cost"], ref["cost"], rtol=1e-9)
+        np.testing.assert_allclose(out["traj"], ref["traj"], atol=1e-6)
+        hist = s.cost_history(24)
+        for b in range(24):
+            h = o.solve_decisions(cfg["init"][b])["cost_hist"]
+            np.testing.assert_allclose(hist[b, :len(h)], h, rtol=1e-8)
+    # (b) the bench's sample
+    cfg = pb.config2(B=64, N=100, seed=2)
+    cfg["Q"] = cfg["Q"] + 0.05 * np.triu(np.random.default_rng(7).uniform(-1, 1, (12, 12)), 1)
+    cfg["options"] = dict(cfg["options"], populate_debug=True)
+    s = capi.from_config(cfg)
+    out = s.solve_batch(cfg["init"])
+    hist = s.cost_history(64)
+    P = oracle_for(cfg)
+    F = orc.OracleSolver(orc.model_params(**cfg["model"]), cfg["Q"], cfg["R"], cfg["desired"], cfg["dt"], orc.options(**cfg["options"]),
+                         library=orc.fast_library(native=False))
+    rf = F.solve_batch(cfg["init"], n_threads=8)
+    assert (out["status"] != 0).all() and np.sum(out["status"] == 3) >= 24 and np.sum(np.isin(out["status"], [1, 3])) >= 62, np.bincount(out["status"], minlength=4)
+    assert np.sum(rf["status"] == 3) >= 24
+    for b in range(64):
+        c0 = P.cost_trajectory(cfg["init"][b])
+        hp = P.solve_decisions(cfg["init"][b])["cost_hist"]
+        assert hist[b, 0] > 1e15 * c0 and hp[0] > 1e15 * c0
+        assert abs(hist[b, 0] - hp[0]) < 0.2 * hp[0], (b, hist[b, 0], hp[0])
+        # it never comes back: no arithmetic repairs the solve.  (Not even monotone from there: with these gains Q_uu is indefinite, the
+        # "expected reduction" of ilqr.hh:186 can be positive, and an accepted step may RAISE the cost.)
+        assert out["cost"][b] > 1e15 * c0 and 0.1 < out["cost"][b] / hist[b, 0] < 10.0, (b, out["cost"][b], hist[b, 0])
+        assert 0.02 < out["cost"][b] / rf["cost"][b] < 50.0, (b, out["cost"][b], rf["cost"][b])
+    ratio = np.median(out["cost"] / rf["cost"])
+    assert 0.8 < ratio < 1.25, ratio   # (typically the first step's cost to a few per cent, as between the oracle's own two arithmetics)
+    # one pass on the first iterate is well defined in both: the gains against the oracle's.  (The recursion amplifies the two
+    # implementations' rounding by the same 1.3 per knot: 1e-16 x 1.3^100 -- the bar is the long-horizon one, not the 1e-9 of a stable pass.)
+    g, tm = s.backwards_pass(cfg["init"][:8])
+    for b in range(8):
+        go, to = P.backwards_pass(cfg["init"][b])
+        assert np.max(np.abs(g[b] - go)) < 1e-4 * np.max(np.abs(go)), (b, np.max(np.abs(g[b] - go)) / np.max(np.abs(go)))
+        np.testing.assert_allclose(g[b][60:], go[60:], rtol=0, atol=1e-9 * np.max(np.abs(go)))  # the last 40 knots: amplification still small
+
+
 def test_batch_cost_history_matches_oracle():
     """ILQRDebug for batches: the cost after every completed forward pass"""
     cfg = pb.config2(B=12, N=60)
