@@ -96,6 +96,7 @@ struct qilqr_solver {
   void *early_out = nullptr;              // EarlyOut *, set by qilqr_solve_batch for the duration of its solve
   hipStream_t early_stream = nullptr;
   hipEvent_t early_evt = nullptr;
+  hipEvent_t early_done = nullptr;  // the early part's copies have landed (the late finishers' rows are written behind it)
   int *d_early = nullptr;                 // [2 B]: early[B] | late_slot[B]
   size_t early_cap = 0;                   // B it was allocated for
   char *d_late = nullptr, *h_late = nullptr;  // compact rows of the trajectories that finished late: device block, pinned host block
@@ -673,9 +674,16 @@ int read_active(qilqr_solver *s, int *n_active) {
 // buffers while the rounds of the others go on.  After the last round the late finishers -- at most B / 8 -- are gathered into
 // a small compact block, copied, and put into their rows by the host.  The caller's arrays end up bit-identical to the
 // one-piece copy.
+int g_force_staged_late = 0;  // (diagnostics build: qilqr_debug_set_staged_late)
 struct EarlyOut {
   double *h_traj, *h_cost;
   int32_t *h_status, *h_iters, *h_bwd, *h_fwd;
+  // the same arrays as the DEVICE addresses them (pinned host memory is mapped: hipHostGetDevicePointer), when every one resolves: the late
+  // finishers' rows are then written by k_gather straight into the caller's arrays over the link (round 6) -- no compact block, no second
+  // copy, no scatter by the host
+  bool direct = false;
+  double *v_traj = nullptr, *v_cost = nullptr;
+  int32_t *v_status = nullptr, *v_iters = nullptr, *v_bwd = nullptr, *v_fwd = nullptr;
   unsigned threshold = 0;  // fire when the active count is at or below this (and not zero)
   bool fired = false;
   int late_cap = 0;        // rows of the compact block: the active count seen when firing (the count only falls)
@@ -697,6 +705,7 @@ inline LateLayout late_layout(long rows, long n) {
 int ensure_early_buffers(qilqr_solver *s, long B, long n, long rows) {
   if (!s->early_stream) HIP_TRY(hipStreamCreateWithFlags(&s->early_stream, hipStreamNonBlocking));
   if (!s->early_evt) HIP_TRY(hipEventCreateWithFlags(&s->early_evt, hipEventDisableTiming));
+  if (!s->early_done) HIP_TRY(hipEventCreateWithFlags(&s->early_done, hipEventDisableTiming));
   if ((size_t)B > s->early_cap) {
     if (s->d_early) (void)hipFree(s->d_early);
     s->d_early = nullptr;
@@ -742,6 +751,7 @@ int fire_early_out(qilqr_solver *s, long B, long n, EarlyOut *eo, unsigned activ
   if (eo->h_iters) HIP_TRY(hipMemcpyAsync(eo->h_iters, d_int + B, sizeof(int) * B, hipMemcpyDeviceToHost, es));
   if (eo->h_bwd) HIP_TRY(hipMemcpyAsync(eo->h_bwd, d_int + 2 * B, sizeof(int) * B, hipMemcpyDeviceToHost, es));
   if (eo->h_fwd) HIP_TRY(hipMemcpyAsync(eo->h_fwd, d_int + 3 * B, sizeof(int) * B, hipMemcpyDeviceToHost, es));
+  HIP_TRY(hipEventRecord(s->early_done, es));
   return QILQR_OK;
 }
 
@@ -1181,6 +1191,12 @@ int solve_batch_device_impl(qilqr_solver *s, const double *d_init, const double 
       return fire_early_out(s, B, n, eo, active);
     };
     if ((rc = run_solve(s, B, n, s->dev.sync_every, [] { return QILQR_OK; }, false, eo ? &hook : nullptr, /*double_ok=*/true))) return rc;
+    if (eo && eo->fired && eo->direct) {
+      // the late finishers' rows straight into the caller's (mapped, pinned) arrays, behind the early part's copies -- which cover every
+      // row of those arrays, the late ones with stale data -- so that nothing overwrites them afterwards
+      HIP_TRY(hipStreamWaitEvent(s->stream, s->early_done, 0));
+      return gather(s, B, n, eo->v_traj, eo->v_cost, eo->v_status, eo->v_iters, eo->v_bwd, eo->v_fwd, s->d_early, 0, nullptr);
+    }
     if (eo && eo->fired) {
       // the late finishers into the compact block, one copy to the pinned host block; qilqr_solve_batch puts them in place
       const LateLayout L = *eo->layout;
@@ -1410,6 +1426,7 @@ void qilqr_destroy(qilqr_solver *s) {
   }
   if (s->early_stream) (void)hipStreamDestroy(s->early_stream);
   if (s->early_evt) (void)hipEventDestroy(s->early_evt);
+  if (s->early_done) (void)hipEventDestroy(s->early_done);
   if (s->d_early) (void)hipFree(s->d_early);
   if (s->d_late) (void)hipFree(s->d_late);
   if (s->h_late) (void)hipHostFree(s->h_late);
@@ -1579,6 +1596,19 @@ int qilqr_solve_batch(qilqr_solver *s, const double *init, const double *desired
   if (early) {
     eo.threshold = (unsigned)(B / 8);
     HIP_TRY(hipSetDevice(s->device));
+    // (the staged form of the late part stays as the fallback for arrays that do not map; the diagnostics build can force it: A/B, its test)
+    auto mapped = [](void *h, auto **v) -> bool {
+      if (!h) return true;
+      void *d = nullptr;
+      if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d) {
+        (void)hipGetLastError();
+        return false;
+      }
+      *v = (std::remove_reference_t<decltype(*v)>)d;
+      return true;
+    };
+    eo.direct = !g_force_staged_late && mapped(out_traj, &eo.v_traj) && mapped(out_cost, &eo.v_cost) && mapped(out_status, &eo.v_status) &&
+                mapped(out_iters, &eo.v_iters) && mapped(out_n_bwd, &eo.v_bwd) && mapped(out_n_fwd, &eo.v_fwd);
     int rc0 = ensure_early_buffers(s, B, n, eo.threshold);
     if (rc0) return rc0;
     s->early_out = &eo;
@@ -1600,7 +1630,7 @@ int qilqr_solve_batch(qilqr_solver *s, const double *init, const double *desired
     e = hipStreamSynchronize(s->early_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess) {
+    if (e == hipSuccess && !eo.direct) {
       const int count = *(const int *)(s->h_late + late.count);
       if (count < 0 || count > eo.late_cap) return fail(QILQR_ERR_HIP, "copy back: more late trajectories than were running");
       const int *idx = (const int *)(s->h_late + late.idx);
@@ -2393,6 +2423,12 @@ int qilqr_debug_stamps(qilqr_solver *s, unsigned long long *out, int32_t B) {
 #ifdef QILQR_DIAG
 // diagnostics build only: from now on the step wavefronts of k_rollout16 withhold the velocity hand-off of knot `knot` (-1: none
 // again), on the device the solver is bound to -- the other wavefront's bounded spin then runs out and the block is abandoned
+// 1: the late finishers of the copy-back under the tail go through the compact block and the host's scatter although the caller's arrays map
+// (the fallback's parity test; A/B of the two forms)
+int qilqr_debug_set_staged_late(int32_t on) {
+  g_force_staged_late = on ? 1 : 0;
+  return QILQR_OK;
+}
 int qilqr_debug_set_rollout_stall(qilqr_solver *s, int32_t knot) {
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));

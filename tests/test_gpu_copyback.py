@@ -1,5 +1,7 @@
 """qilqr_solve_batch with pinned result arrays copies the finished trajectories back to the host while the tail rounds of
-the slowest problems still run (EarlyOut in csrc/ilqr_capi.hip), and puts the late finishers into their rows afterwards.
+the slowest problems still run (EarlyOut in csrc/ilqr_capi.hip), and puts the late finishers into their rows afterwards -- since round 6
+k_gather writes them straight into the caller's mapped arrays over the link; the staged form (compact block, one copy, the host's scatter)
+is the fallback for arrays that do not map and is exercised through the diagnostics build.
 The caller's arrays must be what the one-piece copy gives, bit for bit, in every case: the early path taken, not taken
 (every problem ends in the same round), pageable outputs (never taken), absent outputs."""
 import numpy as np
@@ -49,6 +51,24 @@ def test_two_part_copy_back_is_the_one_piece_copy(B, n, per_problem_desired):
     for k in KEYS:
         np.testing.assert_array_equal(out[k], ref[k], err_msg=k)
     assert lib.qilqr_abi_version() >= 5 and C.sizeof(C.c_double) == 8
+
+
+def test_staged_late_part_is_the_same_copy():
+    """the fallback of the late part (arrays that are pinned but do not map into the device's address space), forced in the diagnostics build"""
+    from tests.diag_lib import capi_diag
+    d = capi_diag()
+    cfg = pb.config2(B=1024, N=100, seed=2)
+    s = d.from_config(cfg)
+    ref = s.solve_batch(cfg["init"].copy())
+    try:
+        assert d.load().qilqr_debug_set_staged_late(1) == 0
+        got = s.solve_batch(cfg["init"], out={k: d.host_array(v.shape, v.dtype) for k, v in pinned_out(1024, 100).items()})
+    finally:
+        d.load().qilqr_debug_set_staged_late(0)
+    direct = s.solve_batch(cfg["init"], out={k: d.host_array(v.shape, v.dtype) for k, v in pinned_out(1024, 100).items()})
+    for k in KEYS:
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+        np.testing.assert_array_equal(direct[k], ref[k], err_msg=k)
 
 
 def test_copy_back_when_every_problem_ends_in_the_same_round():
