@@ -72,7 +72,10 @@ typedef struct {
   int32_t profile;  /* start/stop HIP events attached to kernel dispatches.  Low byte: 0 off; 1 k_backward and
                        k_rollout; 2 every kernel; 3 k_backward only; 4 k_rollout only.  Second byte: sampling
                        stride s (0 or 1: every selected launch; s > 1: every s-th launch of a kind is timed, the
-                       averages of qilqr_profile_get are over the timed launches) */
+                       averages of qilqr_profile_get are over the timed launches).  Bit 16 (0x10000): roctx ranges -- the host thread
+                       marks a batch solve, every round it enqueues and, for a batch on sub-batch streams, every part's share of a round
+                       ("qilqr round 17 part 2"), for `rocprofv3 --marker-trace --kernel-trace` (libroctx64 is bound at first use; absent,
+                       no ranges) */
   int32_t sync_every; /* 1: the host waits for every round's count of active trajectories; k > 1 (default 2 when no
                          configuration is given): it reads the count k rounds late, i.e. keeps the stream k rounds
                          ahead of the device (k <= 6).  The results do not depend on it. */

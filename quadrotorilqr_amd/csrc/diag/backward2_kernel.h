@@ -2,7 +2,7 @@
 // Part of the device code of libquadrotor_ilqr.so (gfx950 only); ilqr_kernels.h includes every part.
 #pragma once
 
-#include "backward_common.h"
+#include "../backward_common.h"
 
 namespace qilqr {
 

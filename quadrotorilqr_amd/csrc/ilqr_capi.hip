@@ -121,6 +121,46 @@ struct qilqr_solver {
 
 namespace {
 
+// roctx ranges (SURVEY.md section 5 "Tracing / profiling"; qilqr_device_config.profile bit 16): the host thread marks the call, every round it
+// enqueues and -- for a batch on sub-batch streams -- every part's share of a round, so that a `rocprofv3 --marker-trace --kernel-trace` of a
+// large solve reads as rounds of named parts instead of four streams of anonymous launches (the ranges bracket the ENQUEUE on the host; the
+// kernels they enqueue carry their correlation).  libroctx64 is bound at first use from beside the HIP runtime; absent, the ranges are nothing.
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    for (const char *name : {"libroctx64.so.4", "libroctx64.so", "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so"}) {
+      if (void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+        push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (push && pop) return;
+        push = nullptr;
+        pop = nullptr;
+      }
+    }
+  }
+  static Roctx &get() {
+    static Roctx r;
+    return r;
+  }
+};
+struct RoctxRange {
+  bool on = false;
+  RoctxRange(const qilqr_solver *s, const char *what, long a = -1, long b = -1);
+  ~RoctxRange() {
+    if (on) (void)Roctx::get().pop();
+  }
+};
+
+RoctxRange::RoctxRange(const qilqr_solver *s, const char *what, long a, long b) {
+  if (!(s->dev.profile & 0x10000) || !Roctx::get().push) return;
+  char buf[96];
+  if (a >= 0 && b >= 0) std::snprintf(buf, sizeof buf, "qilqr %s %ld part %ld", what, a, b);
+  else if (a >= 0) std::snprintf(buf, sizeof buf, "qilqr %s %ld", what, a);
+  else std::snprintf(buf, sizeof buf, "qilqr %s", what);
+  (void)Roctx::get().push(buf);
+  on = true;
+}
 // Slot for the start/stop events of one launch, or null when this kind of kernel is not being timed.
 EventPair *timing_slot(qilqr_solver *s, int kind) {
   const int mode = s->dev.profile & 0xff, stride = (s->dev.profile >> 8) & 0xff;
@@ -816,6 +856,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
     bool two_sets = false;               // a k_round has run in this solve: rounds count into the counter set of their parity
     bool tail_started = false;           // a compacted batch has changed over to the combined launch for the rest of the solve
     for (long round = 0; round < max_rounds; ++round) {
+      const RoctxRange range(s, "round", round);
       // (one more compaction behind the last count above the threshold brings the slots in use under it)
       // (once the compaction has stopped for a batch that changes over to the combined launch it stays stopped: the launches may then hold
       // several rounds, and the sums of counts they report say nothing against the threshold)
@@ -1043,6 +1084,7 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
       for (auto &part : parts) {
         if (part.done) continue;
         PartScope scope(s, part);
+        const RoctxRange range(s, "round", round, (long)(&part - &parts[0]));
         const bool compacting = s->compact && (part.seen_active > tf.stop || (tf.kinds && part.used > tf.slots));
         if (tf.kinds && !compacting && part.used <= tf.slots && in_flight.alone(s->dev.fuse_in_flight == 1)) {
           if ((rc = launch_backward_rollout(s, part.used, n))) return rc;
@@ -1164,6 +1206,7 @@ int solve_batch_device_impl(qilqr_solver *s, const double *d_init, const double 
                             double *d_out_traj, double *d_out_cost, int32_t *d_out_status, int32_t *d_out_iters,
                             int32_t *d_out_n_bwd, int32_t *d_out_n_fwd, bool drain) {
   if (!s || !d_init) return fail(QILQR_ERR_INVALID_ARG, "null argument");
+  const RoctxRange range(s, "batch solve, trajectories:", (long)B);
   int rc = begin_batch(s, B, n, d_desired_batch);
   if (rc) return rc;
   const bool persistent = use_persistent(s, B);

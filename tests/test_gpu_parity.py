@@ -1012,6 +1012,18 @@ def test_diagonal_weights_path_gives_the_same_bits():
             np.testing.assert_array_equal(fast[k], plain[k], err_msg=f"{prec} {k}")
 
 
+def test_roctx_ranges_change_nothing():
+    """qilqr_device_config.profile bit 16: roctx ranges around the call, every round and every sub-batch stream's share of a round (SURVEY.md
+    section 5; for `rocprofv3 --marker-trace --kernel-trace`).  libroctx64 is bound with dlopen at first use; the results are those of the
+    unmarked solve, on one stream and on sub-batch streams."""
+    for B, streams in ((40, 0), (300, 3)):
+        cfg = pb.config2(B=B, N=30, seed=6)
+        a = capi.from_config(cfg, streams=streams).solve_batch(cfg["init"])
+        b = capi.from_config(cfg, streams=streams, profile=0x10000).solve_batch(cfg["init"])
+        for k in ("traj", "cost", "status", "iters", "n_bwd", "n_fwd"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
 def test_retired_kernel_choice_is_refused_by_name():
     """force_general = 6 (the fused k_backward4 with a block barrier per knot, round 3's A/B partner of the barrier-free form)
     was retired in round 4; the library says so instead of silently taking another kernel."""
