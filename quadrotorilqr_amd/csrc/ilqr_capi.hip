@@ -1085,6 +1085,8 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
         if (part.done) continue;
         PartScope scope(s, part);
         const RoctxRange range(s, "round", round, (long)(&part - &parts[0]));
+        // (compacting in EVERY round while it runs is right: waiting until 1/16, 1/8 or 1/4 of the slots in use are known holes measured -2 / -4 /
+        // -5 % at B = 8192 and -9 / -9 / -12 % at 65536 -- profiles/r06_ab.txt)
         const bool compacting = s->compact && (part.seen_active > tf.stop || (tf.kinds && part.used > tf.slots));
         if (tf.kinds && !compacting && part.used <= tf.slots && in_flight.alone(s->dev.fuse_in_flight == 1)) {
           if ((rc = launch_backward_rollout(s, part.used, n))) return rc;

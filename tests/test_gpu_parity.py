@@ -173,6 +173,38 @@ def test_passes_match_oracle(seed, dense):
                                    atol=1e-10)
 
 
+@pytest.mark.parametrize("n", [100, 150])
+def test_general_kernel_pass_at_long_horizons_stays_within_the_recursion_s_own_sensitivity(n):
+    """the general kernel (force_general = 1: the reference's forms, V and V^T alternating in the accumulator) against the oracle's
+    reference form, ONE backward pass at 100 and 150 knots, knot by knot.  The unsymmetrised recursion amplifies rounding by ~1.3 per knot
+    from the horizon's end, so the comparison is (a) tight where the amplification is still small -- the last 60 knots:
+    1e-9 of the largest gain --, and (b) everywhere within 100 x the envelope of what the SAME oracle source shows between its own two
+    arithmetics (with and without fused multiply-adds): the kernel is as close to the reference form as the reference form is to itself.
+    Symmetric weights (the hover problem of configs[1]) and non-symmetric Q at the asymmetry the recursion still tolerates (1e-13)."""
+    U = np.triu(np.random.default_rng(7).uniform(-1, 1, (12, 12)), 1)
+    for eps in (0.0, 1e-13):
+        cfg = pb.config2(B=6, N=n, seed=5)
+        cfg["Q"] = cfg["Q"] + eps * U
+        s = capi.from_config(cfg, force_general=1)
+        assert "general" in s.describe(6)
+        P = oracle_for(cfg)
+        F = orc.OracleSolver(orc.model_params(**cfg["model"]), cfg["Q"], cfg["R"], cfg["desired"], cfg["dt"], orc.options(**cfg["options"]),
+                             library=orc.fast_library(native=False))
+        trajs = s.forward_sim(cfg["init"], np.zeros((6, n, 52)), 1.0)
+        g, tm = s.backwards_pass(trajs)
+        for b in range(6):
+            gp, tp = P.backwards_pass(trajs[b])
+            gf, _ = F.backwards_pass(trajs[b])
+            scale = np.abs(gp).max()
+            np.testing.assert_allclose(g[b][n - 60:], gp[n - 60:], rtol=0, atol=1e-9 * scale)
+            own = np.abs(gf - gp).max(axis=1)
+            env = np.maximum.accumulate(own[::-1])[::-1]           # what rounding has grown to by knot k, counted from the end
+            diff = np.abs(g[b] - gp).max(axis=1)
+            bad = diff > 100.0 * env + 1e-10 * scale
+            assert not bad.any(), (eps, b, int(np.argmax(bad)), diff[bad][:3], env[bad][:3])
+            np.testing.assert_allclose(tm[b], tp, rtol=1e-6 if n == 100 else 1e-2)
+
+
 def test_zero_cost_and_zero_gradient_at_zero_error():
     """cost_test.cc:27-39 (EXPECT_EQ(cost, 0.0) at a random pose) and ilqr_test.cc:143-153 on the
     device: x (-) x is exactly zero for arbitrary unit quaternions, so cost, C_x, k and both
