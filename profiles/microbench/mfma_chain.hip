@@ -8,6 +8,7 @@
 #include <cstdio>
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define MF(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0)
+#define MF4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0)
 template <int MODE>
 __global__ void k(int iters, double *out, long long *cyc, long long *rt) {
   const int lane = threadIdx.x & 63;
@@ -28,6 +29,16 @@ __global__ void k(int iters, double *out, long long *cyc, long long *rt) {
         r0 = MF(a, b, r0); r1 = MF(b, a, r1); r2 = MF(a, a, r2); r3 = MF(b, b, r3); r4 = MF(a, b, r4); r5 = MF(b, a, r5);
       } else if constexpr (MODE == 4) {  // two independent accumulators, alternating
         r0 = MF(a, b, r0); r1 = MF(b, a, r1); r0 = MF(a, b, r0); r1 = MF(b, a, r1); r0 = MF(a, b, r0); r1 = MF(b, a, r1);
+      } else if constexpr (MODE == 6) {  // v_mfma_f64_4x4x4_4b_f64 (four 4x4 blocks, 4 passes): chained through the accumulator
+        double c4 = acc[0];
+        c4 = MF4(a, b, c4); c4 = MF4(a, b, c4); c4 = MF4(a, b, c4); c4 = MF4(a, b, c4); c4 = MF4(a, b, c4); c4 = MF4(a, b, c4);
+        acc[0] = c4;
+      } else if constexpr (MODE == 7) {  // 4x4x4 chained through B (the T -> H hand-over of a knot re-tiled into 4x4 blocks)
+        double c4 = acc[0];
+        c4 = MF4(a, c4, r0[0]); c4 = MF4(a, c4, r0[0]); c4 = MF4(a, c4, r0[0]); c4 = MF4(a, c4, r0[0]); c4 = MF4(a, c4, r0[0]); c4 = MF4(a, c4, r0[0]);
+        acc[0] = c4;
+      } else if constexpr (MODE == 8) {  // 4x4x4, six independent accumulators
+        r0[0] = MF4(a, b, r0[0]); r1[0] = MF4(b, a, r1[0]); r2[0] = MF4(a, a, r2[0]); r3[0] = MF4(b, b, r3[0]); r4[0] = MF4(a, b, r4[0]); r5[0] = MF4(b, a, r5[0]);
       } else {  // the knot
         d4 T = {0, 0, 0, 0};
         T = MF(va[0], m[0], T); T = MF(va[1], m[1], T); T = MF(va[2], m[2], T);
@@ -76,6 +87,10 @@ int main() {
     run<3>("six independent accumulators", tpb, out, cyc, rt);
     run<4>("two independent accumulators, alternating", tpb, out, cyc, rt);
     run<5>("knot pattern: T (A from last H), H (B from T)", tpb, out, cyc, rt);
+    // (the 4 x 4 x 4 instruction -- four independent 4 x 4 blocks per wavefront, 256 flop against 2048: what a dependent one costs)
+    run<6>("4x4x4_4b chained through C", tpb, out, cyc, rt);
+    run<7>("4x4x4_4b chained through B", tpb, out, cyc, rt);
+    run<8>("4x4x4_4b six independent accumulators", tpb, out, cyc, rt);
   }
   return 0;
 }
