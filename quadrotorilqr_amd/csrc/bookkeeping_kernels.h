@@ -331,6 +331,30 @@ __global__ void k_debug_capture(BatchState st, int n, double *dbg_trajs, double 
   }
   if (threadIdx.x == 0) *dbg_seen = it;  // (every thread took `seen` from shared memory in front of the barrier's other side)
 }
+// The same by ONE wavefront inside k_round (round 6): the block's fifth wavefront -- the backward pass's loader, idle while wavefronts 0..2
+// roll out -- looks behind every round's backward pass, so that a single solve with populate_debug (the reference's default,
+// quadrotor_ilqr.py:283) keeps four rounds per launch instead of one launch + k_debug_capture per round.  The settle step's stores (iters,
+// cur, cost: one lane of matrix wavefront 0) are in front of the block barrier this runs behind; the rollout beside it reads the current
+// trajectory and writes the other buffer.
+template <typename S>
+__device__ __forceinline__ void debug_capture_wave(const BatchState &st, int n, int lane) {
+  const int seen = __builtin_amdgcn_readfirstlane(*st.dbg_seen), it = __builtin_amdgcn_readfirstlane(st.iters[0]);
+  if (it <= seen) return;
+  if (seen < st.dbg_cap) {
+    typedef typename GA<S>::v2 sv2;
+    const S *t = (const S *)st.traj[st.cur[0]] + knot_base<true>(0, n, 18);
+    double *o = st.dbg_trajs ? st.dbg_trajs + (size_t)seen * n * 18 : nullptr;
+    if (o)
+      for (int kp = lane; kp < n * 9; kp += 64) {
+        const int i = kp / 9, pr = kp - 9 * i;
+        const sv2 v = *reinterpret_cast<const sv2 *>(t + knot_elem<true>(i, 2 * pr, 18));
+        o[2 * kp] = (double)v.x;
+        o[2 * kp + 1] = (double)v.y;
+      }
+    if (lane == 0 && st.dbg_cost) st.dbg_cost[seen] = st.cost[0];
+  }
+  if (lane == 0) *st.dbg_seen = it;
+}
 // The copy-back of a host-buffer batch solve in two parts (qilqr_solve_batch): k_mark_final, on the solver's stream between two
 // rounds, notes which trajectories have reached their exit status (nothing of theirs changes any more); those are gathered
 // and copied to the host on a second stream while the rounds of the others go on.  k_late_slots, after the last round, gives

@@ -84,6 +84,7 @@ struct qilqr_solver {
   hipEvent_t main_ready = nullptr;
   int *d_part_counters = nullptr;  // [MAX_PARTS][2][COUNT_WORDS]
   long total_B = 0;                // trajectories in flight on the device in this call (kernel choices go by it)
+  bool round_captured = false;     // the round just enqueued was a k_round launch (it fills the single solve's debug ring itself)
   long live_hint = 0;              // trajectories known to be running in this call right now (0: unknown, take the batch): launch_backward
   double *io_aos = nullptr;         // device scratch in the plain [B][n][W] layout (W <= 52), for host I/O (lazy)
   size_t io_cap = 0;                // its capacity in doubles
@@ -805,6 +806,7 @@ template <typename F>
 int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool drain = true,
               const std::function<int(unsigned)> *on_count = nullptr, bool double_ok = false) {
   int rc;
+  s->round_captured = false;
   if ((rc = launch_linearize(s, B, n, 0, 0))) return rc;
   {
     launch(s, K_OTHER, k_init, dim3(cdiv(B, 64)), dim3(64), s->params, s->st, (int)B, (int)n);
@@ -873,6 +875,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
         // thresholds go by the count) and the caller does not look at a solve round by round (the single solve's debug capture)
         const int rounds = ((can_fuse || tail_started) && double_ok) ? rounds_per_launch(s) : 1;
         if ((rc = launch_round(s, used, n, round, pending_publish, rounds))) return rc;
+        s->round_captured = true;
         launched_rounds[round & 7] = rounds;
         pending_publish = true;
         two_sets = true;
@@ -885,6 +888,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
         pending_publish = false;
       }
       launched_rounds[round & 7] = 1;
+      s->round_captured = false;
       {
       const CounterSet counter_set(s, round, two_sets);
       if (fuse_now) {
@@ -1749,10 +1753,20 @@ int qilqr_solve(qilqr_solver *s, const double *init, int32_t n, double *out_traj
     }
     if (!s->dbg_seen) HIP_TRY(hipMalloc((void **)&s->dbg_seen, sizeof(int)));
     HIP_TRY(hipMemsetAsync(s->dbg_seen, 0, sizeof(int), s->stream));
+    // the ring as k_round sees it: an idle wavefront of the launch captures behind every round's backward pass (debug_capture_wave), so the
+    // launches keep their four rounds; rounds of separate launches are followed by k_debug_capture as before (`capture` below)
+    s->st.dbg_trajs = debug_trajs ? s->dbg_trajs : nullptr;
+    s->st.dbg_cost = s->dbg_cost;
+    s->st.dbg_seen = s->dbg_seen;
+    s->st.dbg_cap = (int)debug_cap;
   }
+  struct DebugRingScope {  // (no other entry point sees the ring)
+    qilqr_solver *s;
+    ~DebugRingScope() { s->st.dbg_trajs = s->st.dbg_cost = nullptr; s->st.dbg_seen = nullptr; s->st.dbg_cap = 0; }
+  } ring_scope{s};
   auto capture = [&]() -> int {
     // ilqr.hh:78-80: one entry per completed forward pass (accepted iteration)
-    if (!want_debug) return QILQR_OK;
+    if (!want_debug || s->round_captured) return QILQR_OK;  // (a k_round launch has captured its own rounds)
     if (s->f32)
       launch(s, K_OTHER, k_debug_capture<float>, dim3(1), dim3(256), s->st, (int)n, debug_trajs ? s->dbg_trajs : nullptr, s->dbg_cost, s->dbg_seen, (int)debug_cap);
     else
@@ -1760,7 +1774,7 @@ int qilqr_solve(qilqr_solver *s, const double *init, int32_t n, double *out_traj
     return QILQR_OK;
   };
   // (without debug entries nobody looks at the solve round by round: the launches may hold several rounds)
-  if ((rc = run_solve(s, 1, n, s->dev.sync_every, capture, true, nullptr, /*double_ok=*/!want_debug))) return rc;
+  if ((rc = run_solve(s, 1, n, s->dev.sync_every, capture, true, nullptr, /*double_ok=*/true))) return rc;
   int status = 0, iters = 0, seen = 0;
   double cost = 0;
   HIP_TRY(hipMemcpy(&status, s->st.status, sizeof(int), hipMemcpyDeviceToHost));

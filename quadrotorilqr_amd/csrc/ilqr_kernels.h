@@ -32,8 +32,8 @@
 #include "backward4_kernel.h"      // k_backward4: four trajectories per block
 #include "rollout_kernels.h"       // k_rollout, k_rollout3
 #include "rollout16_kernel.h"      // k_rollout16
-#include "round_kernels.h"         // k_backward_rollout, k_round
 #include "bookkeeping_kernels.h"   // k_accept, k_gather, k_retile, compaction, debug capture
+#include "round_kernels.h"         // k_backward_rollout, k_round
 
 // diagnostics build only (make diag): kernels that measured behind the product's, kept with their parity tests
 #ifdef QILQR_WITH_BACKWARD2

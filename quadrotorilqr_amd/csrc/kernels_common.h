@@ -68,6 +68,11 @@ struct BatchState {
   int *orig;
   int row0;
   int *plan;  // [0] moves, [16 ..] destination slots, [16 + B ..] source slots, [16 + 2 B ..] per pair: row, selectors (k_compact_plan)
+  // ILQRDebug of the single solve (ilqr.hh:78-80): the ring the accepted trajectories and their costs go to (null outside qilqr_solve with
+  // populate_debug): written by k_debug_capture behind a round of separate launches, or by an idle wavefront of k_round inside the launch
+  double *dbg_trajs, *dbg_cost;
+  int *dbg_seen;
+  int dbg_cap;
 };
 
 __device__ __forceinline__ int *active_counter(const BatchState &st) {
