@@ -117,9 +117,14 @@ typedef struct {
                             agree with the reference to rounding up to about 150 knots and stay bounded and convergent
                             beyond, where the reference's results are rounding noise. */
   int32_t single_wave_rollout; /* rollout kernel: 0 (default) = by the batch: sixteen lanes per trajectory, four
-                                  trajectories per block (k_rollout16) up to 4096 trajectories, a lane per trajectory
-                                  in three cooperating wavefronts (k_rollout3) beyond; 1 = k_rollout (a lane per trajectory, one
-                                  wavefront: the Runge-Kutta extension's kernel); 2 = k_rollout3; 3 = k_rollout16 */
+                                  trajectories per block (k_rollout16) up to 4096 trajectories; beyond, a lane per trajectory
+                                  in three cooperating wavefronts (k_rollout3) for a trajectory's first 16 rollouts and k_rollout16
+                                  from its 17th on (round 6: by then a fifth of a batch still runs and the kernels are lone dependent
+                                  chains, where sixteen lanes per trajectory are a third faster; a running trajectory rolls out once per
+                                  round, so the ordinal of a rollout is the round in EVERY call -- the choice is a property of the
+                                  problem and of which side of 4096 its call is on, never of the other problems in the batch);
+                                  1 = k_rollout (a lane per trajectory, one wavefront: the Runge-Kutta extension's kernel);
+                                  2 = k_rollout3; 3 = k_rollout16 */
   int32_t precision; /* 0: fp64 everywhere (reference parity).  1: mixed: trajectories, gains and knot records
                         stored in fp32, rollout and linearisation computed in fp32, Riccati recursion on the fp64
                         matrix core, cost sums / Armijo / convergence tests in fp64 (BASELINE.json configs[2]) */
@@ -304,11 +309,12 @@ void qilqr_host_free(void *p);
  * of the same batch WHEN SHARD AND WHOLE BATCH TAKE THE SAME ROLLOUT KERNEL.  The backward pass, the linearisation, the cost sums and
  * every decision are one arithmetic at every batch size (since round 6: tests/test_gpu_parity.py::
  * test_backward_pass_bits_do_not_depend_on_the_batch_size); what remains is the rollout: with single_wave_rollout = 0 a call with up to
- * 4096 trajectories in flight on its device takes k_rollout16 (sixteen lanes per trajectory) and a larger one k_rollout3 (a lane per
- * trajectory) -- chosen once per call, never changed inside a solve --, the two evaluate the same formulas in different orders, and the
- * same problem differs by about 1e-10 relative in its trajectory between, say, a batch of 8192 and its eight shards of 1024 (a batch of
- * 65536 and its shards of 8192 take the same kernel) -- the exit path of a problem that sits within rounding of a convergence threshold
- * can differ with them.  Forcing one rollout kernel (single_wave_rollout = 2 or 3; QILQR_PIN_ARITHMETIC below) makes a problem's bits
+ * 4096 trajectories in flight on its device takes k_rollout16 (sixteen lanes per trajectory) for every rollout and a larger one k_rollout3
+ * (a lane per trajectory) for a trajectory's first 16 rollouts and k_rollout16 from the 17th on -- a rule in the call's side of 4096 and
+ * the rollout's ordinal, which is the round number in every call, never in what else the batch holds --, the two kernels evaluate the
+ * same formulas in different orders, and the same problem differs by about 1e-10 relative in its trajectory between, say, a batch of
+ * 8192 and its eight shards of 1024 (a batch of 65536 and its shards of 8192 are on one side: the same bits) -- the exit path of a
+ * problem that sits within rounding of a convergence threshold can differ with them.  Forcing one rollout kernel (single_wave_rollout = 2 or 3; QILQR_PIN_ARITHMETIC below) makes a problem's bits
  * independent of how the caller batches or shards it.  A shard that fails makes the call return its error (the lowest failing shard's; text through
  * qilqr_last_error, prefixed with the shard and device); the other shards still complete. */
 typedef struct qilqr_sharded qilqr_sharded;

@@ -538,7 +538,13 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
 #undef QILQR_LAUNCH_BWD
   return QILQR_OK;
 }
-int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
+#ifndef QILQR_ROLLOUT16_FROM
+#define QILQR_ROLLOUT16_FROM 16
+#endif
+constexpr long ROLLOUT16_FROM = QILQR_ROLLOUT16_FROM;
+// ordinal: which rollout of its solve this is for every trajectory that takes part (a running trajectory rolls out exactly once per round, so
+// the k-th rollout of ANY problem happens in round k of ANY call: a property of the problem, not of the batch); -1: the stand-alone entry points
+int launch_rollout(qilqr_solver *s, long B, long n, int need_flag, long ordinal = -1) {
   // Which rollout kernel, by how many trajectories share the chip (qilqr_device_config.single_wave_rollout):
   //   k_rollout16  sixteen lanes per trajectory, four trajectories per block: the shortest chain per trajectory and a
   //                block on every CU from 1024 trajectories on; up to R16_MAX_B trajectories
@@ -555,7 +561,7 @@ int launch_rollout(qilqr_solver *s, long B, long n, int need_flag) {
       launch(s, K_ROLLOUT, (k_rollout<float, 0>), dim3(cdiv(B, 64)), dim3(64), s->constsf, s->st, (int)B, (int)n, need_flag);
     else
       launch(s, K_ROLLOUT, (k_rollout<double, 0>), dim3(cdiv(B, 64)), dim3(64), s->consts, s->st, (int)B, (int)n, need_flag);
-  } else if (choice == 3 || (choice == 0 && load_B <= R16_MAX_B)) {
+  } else if (choice == 3 || (choice == 0 && load_B <= R16_MAX_B) || (choice == 0 && ordinal >= ROLLOUT16_FROM)) {
     if (s->f32)
       launch(s, K_ROLLOUT, k_rollout16<float>, dim3(cdiv(B, 4)), dim3(192), s->consts, s->st, (int)B, (int)n, need_flag);
     else
@@ -829,7 +835,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
       if ((rc = read_active(s, &active))) return rc;
       if ((rc = on_round())) return rc;
       if (active == 0) break;
-      if ((rc = launch_rollout(s, B, n, F_SEARCH))) return rc;
+      if ((rc = launch_rollout(s, B, n, F_SEARCH, round))) return rc;
       if ((rc = launch_linearize(s, B, n, 1, F_SEARCH))) return rc;
     }
   } else {
@@ -899,7 +905,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
           if ((rc = launch_compact(s, used, n))) return rc;
           used = slots_in_use(used, seen_active);
         }
-        if ((rc = launch_rollout(s, used, n, F_SEARCH))) return rc;
+        if ((rc = launch_rollout(s, used, n, F_SEARCH, round))) return rc;
       }
       if ((rc = on_round())) return rc;  // (debug capture of the single solve: one more launch, nothing waited for)
       if ((rc = launch_linearize(s, used, n, 1, F_SEARCH, (int)(round & 0x3fffffff)))) return rc;
@@ -1102,7 +1108,7 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
           if ((rc = launch_compact(s, part.used, n))) return rc;
           part.used = slots_in_use(part.used, part.seen_active);
         }
-        if ((rc = launch_rollout(s, part.used, n, F_SEARCH))) return rc;
+        if ((rc = launch_rollout(s, part.used, n, F_SEARCH, round))) return rc;
         if ((rc = launch_linearize(s, part.used, n, 1, F_SEARCH, (int)(round & 0x3fffffff)))) return rc;
       }
       if (round < lag) continue;

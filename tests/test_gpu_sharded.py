@@ -217,8 +217,19 @@ def test_pinned_arithmetic_gives_batching_independent_bits():
         for k in keys:
             np.testing.assert_array_equal(streams[k], whole[k], err_msg=k)
             np.testing.assert_array_equal(sh[k], whole[k], err_msg=k)
-    # the automatic choice across the 4096 boundary changes the ROLLOUT kernel (k_rollout16 / k_rollout3, chosen once per call): not
-    # bit-identical in general, the same results to rounding
+    # the automatic choice on ONE side of 4096: the rollout kernel goes by the rollout's ordinal (k_rollout3 for the first 16 rollouts of a
+    # trajectory, k_rollout16 from the 17th on), which is the round in every call -- the same bits in a batch of 4500, of 4200, on three
+    # sub-batch streams
+    cfg_long = pb.config2(B=4500, N=40, seed=12)
+    a = capi.from_config(cfg_long).solve_batch(cfg_long["init"])
+    assert a["n_fwd"].max() > 20 and np.isin(a["status"], [0, 1]).all()   # some problems roll out on both kernels
+    b = capi.from_config(cfg_long).solve_batch(cfg_long["init"][:4200])
+    c = capi.from_config(cfg_long, streams=3).solve_batch(cfg_long["init"])
+    for k in keys:
+        np.testing.assert_array_equal(b[k], a[k][:4200], err_msg=k)
+        np.testing.assert_array_equal(c[k], a[k], err_msg=k)
+    # the automatic choice across the 4096 boundary changes the ROLLOUT kernels of a trajectory's first 16 rollouts (k_rollout16 /
+    # k_rollout3): not bit-identical in general, the same results to rounding
     auto_whole = capi.from_config(cfg).solve_batch(cfg["init"])
     auto_part = capi.from_config(cfg).solve_batch(cfg["init"][:1500])
     np.testing.assert_allclose(auto_part["cost"], auto_whole["cost"][:1500], rtol=1e-9)
