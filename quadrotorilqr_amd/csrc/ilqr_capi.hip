@@ -578,17 +578,21 @@ int launch_rollout(qilqr_solver *s, long B, long n, int need_flag, long ordinal 
 // trajectories has a CU to itself (the rollout's register budget allows one block per CU) and the round's kernels are the
 // fused k_backward4 and k_rollout16 anyway.  qilqr_device_config.round_launch = 1 keeps them apart (A/B).
 // (the kernels of the round are the two the combined launch stands for: everything but the room on the chip)
-bool fuse_kinds(const qilqr_solver *s, long B) {
+// (total_B / tiled: the call's batch in flight and its record placement -- the solver's own during a call, the caller's for qilqr_describe,
+// which asks about a batch without touching the handle's state)
+bool fuse_kinds(const qilqr_solver *s, long B, long total_B, bool tiled) {
   const bool off = s->dev.round_launch == 1;  // (qilqr_device_config.round_launch: three launches per round, A/B)
-  const long load_B = std::max(B, s->total_B);
-  if (off || s->integrator != 0 || !s->symmetric || !s->st.layout.tiled) return false;
+  const long load_B = std::max(B, total_B);
+  if (off || s->integrator != 0 || !s->symmetric || !tiled) return false;
   if (!(s->dev.force_general == 0 || s->dev.force_general == 5) || backward_kind(s, load_B) != BW_FUSED) return false;
   if (!(s->dev.single_wave_rollout == 0 || s->dev.single_wave_rollout == 3) || load_B > R16_MAX_B) return false;
   return true;
 }
-bool fuse_backward_rollout(const qilqr_solver *s, long B) {
-  return fuse_kinds(s, B) && cdiv(std::max(B, s->total_B), 4) <= (unsigned)s->num_cus;
+bool fuse_kinds(const qilqr_solver *s, long B) { return fuse_kinds(s, B, s->total_B, s->st.layout.tiled != 0); }
+bool fuse_backward_rollout(const qilqr_solver *s, long B, long total_B, bool tiled) {
+  return fuse_kinds(s, B, total_B, tiled) && cdiv(std::max(B, total_B), 4) <= (unsigned)s->num_cus;
 }
+bool fuse_backward_rollout(const qilqr_solver *s, long B) { return fuse_backward_rollout(s, B, s->total_B, s->st.layout.tiled != 0); }
 // Batch solves in flight on a device, over all the handles of the process.  The combined kernel takes a whole CU per block of
 // four trajectories (the rollout's register budget): alone on the chip that is +3 to +4 % of a solve, beside other solves'
 // kernels it is in their way -- three handles in flight: 306 000-311 000 solves/s with it, 340 000 without.  A solve that
@@ -2434,27 +2438,29 @@ int qilqr_describe(qilqr_solver *s, int32_t B, char *buf, size_t cap) {
   t += "; backward: ";
   t += persistent ? "k_solve4 (one launch per solve)" : kind == BW_FUSED ? "k_backward4, fused matrix + gradient wavefronts" : kind == BW_FOUR ? "k_backward4, six wavefronts"
        : kind == BW_TWO ? "k_backward2" : (s->symmetric ? "k_backward<true>, one wavefront per trajectory" : "k_backward<false>, one wavefront per trajectory (general kernel)");
+  if (kind == BW_FOUR || (kind == BW_FUSED && s->dev.force_general == 0 && load_B >= GFAC_MIN_LIVE))
+    t += kind == BW_FOUR ? " (Q_uu factored by the gradient wavefront in launches with " + std::to_string(GFAC_MIN_LIVE) + " or more running trajectories, by the matrix wavefronts otherwise: the same bits)"
+                         : " (six wavefronts, Q_uu factored by the gradient wavefront, while " + std::to_string(GFAC_MIN_LIVE) + " or more trajectories run: the same bits)";
   if (!persistent) {
     const int choice = s->dev.single_wave_rollout;
     t += "; rollout: ";
-    t += (s->integrator == 1 || choice == 1) ? "k_rollout" : (choice == 3 || (choice == 0 && load_B <= R16_MAX_B)) ? "k_rollout16" : "k_rollout3";
-    const qilqr_solver *cs = s;
-    const long saved_total = s->total_B;
-    const int saved_tiled = s->st.layout.tiled;
-    s->total_B = B;  // (the launch helpers go by the batch a call has in flight and by the record placement begin_batch chooses for it)
-    s->st.layout.tiled = records_tiled(s, B, persistent) ? 1 : 0;
-    const bool fused = fuse_backward_rollout(cs, B) && s->dev.sync_every > 1;
-    const int parts = s->dev.sync_every > 1 ? auto_parts(cs, B) : 1;
-    s->total_B = saved_total;
-    s->st.layout.tiled = saved_tiled;
-    if (fused && parts == 1)
-      t += round_kernel_ok(cs) ? "; round: one launch (k_round), " + std::to_string(rounds_per_launch(cs)) + " rounds per launch, while no other batch solve of the process is in flight on the device"
-                                : std::string("; round: k_backward_rollout + k_linearize");
+    t += (s->integrator == 1 || choice == 1) ? "k_rollout" : (choice == 3 || (choice == 0 && load_B <= R16_MAX_B)) ? "k_rollout16"
+         : choice == 0 ? "k_rollout3 for a trajectory's first " + std::to_string(ROLLOUT16_FROM) + " rollouts, k_rollout16 from there on" : "k_rollout3";
+    // (nothing of the handle is touched: the launch helpers take the batch and the record placement the call WOULD have)
+    const bool tiled = records_tiled(s, B, persistent);
+    const bool fused = fuse_backward_rollout(s, B, B, tiled) && s->dev.sync_every > 1;
+    const int parts = s->dev.sync_every > 1 ? auto_parts(s, B) : 1;
+    const bool compact = s->dev.compaction >= 0 && s->dev.sync_every > 1 &&
+                         (s->dev.compaction == 1 || (!(fused && parts == 1) && kind != BW_ONE && tiled));
+    // the round's launch form by the predicate run_solve uses: the combined launch only where the compaction does not work between its halves
+    if (fused && parts == 1 && !compact)
+      t += round_kernel_ok(s) ? "; round: one launch (k_round), " + std::to_string(rounds_per_launch(s)) + " rounds per launch, while no other batch solve of the process is in flight on the device"
+                               : std::string("; round: k_backward_rollout + k_linearize");
+    else if (compact && fuse_kinds(s, B, B, tiled))
+      t += "; round: three launches while the compaction runs, then the combined launch once the running trajectories fit a block per CU";
     else
       t += "; round: three launches";
     t += "; sub-batch streams: " + std::to_string(parts);
-    const bool compact = s->dev.compaction >= 0 && s->dev.sync_every > 1 &&
-                         (s->dev.compaction == 1 || (!(fused && parts == 1) && kind != BW_ONE));
     t += compact ? "; compaction of the running trajectories: on (device-resident calls)" : "; compaction: off";
   }
   std::snprintf(buf, cap, "%s", t.c_str());
