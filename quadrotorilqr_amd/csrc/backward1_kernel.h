@@ -178,7 +178,11 @@ __global__ __launch_bounds__(64) void k_backward(ModelConsts<double> c, SolvePar
   //           instruction with A[i][kk] = K[kk][i], B[kk][j] = -(K^T Q_uu)[j][kk] -- the same products and sums as the plain form.
   //   kind 2: the accumulator holds V^T.  A = V: T = V M, H = C + M^T T as written (ilqr.hh:118-124); Q_xu[j][a] = H[j][12 + a] is then a
   //           column of the tile and crosses it through LDS; V_new = Q_xx - (K^T Q_uu) K in place (ilqr.hh:133) -- and the next knot is kind 1.
-  // No transpose of V_xx anywhere, one trip through LDS every other knot.  Same operations per value as before (the reference's forms).
+  // No transpose of V_xx anywhere, one trip through LDS every other knot.  The same FORMULAS as the reference's at every knot, NOT one fixed
+  // evaluation order of ilqr.hh:118-124: the triple product M^T V M is grouped (M^T V) M at kind-1 knots and M^T (V M) at kind-2 knots -- the
+  // same products, summed in another grouping every other knot, equal to rounding (and, beyond ~150 knots where the unsymmetrised recursion
+  // is noise in the reference too, noise of another size: tests/test_gpu_parity.py::test_long_horizon_instability...; knot-resolved bound at
+  // 100 and 150 knots: test_general_kernel_pass_at_long_horizons_stays_within_the_recursion_s_own_sensitivity).
   auto knot = [&](int i, auto kind_tag) {
     constexpr int KIND = decltype(kind_tag)::value;
     if (i > 0) {

@@ -99,9 +99,12 @@ QILQR_HD int cxx_source_tab(const RecLayout &L, int row, int col) {
 // instructions (v_div_scale, v_rcp, four refinements, v_div_fmas, v_div_fixup), and a knot has ten of them: half of the general kernel's
 // instructions.  On the device the divisions by one pivot share ONE reciprocal (hardware estimate + one Newton step: 2.2e-15 relative)
 // and every quotient gets one correction step, q = a r, q <- q + r (a - b q) with the residual exact in a fused multiply-add -- a Newton
-// step for the quotient itself, which squares the reciprocal's error: the correctly rounded quotient in every one of 2 x 10^7 random
-// cases over five magnitudes (profiles/microbench/rcp_accuracy.hip), i.e. Eigen's division.  Pivots of magnitude below ~ 1e-292 (the reciprocal overflows) are beyond it; Eigen's own threshold
-// for a zero pivot is 2.2e-308, and such a Q_uu has no usable gains in the reference either.  The host (tests/host_harness.cpp, where
+// step for the quotient itself, which squares the reciprocal's error: a FAITHFULLY rounded quotient (the IEEE quotient or its neighbour: with
+// a reciprocal good to ~2^-48 a misrounding has a probability of the order of 2^-43 per quotient) that EQUALLED the IEEE quotient in every
+// one of 2 x 10^7 random cases over five magnitudes (profiles/microbench/rcp_accuracy.hip) -- not Eigen's division by proof, Eigen's division
+// in every sampled case.  Outside |b| in about [1e-290, 1e290] the reciprocal or a r leaves the representable range where a / b is
+// representable (Eigen gives finite values there, this gives inf or NaN); Eigen's own threshold for a zero pivot is 2.2e-308, and a Q_uu with
+// pivots of 1e-290 has no usable gains in the reference either.  The host (tests/host_harness.cpp, where
 // the oracle's pivoted LDL^T is compared bit for bit) divides.
 struct PivotRcp {
   double b, r;
