@@ -52,8 +52,8 @@ FLOP_BWD_KNOT, FLOP_FWD_KNOT = 30000.0, 1250.0
 BYTES_BWD_KNOT, BYTES_FWD_KNOT, BYTES_IO_KNOT = 86 * 8.0, 103 * 8.0, 53 * 8.0
 # The PMC summary `roofline.traffic` is read from: named explicitly, and only used when its tag is this round's
 # (profiles/run_rocprof.sh <tag> writes profiles/<tag>_rocprof_summary.json from the same bench command).
-ROUND_TAG = "r05"
-TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r05b_rocprof_summary.json")
+ROUND_TAG = "r06"
+TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r06b_rocprof_summary.json")
 
 
 def kernel_table(prof, n_bwd_knots, n_fwd_knots, solves=None):
@@ -698,20 +698,10 @@ def main():
                                          for k in ("backward", "rollout", "solve")},
             }
         # ---- the extra legs (never `value`).  HIP hands hardware queues to streams in the order the streams are created and does
-        # not give a destroyed stream's place back: the B = 8192 solver's four sub-batch streams are therefore created FIRST
-        # (behind other handles they end up sharing queues: 385 000 instead of 444 000-460 000 solves/s), by one untimed solve;
-        # then host_to_host is MEASURED first, on a fresh handle, before any other leg has left streams or work behind.
-        large = None
-        ls = None
-        if not args.no_large_batch and world == 1 and not strong:
-            LB = 8192
-            lcfg = pb.config2(B=LB, N=N, seed=4)
-            ls = capi.from_config(lcfg, device=dev.index, profile=2, sync_every=args.sync_every)
-            linit = torch.from_numpy(lcfg["init"]).to(dev)
-            lbuf = (torch.empty_like(linit), torch.empty(LB, dtype=torch.float64, device=dev),
-                    [torch.empty(LB, dtype=torch.int32, device=dev) for _ in range(4)])
-            ls.solve_batch_device(linit, lbuf[0], lbuf[1], *lbuf[2])
-            torch.cuda.synchronize()
+        # not give a destroyed stream's place back, and GPU_MAX_HW_QUEUES = 8: host_to_host is measured FIRST and on `value`'s own
+        # handle (one more stream: its copy-back's), then the B = 8192 solver creates its five (streams three to eight of the
+        # process: behind further handles they end up sharing queues -- 385 000 instead of 444 000-460 000 solves/s in round 3; and a
+        # fresh host_to_host handle BEHIND them read + 0.60 ms over the device-resident call instead of + 0.43, round 6).
         # ---- the metric as SURVEY.md section 8(d) defines it: host buffers in -> host buffers out (never `value`).  Pinned and
         # pageable buffers alternate call by call; median and 90th percentile of >= 30 calls each.
         h2h = None
@@ -720,7 +710,13 @@ def main():
             hin[...] = cfg["init"]
             hout = dict(traj=capi.host_array(cfg["init"].shape), cost=capi.host_array((B,)),
                         **{k: capi.host_array((B,), np.int32) for k in ("status", "iters", "n_bwd", "n_fwd")})
-            plain = capi.from_config(cfg, device=dev.index, sync_every=args.sync_every)
+            # On `value`'s own handle, its event timing switched off (the profile of the timed region was read above): a fresh handle's two
+            # streams (its own and the copy-back's) would be the ninth and tenth of the process behind the B = 8192 solver's five, and HIP
+            # multiplexes streams onto GPU_MAX_HW_QUEUES = 8 hardware queues -- round 6 measured + 0.60 ms over the device-resident call with
+            # the fresh handle behind the large solver and + 0.43 without the large solver in the process: a collision of the bench's own
+            # making, not the library's (profiles/microbench/h2h_ab.py: + 0.33-0.36 in a process of its own).
+            solver.profile_mode(0)
+            plain = solver
             pg = cfg["init"].copy()  # the same through pageable buffers (HIP stages the copies itself)
             t_settle = time.perf_counter()
             while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:  # clocks and both paths warm
@@ -750,7 +746,17 @@ def main():
                    "device_resident_same_moment": {"ms_per_solve": float(np.median(tdev)), "ms_p90": float(np.percentile(tdev, 90))},
                    "over_device_resident_ms": th - float(np.median(tdev)),
                    "parity_with_device_path": bool(np.array_equal(hout["cost"], out_cost[0].cpu().numpy()))}
-            plain.close()
+        large = None
+        ls = None
+        if not args.no_large_batch and world == 1 and not strong:
+            LB = 8192
+            lcfg = pb.config2(B=LB, N=N, seed=4)
+            ls = capi.from_config(lcfg, device=dev.index, profile=2, sync_every=args.sync_every)
+            linit = torch.from_numpy(lcfg["init"]).to(dev)
+            lbuf = (torch.empty_like(linit), torch.empty(LB, dtype=torch.float64, device=dev),
+                    [torch.empty(LB, dtype=torch.int32, device=dev) for _ in range(4)])
+            ls.solve_batch_device(linit, lbuf[0], lbuf[1], *lbuf[2])
+            torch.cuda.synchronize()
         # ---- the saturated machine: the shard one GPU solves in configs[3] (never `value`)
         if ls is not None:
             t_settle = time.perf_counter()  # untimed solves first: the legs before this one leave the GPU idle for seconds and its clocks low

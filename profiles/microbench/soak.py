@@ -15,12 +15,13 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 orig = capi.from_config
 bad = 0
-for label, kw in [("automatic", {}), ("k_backward4 six waves", dict(force_general=4)), ("k_backward4 fused", dict(force_general=5)),
+for label, kw in [("automatic", {}), ("k_backward4 six waves", dict(force_general=4)), ("six waves, G factors", dict(force_general=7)), ("six waves, M factors", dict(force_general=8)),
+                  ("k_backward4 fused", dict(force_general=5)),
                   ("one wavefront", dict(force_general=2)), ("general", dict(force_general=1)),
                   ("k_rollout", dict(single_wave_rollout=1)), ("k_rollout3", dict(single_wave_rollout=2)), ("k_rollout16", dict(single_wave_rollout=3)),
                   ("three streams", dict(streams=3)), ("compaction", dict(compaction=1)), ("compaction, six waves, k_rollout3", dict(compaction=1, force_general=4, single_wave_rollout=2)),
                   ("compaction, three streams", dict(compaction=1, streams=3)), ("restarts, compaction", dict(compaction=1)),
-                  ("restarts, compaction, six waves", dict(compaction=1, force_general=4)), ("restarts", dict()), ("restarts, six waves", dict(force_general=4)), ("restarts, fused", dict(force_general=5)),
+                  ("restarts, compaction, six waves", dict(compaction=1, force_general=4)), ("restarts", dict()), ("restarts, six waves", dict(force_general=4)), ("restarts, six waves, G factors", dict(force_general=7)), ("restarts, fused", dict(force_general=5)),
                   ("restarts, one wavefront", dict(force_general=2)), ("restarts, general", dict(force_general=1))]:
     capi.from_config = lambda cfg, _kw=kw, **k: orig(cfg, **{**_kw, **k})
     fails = 0
