@@ -81,6 +81,9 @@ __device__ __forceinline__ double bw4_gradient_wave(double (&ring)[4][4][BW2_BUF
   const long kst = kowner ? (knot_elem<true>(1, 0, 52) - knot_elem<true>(0, 0, 52)) / 2 : 0;
   double vx = 0.0;  // V_x[j] (lanes j < 12)
   double QuTk = 0.0;
+  // (the gradient wavefront holds its block's matrix wavefronts at every knot's barrier: it issues at their priority, as in the form below --
+  // round 6; within noise alone, + 0.5-1 % where several sub-batches' blocks share a CU)
+  __builtin_amdgcn_s_setprio(3);
   __syncthreads();
   auto gradient_slot = [&](int q, auto slot_tag) {
     constexpr int SLOT = decltype(slot_tag)::value;

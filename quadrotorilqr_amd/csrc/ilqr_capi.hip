@@ -306,7 +306,11 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
 }
 
 inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
-constexpr long R16_MAX_B = 4096;  // k_rollout16 up to this many trajectories (launch_rollout)
+#ifndef QILQR_REGIME_B
+#define QILQR_REGIME_B 4096
+#endif
+constexpr long REGIME_B = QILQR_REGIME_B;  // calls with more trajectories in flight take the kernels built for a full chip
+constexpr long R16_MAX_B = REGIME_B;  // k_rollout16 for every rollout up to this many trajectories (launch_rollout)
 // largest number of consecutive restarts lm_restart (kernels_common.h) can grant one iteration
 inline double max_restarts(const SolveParams &p) {
   if (!(p.mu_init > 0.0) || !(p.mu_init <= p.mu_max)) return 0.0;
@@ -464,7 +468,7 @@ BackwardKind backward_kind(const qilqr_solver *s, long load_B) {
 #ifdef QILQR_WITH_BACKWARD2
   if (s->dev.force_general == 3) return BW_TWO;
 #endif
-  if (s->dev.force_general == 5 || (s->dev.force_general == 0 && load_B <= 4096)) return BW_FUSED;
+  if (s->dev.force_general == 5 || (s->dev.force_general == 0 && load_B <= REGIME_B)) return BW_FUSED;
   if (s->dev.force_general != 2) return BW_FOUR;
   return BW_ONE;
 }
@@ -499,7 +503,7 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
   } else if (kind == BW_FOUR) {
     // four matrix wavefronts + one gradient wavefront + one loader wavefront per four trajectories
     // (register budget by how many blocks the chip has to hold: see k_backward4)
-    const bool many = load_B > 4096;
+    const bool many = load_B > REGIME_B;
     // Who factors Q_uu (round 6; the same bits either way, backward4_kernel.h): the gradient wavefront when the chip is saturated -- a SIMD
     // is then bound by what its wavefronts issue, and one instruction stream factors four trajectories' Q_uu instead of four (a launch with
     // every trajectory live, MI355X, N = 100: B = 65536 3807 -> 3515 us, 8192 509 -> 484) -- and the matrix wavefronts when a launch's
@@ -1040,7 +1044,7 @@ int auto_parts(const qilqr_solver *s, long B) {
   // the parts collide with each other and with the caller's streams and two are the safer choice.
   // Round 4 (compaction, k_backward4 and k_rollout3 at every size beyond 4096): four parts are ahead at 16384 and 65536 as well
   // (596k against 591k, 698k against 686k).
-  int want = s->dev.streams > 0 ? s->dev.streams : (B >= 4096 ? ((B > 4096 && hw_queues() >= 8) ? 4 : 2) : 1);
+  int want = s->dev.streams > 0 ? s->dev.streams : (B >= REGIME_B ? ((B > REGIME_B && hw_queues() >= 8) ? 4 : 2) : 1);
   if (want > qilqr_solver::MAX_PARTS) want = qilqr_solver::MAX_PARTS;
   while (want > 1 && tiles < 2 * want) --want;  // at least two tiles per part
   return want;
