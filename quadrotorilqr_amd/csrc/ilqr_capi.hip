@@ -503,7 +503,11 @@ int launch_backward(qilqr_solver *s, long B, long n, int force) {
   } else if (kind == BW_FOUR) {
     // four matrix wavefronts + one gradient wavefront + one loader wavefront per four trajectories
     // (register budget by how many blocks the chip has to hold: see k_backward4)
+#ifdef QILQR_FORCE_MANY  // (experiment: the four-blocks-per-CU register budget and the unrolled knot loop at every size)
+    const bool many = true;
+#else
     const bool many = load_B > REGIME_B;
+#endif
     // Who factors Q_uu (round 6; the same bits either way, backward4_kernel.h): the gradient wavefront when the chip is saturated -- a SIMD
     // is then bound by what its wavefronts issue, and one instruction stream factors four trajectories' Q_uu instead of four (a launch with
     // every trajectory live, MI355X, N = 100: B = 65536 3807 -> 3515 us, 8192 509 -> 484) -- and the matrix wavefronts when a launch's
@@ -588,7 +592,10 @@ bool fuse_kinds(const qilqr_solver *s, long B, long total_B, bool tiled) {
   const bool off = s->dev.round_launch == 1;  // (qilqr_device_config.round_launch: three launches per round, A/B)
   const long load_B = std::max(B, total_B);
   if (off || s->integrator != 0 || !s->symmetric || !tiled) return false;
-  if (!(s->dev.force_general == 0 || s->dev.force_general == 5) || backward_kind(s, load_B) != BW_FUSED) return false;
+  // (force_general = 8 with the combined launch: k_round with the six-wavefront backward pass in EVERY launch -- tests, A/B)
+  if (!(s->dev.force_general == 0 || s->dev.force_general == 5 || s->dev.force_general == 8)) return false;
+  if (s->dev.force_general != 8 && backward_kind(s, load_B) != BW_FUSED) return false;
+  if (s->dev.force_general == 8 && (s->dev.round_launch != 0 || s->f32)) return false;  // (only k_round has the form: not k_backward_rollout)
   if (!(s->dev.single_wave_rollout == 0 || s->dev.single_wave_rollout == 3) || load_B > R16_MAX_B) return false;
   return true;
 }
@@ -621,9 +628,10 @@ int rounds_per_launch(const qilqr_solver *s) {
   const int v = s->dev.rounds_per_launch;
   return (v == 1 || v == 2) ? v : 4;
 }
-int launch_round(qilqr_solver *s, long B, long n, long round, bool publish_prev, int rounds) {
+int launch_round(qilqr_solver *s, long B, long n, long round, bool publish_prev, int rounds, bool six = false) {
   const ModelConsts<double> *cp = (const ModelConsts<double> *)s->d_consts;
-  const dim3 grid(cdiv(B, 4)), block(320);
+  if (rounds == 2) six = false;  // (the six-wavefront form is instantiated for launches of one and of four rounds)
+  const dim3 grid(cdiv(B, 4)), block(six ? 384 : 320);
   BatchState st = s->st;
   int *base = s->st.counters;
   st.counters = base + (round & 1) * COUNT_WORDS;
@@ -631,7 +639,16 @@ int launch_round(qilqr_solver *s, long B, long n, long round, bool publish_prev,
   const int prev_round = publish_prev ? (int)((round - 1) & 0x3fffffff) : -1;
   const int lk = (s->q_diag && layout_kind(s->layout) == 2) ? 3 : (layout_kind(s->layout) == 2 ? 2 : 1);
 #define QILQR_LAUNCH_ROUND(LK, R) launch(s, K_BACKWARD, (k_round<LK, R>), grid, block, s->consts, cp, s->params, st, (int)B, (int)n, prev, prev_round)
-  if (rounds == 4) {
+#define QILQR_LAUNCH_ROUND6(LK, R) launch(s, K_BACKWARD, (k_round<LK, R, true>), grid, block, s->consts, cp, s->params, st, (int)B, (int)n, prev, prev_round)
+  if (six && rounds == 4) {
+    if (lk == 3) QILQR_LAUNCH_ROUND6(3, 4);
+    else if (lk == 2) QILQR_LAUNCH_ROUND6(2, 4);
+    else QILQR_LAUNCH_ROUND6(1, 4);
+  } else if (six) {
+    if (lk == 3) QILQR_LAUNCH_ROUND6(3, 1);
+    else if (lk == 2) QILQR_LAUNCH_ROUND6(2, 1);
+    else QILQR_LAUNCH_ROUND6(1, 1);
+  } else if (rounds == 4) {
     if (lk == 3) QILQR_LAUNCH_ROUND(3, 4);
     else if (lk == 2) QILQR_LAUNCH_ROUND(2, 4);
     else QILQR_LAUNCH_ROUND(1, 4);
@@ -645,6 +662,7 @@ int launch_round(qilqr_solver *s, long B, long n, long round, bool publish_prev,
     else QILQR_LAUNCH_ROUND(1, 1);
   }
 #undef QILQR_LAUNCH_ROUND
+#undef QILQR_LAUNCH_ROUND6
   return QILQR_OK;
 }
 int launch_backward_rollout(qilqr_solver *s, long B, long n) {
@@ -888,7 +906,10 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
         // several rounds per launch where the rounds are this kernel for the rest of the solve (no compaction any more, whose
         // thresholds go by the count) and the caller does not look at a solve round by round (the single solve's debug capture)
         const int rounds = ((can_fuse || tail_started) && double_ok) ? rounds_per_launch(s) : 1;
-        if ((rc = launch_round(s, used, n, round, pending_publish, rounds))) return rc;
+        // the backward pass's form by how many trajectories a block holds on average (the same bits: round_kernels.h)
+        // (and only in launches of several rounds: with one round per launch the 384-thread form measured slower)
+        const bool six = s->dev.force_general == 8 || (s->dev.force_general == 0 && rounds > 1 && 2L * (long)seen_active <= cdiv(used, 4) * 4L);
+        if ((rc = launch_round(s, used, n, round, pending_publish, rounds, six))) return rc;
         s->round_captured = true;
         launched_rounds[round & 7] = rounds;
         pending_publish = true;

@@ -105,8 +105,23 @@ __global__ void k_publish_active(int *counters, unsigned long long *host_active,
 // ROUNDS > 1: several rounds per launch (a round's settle step finds the knot costs the block has just written): the launch
 // boundaries between them are gone too.  All of them count into the launch's counter set: the host reads the SUM of their counts of
 // running trajectories, an upper bound of the last one's and zero exactly when the first one's is.  The rounds share the block's LDS.
-template <int LK, int ROUNDS>
-__global__ __launch_bounds__(320) void k_round(ModelConsts<double> c, const ModelConsts<double> *__restrict__ cp, SolveParams p, BatchState st, int B,
+// SIX: six wavefronts per block (384 threads) and the backward pass in the six-wavefront form with the matrix wavefronts factoring (round 6).  One
+// launch of each k_backward4 form by how many of a block's four trajectories run (profiles/microbench/bw_forms_live.py, us per 100 knots):
+//       running     fused     six wavefronts, knot loop unrolled
+//          1        67.3            61.5
+//          2        67.2            62.3
+//          3        67.7            69.6
+//          4        67.4            72.1
+// -- in the fused form the gradient recursion rides on the matrix wavefront's own instruction stream whatever the block holds; in the
+// six-wavefront form it is another wavefront's, and the per-knot barrier costs by how many matrix wavefronts meet at it.  The bits are the
+// same (round 6), so the host takes this form for the launches in which, on average, at most two trajectories per block still run: the late
+// rounds, where the slowest problem of a batch is alone in its block.  Inside k_round most of the stand-alone kernels' 5.7 us does not
+// arrive: a lone trajectory's round takes 126.0 us instead of 127.9 (B = 1, four rounds per launch; with ONE round per launch the form is
+// 3.4 us per round SLOWER: something per launch of the 384-thread block), a B = 1024 solve 4.739 instead of 4.756 ms on configs[1]'s
+// problems (- 0.4 %) and 5.554 instead of 5.646 on configs[3]'s (- 1.6 %), B = 64 - 0.6 %; forced in every launch it loses 2.6 % at
+// B = 1024 (the early rounds, four running trajectories per block).  Kept: never slower where the host takes it.
+template <int LK, int ROUNDS, bool SIX = false>
+__global__ __launch_bounds__(SIX ? 384 : 320) void k_round(ModelConsts<double> c, const ModelConsts<double> *__restrict__ cp, SolveParams p, BatchState st, int B,
                                                 int n, int *prev_counters, int prev_round) {
   typedef double S;
   __shared__ double qr_w[160];  // the weights of the cost half (k_linearize keeps a copy per wavefront: here the block's)
@@ -119,7 +134,7 @@ __global__ __launch_bounds__(320) void k_round(ModelConsts<double> c, const Mode
   // the constant operand table behind the ring slots, once for all the rounds of the launch (a round whose block has nothing to run
   // leaves before it would fill it, and a later round of the same launch may have something: so here, unconditionally; the records and
   // the settle step's scratch use the slots' other words)
-  bw4_fill_ctab<S>(ring, st.ctab, 320);
+  bw4_fill_ctab<S>(ring, st.ctab, SIX ? 384 : 320);
   // (an idle wavefront of block 0 hands the host the count of the launch before this one while the others roll out)
 #define ROUND_BEHIND_BACKWARD \
   if (blockIdx.x == 0 && (threadIdx.x >> 6) == 4 && prev_round >= 0) publish_active(prev_counters, st.host_active, prev_round, threadIdx.x & 63);

@@ -49,6 +49,24 @@ def test_one_launch_for_backward_and_rollout_gives_the_same_bits():
     assert np.isin(fused["f64_1024_status"], [0, 1]).all() and (fused["restarts_n_bwd"] > fused["restarts_iters"] + 1).any()
 
 
+@pytest.mark.parametrize("rounds", [0, 1])
+def test_k_round_with_the_six_wavefront_backward_pass_gives_the_same_bits(rounds):
+    """Round 6: k_round<.., SIX> -- the same launch with the backward pass in the six-wavefront form (the matrix wavefronts factor, knot loop
+    unrolled), which the host takes once at most two trajectories per block run on average (5.7 us of a 127 us round with one running
+    trajectory per block).  force_general = 8 takes it in EVERY launch, 5 never; the automatic choice changes over inside a solve.  Four
+    rounds per launch and one; every case of `solves` (ragged batches, per-problem desired trajectories, restarts; the mixed mode keeps
+    k_backward_rollout) and the profile says that the launches were k_round's (no separate rollout launches)."""
+    six, fused, auto = solves(force_general=8, rounds_per_launch=rounds), solves(force_general=5, rounds_per_launch=rounds), solves(rounds_per_launch=rounds)
+    for k in fused:
+        np.testing.assert_array_equal(six[k], fused[k], err_msg="six wavefronts: " + k)
+        np.testing.assert_array_equal(auto[k], fused[k], err_msg="automatic: " + k)
+    cfg = pb.config2(B=1024, N=100, seed=2)
+    s = capi.from_config(cfg, force_general=8, profile=2, rounds_per_launch=rounds)
+    s.solve_batch(cfg["init"])
+    p = s.profile_get()
+    assert p["rollout_launches"] == 0 and p["backward_launches"] > 0 and "k_round" in s.describe(1024)
+
+
 @pytest.mark.parametrize("rounds", [1, 2])
 def test_rounds_per_launch_changes_no_bit(rounds):
     """(qilqr_solve_batch from pageable arrays: staging, then the device-resident solve whose launches may hold several rounds)"""
