@@ -88,7 +88,9 @@ typedef struct {
                             Q, R are symmetric; 2: the one-wavefront kernel for symmetric weights (k_backward<true>);
                             3: k_backward2 (diagnostics build only); 4: k_backward4, six wavefronts (Q_uu factored by the gradient
                             wavefront in launches with 3072 or more running trajectories, by the matrix wavefronts otherwise; 7 / 8:
-                            the one / the other at every launch); 5: k_backward4, fused
+                            the one / the other at every launch -- 8 where the round is the combined launch k_round: its backward phase in
+                            the six-wavefront form in every launch, which 0 takes for the launches in which at most two trajectories per
+                            block still run); 5: k_backward4, fused
                             (its wavefronts meet through tagged LDS slots, no block barrier in the knot loop: what 0
                             selects up to 4096 trajectories; forced, it is used at every size); 6: retired in round 4
                             (the fused form with a block barrier per knot: refused by name).  When the round's kernels are the fused k_backward4 and k_rollout16 and
