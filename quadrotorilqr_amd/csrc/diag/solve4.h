@@ -139,6 +139,7 @@ __global__ __launch_bounds__(S4_THREADS) void k_solve4(ModelConsts<double> c, co
   const RecLayout L = st.layout;
   for (int k = threadIdx.x; k < 160; k += S4_THREADS) qr[k] = (k < 144) ? cp->Q[k] : cp->R[k - 144];
   bw4_fill_ctab<S>(ring, st.ctab, S4_THREADS);
+  if (threadIdx.x < 64) r16_exp2_lds[threadIdx.x >> 4][threadIdx.x & 15] = Series<double>::exp2[threadIdx.x >> 4][threadIdx.x & 15];  // (rollout16_body.inc)
   const int ngroups = (B + 3) / 4;
 #ifdef QILQR_STAMPS
   // diagnostic build: cycles of wave `w` per phase, summed over the block's life: [0] first linearisation, [1] settle,

@@ -27,6 +27,9 @@ namespace qilqr {
 // rows compute a duplicate that nobody stores): no row wanders onto a slow branch, no extra memory traffic.
 // S = storage precision of trajectories and gains; the arithmetic is fp64 in either mode.
 // ---------------------------------------------------------------------------------------------
+// the sixteen-term series of Exp's four coefficients (se3_math.h, Series::exp2) in LDS: [place in the row][coefficient]; rollout16_body.inc
+// fills it in front of the kernel's first barrier
+__shared__ double r16_exp2_lds[4][16];
 struct DevWave {
   typedef double V;
   typedef bool M;
@@ -81,6 +84,7 @@ struct DevWave {
   static __device__ __forceinline__ M lor(M a, M b) { return a || b; }
   static __device__ __forceinline__ M lnot(M a) { return !a; }
   static __device__ __forceinline__ V abs_(V a) { return fabs(a); }
+  static __device__ __forceinline__ V exp2_coeff(int k) { return r16_exp2_lds[threadIdx.x & 3][k]; }
   static __device__ __forceinline__ V sqrt_(V a) { return sqrt(a); }
   static __device__ __forceinline__ V sin_(V a) { return sin(a); }
   static __device__ __forceinline__ V cos_(V a) { return cos(a); }

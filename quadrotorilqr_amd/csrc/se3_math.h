@@ -1108,6 +1108,26 @@ struct Series {
   static constexpr T jac_b[8] = {0.16666666666666666, -0.008333333333333333, 0.0001984126984126984,
                                  -2.7557319223985893e-06, 2.505210838544172e-08, -1.6059043836821613e-10,
                                  7.647163731819816e-13, -2.8114572543455206e-15};  // (th - sin th)/th^3
+  // The same four functions as sixteen-term series, for EXP_MAX < x <= EXP2_MAX (round 6: k_rollout16's Exp; |dt omega| up to 3.46 rad per
+  // step).  They are entire functions: the series converges everywhere, the first omitted term is below 1e-21 at x = 12, and the
+  // alternating sum's rounding stays at 3e-16 absolute (checked against 50-digit sums: tests/test_device_math_on_host.py) -- what sqrt, two
+  // sines, two cosines and three divisions give, at a tenth of their cost.  [0] cos(th/2), [1] sin(th/2)/th, [2] (1 - cos th)/th^2,
+  // [3] (th - sin th)/th^3; coefficient k of [f] is (-1)^k over 4^k (2k)!, 2^(2k+1) (2k+1)!, (2k+2)!, (2k+3)!.
+  static constexpr T EXP2_MAX = T(12.0);
+  static constexpr T exp2[4][16] = {
+      {1.0, -0.125, 0.0026041666666666665, -2.170138888888889e-05, 9.68812003968254e-08, -2.691144455467372e-10, 5.096864498991235e-13,
+       -7.001187498614334e-16, 7.292903644389931e-19, -5.958254611429682e-22, 3.919904349624791e-25, -2.1211603623510776e-28,
+       9.606704539633503e-32, -3.694886361397501e-35, 1.2218539554885916e-38, -3.511074584737332e-42},
+      {0.5, -0.020833333333333332, 0.00026041666666666666, -1.5500992063492063e-06, 5.382288910934745e-09, -1.2232474797578965e-11,
+       1.9603324996120133e-14, -2.333729166204778e-17, 2.1449716601146855e-20, -1.5679617398499164e-23, 9.333105594344741e-27,
+       -4.6112181790240814e-30, 1.9213409079267006e-33, -6.842382150736113e-37, 2.106644750842399e-40, -5.66302352376989e-44},
+      {0.5, -0.041666666666666664, 0.001388888888888889, -2.48015873015873e-05, 2.755731922398589e-07, -2.08767569878681e-09,
+       1.1470745597729725e-11, -4.779477332387385e-14, 1.5619206968586225e-16, -4.110317623312165e-19, 8.896791392450574e-22,
+       -1.6117375710961184e-24, 2.4795962632247976e-27, -3.279889237069838e-30, 3.7699876288159054e-33, -3.8003907548547434e-36},
+      {0.16666666666666666, -0.008333333333333333, 0.0001984126984126984, -2.7557319223985893e-06, 2.505210838544172e-08,
+       -1.6059043836821613e-10, 7.647163731819816e-13, -2.8114572543455206e-15, 8.22063524662433e-18, -1.9572941063391263e-20,
+       3.868170170630684e-23, -6.446950284384474e-26, 9.183689863795546e-29, -1.1309962886447716e-31, 1.216125041553518e-34,
+       -1.151633562077195e-37}};
   // Barfoot Q-block coefficients C = (1 - x/2 - cos th)/x^2 and D = (C - 3 (th - sin th - th^3/6)/th^5)/2
   // in x = theta^2 (B is jac_b), valid for x <= EXP_MAX
   static constexpr T fillq_C[8] = {-0.041666666666666664, 0.001388888888888889, -2.48015873015873e-05,

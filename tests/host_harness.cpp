@@ -87,6 +87,7 @@ struct HostWave {
   HV_FUN(abs_, std::fabs) HV_FUN(sqrt_, std::sqrt) HV_FUN(sin_, std::sin) HV_FUN(cos_, std::cos)
   static V atan2_(const V &a, const V &b) { V r; for (int l = 0; l < 64; ++l) r.v[l] = std::atan2(a.v[l], b.v[l]); return r; }
   // the rarely-taken closed forms (out of line on the device)
+  static V exp2_coeff(int k) { return vconst([k](int l) { return qilqr::Series<double>::exp2[l & 3][k]; }); }
   static V exp_closed(const M &c, const V &x, const V &p, const M &l0, const M &l1, const M &l2, const M &l3) {
     return qilqr::r16::exp_closed_forms<HostWave>(c, x, p, l0, l1, l2, l3);
   }

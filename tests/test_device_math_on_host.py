@@ -431,6 +431,16 @@ def test_rollout16_branches(hh):
     out, _ = _rollout16(hh, c, init, gains, np.array([1.0, 1.0, 0.5, 0.5]))
     for b in range(4):
         np.testing.assert_allclose(out[b], s.forward_sim(init[b], gains[b], [1.0, 1.0, 0.5, 0.5][b]), rtol=1e-10, atol=1e-11)
+    # (b') the three ranges of Exp in ONE wavefront and across their boundaries: |dt omega|^2 = 0.2 (eight-term series), 3 and 11.5
+    # (sixteen-term series, round 6), 13 and 30 (closed forms)
+    for x2s in ((0.2, 3.0, 11.5, 13.0), (0.26, 11.9, 12.1, 30.0), (6.0, 6.0, 6.0, 6.0)):
+        spin = cfg["init"].copy()
+        for b, x2 in enumerate(x2s):
+            d = r.normal(size=3)
+            spin[b, 0, 11:14] = d / np.linalg.norm(d) * np.sqrt(x2) / cfg["dt"]
+        out, _ = _rollout16(hh, c, spin, np.zeros((4, 12, 52)), np.ones(4))
+        for b in range(4):
+            np.testing.assert_allclose(out[b], s.forward_sim(spin[b], zero, 1.0), rtol=1e-10, atol=1e-11)
     # (c) the demo's box climb, 40 knots, first iterations of its solve
     cfg1 = pb.config1(4.0)
     c1 = consts(hh, cfg1["model"], cfg1["Q"], cfg1["R"], cfg1["dt"])

@@ -838,8 +838,9 @@ def test_long_horizon_instability_of_the_unsymmetrised_recursion():
     # same failure class as the reference: no problem reaches the optimum -- costs two to nine orders of magnitude above the convergent
     # regime -- and the gains of one backward pass are several times the bounded recursion's.  Which problem lands where, and how far, is
     # rounding noise (that is the finding): the oracle's dense products leave every cost above 1e9; the general kernel's matrix-core products
-    # (round 5: an accumulator carried alternately as V and V^T, no transposes) leave them between 7e4 and 3e11, |K| ~ 2.4e2 against ~ 1e3.
-    assert (gen["cost"] > 20 * sym["cost"]).all() and np.median(gen["cost"]) > 1e5 and (gen["cost"] > 1e8).sum() >= 4
+    # (round 5: an accumulator carried alternately as V and V^T, no transposes) leave them between 2e4 and 3e11, |K| ~ 2.4e2 against ~ 1e3
+    # (any change of a rounding anywhere re-draws them: round 6's sixteen-term series in the rollout took the smallest ratio from 60 to 14.6).
+    assert (gen["cost"] > 8 * sym["cost"]).all() and (gen["cost"] > 100 * sym["cost"]).sum() >= 12 and np.median(gen["cost"]) > 1e5 and (gen["cost"] > 1e8).sum() >= 4
     g_gen, _ = capi.from_config(cfg, force_general=True).backwards_pass(cfg["init"][1:2])
     assert np.abs(g_gen).max() > 100
     assert np.isin(sym["status"], [0, 1]).all() and (sym["cost"] < 1e4).all()
