@@ -145,9 +145,10 @@ typedef struct {
                          slowest problem and the kernels hand out work in groups of 4 and 64 trajectories that cost the same
                          with one running as with all.  Results are bit-identical with and without.  0 = automatic (whenever the
                          round's backward pass is a k_backward4 launch of its own, i.e. symmetric weights and more than 1024
-                         trajectories, while more than 512 of a sub-batch are running -- up to 4096 trajectories per call: until the running
-                         ones fit the combined launch k_backward_rollout, which the rounds then change over to), 1 = at every size and
-                         count the call allows
+                         trajectories, while more than 512 of a sub-batch are running, and until the running ones fit the combined launch
+                         -- k_backward_rollout, then k_round -- which the rounds then change over to: at once in a call of up to 4096
+                         trajectories, in a larger one from the round in which its rollouts are k_rollout16's anyway, see
+                         single_wave_rollout), 1 = at every size and count the call allows
                          (not with populate_debug's cost history, per-problem desired trajectories, or the copy-back under the
                          tail of qilqr_solve_batch), -1 = never */
   int32_t round_launch; /* (ABI version 7; until then the environment variables QILQR_FUSE_BACKWARD_ROLLOUT / QILQR_ROUND_KERNEL) how a round of

@@ -712,16 +712,32 @@ int launch_compact(qilqr_solver *s, long B, long n) {
 // A batch of 1025 ... 4096 trajectories runs the same two kernels apart, with the compaction between them; once the running
 // trajectories fit the combined launch -- `slots` of them for this (sub-)batch: a block of four per CU over all the sub-batches --
 // the compaction has nothing left to give (a block per CU whatever the slots) and the rounds change over to the one launch.
+// Round 6: a batch BEYOND 4096 does the same from the round in which its rollouts are k_rollout16's anyway (launch_rollout: the 17th, or
+// every round with single_wave_rollout = 3) -- the backward pass is one arithmetic in every form, so the combined launch's fused form gives
+// the bits of the six-wavefront launches it replaces, and a problem's bits stay independent of its batch.
 struct TailFuse {
-  bool kinds = false;  // the round's kernels are the fused k_backward4 and k_rollout16
+  bool kinds = false;  // the round's kernels are the fused k_backward4 and k_rollout16 (or, from round `from` on, stand for the same bits)
   long slots = 0;      // slots in use at or below which this (sub-)batch's rounds are one launch
   unsigned stop = 0;   // the compaction runs while more trajectories than this are running
+  long from = 0;       // first round in which the changeover may happen
 };
+#ifndef QILQR_LATE_TAIL
+#define QILQR_LATE_TAIL 1  // (0: batches beyond 4096 keep three launches per round to the end -- A/B)
+#endif
+bool late_tail_kinds(const qilqr_solver *s, long B, long total_B, bool tiled, long *from) {
+  const long load_B = std::max(B, total_B);
+  if (!QILQR_LATE_TAIL || s->dev.round_launch == 1 || s->integrator != 0 || !s->symmetric || !tiled) return false;
+  if (s->dev.force_general != 0 || load_B <= R16_MAX_B || backward_kind(s, load_B) != BW_FOUR) return false;
+  if (s->dev.single_wave_rollout == 0) *from = ROLLOUT16_FROM;
+  else if (s->dev.single_wave_rollout == 3) *from = 0;
+  else return false;
+  return true;
+}
 TailFuse tail_fuse(const qilqr_solver *s, long B, int nparts) {
   TailFuse t;
   t.stop = compact_stop(s);
   if (!s->compact || s->dev.compaction == 1) return t;  // (forced: the compaction runs to the last trajectory)
-  t.kinds = fuse_kinds(s, B);
+  t.kinds = fuse_kinds(s, B) || late_tail_kinds(s, B, s->total_B, s->st.layout.tiled != 0, &t.from);
   if (t.kinds) {
     t.slots = std::max<long>(64, 4L * s->num_cus / nparts / 64 * 64);
     t.stop = std::max<unsigned>(t.stop, (unsigned)t.slots);
@@ -895,7 +911,7 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
       // (once the compaction has stopped for a batch that changes over to the combined launch it stays stopped: the launches may then hold
       // several rounds, and the sums of counts they report say nothing against the threshold)
       const bool compacting = s->compact && !tail_started && (seen_active > tf.stop || (tf.kinds && used > tf.slots));
-      if (s->compact && tf.kinds && !compacting && used <= tf.slots) tail_started = true;
+      if (s->compact && tf.kinds && !compacting && used <= tf.slots && round >= tf.from) tail_started = true;
       s->live_hint = (long)seen_active;
       const bool fuse_now = (can_fuse || tail_started) && in_flight.alone(s->dev.fuse_in_flight == 1);
       // k_round linearises a block's candidates with the block's own five wavefronts: as fast as k_linearize when a block has one
@@ -1002,6 +1018,9 @@ struct Part {
   bool done;
   unsigned seen_active;  // the last count of running trajectories the host has read
   long used;             // slots its kernels are launched over (slots_in_use)
+  bool tail = false;          // the part has changed over to the combined launch for the rest of the solve (tail_fuse)
+  bool round_kernel = false;  // ... and from there to k_round, several rounds per launch
+  unsigned launched_rounds[8] = {1, 1, 1, 1, 1, 1, 1, 1};  // rounds in launch `round & 7` (its count is the sum of theirs)
 };
 // the workspace of trajectories [b0, b0 + nb), b0 a multiple of 64
 BatchState slice_state(const qilqr_solver *s, long b0, long n, int part) {
@@ -1126,8 +1145,22 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
         const RoctxRange range(s, "round", round, (long)(&part - &parts[0]));
         // (compacting in EVERY round while it runs is right: waiting until 1/16, 1/8 or 1/4 of the slots in use are known holes measured -2 / -4 /
         // -5 % at B = 8192 and -9 / -9 / -12 % at 65536 -- profiles/r06_ab.txt)
-        const bool compacting = s->compact && (part.seen_active > tf.stop || (tf.kinds && part.used > tf.slots));
-        if (tf.kinds && !compacting && part.used <= tf.slots && in_flight.alone(s->dev.fuse_in_flight == 1)) {
+        const bool compacting = s->compact && !part.tail && (part.seen_active > tf.stop || (tf.kinds && part.used > tf.slots));
+        if (tf.kinds && !compacting && part.used <= tf.slots && round >= tf.from) part.tail = true;  // (counts and slots only fall)
+        part.launched_rounds[round & 7] = 1;
+        if (part.tail && (part.round_kernel || in_flight.alone(s->dev.fuse_in_flight == 1))) {
+          // as in run_solve: k_round, four rounds per launch, once the blocks hold two candidates or fewer on average (it linearises them with
+          // the block's own wavefronts); until then the combined launch and k_linearize.  One way only -- the counts fall, the slots stay --
+          // so the round before a k_round has always been published by its own k_linearize or by the k_round before.
+          const bool blocks_full = (long)part.seen_active > 2L * cdiv(part.used, 4);
+          if (round_kernel_ok(s) && QILQR_LATE_TAIL && (part.round_kernel || !blocks_full)) {
+            const int rounds = rounds_per_launch(s);
+            const bool six = rounds > 1 && 2L * (long)part.seen_active <= cdiv(part.used, 4) * 4L;
+            if ((rc = launch_round(s, part.used, n, round, part.round_kernel, rounds, six))) return rc;
+            part.launched_rounds[round & 7] = (unsigned)rounds;
+            part.round_kernel = true;
+            continue;
+          }
           if ((rc = launch_backward_rollout(s, part.used, n))) return rc;
           if ((rc = launch_linearize(s, part.used, n, 1, F_SEARCH, (int)(round & 0x3fffffff)))) return rc;
           continue;
@@ -1159,7 +1192,8 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
           }
           __builtin_ia32_pause();
         }
-        part.seen_active = (unsigned)v;
+        // (a launch of several rounds reports the sum of their counts: the mean bounds the last round's)
+        part.seen_active = ((unsigned)v + part.launched_rounds[old & 7] - 1) / part.launched_rounds[old & 7];
         if ((unsigned)v == 0) {
           part.done = true;
           --remaining;
@@ -2482,7 +2516,10 @@ int qilqr_describe(qilqr_solver *s, int32_t B, char *buf, size_t cap) {
       t += round_kernel_ok(s) ? "; round: one launch (k_round), " + std::to_string(rounds_per_launch(s)) + " rounds per launch, while no other batch solve of the process is in flight on the device"
                                : std::string("; round: k_backward_rollout + k_linearize");
     else if (compact && fuse_kinds(s, B, B, tiled))
-      t += "; round: three launches while the compaction runs, then the combined launch once the running trajectories fit a block per CU";
+      t += "; round: three launches while the compaction runs, then the combined launch (k_backward_rollout, then k_round) once the running trajectories fit a block per CU";
+    else if (long from = 0; compact && s->dev.compaction != 1 && late_tail_kinds(s, B, B, tiled, &from))
+      t += "; round: three launches, then the combined launch (k_backward_rollout, then k_round: the same bits) once the running trajectories fit a block per CU"
+           + (from > 0 ? " and the rollouts are k_rollout16's (round " + std::to_string(from) + " on)" : std::string());
     else
       t += "; round: three launches";
     t += "; sub-batch streams: " + std::to_string(parts);

@@ -117,6 +117,26 @@ def test_full_size_shard_with_and_without():
     assert auto.compaction_moves() > 2000 and never.compaction_moves() == 0, auto.compaction_moves()
 
 
+@pytest.mark.parametrize("B,N,kw", [(4352, 40, {}), (4352, 40, dict(streams=1)), (4608, 40, dict(single_wave_rollout=3)), (4352, 40, dict(precision="f32", single_wave_rollout=3)), (4096, 40, {})])
+def test_late_rounds_of_a_large_batch_take_the_combined_launch(B, N, kw):
+    """Round 6: a batch beyond 4096 changes over to the combined launch (k_backward_rollout, then k_round with four rounds per launch) once its
+    running trajectories fit it AND its rollouts are k_rollout16's by their ordinal (the 17th on; every one with single_wave_rollout = 3) --
+    the same bits as three launches per round to the end (round_launch = 1) and as no compaction at all, and fewer launches."""
+    cfg = pb.config2(B=B, N=N, seed=12)
+    if kw.get("precision") == "f32":
+        cfg["options"] = dict(cfg["options"], rtol=1e-5, atol=1e-5)   # (what fp32 storage can resolve: DESIGN.md section 6)
+    tail, three, never = (capi.from_config(cfg, profile=1, **kw), capi.from_config(cfg, profile=1, round_launch=1, **kw),
+                          capi.from_config(cfg, compaction=-1, **kw))
+    a, b, c = solve_device(tail, cfg["init"]), solve_device(three, cfg["init"]), solve_device(never, cfg["init"])
+    assert_same(a, b, f"B={B} {kw}: combined launch in the tail / three launches")
+    assert_same(a, c, f"B={B} {kw}: / no compaction")
+    assert np.isin(a["status"], [0, 1]).all()
+    pa, pt = tail.profile_get(), three.profile_get()
+    assert pa["rollout_launches"] + 4 <= pt["rollout_launches"], (pa, pt)   # the tail's rounds have no rollout launch of their own
+    for h in (tail, three, never):
+        h.close()
+
+
 def test_bad_value_is_refused():
     cfg = pb.config2(B=4, N=10)
     with pytest.raises(TypeError, match="compaction"):
