@@ -408,6 +408,28 @@ def test_rollout_kernels_agree():
         np.testing.assert_array_equal(o["n_fwd"], outs[0]["n_fwd"])
 
 
+def test_rollout_fast_spins_through_the_three_ranges_of_exp():
+    """The body-rate step's Exp (manif's SO3Tangent::exp, quadrotor_model.cc:47) by |dt omega|^2: up to 0.25 an eight-term series, up to 12 (round
+    6, k_rollout16 only) a sixteen-term series, beyond the closed forms -- several ranges inside one wavefront, values either side of both
+    boundaries, every rollout kernel against the oracle's forward_sim."""
+    x2 = np.array([1e-12, 0.2, 0.249, 0.251, 0.26, 1.0, 3.0, 6.0, 9.0, 11.5, 11.99, 12.01, 13.0, 20.0, 30.0, 39.0, 0.0, 6.1, 2.0])
+    B, n = len(x2), 14
+    cfg = pb.config2(B=B, N=n, seed=3)
+    r = np.random.default_rng(17)
+    trajs = cfg["init"].copy()
+    d = r.normal(size=(B, 3))
+    trajs[:, 0, 11:14] = d / np.linalg.norm(d, axis=1)[:, None] * np.sqrt(x2)[:, None] / cfg["dt"]
+    gains = np.zeros((B, n, 52))
+    gains[:, :, :4] = 0.01 * r.uniform(-1, 1, (B, n, 4))   # a little feed-forward, no feedback: the spin persists over the horizon
+    ref = oracle_for(cfg)
+    want = np.stack([ref.forward_sim(trajs[b], gains[b], 1.0) for b in range(B)])
+    w = np.linalg.norm(want[:, :, 11:14], axis=2) * cfg["dt"]
+    assert (w[5:16] ** 2 > 0.25).all()   # (the fast rows stay beyond the eight-term series at every knot)
+    for choice, tol in ((1, 1e-12), (2, 1e-12), (3, 1e-11)):
+        got = capi.from_config(cfg, single_wave_rollout=choice).forward_sim(trajs, gains, 1.0)
+        np.testing.assert_allclose(got, want, rtol=tol, atol=tol, err_msg=f"single_wave_rollout={choice}")
+
+
 # ------------------------------------------------------------------ full solves
 def test_config2_batch_matches_oracle():
     cfg = pb.config2(B=64)
