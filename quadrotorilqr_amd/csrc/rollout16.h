@@ -421,11 +421,13 @@ QILQR_HD void make_pconsts(PConsts<W> &p) {
   // elements of the knot: 1..3 t, 4 qw, 5..7 q(x, y, z), 8..10 v_lin, 11..13 omega, 14..17 u
   p.e_uj = W::iconst([&](int l) { return 5 + (j(l) < 3 ? j(l) : 0); });
   // row c of hat(u): H[c][j] = sign * u_idx:   row 0 = (0, -z, y), row 1 = (z, 0, -x), row 2 = (-y, x, 0)
-  const int hidx[3][3] = {{0, 2, 1}, {2, 0, 0}, {1, 0, 0}};
-  const double hsgn[3][3] = {{0, -1, 1}, {1, 0, -1}, {-1, 1, 0}};
+  // (the index is the third of {0, 1, 2} beside c and j, the sign that of the permutation (c, j, index) -- written as arithmetic: a table
+  // indexed by the lane put nine words into scratch memory, and P's first knot waited for them at the start of every rollout)
+  auto hidx = [](int c, int jj) { return c == jj ? 0 : 3 - c - jj; };
+  auto hsgn = [](int c, int jj) { return c == jj ? 0.0 : ((jj - c + 3) % 3 == 1 ? -1.0 : 1.0); };
   for (int c = 0; c < 3; ++c) {
-    p.e_h[c] = W::iconst([&](int l) { return 5 + hidx[c][j(l) < 3 ? j(l) : 0]; });
-    p.s_h[c] = W::vconst([&](int l) { return (q(l) == 0 && j(l) < 3) ? hsgn[c][j(l)] : 0.0; });
+    p.e_h[c] = W::iconst([&](int l) { return 5 + hidx(c, j(l) < 3 ? j(l) : 0); });
+    p.s_h[c] = W::vconst([&](int l) { return (q(l) == 0 && j(l) < 3) ? hsgn(c, j(l)) : 0.0; });
     p.d_c[c] = W::vconst([&](int l) { return (q(l) == 0 && j(l) == c) ? 1.0 : 0.0; });
   }
   // left multiplication by a = conj(q_n) = (-x, -y, -z, w): rows (o_x, o_y, o_z, o_w), columns (b_x, b_y, b_z, b_w)
