@@ -131,6 +131,7 @@ __global__ __launch_bounds__(SIX ? 384 : 320) void k_round(ModelConsts<double> c
 #define R16_LDS_DECLARED
 #define BW4_CTAB_FILLED
   for (int k = threadIdx.x; k < 160; k += blockDim.x) qr_w[k] = (k < 144) ? cp->Q[k] : cp->R[k - 144];
+  if (threadIdx.x < 64) r16_exp2_lds[threadIdx.x >> 4][threadIdx.x & 15] = Series<double>::exp2[threadIdx.x >> 4][threadIdx.x & 15];  // (rollout16_body.inc)
   // the constant operand table behind the ring slots, once for all the rounds of the launch (a round whose block has nothing to run
   // leaves before it would fill it, and a later round of the same launch may have something: so here, unconditionally; the records and
   // the settle step's scratch use the slots' other words)
