@@ -62,7 +62,7 @@ __device__ __attribute__((noinline)) void s4_steps(const ModelConsts<double> &c,
   auto ld0 = [&](int e) -> double { return e >= 0 ? (double)traj[knot_elem<true>(0, e, 18)] : 0.0; };
   const double TT = ld0(tt_elem(lane)), QQ = ld0(qq_elem(lane)), VL = ld0(vl_elem(lane)), VW = ld0(vw_elem(lane));
   R16_LOADS_DONE();
-  r16_wave_X<S, true>(s4_r16, c, parity, TT, QQ, VL, VW, out, live, n, lane, nullptr);
+  r16_wave_X<S, 1>(s4_r16, c, parity, TT, QQ, VL, VW, out, live, n, lane, nullptr);
 }
 
 // one lane's share of a linearisation: the dynamics blocks (half = 0) or the cost differentials and the knot cost (half = 1)

@@ -914,11 +914,10 @@ int run_solve(qilqr_solver *s, long B, long n, int sync_every, F on_round, bool 
       if (s->compact && tf.kinds && !compacting && used <= tf.slots && round >= tf.from) tail_started = true;
       s->live_hint = (long)seen_active;
       const bool fuse_now = (can_fuse || tail_started) && in_flight.alone(s->dev.fuse_in_flight == 1);
-      // k_round linearises a block's candidates with the block's own five wavefronts: as fast as k_linearize when a block has one
-      // candidate (the tail of every solve) or when the chip is full anyway, 2.5 times slower with four candidates per block and
-      // idle CUs beside it (B = 64 ... 512 in their first rounds: -0.3 to -1.2 % of a solve if taken there)
-      const bool blocks_full = (long)seen_active > 2L * cdiv(used, 4);  // (more than two candidates per block)
-      if (fuse_now && round_kernel_ok(s) && (!blocks_full || used >= 768)) {
+      // (until round 6 k_round linearised a block's candidates AFTER the rollout, 2.5 times slower than k_linearize with four candidates per
+      // block and idle CUs beside it, and B = 64 ... 512 took k_backward_rollout + k_linearize in their first rounds; with the linearisation
+      // behind the rollout -- round_follow -- k_round is ahead at every size: B = 64 + 2.1 %, 128 + 2.3 %, 256 + 3 %, 512 + 3.6 %)
+      if (fuse_now && round_kernel_ok(s)) {
         // several rounds per launch where the rounds are this kernel for the rest of the solve (no compaction any more, whose
         // thresholds go by the count) and the caller does not look at a solve round by round (the single solve's debug capture)
         const int rounds = ((can_fuse || tail_started) && double_ok) ? rounds_per_launch(s) : 1;
@@ -1149,11 +1148,9 @@ int run_solve_parts(qilqr_solver *s, long B, long n, int nparts) {
         if (tf.kinds && !compacting && part.used <= tf.slots && round >= tf.from) part.tail = true;  // (counts and slots only fall)
         part.launched_rounds[round & 7] = 1;
         if (part.tail && (part.round_kernel || in_flight.alone(s->dev.fuse_in_flight == 1))) {
-          // as in run_solve: k_round, four rounds per launch, once the blocks hold two candidates or fewer on average (it linearises them with
-          // the block's own wavefronts); until then the combined launch and k_linearize.  One way only -- the counts fall, the slots stay --
-          // so the round before a k_round has always been published by its own k_linearize or by the k_round before.
-          const bool blocks_full = (long)part.seen_active > 2L * cdiv(part.used, 4);
-          if (round_kernel_ok(s) && QILQR_LATE_TAIL && (part.round_kernel || !blocks_full)) {
+          // as in run_solve: k_round, four rounds per launch (fp64; the mixed mode keeps the combined launch and k_linearize).  One way only,
+          // so the round before the first k_round has been published by its own k_linearize and every later one by the k_round behind it.
+          if (round_kernel_ok(s) && QILQR_LATE_TAIL) {
             const int rounds = rounds_per_launch(s);
             const bool six = rounds > 1 && 2L * (long)part.seen_active <= cdiv(part.used, 4) * 4L;
             if ((rc = launch_round(s, part.used, n, round, part.round_kernel, rounds, six))) return rc;

@@ -111,7 +111,7 @@ constexpr int R16_SPIN_MAX = 1 << 22;
 __device__ int g_r16_stall_knot = -1;
 #endif
 constexpr int R16_CHUNK = 16;  // knots per "stored and visible" announcement of wave A (k_solve4's linearisation follows it)
-enum { R16_F_PROD = 0, R16_F_V, R16_F_T, R16_F_K0, R16_F_K1, R16_F_ABORT, R16_NFLAGS };
+enum { R16_F_PROD = 0, R16_F_V, R16_F_T, R16_F_K0, R16_F_K1, R16_F_ABORT, R16_F_TASK, R16_NFLAGS };  // (R16_F_TASK: k_round's followers, round_kernels.h)
 enum { X_V = 0, X_T = 1 };
 // LDS of the three rollout roles
 struct R16Lds {
@@ -151,7 +151,7 @@ __device__ __forceinline__ bool r16_flag_wait_relaxed(R16Lds &sh, int which, int
       return true;
     }
     if (r16_flag_read(sh, R16_F_ABORT)) return false;
-    __builtin_amdgcn_s_sleep(16);
+    __builtin_amdgcn_s_sleep(4);
   }
   r16_flag_post(sh, R16_F_ABORT, 1, lane);
   return false;
@@ -199,7 +199,23 @@ __device__ __forceinline__ bool r16_handoff_finish(R16Lds &sh, int which, int ta
 // right while a step issues exactly two stores and nothing else that counts: a spill inside the loop would have made the
 // announcement early and the followers read knots not yet written, silently.  The full wait costs one store latency per
 // eight knots on a path that only k_solve4 takes.)
+// PUBLISH = 2 (k_round, whose other wavefronts linearise the candidate's knots behind the rollout, a chunk of sixteen at a time:
+// round_kernels.h): the wavefront's first knot of a chunk announces its last knot of the chunk before -- all vector-memory operations but the
+// two youngest are complete (s_waitcnt vmcnt(2): a step's two stores are
+// the only ones the loop issues; memory operations of one kind complete in order; anything else the compiler might add there -- a spill --
+// would be younger still and only make the wait longer, never the announcement early), which stalls for nothing in the steady state.
+template <int PUBLISH>
 __device__ __forceinline__ void r16_publish_stores(R16Lds &sh, int which, int i, int last, int lane) {
+  if (PUBLISH == 2) {
+    if (i == last) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      r16_flag_post(sh, which, i + 1, lane);
+    } else if (i >= R16_CHUNK && (i & (R16_CHUNK - 2)) == 0) {  // (i = 16 k or 16 k + 1: the wavefront's knot i - 2 completes a chunk of sixteen)
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      r16_flag_post(sh, which, i - 1, lane);
+    }
+    return;
+  }
   if (i == last) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     r16_flag_post(sh, which, i + 1, lane);
@@ -269,8 +285,8 @@ __device__ __forceinline__ void r16_wave_P(R16Lds &sh, const S *traj, const S *g
 // with v_i and T_{i+1} from the other wave's step i - 1.  The recurrence spans two knots, so two such waves, one knot apart,
 // never wait for each other in the steady state: v_i is posted about half a step before step i needs it, T_{i+1} likewise --
 // the hand-offs' LDS latency (~450 cycles from post to use through a progress word, which bounded every partition of a
-// knot into roles: 74 us) is off the chain.  (TT, QQ, VL, VW): the state of knot 0.  PUBLISH: announce the stored knots.
-template <typename S, bool PUBLISH>
+// knot into roles: 74 us) is off the chain.  (TT, QQ, VL, VW): the state of knot 0.  PUBLISH: announce the stored knots (1: a chunk at a time, k_solve4; 2: every knot, k_round).
+template <typename S, int PUBLISH>
 __device__ __forceinline__ void r16_wave_X(R16Lds &sh, const ModelConsts<double> &c, int p, double TT, double QQ, double VL, double VW, S *out,
                                            bool live, int n, int lane, unsigned long long *stamps_out) {
   using namespace r16;
@@ -336,7 +352,7 @@ __device__ __forceinline__ void r16_wave_X(R16Lds &sh, const ModelConsts<double>
       r16_flag_post(sh, R16_F_V, i + 1, lane);
     }
     if (wa) ok_[oa] = (S)st;
-    if (PUBLISH) r16_publish_stores(sh, R16_F_K0 + p, i, last, lane);
+    if (PUBLISH) r16_publish_stores<PUBLISH>(sh, R16_F_K0 + p, i, last, lane);
     QSTAMP(3);  // X: control, velocity, hand-off, store
     if (i + 2 < n) {
       int ft;

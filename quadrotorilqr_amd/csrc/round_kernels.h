@@ -37,9 +37,10 @@ backward_done:
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_round: a whole round in ONE launch, where k_backward_rollout is allowed (a block per CU) -- its backward pass and rollout, then the
-// linearisation of the block's own candidates by all five wavefronts (k_linearize's arithmetic: se3_math.h forms its fused
-// multiply-adds from the source alone, so the records are the same bits whichever kernel writes them).  One launch boundary and one
+// k_round: a whole round in ONE launch, where k_backward_rollout is allowed (a block per CU) -- its backward pass, then its rollout with the
+// linearisation of the block's own candidates behind it (round_follow below; until round 6 after it, linearize_block: kept for
+// -DQILQR_ROUND_NO_FOLLOW) -- k_linearize's arithmetic: se3_math.h forms its fused
+// multiply-adds from the source alone, so the records are the same bits whichever kernel writes them.  One launch boundary and one
 // kernel start and end fewer per round than k_backward_rollout + k_linearize.  The count of running trajectories is complete only
 // when every block has settled, so a launch hands the host the count of the round BEFORE it (prev_counters, prev_round): the host
 // alternates between two sets of counters, and an idle wavefront of block 0 publishes while the others roll out.
@@ -86,6 +87,53 @@ __device__ __forceinline__ void linearize_block(const ModelConsts<S> &c, const S
       const S cost = linearize_cost<LK>(qr, qr + 144, pt, pd, w);
       w.flush();
       st.knot_cost[buf][cost_index(b, i, n)] = (double)cost;
+    }
+  }
+}
+// The same work BEHIND the rollout (round 6): while three of the block's wavefronts roll the candidates out, the others linearise the knots
+// already stored -- tasks (chunk of sixteen knots, half) from a counter in LDS in the order the rollout produces them; lane = (row of the
+// block, knot of the chunk) -- and the rollout's wavefronts join when they are through.  With four candidates in a block the round no longer
+// ends three passes of lane-tasks after the rollout (22 us) but one task after it (9 us: the last knots' cost half); with one candidate it ends
+// as before.  A lane-task's arithmetic is k_linearize's: the same bits.  The step wavefronts announce every stored knot (r16_publish_stores<2>).
+template <typename S, int LK>
+__device__ __forceinline__ void round_follow(R16Lds &sh, const ModelConsts<S> &c, const S *qr, const BatchState &st, int b, int bs, int buf, bool live,
+                                             bool single, int n, int lane) {
+  // `single`: ONE of the block's four trajectories rolls out (most launches of a solve's tail).  Its knots are then taken sixty-four to a
+  // task AFTER the rollout, as linearize_block does -- a chunk task would have sixteen busy lanes, and followers that work beside a lone
+  // rollout cost its chain 2 us per round (their LDS and memory traffic between its hand-offs) for nothing: the round ends one cost half
+  // after the rollout either way.  The waiting wavefronts sleep.
+  const int per_task = single ? 64 : R16_CHUNK;
+  const int groups = (n + per_task - 1) / per_task, ntasks = 2 * groups;
+  for (;;) {
+    int t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(&sh.flags[R16_F_TASK], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= ntasks) break;
+    // (the longer chain -- the cost half -- first: of every chunk, and of the whole trajectory when single)
+    const bool cost_half = single ? (t < groups) : ((t & 1) == 0);
+    const int k0 = (single ? (cost_half ? t : t - groups) : (t >> 1)) * per_task;
+    const int need = single ? n : ((k0 + R16_CHUNK < n) ? k0 + R16_CHUNK : n);
+    // knots [0, need) are stored when each step wavefront has announced its last knot below `need`
+    const int m0 = (need - 1) - ((need - 1) & 1), m1 = (need - 1) - (((need - 1) & 1) ^ 1);
+    if (!(r16_flag_wait_relaxed(sh, R16_F_K0, m0 + 1, lane) && (m1 < 0 || r16_flag_wait_relaxed(sh, R16_F_K1, m1 + 1, lane)))) break;
+    const int i = k0 + (single ? lane : (lane & 15));
+    if (!(single || live) || i >= n) continue;
+    const int bb = single ? bs : b;  // (a dead row's lanes carry the first running row's slot and buffer: rollout16_body.inc)
+    S pt[18];
+    load_knot<true>((const S *)st.traj[buf] + knot_base<true>(bb, n, 18), i, 18, pt);
+    S *rec = (S *)st.lin[buf] + rec_base(st.layout, bb, n) + rec_elem(st.layout, i, 0);
+    if (!cost_half) {
+      const TiledRecWriter<S> wd{rec};
+      linearize_dynamics(c, pt, wd);
+      wd.flush();
+    } else {
+      const TiledRecWriter<S> w{rec};
+      S pd[18];
+      if (st.desired_tiled) load_knot<true>((const S *)st.desired + knot_base<true>(bb, n, 18), i, 18, pd);
+      else load_knot<false>((const S *)st.desired, i, 18, pd);
+      const S cost = linearize_cost<LK>(qr, qr + 144, pt, pd, w);
+      w.flush();
+      st.knot_cost[buf][cost_index(bb, i, n)] = (double)cost;
     }
   }
 }
