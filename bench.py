@@ -53,7 +53,7 @@ BYTES_BWD_KNOT, BYTES_FWD_KNOT, BYTES_IO_KNOT = 86 * 8.0, 103 * 8.0, 53 * 8.0
 # The PMC summary `roofline.traffic` is read from: named explicitly, and only used when its tag is this round's
 # (profiles/run_rocprof.sh <tag> writes profiles/<tag>_rocprof_summary.json from the same bench command).
 ROUND_TAG = "r06"
-TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r06e_rocprof_summary.json")
+TRAFFIC_SUMMARY = os.path.join(ROOT, "profiles", "r06g_rocprof_summary.json")
 
 
 def kernel_table(prof, n_bwd_knots, n_fwd_knots, solves=None):
