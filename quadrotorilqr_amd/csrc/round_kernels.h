@@ -205,6 +205,9 @@ __global__ __launch_bounds__(SIX ? 384 : 320) void k_round(ModelConsts<double> c
 #include "round_body.inc"
 #undef ROUND_ID
   }
+  // (More than four rounds per launch, measured in round 6 at B = 1024 -- a launch boundary costs 5-10 us, 4.715 / 4.628 / 4.545 ms per solve
+  // with 1 / 2 / 4 rounds per launch: EIGHT copies 5.25 ms, and a LOOP over one copy, for 8, 16 or 32 rounds, 6.4 ms: in a loop the compiler
+  // keeps the round's invariants in registers across the iterations and the kernel spills 1 KB per lane.  Four copies stay.)
 #undef ROUND_BEHIND_BACKWARD
 #undef BW4_LDS_DECLARED
 #undef R16_LDS_DECLARED
