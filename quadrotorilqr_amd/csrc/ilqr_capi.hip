@@ -711,7 +711,7 @@ int launch_compact(qilqr_solver *s, long B, long n) {
 
 // A batch of 1025 ... 4096 trajectories runs the same two kernels apart, with the compaction between them; once the running
 // trajectories fit the combined launch -- `slots` of them for this (sub-)batch: a block of four per CU over all the sub-batches --
-// the compaction has nothing left to give (a block per CU whatever the slots) and the rounds change over to the one launch.
+// the compaction has nothing left to give and the rounds change over to the one launch.
 // Round 6: a batch BEYOND 4096 does the same from the round in which its rollouts are k_rollout16's anyway (launch_rollout: the 17th, or
 // every round with single_wave_rollout = 3) -- the backward pass is one arithmetic in every form, so the combined launch's fused form gives
 // the bits of the six-wavefront launches it replaces, and a problem's bits stay independent of its batch.
@@ -739,7 +739,10 @@ TailFuse tail_fuse(const qilqr_solver *s, long B, int nparts) {
   if (!s->compact || s->dev.compaction == 1) return t;  // (forced: the compaction runs to the last trajectory)
   t.kinds = fuse_kinds(s, B) || late_tail_kinds(s, B, s->total_B, s->st.layout.tiled != 0, &t.from);
   if (t.kinds) {
-    t.slots = std::max<long>(64, 4L * s->num_cus / nparts / 64 * 64);
+    // (a block of four per CU over the sub-batches of ONE stream, two per CU over two streams', three over three and more: measured once
+    // the tail ran on k_round -- profiles/r06_ab.txt section 14: B = 4096 + 1 %, 8192 + 2-3 %, 16384 + 1.5 %; a single stream at two blocks
+    // per CU loses 17 % at B = 2048, whose whole solve would then be the tail)
+    t.slots = std::max<long>(64, std::min(nparts, 3) * 4L * s->num_cus / nparts / 64 * 64);
     t.stop = std::max<unsigned>(t.stop, (unsigned)t.slots);
   }
   return t;
@@ -2513,9 +2516,9 @@ int qilqr_describe(qilqr_solver *s, int32_t B, char *buf, size_t cap) {
       t += round_kernel_ok(s) ? "; round: one launch (k_round), " + std::to_string(rounds_per_launch(s)) + " rounds per launch, while no other batch solve of the process is in flight on the device"
                                : std::string("; round: k_backward_rollout + k_linearize");
     else if (compact && fuse_kinds(s, B, B, tiled))
-      t += "; round: three launches while the compaction runs, then the combined launch (k_backward_rollout, then k_round) once the running trajectories fit a block per CU";
+      t += "; round: three launches while the compaction runs, then k_round (the mixed mode: k_backward_rollout + k_linearize) once the running trajectories fit " + std::to_string(std::min(parts, 3)) + " block(s) of four per CU";
     else if (long from = 0; compact && s->dev.compaction != 1 && late_tail_kinds(s, B, B, tiled, &from))
-      t += "; round: three launches, then the combined launch (k_backward_rollout, then k_round: the same bits) once the running trajectories fit a block per CU"
+      t += "; round: three launches, then k_round (the same bits; the mixed mode: k_backward_rollout + k_linearize) once the running trajectories fit " + std::to_string(std::min(parts, 3)) + " block(s) of four per CU"
            + (from > 0 ? " and the rollouts are k_rollout16's (round " + std::to_string(from) + " on)" : std::string());
     else
       t += "; round: three launches";

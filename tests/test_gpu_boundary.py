@@ -108,13 +108,14 @@ def test_describe_says_which_arithmetic_a_handle_uses():
     assert "symmetric-weight forms" in d and "k_backward4, fused" in d and "k_rollout16" in d and "k_round" in d and "4 rounds per launch" in d
     d = capi.from_config(cfg).describe(8192)
     assert "six wavefronts" in d and "k_rollout3" in d and "three launches" in d and "sub-batch streams: " in d and "compaction of the running trajectories: on" in d
+    assert "three launches, then k_round (the same bits" in d and "block(s) of four per CU and the rollouts are k_rollout16's (round 16 on)" in d
     assert "factored by the gradient wavefront" in d and "first 16 rollouts, k_rollout16 from there on" in d
     # a mid-size batch: the fused kernels, the compaction first and the combined launch once the running trajectories fit (the text
     # follows run_solve's predicate -- no "one launch" beside "compaction: on"), and describing is READ-ONLY: the answers do not depend on
     # what was asked before, and a solve between two questions changes nothing
     h = capi.from_config(cfg)
     d2048, d64 = h.describe(2048), h.describe(64)
-    assert "k_backward4, fused" in d2048 and "three launches while the compaction runs, then the combined launch" in d2048 and "one launch (k_round)" not in d2048
+    assert "k_backward4, fused" in d2048 and "three launches while the compaction runs, then k_round" in d2048 and "fit 1 block(s) of four per CU" in d2048 and "one launch (k_round)" not in d2048
     assert "one launch (k_round)" in d64 and "compaction: off" in d64
     h.solve_batch(cfg["init"])
     assert h.describe(2048) == d2048 and h.describe(64) == d64 and h.describe(8192) == d
