@@ -288,7 +288,7 @@ int ensure_workspace(qilqr_solver *s, long B, long n) {
   if ((rc = dalloc(s, &st.orig, cB))) return rc;
   if ((rc = dalloc(s, &st.plan, (size_t)PLAN_HEAD * (qilqr_solver::MAX_PARTS + 2) + 4 * (size_t)cB))) return rc;  // (a part: head, B holes, B live slots, B / 2 pairs x 4)
   st.row0 = 0;
-#ifdef QILQR_STAMPS
+#if defined(QILQR_STAMPS) || defined(QILQR_ROUND_STAMPS)
   if ((rc = dalloc(s, &st.stamps, 8 * cB))) return rc;
 #else
   st.stamps = nullptr;
@@ -2543,7 +2543,7 @@ int qilqr_compaction_moves(qilqr_solver *s, int64_t *moves) {
   return QILQR_OK;
 }
 
-#ifdef QILQR_STAMPS
+#if defined(QILQR_STAMPS) || defined(QILQR_ROUND_STAMPS)
 // diagnostic build only: per-trajectory section cycle sums of the last k_backward launch
 int qilqr_debug_stamps(qilqr_solver *s, unsigned long long *out, int32_t B) {
   HIP_TRY(hipSetDevice(s->device));

@@ -175,6 +175,10 @@ __global__ __launch_bounds__(SIX ? 384 : 320) void k_round(ModelConsts<double> c
   __shared__ double qr_w[160];  // the weights of the cost half (k_linearize keeps a copy per wavefront: here the block's)
   BW4_DECLARE_LDS
   __shared__ R16Lds sh;
+#ifdef QILQR_ROUND_STAMPS
+  __shared__ unsigned long long round_stamp_x0;
+  unsigned long long rs_t0 = 0, rs_t1 = 0, rs_t2 = 0, rs_t3 = 0;
+#endif
 #define BW4_LDS_DECLARED
 #define R16_LDS_DECLARED
 #define BW4_CTAB_FILLED
