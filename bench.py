@@ -683,8 +683,8 @@ def main():
                             "profiles/r04_knot_anatomy.txt) and the rollout at 51.8 us.  The numerator is the reference's dense-as-written 30 kflop "
                             "per backward knot; the kernel issues 7 x 2048 flop of MFMA + ~68 fp64 vector instructions per knot"} if dom == "k_backward_rollout" else {}),
                 **({"note": "k_round = a whole round in one launch (up to 1024 trajectories, a block of four per CU): the block's backward pass, the "
-                            "rollout of its four trajectories and the linearisation of the candidates, three serial chains one after the other "
-                            "(about 66 + 52 + 9 us with one running trajectory per block), and up to FOUR such rounds per launch (avg_launch_us is a "
+                            "rollout of its four trajectories with the linearisation of the candidates behind it (round 6), serial chains one after the other "
+                            "(about 152 + 134 + 11 thousand shader cycles with one running trajectory per block), and up to FOUR such rounds per launch (avg_launch_us is a "
                             "launch of four).  Its work is the backward and forward knots' algorithmic "
                             "flops -- the reference's backward knot, 30 kflop dense-as-written, calls the dynamics and cost differentials itself (ilqr.hh:110-116), which "
                             "until round 4 ran in a launch of its own outside this denominator: the fraction fell from 0.129 (k_backward_rollout, "
