@@ -2,7 +2,7 @@
 """Diagnostic: throughput with several independent batch solves in flight on one GPU (one solver handle and one
 host thread per batch in flight; ctypes releases the GIL during the call).  A stream of 1024-problem batches is
 the serving case: the tail of one batch (few trajectories still iterating) overlaps the head of the next.
-usage: inflight.py [batch [steps]]"""
+usage: inflight.py [batch [steps [fuse_in_flight]]]"""
 import sys
 import threading
 import time
@@ -15,13 +15,14 @@ from quadrotorilqr_amd import capi, problems as pb  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+FUSE = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # 1: keep the combined launch (k_round) although other solves are in flight
 dev = torch.device("cuda", 0)
 cfg = pb.config2(B=B, N=100, seed=2)
 init = torch.from_numpy(cfg["init"]).to(dev)
 for inflight in (1, 2, 3, 4):
     workers = []
     for _ in range(inflight):
-        s = capi.from_config(cfg, sync_every=2)
+        s = capi.from_config(cfg, sync_every=2, fuse_in_flight=FUSE)
         out = torch.empty_like(init)
         cost = torch.empty(B, dtype=torch.float64, device=dev)
         ints = [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(4)]
