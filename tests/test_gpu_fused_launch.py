@@ -49,6 +49,23 @@ def test_one_launch_for_backward_and_rollout_gives_the_same_bits():
     assert np.isin(fused["f64_1024_status"], [0, 1]).all() and (fused["restarts_n_bwd"] > fused["restarts_iters"] + 1).any()
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 15, 16, 17, 18, 31, 32, 33, 64, 65, 127])
+def test_linearisation_behind_the_rollout_at_horizons_around_its_chunk_size(n):
+    """Round 6: k_round's other wavefronts linearise the candidates' knots BEHIND the rollout, sixteen knots x four rows to a task, as the step
+    wavefronts announce them (round_follow; one running trajectory per block: sixty-four knots to a task, after the rollout).  Horizons either
+    side of the chunk boundaries, ragged batches whose last block holds one, two or three trajectories, blocks in which trajectories finish in
+    different rounds: the same bits as three launches per round, every array."""
+    for B in (1, 6, 7, 9):
+        cfg = pb.config2(B=B, N=n, seed=30 + B)
+        a = capi.from_config(cfg).solve_batch(cfg["init"])
+        b = capi.from_config(cfg, round_launch=1).solve_batch(cfg["init"])
+        six = capi.from_config(cfg, force_general=8).solve_batch(cfg["init"])
+        for k in ("traj", "cost", "status", "iters", "n_bwd", "n_fwd"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=f"B={B} n={n} {k}")
+            np.testing.assert_array_equal(six[k], b[k], err_msg=f"six wavefronts, B={B} n={n} {k}")
+        assert (a["status"] >= 0).all() and np.isfinite(a["traj"]).all()
+
+
 @pytest.mark.parametrize("rounds", [0, 1])
 def test_k_round_with_the_six_wavefront_backward_pass_gives_the_same_bits(rounds):
     """Round 6: k_round<.., SIX> -- the same launch with the backward pass in the six-wavefront form (the matrix wavefronts factor, knot loop
